@@ -1,0 +1,190 @@
+"""Generate tests/golden/*.pt by running the UNMODIFIED reference.
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    PYTHONPATH=/root/reference python tests/golden/make_golden.py
+
+For every case: build the reference model through its public API
+(ModelBuilder.build_encoder/build_decoder with a weights= file so no download is
+attempted), overwrite the state dict with seeded synthetic tensors
+(oracle.semseg_oracle.synth_state_dict), replace nn.Dropout2d by a replayable
+mask, run SegmentationModule.forward (+ backward + 2x SGD step as train.py:34-48
+does) and record outputs.  The fixtures pin oracle/semseg_oracle.py and, through
+it, the HIP path.
+"""
+import json
+import os
+import sys
+import tempfile
+
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get('SEMSEG_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+
+from mit_semseg.models import ModelBuilder, SegmentationModule   # noqa: E402  (the reference)
+from mit_semseg.models import resnet, hrnet, models as ref_models  # noqa: E402
+from oracle import semseg_oracle as O                              # noqa: E402
+
+assert os.path.realpath(ref_models.__file__).startswith(os.path.realpath(REF)), ref_models.__file__
+
+
+class ReplayDropout(nn.Module):
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        if not self.training or self.mask is None:
+            return x
+        return x * self.mask[:, :, None, None]
+
+
+def build_reference(arch_enc, arch_dec, fc_dim, use_softmax=False):
+    """SURVEY 8c oracle recipe (1)-(2)."""
+    base = arch_enc.replace('dilated', '')
+    if arch_enc == 'hrnetv2':
+        enc0 = hrnet.hrnetv2(pretrained=False)
+    else:
+        r = resnet.__dict__[base](pretrained=False)
+        enc0 = ref_models.ResnetDilated(r, 8) if arch_enc.endswith('dilated') else ref_models.Resnet(r)
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, 'enc.pth')
+        torch.save(enc0.state_dict(), p)
+        enc = ModelBuilder.build_encoder(arch=arch_enc, fc_dim=fc_dim, weights=p)
+    dec = ModelBuilder.build_decoder(arch=arch_dec, fc_dim=fc_dim, num_class=150, weights='',
+                                     use_softmax=use_softmax)
+    return enc, dec
+
+
+def manifest_of(m):
+    return {k: list(v.shape) for k, v in m.state_dict().items()}
+
+
+def summarize(t, full_limit=4096):
+    """Small tensors in full; large ones as (sum, abs-sum, 16 head + 16 tail values)."""
+    t = t.detach().float()
+    if t.numel() <= full_limit:
+        return {'full': t.clone()}
+    f = t.flatten()
+    return {'sum': f.double().sum().item(), 'abssum': f.double().abs().sum().item(),
+            'head': f[:16].clone(), 'tail': f[-16:].clone(), 'numel': t.numel()}
+
+
+def group_weight(module):
+    """train.py:92-112 -- decay on conv/linear weights only."""
+    decay, no_decay = [], []
+    for m in module.modules():
+        if isinstance(m, nn.modules.conv._ConvNd):
+            decay.append(m.weight)
+            if m.bias is not None:
+                no_decay.append(m.bias)
+        elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+            if m.weight is not None:
+                no_decay.append(m.weight)
+            if m.bias is not None:
+                no_decay.append(m.bias)
+    return [dict(params=decay), dict(params=no_decay, weight_decay=.0)]
+
+
+def run_case(name, arch_enc, arch_dec, fc_dim, n, h, w, seg_rate, training, deep_sup_scale,
+             step=False, seg_size=None, seed=0):
+    torch.manual_seed(304)
+    enc, dec = build_reference(arch_enc, arch_dec, fc_dim, use_softmax=seg_size is not None)
+    man_e, man_d = manifest_of(enc), manifest_of(dec)
+    enc.load_state_dict(O.synth_state_dict(man_e, seed))
+    dec.load_state_dict(O.synth_state_dict(man_d, seed + 1))
+    masks = {}
+    if training:
+        # conv_last.3 is the main-head Dropout2d, dropout_deepsup the deepsup one (models.py:455-465)
+        if hasattr(dec, 'conv_last') and isinstance(dec.conv_last, nn.Sequential) and len(dec.conv_last) == 5:
+            masks['main'] = O.synth_dropout_mask(n, 512, seed=seed)
+            dec.conv_last[3] = ReplayDropout(masks['main'])
+        if hasattr(dec, 'dropout_deepsup'):
+            masks['deepsup'] = O.synth_dropout_mask(n, fc_dim // 4, seed=seed + 1)
+            dec.dropout_deepsup = ReplayDropout(masks['deepsup'])
+    crit = nn.NLLLoss(ignore_index=-1)
+    sm = SegmentationModule(enc, dec, crit, deep_sup_scale)
+    sm.train(training)
+    img, lab = O.synth_batch(n, h, w, seg_rate, seed=304 + seed)
+    feed = {'img_data': img, 'seg_label': lab}
+    meta = dict(name=name, arch_encoder=arch_enc, arch_decoder=arch_dec, fc_dim=fc_dim, n=n, h=h, w=w,
+                seg_rate=seg_rate, training=training, deep_sup_scale=deep_sup_scale, step=step,
+                seg_size=seg_size, seed=seed, lr=0.02, torch=torch.__version__)
+    out = {'meta': meta, 'manifest_enc': man_e, 'manifest_dec': man_d,
+           'dropout': {k: v.clone() for k, v in masks.items()}}
+    if seg_size is not None:
+        with torch.no_grad():
+            out['prob'] = sm(feed, segSize=tuple(seg_size)).clone()
+        return out
+    # capture decoder outputs through a hook (SegmentationModule returns only loss/acc)
+    cap = {}
+    hk = dec.register_forward_hook(lambda m, i, o: cap.__setitem__('out', o))
+    hk2 = enc.register_forward_hook(lambda m, i, o: cap.__setitem__('feats', o))
+    if not step:
+        with torch.no_grad():
+            loss, acc = sm(feed)
+    else:
+        opts = [torch.optim.SGD(group_weight(enc), lr=0.02, momentum=0.9, weight_decay=1e-4),
+                torch.optim.SGD(group_weight(dec), lr=0.02, momentum=0.9, weight_decay=1e-4)]
+        sm.zero_grad()
+        loss, acc = sm(feed)
+        loss.backward()
+    hk.remove(); hk2.remove()
+    o = cap['out']
+    pred, pred_ds = (o if isinstance(o, tuple) else (o, None))
+    out.update(loss=loss.detach().clone(), acc=acc.detach().clone(), pred=pred.detach().clone(),
+               pred_deepsup=None if pred_ds is None else pred_ds.detach().clone(),
+               feats=[summarize(f) for f in cap['feats']])
+    if step:
+        out['grads_enc'] = {k: summarize(p.grad) for k, p in enc.named_parameters()}
+        out['grads_dec'] = {k: summarize(p.grad) for k, p in dec.named_parameters()}
+        for op in opts:
+            op.step()
+        out['after_enc'] = {k: summarize(v) for k, v in enc.state_dict().items() if v.is_floating_point()}
+        out['after_dec'] = {k: summarize(v) for k, v in dec.state_dict().items() if v.is_floating_point()}
+    return out
+
+
+CASES = [
+    # BASELINE.json configs[0]: R18dilated+PPM_deepsup, 1 image 384x384, CPU reference forward+loss (eval, SURVEY 0 trap 2)
+    dict(name='cfg0_r18d_ppmds_384_eval', arch_enc='resnet18dilated', arch_dec='ppm_deepsup', fc_dim=512,
+         n=1, h=384, w=384, seg_rate=8, training=False, deep_sup_scale=0.4),
+    dict(name='r18d_ppmds_64_train', arch_enc='resnet18dilated', arch_dec='ppm_deepsup', fc_dim=512,
+         n=2, h=64, w=64, seg_rate=8, training=True, deep_sup_scale=0.4, step=True),
+    dict(name='r50d_ppmds_64_train', arch_enc='resnet50dilated', arch_dec='ppm_deepsup', fc_dim=2048,
+         n=2, h=64, w=64, seg_rate=8, training=True, deep_sup_scale=0.4, step=True),
+    dict(name='r50_upernet_128_train', arch_enc='resnet50', arch_dec='upernet', fc_dim=2048,
+         n=2, h=128, w=128, seg_rate=4, training=True, deep_sup_scale=None, step=True),
+    dict(name='r101d_ppmds_72x104_eval', arch_enc='resnet101dilated', arch_dec='ppm_deepsup', fc_dim=2048,
+         n=1, h=72, w=104, seg_rate=8, training=False, deep_sup_scale=0.4),
+    dict(name='hrnetv2_c1_64_train', arch_enc='hrnetv2', arch_dec='c1', fc_dim=720,
+         n=2, h=64, w=64, seg_rate=4, training=True, deep_sup_scale=None, step=True),
+    dict(name='r18d_ppm_infer_64x80', arch_enc='resnet18dilated', arch_dec='ppm', fc_dim=512,
+         n=1, h=64, w=80, seg_rate=8, training=False, deep_sup_scale=None, seg_size=[35, 45]),
+    dict(name='r50_upernet_infer_64', arch_enc='resnet50', arch_dec='upernet', fc_dim=2048,
+         n=1, h=64, w=64, seg_rate=4, training=False, deep_sup_scale=None, seg_size=[40, 40]),
+]
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    manifests = {}
+    for c in CASES:
+        r = run_case(**c)
+        path = os.path.join(HERE, c['name'] + '.pt')
+        manifests[c['arch_enc']] = r['manifest_enc']
+        manifests[c['arch_dec'] + '@%d' % c['fc_dim']] = r['manifest_dec']
+        torch.save(r, path)
+        extra = '' if 'loss' not in r else ' loss=%.6f acc=%.6f' % (r['loss'].item(), r['acc'].item())
+        print('%-28s %7.1f KB%s' % (c['name'], os.path.getsize(path) / 1024, extra))
+    with open(os.path.join(HERE, 'manifests.json'), 'w') as f:
+        json.dump(manifests, f)
+
+
+if __name__ == '__main__':
+    main()
