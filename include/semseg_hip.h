@@ -1,0 +1,174 @@
+/* libsemseg_hip.so -- C ABI of the MI355X (gfx950) hot path that replaces the torch
+ * operators called on SegmentationModule.forward/backward of
+ * CSAILVision/semantic-segmentation-pytorch (reference: /root/reference/mit_semseg).
+ *
+ * The reference is pure Python: it has no FFI for this path.  Each entry point below
+ * therefore names the torch call site (reference file:line) whose arithmetic it
+ * replaces; INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; fp32 unless said
+ *  - activations are NHWC: element (n,h,w,c) at ((n*H+h)*W+w)*ld + c, ld >= C is the
+ *    pixel stride in floats (ld > C addresses a channel slice of a wider concat buffer)
+ *  - conv weights are KRSC (= a torch [K,C,R,S] tensor in channels_last memory format)
+ *  - `stream` is a hipStream_t; nothing allocates, synchronises or reads back to the
+ *    host, so every call can be captured into a hipGraph
+ *  - return value: 0 on success, a hipError_t (>0) from the launch, or SEMSEG_E* (<0)
+ */
+#ifndef SEMSEG_HIP_H
+#define SEMSEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEMSEG_EINVAL   (-1)   /* bad argument (shape/alignment not supported) */
+#define SEMSEG_EWORKSPACE (-2) /* workspace too small */
+
+int semseg_abi_version(void);
+
+/* ---------------- convolution (nn.Conv2d; resnet.py:18-21,61-66,130; models.py:163,406,448,
+ *                  456,461,519-540; hrnet.py:26-29,188-205,316-338) ---------------------- */
+
+/* bytes of scratch the three conv entry points may need for this geometry (split-K / split-M
+ * partial sums).  Pass a buffer at least this large as `workspace`. */
+size_t semseg_conv2d_workspace_bytes(int N, int H, int W, int C, int K, int R, int S,
+                                     int stride, int pad, int dil);
+
+/* y[n,oh,ow,k] = bias[k] + sum_{r,s,c} x[n, oh*stride-pad+r*dil, ow*stride-pad+s*dil, c] * w[k,r,s,c]
+ * x: [N,H,W,C] (ld x_ld), w: [K,R,S,C], bias: [K] or NULL, y: [N,OH,OW,K] (ld y_ld).
+ * Any C/K; C % 4 == 0 with 16-byte aligned x (x_ld % 4 == 0) takes the float4 path, anything else
+ * (the 3-channel stem, resnet.py:100) a scalar-load path of the same kernel. */
+int semseg_conv2d_fwd(const float* x, int x_ld, const float* w, const float* bias, float* y, int y_ld,
+                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* dx = conv2d_fwd^T(dy).  wt: the weights transposed to [C,R,S,K] by semseg_weight_krsc_to_crsk.
+ * dy: [N,OH,OW,K] (ld dy_ld), dx: [N,H,W,C] (ld dx_ld). */
+int semseg_conv2d_dgrad(const float* dy, int dy_ld, const float* wt, float* dx, int dx_ld,
+                        int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* dw[k,r,s,c] = sum_{n,oh,ow} dy[n,oh,ow,k] * x[n, oh*stride-pad+r*dil, ow*stride-pad+s*dil, c]
+ * db[k] (optional) = sum dy[.,k]. */
+int semseg_conv2d_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, float* dw, float* db,
+                        int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* [K,R,S,C] -> [C,R,S,K] (T = R*S taps) */
+int semseg_weight_krsc_to_crsk(const float* w, float* wt, int K, int T, int C, void* stream);
+
+/* ---------------- batch norm (lib/nn/modules/batchnorm.py:56-61 = F.batch_norm) ---------- */
+
+/* scratch (bytes) for bn_stats / bn_bwd_reduce partial sums */
+size_t semseg_bn_workspace_bytes(int P, int C);
+
+/* stats[0..C) = sum_p z[p,c], stats[C..2C) = sum_p z[p,c]^2, stats[2C] = P   (all fp64).
+ * z: [P,C] dense.  A data-parallel caller all-reduces `stats` (2C+1 doubles) before finalize
+ * (replaces batchnorm.py:63-76,98-117). */
+int semseg_bn_stats(const float* z, int P, int C, double* stats, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* mean = S/n; var = SS/n - mean^2 (biased); invstd = 1/sqrt(var+eps);
+ * scale = gamma*invstd; shift = beta - mean*scale;
+ * running_mean = (1-m)*running_mean + m*mean; running_var = (1-m)*running_var + m*var*n/(n-1).
+ * running_* may be NULL.  mean/invstd/scale/shift: [C]. */
+int semseg_bn_finalize(const double* stats, int C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps,
+                       float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* eval mode: scale = gamma/sqrt(running_var+eps); shift = beta - running_mean*scale;
+ * also fills mean = running_mean, invstd = 1/sqrt(running_var+eps). */
+int semseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, int C,
+                          float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* y = act(z*scale + shift (+ residual)), act = relu if relu!=0 (resnet.py:76-90 fused).
+ * z,residual: [P,C] dense (residual may be NULL, res_ld its pixel stride); y: [P,C] with ld y_ld. */
+int semseg_bn_apply(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
+                    int relu, float* y, int y_ld, int P, int C, void* stream);
+
+/* g = dy * (relu ? y>0 : 1);  sums[0..C) = sum_p g, sums[C..2C) = sum_p g*xhat, xhat=(z-mean)*invstd
+ * (fp64; all-reduced by a data-parallel caller).  dgamma = sum g*xhat, dbeta = sum g (local, fp32). */
+int semseg_bn_bwd_reduce(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                         const float* mean, const float* invstd, int relu, int P, int C,
+                         double* sums, float* dgamma, float* dbeta,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* training: dz = gamma*invstd*(g - sums[c]/n - xhat*sums[C+c]/n), n = stats_count[0] (device fp64:
+ *           the all-reduced element count, i.e. stats[2C] of the forward)
+ * eval    : dz = gamma*invstd*g
+ * dres (optional, dense [P,C]) = g  -- gradient of the fused residual input. */
+int semseg_bn_bwd_apply(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                        const float* mean, const float* invstd, const float* gamma,
+                        const double* sums, const double* stats_count, int training, int relu,
+                        float* dz, float* dres, int P, int C, void* stream);
+
+/* ---------------- elementwise helpers ------------------------------------------------------ */
+/* out = act(a + b) (hrnet.py:231-248 fuse sums); a,b,out [P,C] with their own ld */
+int semseg_add_act(const float* a, int a_ld, const float* b, int b_ld, int relu, float* out, int out_ld,
+                   int P, int C, void* stream);
+/* dx = dy * (y > 0) */
+int semseg_relu_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* dx, int dx_ld,
+                    int P, int C, void* stream);
+/* strided 2-D copy (torch.cat slices, models.py:424,476,553,575; hrnet.py:434) */
+int semseg_copy2d(const float* src, int src_ld, float* dst, int dst_ld, int P, int C, int accumulate,
+                  void* stream);
+/* y[n,p,c] = x[n,p,c] * mask[n,c]  (nn.Dropout2d models.py:460,464 with an explicit mask; fwd == bwd) */
+int semseg_scale_nc(const float* x, const float* mask, float* y, int N, int HW, int C, void* stream);
+/* NCHW <-> NHWC layout changes at the API edge */
+int semseg_nchw_to_nhwc(const float* x, float* y, int N, int C, int HW, void* stream);
+int semseg_nhwc_to_nchw(const float* x, float* y, int N, int C, int HW, void* stream);
+
+/* ---------------- pooling / resize ---------------------------------------------------------- */
+/* nn.MaxPool2d(3,2,1) resnet.py:109.  idx: uint8 [N,OH,OW,C] window position (r*3+s) of the first max */
+int semseg_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int semseg_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C,
+                            void* stream);
+/* nn.AdaptiveAvgPool2d(s) models.py:447,511: bins [floor(i*H/s), ceil((i+1)*H/s)) */
+int semseg_adaptive_avgpool_fwd(const float* x, int x_ld, float* y, int N, int H, int W, int C, int OH, int OW,
+                                void* stream);
+int semseg_adaptive_avgpool_bwd(const float* dy, float* dx, int dx_ld, int accumulate, int N, int H, int W, int C,
+                                int OH, int OW, void* stream);
+/* F.interpolate(bilinear, align_corners=False) models.py:420-423,472-475,549-552,561-574; hrnet.py:241-245,427-432
+ * x: [N,IH,IW,C] ld x_ld; y: [N,OH,OW,C] ld y_ld; accumulate: y += (FPN top-down add, HRNet fuse);
+ * relu: y = max(y, 0) after the (accumulated) result (hrnet.py:248) */
+int semseg_bilinear_fwd(const float* x, int x_ld, float* y, int y_ld, int accumulate, int relu,
+                        int N, int IH, int IW, int OH, int OW, int C, void* stream);
+/* dx[N,IH,IW,C] (+)= bilinear^T(dy[N,OH,OW,C]) -- gather form, deterministic */
+int semseg_bilinear_bwd(const float* dy, int dy_ld, float* dx, int dx_ld, int accumulate,
+                        int N, int IH, int IW, int OH, int OW, int C, void* stream);
+
+/* ---------------- head: softmax / NLL / pixel accuracy -------------------------------------- */
+/* F.log_softmax(dim=1) models.py:383,492-493,584 on [P,C] rows (C <= 1024) */
+int semseg_log_softmax_fwd(const float* z, float* logp, int P, int C, void* stream);
+int semseg_log_softmax_bwd(const float* dlogp, const float* logp, float* dz, int P, int C, void* stream);
+/* F.softmax(dim=1) of the inference branch models.py:482-483 */
+int semseg_softmax_fwd(const float* z, float* prob, int P, int C, void* stream);
+/* nn.NLLLoss(ignore_index) train.py:154 + pixel_acc models.py:12-18 in one pass over logp [P,C]:
+ * out[0] = -sum_valid logp[p,label]/n_valid, out[1] = acc = hits/(n_valid+1e-10), out[2] = n_valid (fp32).
+ * label: int64 [P]. */
+int semseg_nll_acc_fwd(const float* logp, const int64_t* label, int ignore_index, int P, int C,
+                       float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* dlogp[p,c] = -(gloss[0]/n_valid) if c==label[p] (valid) else 0 */
+int semseg_nll_bwd(const float* gloss, const float* nll_out, const int64_t* label, int ignore_index,
+                   float* dlogp, int P, int C, void* stream);
+
+/* ---------------- optimiser (torch.optim.SGD, train.py:117-126) ----------------------------- */
+typedef struct {
+    float* param; const float* grad; float* momentum_buf; int64_t numel; float weight_decay; int first_step;
+} semseg_sgd_tensor;
+/* tensors_host: host array of n descriptors, copied into the kernel launch by value in chunks;
+ * lr: device pointer to the current learning rate (so a captured graph can be replayed while
+ * the poly schedule of train.py:130-139 changes it).  g = grad*grad_scale + wd*p; buf = m*buf + g
+ * (buf = g on first_step); p -= lr*buf. */
+int semseg_sgd_step(const semseg_sgd_tensor* tensors_host, int n, const float* lr, float momentum,
+                    float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,49 @@
+"""Build libsemseg_hip.so (gfx950) in-tree with hipcc.  No torch headers are involved: the library is a
+plain C ABI (include/semseg_hip.h).  Usage: python build_native.py [--force]"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+OUT_DIR = os.path.join(HERE, 'mit_semseg', '_native')
+LIB = os.path.join(OUT_DIR, 'libsemseg_hip.so')
+SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'bn.hip', 'pool_resize.hip', 'head.hip', 'api.hip']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC,
+         '-Wno-unused-result']
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    deps = [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'semseg_hip.h')]
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OUT_DIR, s.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+            jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
+    if jobs:
+        def run(cmd):
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,60 @@
+// Shared device/host helpers for libsemseg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "semseg_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SEMSEG_LAUNCH_CHECK()                       \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t ceil_div_sz(size_t a, size_t b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// load up to 4 consecutive floats; VEC: nvalid is 0 or 4 and p is 16-byte aligned
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int nvalid) {
+    if (VEC) {
+        return nvalid > 0 ? *reinterpret_cast<const float4*>(p) : f4zero();
+    } else {
+        float4 v = f4zero();
+        if (nvalid > 0) v.x = p[0];
+        if (nvalid > 1) v.y = p[1];
+        if (nvalid > 2) v.z = p[2];
+        if (nvalid > 3) v.w = p[3];
+        return v;
+    }
+}
+
+// 64-lane wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks b, b+8, b+16.. (same XCD, MI355X dispatches
+// block b to XCD b%8) receive CONSECUTIVE logical ids so tiles sharing an operand share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
+    const int xcd = b & 7, q = nblocks >> 3, r = nblocks & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}

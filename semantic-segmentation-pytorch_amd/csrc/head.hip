@@ -1,0 +1,236 @@
+// Per-pixel softmax head of the segmentation hot path (gfx950): log_softmax / softmax over the class
+// axis (150 classes, NHWC so a pixel's classes are one contiguous 600-byte row), NLL loss with
+// ignore_index, pixel accuracy, and their backward.  One 64-lane wavefront owns one pixel: the row is
+// read once (3 values per lane for C=150), max and sum(exp) are wavefront shuffle reductions.
+// Replaces F.log_softmax / F.softmax (reference models.py:383,482-484,492-493,584), nn.NLLLoss
+// (train.py:154) and SegmentationModuleBase.pixel_acc (models.py:12-18).
+#include "common.h"
+
+constexpr int HEAD_MAX_PER_LANE = 16;   // C <= 1024
+
+template <bool LOG>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ z, float* __restrict__ out, int P, int C) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const float* row = z + (size_t)p * C;
+    float v[HEAD_MAX_PER_LANE];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_PER_LANE; ++k) {
+        const int c = lane + 64 * k;
+        v[k] = (c < C) ? row[c] : -INFINITY;
+        m = fmaxf(m, v[k]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_PER_LANE; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) s += expf(v[k] - m);
+    }
+    s = wave_sum(s);
+    float* o = out + (size_t)p * C;
+    if (LOG) {
+        const float lse = m + logf(s);
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_PER_LANE; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) o[c] = v[k] - lse;
+        }
+    } else {
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_PER_LANE; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) o[c] = expf(v[k] - m) * inv;
+        }
+    }
+}
+
+extern "C" int semseg_log_softmax_fwd(const float* z, float* logp, int P, int C, void* stream) {
+    if (!z || !logp || P <= 0 || C <= 0 || C > 64 * HEAD_MAX_PER_LANE) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(softmax_fwd_kernel<true>, dim3(ceil_div(P, 4)), dim3(256), 0, (hipStream_t)stream, z, logp, P, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int semseg_softmax_fwd(const float* z, float* prob, int P, int C, void* stream) {
+    if (!z || !prob || P <= 0 || C <= 0 || C > 64 * HEAD_MAX_PER_LANE) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(softmax_fwd_kernel<false>, dim3(ceil_div(P, 4)), dim3(256), 0, (hipStream_t)stream, z, prob, P, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dz = dlogp - exp(logp) * sum_c dlogp
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp,
+                                                              float* __restrict__ dz, int P, int C) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const float* g = dlogp + (size_t)p * C;
+    const float* l = logp + (size_t)p * C;
+    float gv[HEAD_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_PER_LANE; ++k) {
+        const int c = lane + 64 * k;
+        gv[k] = (c < C) ? g[c] : 0.f;
+        s += gv[k];
+    }
+    s = wave_sum(s);
+    float* o = dz + (size_t)p * C;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_PER_LANE; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) o[c] = gv[k] - expf(l[c]) * s;
+    }
+}
+
+extern "C" int semseg_log_softmax_bwd(const float* dlogp, const float* logp, float* dz, int P, int C, void* stream) {
+    if (!dlogp || !logp || !dz || P <= 0 || C <= 0 || C > 64 * HEAD_MAX_PER_LANE) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(ceil_div(P, 4)), dim3(256), 0, (hipStream_t)stream, dlogp, logp, dz, P, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// pass 1: per-block partial (loss sum fp64, valid count, hit count); one wave per pixel
+constexpr int NLL_BLOCKS = 256;
+__global__ __launch_bounds__(256) void nll_acc_partial_kernel(const float* __restrict__ logp, const int64_t* __restrict__ label,
+                                                              int ignore_index, int P, int C, double* __restrict__ partial) {
+    __shared__ double sl[4];
+    __shared__ int sv[4], sh[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double loss = 0.0;
+    int valid = 0, hits = 0;
+    for (int p = blockIdx.x * 4 + w; p < P; p += gridDim.x * 4) {
+        const float* row = logp + (size_t)p * C;
+        // first-max argmax over C (torch.max(dim=1) returns the first index of the maximum)
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float v = row[c];
+            if (v > best || (v != v && best == best)) { best = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) {
+            const long long lab = label[p];
+            // pixel_acc (models.py:12-18): valid = label >= 0 ; NLLLoss: valid = label != ignore_index
+            if (lab >= 0) hits += ((long long)bi == lab) ? 1 : 0;
+            if (lab != ignore_index) {
+                valid += 1;
+                if (lab >= 0 && lab < C) loss -= (double)row[lab];
+            }
+        }
+    }
+    if (lane == 0) { sl[w] = loss; sv[w] = valid; sh[w] = hits; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 3 + 0] = sl[0] + sl[1] + sl[2] + sl[3];
+        partial[blockIdx.x * 3 + 1] = (double)(sv[0] + sv[1] + sv[2] + sv[3]);
+        partial[blockIdx.x * 3 + 2] = (double)(sh[0] + sh[1] + sh[2] + sh[3]);
+    }
+}
+
+__global__ void nll_acc_finish_kernel(const double* __restrict__ partial, int nblocks, const int64_t* __restrict__ label, int P,
+                                      float* __restrict__ out) {
+    // single wave; also counts label>=0 for the accuracy denominator (== n_valid when ignore_index == -1)
+    const int lane = threadIdx.x;
+    double l = 0.0, v = 0.0, h = 0.0;
+    for (int b = lane; b < nblocks; b += 64) { l += partial[b * 3]; v += partial[b * 3 + 1]; h += partial[b * 3 + 2]; }
+    l = wave_sum_d(l); v = wave_sum_d(v); h = wave_sum_d(h);
+    double nonneg = 0.0;
+    for (int p = lane; p < P; p += 64) nonneg += label[p] >= 0 ? 1.0 : 0.0;
+    nonneg = wave_sum_d(nonneg);
+    if (lane == 0) {
+        out[0] = (float)(l / v);                                   // mean over non-ignored (0/0 -> NaN as torch)
+        out[1] = (float)h / ((float)nonneg + 1e-10f);              // models.py:17
+        out[2] = (float)v;
+    }
+}
+
+extern "C" int semseg_nll_acc_fwd(const float* logp, const int64_t* label, int ignore_index, int P, int C, float* out,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!logp || !label || !out || P <= 0 || C <= 0) return SEMSEG_EINVAL;
+    const int blocks = min(NLL_BLOCKS, ceil_div(P, 4));
+    if (!workspace || workspace_bytes < (size_t)blocks * 3 * sizeof(double)) return SEMSEG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nll_acc_partial_kernel, dim3(blocks), dim3(256), 0, st, logp, label, ignore_index, P, C, (double*)workspace);
+    SEMSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nll_acc_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, blocks, label, P, out);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void nll_bwd_kernel(const float* __restrict__ gloss, const float* __restrict__ nll_out,
+                               const int64_t* __restrict__ label, int ignore_index, float* __restrict__ dlogp, int P, int C) {
+    const size_t total = (size_t)P * C;
+    const float g = -gloss[0] / nll_out[2];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / C);
+        const int c = (int)(i - (size_t)p * C);
+        const long long lab = label[p];
+        dlogp[i] = (lab != ignore_index && lab == c) ? g : 0.f;
+    }
+}
+
+extern "C" int semseg_nll_bwd(const float* gloss, const float* nll_out, const int64_t* label, int ignore_index, float* dlogp,
+                              int P, int C, void* stream) {
+    if (!gloss || !nll_out || !label || !dlogp || P <= 0 || C <= 0) return SEMSEG_EINVAL;
+    size_t b = ceil_div_sz((size_t)P * C, 256);
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, gloss, nll_out, label, ignore_index, dlogp,
+                       P, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- SGD (train.py:117-126) ----------
+constexpr int SGD_MAX_TENSORS = 48;
+struct SgdBatch {
+    semseg_sgd_tensor t[SGD_MAX_TENSORS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void sgd_kernel(const SgdBatch b, const float* __restrict__ lr_ptr, float momentum,
+                                                  float grad_scale) {
+    const semseg_sgd_tensor t = b.t[blockIdx.y];
+    const float lr = lr_ptr[0];
+    const int64_t n = t.numel;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float w = t.param[i];
+        const float g = fmaf(t.weight_decay, w, t.grad[i] * grad_scale);
+        const float m = t.first_step ? g : fmaf(momentum, t.momentum_buf[i], g);
+        t.momentum_buf[i] = m;
+        t.param[i] = w - lr * m;
+    }
+}
+
+extern "C" int semseg_sgd_step(const semseg_sgd_tensor* tensors_host, int n, const float* lr, float momentum, float grad_scale,
+                               void* stream) {
+    if (!tensors_host || n < 0 || !lr) return SEMSEG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += SGD_MAX_TENSORS) {
+        SgdBatch b;
+        b.n = min(SGD_MAX_TENSORS, n - base);
+        int64_t maxn = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.t[i] = tensors_host[base + i];
+            if (!b.t[i].param || !b.t[i].grad || !b.t[i].momentum_buf) return SEMSEG_EINVAL;
+            if (b.t[i].numel > maxn) maxn = b.t[i].numel;
+        }
+        int gx = (int)((maxn + 256 * 8 - 1) / (256 * 8));
+        if (gx < 1) gx = 1;
+        if (gx > 512) gx = 512;
+        hipLaunchKernelGGL(sgd_kernel, dim3(gx, b.n), dim3(256), 0, st, b, lr, momentum, grad_scale);
+        SEMSEG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int semseg_abi_version(void) { return 1; }

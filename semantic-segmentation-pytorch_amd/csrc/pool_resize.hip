@@ -1,0 +1,453 @@
+// HBM-bound NHWC side ops of the segmentation hot path (gfx950): max-pool, adaptive average pool,
+// bilinear resize (align_corners=False), strided copies / adds for concat and FPN/HRNet fusion,
+// layout changes at the API edge.  All are float4-per-lane coalesced along the channel axis; every
+// backward is written in GATHER form (each output element owned by exactly one thread, fixed
+// summation order) so results are deterministic without atomics.
+#include "common.h"
+
+static inline int stream_blocks(size_t items) {
+    size_t b = ceil_div_sz(items, 256);
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+#define GRID_STRIDE(i, total) \
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (size_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------ elementwise -----------------
+template <bool RELU>
+__global__ void add_act_kernel(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld,
+                               float* __restrict__ out, int out_ld, int P, int C) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)P * qpr;
+    GRID_STRIDE(i, total) {
+        const int p = (int)(i / qpr);
+        const int c = (int)(i - (size_t)p * qpr) * 4;
+        const float4 x = *reinterpret_cast<const float4*>(a + (size_t)p * a_ld + c);
+        const float4 y = *reinterpret_cast<const float4*>(b + (size_t)p * b_ld + c);
+        float4 o = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(out + (size_t)p * out_ld + c) = o;
+    }
+}
+
+extern "C" int semseg_add_act(const float* a, int a_ld, const float* b, int b_ld, int relu, float* out, int out_ld,
+                              int P, int C, void* stream) {
+    if (!a || !b || !out || P <= 0 || C <= 0 || (C % 4) || (a_ld % 4) || (b_ld % 4) || (out_ld % 4)) return SEMSEG_EINVAL;
+    const int blocks = stream_blocks((size_t)P * (C / 4));
+    if (relu) hipLaunchKernelGGL(add_act_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, a_ld, b, b_ld, out, out_ld, P, C);
+    else      hipLaunchKernelGGL(add_act_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, a_ld, b, b_ld, out, out_ld, P, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ y, int y_ld,
+                                float* __restrict__ dx, int dx_ld, int P, int C) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)P * qpr;
+    GRID_STRIDE(i, total) {
+        const int p = (int)(i / qpr);
+        const int c = (int)(i - (size_t)p * qpr) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c);
+        const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c);
+        const float4 o = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+        *reinterpret_cast<float4*>(dx + (size_t)p * dx_ld + c) = o;
+    }
+}
+
+extern "C" int semseg_relu_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* dx, int dx_ld, int P, int C,
+                               void* stream) {
+    if (!dy || !y || !dx || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) || (y_ld % 4) || (dx_ld % 4)) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_blocks((size_t)P * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
+                       y, y_ld, dx, dx_ld, P, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool ACC, bool VEC>
+__global__ void copy2d_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld, int P, int C) {
+    if (VEC) {
+        const int qpr = C / 4;
+        const size_t total = (size_t)P * qpr;
+        GRID_STRIDE(i, total) {
+            const int p = (int)(i / qpr);
+            const int c = (int)(i - (size_t)p * qpr) * 4;
+            float4 v = *reinterpret_cast<const float4*>(src + (size_t)p * src_ld + c);
+            float4* d = reinterpret_cast<float4*>(dst + (size_t)p * dst_ld + c);
+            if (ACC) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *d = v;
+        }
+    } else {
+        const size_t total = (size_t)P * C;
+        GRID_STRIDE(i, total) {
+            const int p = (int)(i / C);
+            const int c = (int)(i - (size_t)p * C);
+            float v = src[(size_t)p * src_ld + c];
+            float* d = dst + (size_t)p * dst_ld + c;
+            if (ACC) v += *d;
+            *d = v;
+        }
+    }
+}
+
+extern "C" int semseg_copy2d(const float* src, int src_ld, float* dst, int dst_ld, int P, int C, int accumulate,
+                             void* stream) {
+    if (!src || !dst || P <= 0 || C <= 0 || src_ld < C || dst_ld < C) return SEMSEG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (C % 4 == 0) && (src_ld % 4 == 0) && (dst_ld % 4 == 0) && aligned16(src) && aligned16(dst);
+    const int blocks = stream_blocks(vec ? (size_t)P * (C / 4) : (size_t)P * C);
+#define LAUNCH(A, V) hipLaunchKernelGGL((copy2d_kernel<A, V>), dim3(blocks), dim3(256), 0, st, src, src_ld, dst, dst_ld, P, C)
+    if (accumulate) { if (vec) LAUNCH(true, true); else LAUNCH(true, false); }
+    else            { if (vec) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void scale_nc_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y, int N,
+                                int HW, int C) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)N * HW * qpr;
+    GRID_STRIDE(i, total) {
+        const size_t p = i / qpr;
+        const int c = (int)(i - p * qpr) * 4;
+        const int n = (int)(p / HW);
+        const float4 v = *reinterpret_cast<const float4*>(x + p * C + c);
+        const float4 m = *reinterpret_cast<const float4*>(mask + (size_t)n * C + c);
+        *reinterpret_cast<float4*>(y + p * C + c) = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+    }
+}
+
+extern "C" int semseg_scale_nc(const float* x, const float* mask, float* y, int N, int HW, int C, void* stream) {
+    if (!x || !mask || !y || N <= 0 || HW <= 0 || C <= 0 || (C % 4)) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(scale_nc_kernel, dim3(stream_blocks((size_t)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                       mask, y, N, HW, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// NCHW <-> NHWC: per image a [C][HW] <-> [HW][C] transpose through a 32x33 LDS tile
+__global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+    // x: [batch][rows][cols] -> y: [batch][cols][rows]
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? x[base + (size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) y[base + (size_t)c * rows + r] = tile[tx][i];
+    }
+}
+
+extern "C" int semseg_nchw_to_nhwc(const float* x, float* y, int N, int C, int HW, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(HW, 32), ceil_div(C, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, C, HW);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int semseg_nhwc_to_nchw(const float* x, float* y, int N, int C, int HW, void* stream) {
+    if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(HW, 32), N), dim3(256), 0, (hipStream_t)stream, x, y, HW, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ max pool 3x3 s2 p1 ----------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int N, int H,
+                                   int W, int C, int OH, int OW) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)N * OH * OW * qpr;
+    GRID_STRIDE(i, total) {
+        const size_t op = i / qpr;
+        const int c = (int)(i - op * qpr) * 4;
+        const int ow = (int)(op % OW);
+        const int oh = (int)((op / OW) % OH);
+        const int n = (int)(op / ((size_t)OW * OH));
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        bool first = true;
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * 2 - 1 + r;
+            if (ih < 0 || ih >= H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int iw = ow * 2 - 1 + s;
+                if (iw < 0 || iw >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + ih) * W + iw) * C + c);
+                const int t = r * 3 + s;
+                // torch CPU max_pool2d: take val if (val > max) || isnan(val); first visited wins ties
+                if (first || v.x > best.x || v.x != v.x) { best.x = v.x; b0 = t; }
+                if (first || v.y > best.y || v.y != v.y) { best.y = v.y; b1 = t; }
+                if (first || v.z > best.z || v.z != v.z) { best.z = v.z; b2 = t; }
+                if (first || v.w > best.w || v.w != v.w) { best.w = v.w; b3 = t; }
+                first = false;
+            }
+        }
+        *reinterpret_cast<float4*>(y + op * C + c) = best;
+        *reinterpret_cast<uchar4*>(idx + op * C + c) = make_uchar4((unsigned char)b0, (unsigned char)b1, (unsigned char)b2, (unsigned char)b3);
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx, int N,
+                                   int H, int W, int C, int OH, int OW) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)N * H * W * qpr;
+    GRID_STRIDE(i, total) {
+        const size_t ip = i / qpr;
+        const int c = (int)(i - ip * qpr) * 4;
+        const int iw = (int)(ip % W);
+        const int ih = (int)((ip / W) % H);
+        const int n = (int)(ip / ((size_t)W * H));
+        float4 acc = f4zero();
+        // windows (oh, r) with oh*2-1+r == ih
+        for (int r = 0; r < 3; ++r) {
+            const int t = ih + 1 - r;
+            if (t < 0 || (t & 1)) continue;
+            const int oh = t >> 1;
+            if (oh >= OH) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int u = iw + 1 - s;
+                if (u < 0 || (u & 1)) continue;
+                const int ow = u >> 1;
+                if (ow >= OW) continue;
+                const size_t op = ((size_t)(n * OH + oh) * OW + ow);
+                const uchar4 k = *reinterpret_cast<const uchar4*>(idx + op * C + c);
+                const float4 g = *reinterpret_cast<const float4*>(dy + op * C + c);
+                const int tt = r * 3 + s;
+                if (k.x == tt) acc.x += g.x;
+                if (k.y == tt) acc.y += g.y;
+                if (k.z == tt) acc.z += g.z;
+                if (k.w == tt) acc.w += g.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + ip * C + c) = acc;
+    }
+}
+
+extern "C" int semseg_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4)) return SEMSEG_EINVAL;
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_blocks((size_t)N * OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       x, y, idx, N, H, W, C, OH, OW);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int semseg_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream) {
+    if (!dy || !dx || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4)) return SEMSEG_EINVAL;
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_blocks((size_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy,
+                       idx, dx, N, H, W, C, OH, OW);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ adaptive average pool -------
+__device__ __forceinline__ int bin_start(int i, int in, int out) { return (i * in) / out; }
+__device__ __forceinline__ int bin_end(int i, int in, int out) { return ((i + 1) * in + out - 1) / out; }
+
+// block = 16 channel quads (64 channels) x 16 pixel lanes; one output bin per block.x, channel chunk per block.y
+__global__ __launch_bounds__(256) void adaptive_avgpool_fwd_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ y,
+                                                                   int N, int H, int W, int C, int OH, int OW) {
+    __shared__ float4 red[16][16];
+    const int tq = threadIdx.x & 15, tp = threadIdx.x >> 4;
+    const int c = (blockIdx.y * 16 + tq) * 4;
+    const int bin = blockIdx.x;
+    const int ow = bin % OW, oh = (bin / OW) % OH, n = bin / (OW * OH);
+    const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
+    const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
+    const int bw = w1 - w0, cnt = (h1 - h0) * bw;
+    float4 s = f4zero();
+    if (c < C) {
+        for (int k = tp; k < cnt; k += 16) {
+            const int ih = h0 + k / bw, iw = w0 + k % bw;
+            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + ih) * W + iw) * x_ld + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[tp][tq] = s;
+    __syncthreads();
+    if (tp == 0 && c < C) {
+        float4 a = f4zero();
+        for (int k = 0; k < 16; ++k) { const float4 v = red[k][tq]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        const float inv = 1.0f / (float)cnt;
+        *reinterpret_cast<float4*>(y + (size_t)bin * C + c) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    }
+}
+
+template <bool ACC>
+__global__ void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int dx_ld, int N, int H,
+                                            int W, int C, int OH, int OW) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)N * H * W * qpr;
+    GRID_STRIDE(i, total) {
+        const size_t ip = i / qpr;
+        const int c = (int)(i - ip * qpr) * 4;
+        const int iw = (int)(ip % W);
+        const int ih = (int)((ip / W) % H);
+        const int n = (int)(ip / ((size_t)W * H));
+        float4 acc = f4zero();
+        // bins containing ih: oh in [floor(ih*OH/H) - 1, ...] -- scan the (at most 2-3) candidates
+        int oh_lo = (ih * OH) / H; if (oh_lo > 0) --oh_lo;
+        int ow_lo = (iw * OW) / W; if (ow_lo > 0) --ow_lo;
+        for (int oh = oh_lo; oh < OH && bin_start(oh, H, OH) <= ih; ++oh) {
+            const int h0 = bin_start(oh, H, OH), h1 = bin_end(oh, H, OH);
+            if (ih < h0 || ih >= h1) continue;
+            for (int ow = ow_lo; ow < OW && bin_start(ow, W, OW) <= iw; ++ow) {
+                const int w0 = bin_start(ow, W, OW), w1 = bin_end(ow, W, OW);
+                if (iw < w0 || iw >= w1) continue;
+                const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+                const float4 g = *reinterpret_cast<const float4*>(dy + ((size_t)(n * OH + oh) * OW + ow) * C + c);
+                acc.x += g.x * inv; acc.y += g.y * inv; acc.z += g.z * inv; acc.w += g.w * inv;
+            }
+        }
+        float4* d = reinterpret_cast<float4*>(dx + ip * dx_ld + c);
+        if (ACC) { const float4 o = *d; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        *d = acc;
+    }
+}
+
+extern "C" int semseg_adaptive_avgpool_fwd(const float* x, int x_ld, float* y, int N, int H, int W, int C, int OH, int OW,
+                                           void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) || (x_ld % 4) || OH <= 0 || OW <= 0) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel, dim3(N * OH * OW, ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream, x, x_ld,
+                       y, N, H, W, C, OH, OW);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int semseg_adaptive_avgpool_bwd(const float* dy, float* dx, int dx_ld, int accumulate, int N, int H, int W, int C,
+                                           int OH, int OW, void* stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) || (dx_ld % 4) || OH <= 0 || OW <= 0) return SEMSEG_EINVAL;
+    const int blocks = stream_blocks((size_t)N * H * W * (C / 4));
+    if (accumulate) hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dx, dx_ld, N, H, W, C, OH, OW);
+    else            hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dx, dx_ld, N, H, W, C, OH, OW);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ bilinear, align_corners=False
+// torch area_pixel_compute_source_index: src = max(0, scale*(dst+0.5)-0.5), scale = in/out (float);
+// i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.
+__device__ __forceinline__ void bl_coord(int d, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+    float src = scale * ((float)d + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+template <bool ACC, bool RELU>
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ y, int y_ld, int N, int IH,
+                                    int IW, int OH, int OW, int C, float sh, float sw) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)N * OH * OW * qpr;
+    GRID_STRIDE(i, total) {
+        const size_t op = i / qpr;
+        const int c = (int)(i - op * qpr) * 4;
+        const int ow = (int)(op % OW);
+        const int oh = (int)((op / OW) % OH);
+        const int n = (int)(op / ((size_t)OW * OH));
+        int h0, h1, w0, w1;
+        float lh0, lh1, lw0, lw1;
+        bl_coord(oh, sh, IH, h0, h1, lh0, lh1);
+        bl_coord(ow, sw, IW, w0, w1, lw0, lw1);
+        const float* b = x + (size_t)n * IH * IW * x_ld + c;
+        const float4 v00 = *reinterpret_cast<const float4*>(b + ((size_t)h0 * IW + w0) * x_ld);
+        const float4 v01 = *reinterpret_cast<const float4*>(b + ((size_t)h0 * IW + w1) * x_ld);
+        const float4 v10 = *reinterpret_cast<const float4*>(b + ((size_t)h1 * IW + w0) * x_ld);
+        const float4 v11 = *reinterpret_cast<const float4*>(b + ((size_t)h1 * IW + w1) * x_ld);
+        float4 o;
+        // same association as torch upsample_bilinear2d: h0lambda*(w0lambda*v00 + w1lambda*v01) + h1lambda*(...)
+        o.x = lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
+        o.y = lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
+        o.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
+        o.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
+        float4* d = reinterpret_cast<float4*>(y + op * y_ld + c);
+        if (ACC) { const float4 p = *d; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *d = o;
+    }
+}
+
+extern "C" int semseg_bilinear_fwd(const float* x, int x_ld, float* y, int y_ld, int accumulate, int relu, int N, int IH, int IW,
+                                   int OH, int OW, int C, void* stream) {
+    if (!x || !y || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || (C % 4) || (x_ld % 4) || (y_ld % 4))
+        return SEMSEG_EINVAL;
+    const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+    const int blocks = stream_blocks((size_t)N * OH * OW * (C / 4));
+#define LAUNCH(A, R) hipLaunchKernelGGL((bilinear_fwd_kernel<A, R>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, y, y_ld, N, IH, IW, OH, OW, C, sh, sw)
+    if (accumulate) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
+    else            { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// gather-form backward: block.x = one input pixel, block.y = 64-channel chunk; 16 pixel lanes sweep the
+// window of output pixels that can touch this input pixel, fixed-order LDS combine.
+template <bool ACC>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int dy_ld, float* __restrict__ dx,
+                                                           int dx_ld, int N, int IH, int IW, int OH, int OW, int C, float sh,
+                                                           float sw) {
+    __shared__ float4 red[16][16];
+    const int tq = threadIdx.x & 15, tp = threadIdx.x >> 4;
+    const int c = (blockIdx.y * 16 + tq) * 4;
+    const int ip = blockIdx.x;
+    const int iw = ip % IW, ih = (ip / IW) % IH, n = ip / (IW * IH);
+    // candidate output rows: src in (ih-1, ih+1)  =>  d in ((ih-0.5)/s - 0.5, (ih+1.5)/s - 0.5); widen by 1, clamp
+    int oh_lo = (int)floorf(((float)ih - 0.5f) / sh - 0.5f) - 1; if (oh_lo < 0) oh_lo = 0;
+    int oh_hi = (int)ceilf(((float)ih + 1.5f) / sh - 0.5f) + 1; if (oh_hi > OH - 1) oh_hi = OH - 1;
+    int ow_lo = (int)floorf(((float)iw - 0.5f) / sw - 0.5f) - 1; if (ow_lo < 0) ow_lo = 0;
+    int ow_hi = (int)ceilf(((float)iw + 1.5f) / sw - 0.5f) + 1; if (ow_hi > OW - 1) ow_hi = OW - 1;
+    if (ih == 0) oh_lo = 0;            // clamped-at-zero source rows all map to i0 = 0
+    if (iw == 0) ow_lo = 0;
+    if (ih == IH - 1) oh_hi = OH - 1;
+    if (iw == IW - 1) ow_hi = OW - 1;
+    const int nh = oh_hi - oh_lo + 1, nw = ow_hi - ow_lo + 1;
+    float4 s = f4zero();
+    if (c < C) {
+        for (int k = tp; k < nh * nw; k += 16) {
+            const int oh = oh_lo + k / nw, ow = ow_lo + k % nw;
+            int h0, h1, w0, w1;
+            float lh0, lh1, lw0, lw1;
+            bl_coord(oh, sh, IH, h0, h1, lh0, lh1);
+            bl_coord(ow, sw, IW, w0, w1, lw0, lw1);
+            float wh = 0.f, ww = 0.f;
+            if (h0 == ih) wh += lh0;
+            if (h1 == ih) wh += lh1;
+            if (w0 == iw) ww += lw0;
+            if (w1 == iw) ww += lw1;
+            const float wgt = wh * ww;
+            if (wgt != 0.f) {
+                const float4 g = *reinterpret_cast<const float4*>(dy + ((size_t)(n * OH + oh) * OW + ow) * dy_ld + c);
+                s.x += wgt * g.x; s.y += wgt * g.y; s.z += wgt * g.z; s.w += wgt * g.w;
+            }
+        }
+    }
+    red[tp][tq] = s;
+    __syncthreads();
+    if (tp == 0 && c < C) {
+        float4 a = f4zero();
+        for (int k = 0; k < 16; ++k) { const float4 v = red[k][tq]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        float4* d = reinterpret_cast<float4*>(dx + (size_t)ip * dx_ld + c);
+        if (ACC) { const float4 o = *d; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+        *d = a;
+    }
+}
+
+extern "C" int semseg_bilinear_bwd(const float* dy, int dy_ld, float* dx, int dx_ld, int accumulate, int N, int IH, int IW,
+                                   int OH, int OW, int C, void* stream) {
+    if (!dy || !dx || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) || (dx_ld % 4))
+        return SEMSEG_EINVAL;
+    const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+    dim3 grid(N * IH * IW, ceil_div(C, 64));
+    if (accumulate) hipLaunchKernelGGL(bilinear_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw);
+    else            hipLaunchKernelGGL(bilinear_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,83 @@
+"""ctypes binding of libsemseg_hip.so (C ABI declared in include/semseg_hip.h).
+
+The product path has NO CPU or eager-torch fallback: if the shared library is missing, or a kernel
+returns a non-zero code, this raises.  The library is loaded after `import torch` so that it binds
+to the HIP runtime torch already loaded (same soname libamdhip64.so.7)."""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads libamdhip64 first)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsemseg_hip.so')
+_lib = None
+
+c_int, c_f, c_sz, vp = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+
+class SgdTensor(ctypes.Structure):
+    _fields_ = [('param', vp), ('grad', vp), ('momentum_buf', vp), ('numel', ctypes.c_int64),
+                ('weight_decay', c_f), ('first_step', c_int)]
+
+
+# name -> (restype, argtypes); mirrors include/semseg_hip.h one to one
+SIGNATURES = {
+    'semseg_abi_version': (c_int, []),
+    'semseg_conv2d_workspace_bytes': (c_sz, [c_int] * 10),
+    'semseg_conv2d_fwd': (c_int, [vp, c_int, vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
+    'semseg_conv2d_dgrad': (c_int, [vp, c_int, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
+    'semseg_conv2d_wgrad': (c_int, [vp, c_int, vp, c_int, vp, vp] + [c_int] * 10 + [vp, c_sz, vp]),
+    'semseg_weight_krsc_to_crsk': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
+    'semseg_bn_workspace_bytes': (c_sz, [c_int, c_int]),
+    'semseg_bn_stats': (c_int, [vp, c_int, c_int, vp, vp, c_sz, vp]),
+    'semseg_bn_finalize': (c_int, [vp, c_int, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp]),
+    'semseg_bn_eval_coeffs': (c_int, [vp, vp, vp, vp, c_f, c_int, vp, vp, vp, vp, vp]),
+    'semseg_bn_apply': (c_int, [vp, vp, vp, vp, c_int, c_int, vp, c_int, c_int, c_int, vp]),
+    'semseg_bn_bwd_reduce': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_sz, vp]),
+    'semseg_bn_bwd_apply': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int, vp]),
+    'semseg_add_act': (c_int, [vp, c_int, vp, c_int, c_int, vp, c_int, c_int, c_int, vp]),
+    'semseg_relu_bwd': (c_int, [vp, c_int, vp, c_int, vp, c_int, c_int, c_int, vp]),
+    'semseg_copy2d': (c_int, [vp, c_int, vp, c_int, c_int, c_int, c_int, vp]),
+    'semseg_scale_nc': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
+    'semseg_nchw_to_nhwc': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
+    'semseg_nhwc_to_nchw': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
+    'semseg_maxpool3x3s2_fwd': (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
+    'semseg_maxpool3x3s2_bwd': (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
+    'semseg_adaptive_avgpool_fwd': (c_int, [vp, c_int, vp] + [c_int] * 6 + [vp]),
+    'semseg_adaptive_avgpool_bwd': (c_int, [vp, vp, c_int, c_int] + [c_int] * 6 + [vp]),
+    'semseg_bilinear_fwd': (c_int, [vp, c_int, vp, c_int, c_int, c_int] + [c_int] * 6 + [vp]),
+    'semseg_bilinear_bwd': (c_int, [vp, c_int, vp, c_int, c_int] + [c_int] * 6 + [vp]),
+    'semseg_log_softmax_fwd': (c_int, [vp, vp, c_int, c_int, vp]),
+    'semseg_log_softmax_bwd': (c_int, [vp, vp, vp, c_int, c_int, vp]),
+    'semseg_softmax_fwd': (c_int, [vp, vp, c_int, c_int, vp]),
+    'semseg_nll_acc_fwd': (c_int, [vp, vp, c_int, c_int, c_int, vp, vp, c_sz, vp]),
+    'semseg_nll_bwd': (c_int, [vp, vp, vp, c_int, vp, c_int, c_int, vp]),
+    'semseg_sgd_step': (c_int, [ctypes.POINTER(SgdTensor), c_int, vp, c_f, c_f, vp]),
+}
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises NativeLibraryMissing if the .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                '%s not built: run `python semantic-segmentation-pytorch_amd/build_native.py` '
+                '(there is no CPU/eager fallback for the HIP hot path)' % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed with code %d (%s)' % (
+            what, rc, {-1: 'SEMSEG_EINVAL', -2: 'SEMSEG_EWORKSPACE'}.get(rc, 'hipError_t')))

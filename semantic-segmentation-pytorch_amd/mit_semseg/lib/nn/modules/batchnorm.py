@@ -1,0 +1,78 @@
+"""SynchronizedBatchNorm for one-process-per-GPU data parallelism on MI355X.
+
+Mirrors the public surface of reference lib/nn/modules/batchnorm.py:38-139 (class names, ctor
+arguments eps=1e-5 / momentum=0.001 / affine, parameter and buffer names incl. the fork's
+`_tmp_running_mean/_tmp_running_var/_running_iter`) so reference checkpoints load unchanged.
+
+Numerics follow the path the CPU reference executes, F.batch_norm (batchnorm.py:58-61): biased
+variance + eps for normalisation, unbiased variance in the running-average EMA.  Cross-replica
+synchronisation is NOT the reference's thread rendezvous (comm.py, batchnorm.py:63-117): each rank
+computes [sum, sum^2, n] with a HIP kernel and the vector is all-reduced over RCCL
+(ops.set_sync_bn_group), so every rank finalises identical statistics.
+"""
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+__all__ = ['SynchronizedBatchNorm1d', 'SynchronizedBatchNorm2d', 'SynchronizedBatchNorm3d']
+
+
+class _SynchronizedBatchNorm(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.001, affine=True):
+        super().__init__()
+        if not affine:
+            raise NotImplementedError('affine=False is not used by any mit_semseg model')
+        self.num_features = num_features
+        self.eps = eps
+        self.momentum = momentum
+        self.affine = affine
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        # fork-only bookkeeping buffers of the reference (batchnorm.py:50-52); kept for state-dict parity
+        self.register_buffer('_tmp_running_mean', torch.zeros(num_features))
+        self.register_buffer('_tmp_running_var', torch.ones(num_features))
+        self.register_buffer('_running_iter', torch.ones(1))
+
+    def _as4d(self, x):
+        raise NotImplementedError
+
+    def forward(self, input, residual=None, relu=False):
+        """y = BN(input); the fused form y = relu(BN(input) + residual) is what the blocks call."""
+        x, shape = self._as4d(input)
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        y = ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                               residual=residual, training=self.training, momentum=self.momentum,
+                               eps=self.eps, relu=relu)
+        return y if shape is None else y.reshape(shape)
+
+    def extra_repr(self):
+        return '{num_features}, eps={eps}, momentum={momentum}, affine={affine}'.format(**self.__dict__)
+
+
+class SynchronizedBatchNorm2d(_SynchronizedBatchNorm):
+    def _as4d(self, x):
+        if x.dim() != 4:
+            raise ValueError('expected 4D input (got {}D input)'.format(x.dim()))
+        return x, None
+
+
+class SynchronizedBatchNorm1d(_SynchronizedBatchNorm):
+    def _as4d(self, x):
+        if x.dim() == 2:
+            return x[:, :, None, None], x.shape
+        if x.dim() == 3:
+            return x[:, :, :, None], x.shape
+        raise ValueError('expected 2D or 3D input (got {}D input)'.format(x.dim()))
+
+
+class SynchronizedBatchNorm3d(_SynchronizedBatchNorm):
+    def _as4d(self, x):
+        if x.dim() != 5:
+            raise ValueError('expected 5D input (got {}D input)'.format(x.dim()))
+        n, c, d, h, w = x.shape
+        return x.reshape(n, c, d * h, w), x.shape

@@ -1,0 +1,118 @@
+"""nn.Module leaves of the MI355X build.  They own parameters with the reference's names/logical shapes
+(so reference checkpoints load) and call the HIP operators in mit_semseg.ops."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lib.nn import SynchronizedBatchNorm2d
+
+BatchNorm2d = SynchronizedBatchNorm2d
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class Conv2d(nn.Module):
+    """Drop-in for the nn.Conv2d uses of the reference (square kernels, groups=1).  The weight keeps the
+    logical [K,C,R,S] shape but is stored KRSC (channels_last) -- the layout the MFMA kernels read."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        for t in (self.kernel_size, self.stride, self.padding, self.dilation):
+            if t[0] != t[1]:
+                raise NotImplementedError('only square conv geometry is used by mit_semseg models')
+        k = self.kernel_size[0]
+        w = torch.empty(out_channels, k, k, in_channels).permute(0, 3, 1, 2)      # KRSC memory, KCRS shape
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # torch nn.Conv2d default init (kaiming_uniform(a=sqrt(5)) + uniform bias)
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+
+    def extra_repr(self):
+        return '{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}, padding={padding}, ' \
+               'dilation={dilation}'.format(**self.__dict__) + (', bias=False' if self.bias is None else '')
+
+
+class ReLU(nn.Module):
+    """Standalone ReLU (only used where the reference applies it outside a conv-BN pair)."""
+
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x):
+        return ops.add_act(x, torch.zeros_like(x), relu=True)
+
+
+class MaxPool3x3s2(nn.Module):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (resnet.py:109)."""
+    kernel_size, stride, padding = 3, 2, 1
+
+    def forward(self, x):
+        return ops.max_pool_3x3_s2(x)
+
+
+class AdaptiveAvgPool2d(nn.Module):
+    def __init__(self, output_size):
+        super().__init__()
+        self.output_size = output_size
+
+    def forward(self, x):
+        return ops.adaptive_avg_pool(x, self.output_size)
+
+
+class Dropout2d(nn.Module):
+    """nn.Dropout2d (models.py:460,464): per-(n,c) Bernoulli keep mask scaled by 1/(1-p), training only.
+    `mask_override` ([N,C] multipliers) replays a fixed mask -- used by the parity tests."""
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+        self.mask_override = None
+
+    def forward(self, x):
+        if not self.training or (self.p == 0 and self.mask_override is None):
+            return x
+        if self.mask_override is not None:
+            mask = self.mask_override
+        else:
+            keep = torch.rand(x.shape[0], x.shape[1], device=x.device) >= self.p
+            mask = keep.float() / (1.0 - self.p)
+        return ops.scale_nc(x, mask)
+
+
+class ConvBNReLU(nn.Sequential):
+    """Conv -> BN -> ReLU with the reference's Sequential child indices ('0' conv, '1' bn[, '2' relu]);
+    executes as conv kernel + fused BN/ReLU kernels."""
+
+    def __init__(self, conv, bn, relu=True, first_index=0):
+        super().__init__()
+        self.add_module(str(first_index), conv)
+        self.add_module(str(first_index + 1), bn)
+        self._relu = relu
+        self._conv, self._bn = str(first_index), str(first_index + 1)
+
+    def forward(self, x, residual=None):
+        return self._modules[self._bn](self._modules[self._conv](x), residual=residual, relu=self._relu)
+
+
+def conv3x3_bn_relu(in_planes, out_planes, stride=1):
+    """3x3 convolution + BN + relu (models.py:160-167)."""
+    return ConvBNReLU(Conv2d(in_planes, out_planes, 3, stride=stride, padding=1, bias=False),
+                      BatchNorm2d(out_planes))

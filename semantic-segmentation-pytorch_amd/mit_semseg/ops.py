@@ -1,0 +1,589 @@
+"""Autograd operators of the MI355X hot path.  Every op is a thin torch.autograd.Function around the
+C ABI of libsemseg_hip.so (include/semseg_hip.h): torch supplies device memory, the current HIP
+stream and the autograd tape -- all arithmetic runs in the hand-written gfx950 kernels.
+
+Tensor convention: tensors keep the reference's LOGICAL shape [N,C,H,W] but live in NHWC memory
+(torch channels_last strides, possibly a channel slice of a wider buffer).  `as_nhwc` returns the
+pixel stride `ld` the kernels take; anything else (e.g. the NCHW-contiguous input image of
+train.py:41) is converted once by the nchw_to_nhwc kernel.
+
+There is no CPU / eager fallback: non-CUDA tensors raise.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _native
+
+vp = ctypes.c_void_p
+
+
+def _p(t):
+    return vp(t.data_ptr()) if t is not None else vp(0)
+
+
+def _st():
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('mit_semseg (MI355X build): tensors must live on a HIP device; '
+                               'there is no CPU fallback for the native hot path')
+
+
+# ------------------------------------------------------------------------------------------------
+# workspace: one persistent scratch buffer per device (split-K / split-M slabs, BN partial sums)
+# ------------------------------------------------------------------------------------------------
+_WS = {}
+_WS_MIN = 64 << 20
+
+
+def workspace(nbytes, device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        size = max(_WS_MIN, int(nbytes * 1.25))
+        t = torch.empty(size, dtype=torch.uint8, device=device)
+        _WS[key] = t
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# layout helpers
+# ------------------------------------------------------------------------------------------------
+def nhwc_ld(x):
+    """Pixel stride (floats) if logical-NCHW tensor `x` is NHWC-addressable, else None."""
+    n, c, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    if c > 1 and sc != 1:
+        return None
+    if w > 1:
+        ld = sw
+    elif h > 1:
+        ld = sh // max(w, 1)
+    elif n > 1:
+        ld = sn // max(h * w, 1)
+    else:
+        ld = c
+    if ld < c:
+        return None
+    if w > 1 and sw != ld:
+        return None
+    if h > 1 and sh != w * ld:
+        return None
+    if n > 1 and sn != h * w * ld:
+        return None
+    return ld
+
+
+def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
+    """New dense NHWC buffer, returned as its logical-NCHW view."""
+    return torch.empty((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+def as_nhwc(x):
+    """Returns (tensor, ld): `tensor` is logical NCHW over NHWC memory."""
+    _require_cuda(x)
+    if x.dtype != torch.float32:
+        raise RuntimeError('native hot path computes in fp32, got %s' % x.dtype)
+    ld = nhwc_ld(x)
+    if ld is not None:
+        return x, ld
+    n, c, h, w = x.shape
+    if x.is_contiguous():                      # NCHW -> NHWC on the device
+        out = empty_nhwc(n, c, h, w, x.device)
+        _native.check(_native.lib().semseg_nchw_to_nhwc(_p(x), _p(out), n, c, h * w, _st()), 'nchw_to_nhwc')
+        return out, c
+    out = empty_nhwc(n, c, h, w, x.device)
+    out.copy_(x)                               # exotic strides: torch glue copy (never on the hot path)
+    return out, c
+
+
+def krsc(w):
+    """[K,C,R,S] parameter -> (tensor whose memory is KRSC, same logical shape)."""
+    if w.permute(0, 2, 3, 1).is_contiguous():
+        return w
+    return w.contiguous(memory_format=torch.channels_last) if (w.shape[2] > 1 or w.shape[3] > 1) else \
+        w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+class Conv2dFn(Function):
+    """nn.Conv2d forward/backward (square stride/pad/dilation) on the MFMA implicit-GEMM kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        L = _native.lib()
+        x, x_ld = as_nhwc(x.detach())
+        w = krsc(weight.detach())
+        _require_cuda(w, bias)
+        n, c, h, wd = x.shape
+        k, c2, r, s = w.shape
+        if c2 != c:
+            raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (c, c2))
+        oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
+        y = empty_nhwc(n, k, oh, ow, x.device)
+        wsb = L.semseg_conv2d_workspace_bytes(n, h, wd, c, k, r, s, stride, pad, dil)
+        ws = workspace(wsb, x.device)
+        _native.check(L.semseg_conv2d_fwd(_p(x), x_ld, _p(w), _p(bias.detach() if bias is not None else None),
+                                          _p(y), k, n, h, wd, c, k, r, s, stride, pad, dil,
+                                          _p(ws), ws.numel(), _st()), 'conv2d_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.geom = (x_ld, stride, pad, dil, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        L = _native.lib()
+        x, w = ctx.saved_tensors
+        x_ld, stride, pad, dil, has_bias = ctx.geom
+        n, c, h, wd = x.shape
+        k, _, r, s = w.shape
+        dy, dy_ld = as_nhwc(dy)
+        ws = workspace(L.semseg_conv2d_workspace_bytes(n, h, wd, c, k, r, s, stride, pad, dil), x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty((c, r, s, k), device=x.device, dtype=torch.float32)
+            _native.check(L.semseg_weight_krsc_to_crsk(_p(w), _p(wt), k, r * s, c, _st()), 'weight_transpose')
+            dx = empty_nhwc(n, c, h, wd, x.device)
+            _native.check(L.semseg_conv2d_dgrad(_p(dy), dy_ld, _p(wt), _p(dx), c, n, h, wd, c, k, r, s,
+                                                stride, pad, dil, _p(ws), ws.numel(), _st()), 'conv2d_dgrad')
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dwb = torch.empty((k, r, s, c), device=x.device, dtype=torch.float32)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty((k,), device=x.device, dtype=torch.float32)
+            _native.check(L.semseg_conv2d_wgrad(_p(x), x_ld, _p(dy), dy_ld, _p(dwb), _p(db), n, h, wd, c, k, r, s,
+                                                stride, pad, dil, _p(ws), ws.numel(), _st()), 'conv2d_wgrad')
+            dw = dwb.permute(0, 3, 1, 2)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    return Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm (+ residual add + ReLU), optional cross-rank statistics
+# ------------------------------------------------------------------------------------------------
+_SYNC_GROUP = {'group': None, 'enabled': False}
+
+
+def set_sync_bn_group(group, enabled=True):
+    """Enable SyncBN: statistics are all-reduced (RCCL) over `group` between bn_stats and bn_finalize --
+    the one-process-per-GPU replacement of reference batchnorm.py:63-117 / comm.py."""
+    _SYNC_GROUP['group'] = group
+    _SYNC_GROUP['enabled'] = enabled
+
+
+def _maybe_allreduce(buf):
+    if _SYNC_GROUP['enabled']:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_GROUP['group']) > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=_SYNC_GROUP['group'])
+
+
+class BatchNormActFn(Function):
+    """y = act(BN(z) [+ residual]); training: batch statistics + running-stat EMA; eval: running stats."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu):
+        L = _native.lib()
+        z, z_ld = as_nhwc(z.detach())
+        n, c, h, w = z.shape
+        if z_ld != c:
+            z = z.contiguous(memory_format=torch.channels_last)
+        _require_cuda(gamma, beta, running_mean, running_var)
+        P = n * h * w
+        dev = z.device
+        coef = torch.empty((4, c), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
+        stats = None
+        g, b = gamma.detach(), beta.detach()
+        if training:
+            if P <= 1:
+                raise ValueError('Expected more than 1 value per channel when training, got input size %s'
+                                 % str(list(z.shape)))
+            stats = torch.empty((2 * c + 1,), device=dev, dtype=torch.float64)
+            ws = workspace(L.semseg_bn_workspace_bytes(P, c), dev)
+            _native.check(L.semseg_bn_stats(_p(z), P, c, _p(stats), _p(ws), ws.numel(), _st()), 'bn_stats')
+            _maybe_allreduce(stats)
+            _native.check(L.semseg_bn_finalize(_p(stats), c, _p(g), _p(b), _p(running_mean), _p(running_var),
+                                               float(momentum), float(eps), _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                               _p(coef[3]), _st()), 'bn_finalize')
+        else:
+            _native.check(L.semseg_bn_eval_coeffs(_p(g), _p(b), _p(running_mean), _p(running_var), float(eps), c,
+                                                  _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _st()),
+                          'bn_eval_coeffs')
+        res, res_ld = (None, 0)
+        if residual is not None:
+            res, res_ld = as_nhwc(residual.detach())
+        y = empty_nhwc(n, c, h, w, dev)
+        _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), c, P, c,
+                                        _st()), 'bn_apply')
+        ctx.save_for_backward(z, y if relu else None, coef, g, stats)
+        ctx.cfg = (bool(training), bool(relu), residual is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        L = _native.lib()
+        z, y, coef, gamma, stats = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        n, c, h, w = z.shape
+        P = n * h * w
+        dev = z.device
+        dy, dy_ld = as_nhwc(dy)
+        need_param = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        sums = torch.empty((2 * c,), device=dev, dtype=torch.float64)
+        dgamma = torch.empty((c,), device=dev, dtype=torch.float32)
+        dbeta = torch.empty((c,), device=dev, dtype=torch.float32)
+        if training or need_param:
+            ws = workspace(L.semseg_bn_workspace_bytes(P, c), dev)
+            _native.check(L.semseg_bn_bwd_reduce(_p(dy), dy_ld, _p(y), c, _p(z), _p(coef[0]), _p(coef[1]), int(relu),
+                                                 P, c, _p(sums), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _st()),
+                          'bn_bwd_reduce')
+            if training:
+                _maybe_allreduce(sums)
+        dz = empty_nhwc(n, c, h, w, dev)
+        dres = empty_nhwc(n, c, h, w, dev) if (has_res and ctx.needs_input_grad[5]) else None
+        count = stats[2 * c:] if stats is not None else None
+        _native.check(L.semseg_bn_bwd_apply(_p(dy), dy_ld, _p(y), c, _p(z), _p(coef[0]), _p(coef[1]), _p(gamma),
+                                            _p(sums), _p(count), int(training), int(relu), _p(dz), _p(dres), P, c,
+                                            _st()), 'bn_bwd_apply')
+        return (dz, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                None, None, dres, None, None, None, None)
+
+
+def batch_norm_act(z, gamma, beta, running_mean, running_var, residual=None, training=False, momentum=0.1,
+                   eps=1e-5, relu=False):
+    return BatchNormActFn.apply(z, gamma, beta, running_mean, running_var, residual, bool(training),
+                                float(momentum), float(eps), bool(relu))
+
+
+# ------------------------------------------------------------------------------------------------
+# elementwise
+# ------------------------------------------------------------------------------------------------
+class AddActFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, relu):
+        L = _native.lib()
+        a, a_ld = as_nhwc(a.detach())
+        b, b_ld = as_nhwc(b.detach())
+        n, c, h, w = a.shape
+        out = empty_nhwc(n, c, h, w, a.device)
+        _native.check(L.semseg_add_act(_p(a), a_ld, _p(b), b_ld, int(relu), _p(out), c, n * h * w, c, _st()), 'add_act')
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        if not ctx.relu:
+            return dy, dy, None
+        (out,) = ctx.saved_tensors
+        dy, dy_ld = as_nhwc(dy)
+        n, c, h, w = out.shape
+        dx = empty_nhwc(n, c, h, w, out.device)
+        _native.check(_native.lib().semseg_relu_bwd(_p(dy), dy_ld, _p(out), c, _p(dx), c, n * h * w, c, _st()), 'relu_bwd')
+        return dx, dx, None
+
+
+def add_act(a, b, relu=False):
+    return AddActFn.apply(a, b, bool(relu))
+
+
+class ConcatFn(Function):
+    """torch.cat(dim=1) into one NHWC buffer; backward hands out channel-slice VIEWS (no copy)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        L = _native.lib()
+        xs = [as_nhwc(x.detach()) for x in xs]
+        n, _, h, w = xs[0][0].shape
+        ctot = sum(x.shape[1] for x, _ in xs)
+        out = empty_nhwc(n, ctot, h, w, xs[0][0].device)
+        off = 0
+        base = out.data_ptr()
+        for x, ld in xs:
+            c = x.shape[1]
+            _native.check(L.semseg_copy2d(_p(x), ld, vp(base + 4 * off), ctot, n * h * w, c, 0, _st()), 'copy2d')
+            off += c
+        ctx.chans = [x.shape[1] for x, _ in xs]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy, _ = as_nhwc(dy)
+        outs, off = [], 0
+        for c in ctx.chans:
+            outs.append(dy[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+
+def concat(xs):
+    return ConcatFn.apply(*xs)
+
+
+class ScaleNCFn(Function):
+    """Dropout2d with an explicit per-(n,c) multiplier (models.py:460,464)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        x, ld = as_nhwc(x.detach())
+        n, c, h, w = x.shape
+        if ld != c:
+            x = x.contiguous(memory_format=torch.channels_last)
+        mask = mask.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        y = empty_nhwc(n, c, h, w, x.device)
+        _native.check(_native.lib().semseg_scale_nc(_p(x), _p(mask), _p(y), n, h * w, c, _st()), 'scale_nc')
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy, ld = as_nhwc(dy)
+        n, c, h, w = dy.shape
+        if ld != c:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = empty_nhwc(n, c, h, w, dy.device)
+        _native.check(_native.lib().semseg_scale_nc(_p(dy), _p(mask), _p(dx), n, h * w, c, _st()), 'scale_nc')
+        return dx, None
+
+
+def scale_nc(x, mask):
+    return ScaleNCFn.apply(x, mask)
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / resize
+# ------------------------------------------------------------------------------------------------
+class MaxPool3x3s2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ld = as_nhwc(x.detach())
+        n, c, h, w = x.shape
+        if ld != c:
+            x = x.contiguous(memory_format=torch.channels_last)
+        oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = empty_nhwc(n, c, oh, ow, x.device)
+        idx = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
+        _native.check(_native.lib().semseg_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), n, h, w, c, _st()), 'maxpool_fwd')
+        ctx.save_for_backward(idx)
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        dy, ld = as_nhwc(dy)
+        if ld != c:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = empty_nhwc(n, c, h, w, dy.device)
+        _native.check(_native.lib().semseg_maxpool3x3s2_bwd(_p(dy), _p(idx), _p(dx), n, h, w, c, _st()), 'maxpool_bwd')
+        return dx
+
+
+def max_pool_3x3_s2(x):
+    return MaxPool3x3s2Fn.apply(x)
+
+
+class AdaptiveAvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        x, ld = as_nhwc(x.detach())
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, oh, ow, x.device)
+        _native.check(_native.lib().semseg_adaptive_avgpool_fwd(_p(x), ld, _p(y), n, h, w, c, oh, ow, _st()),
+                      'adaptive_avgpool_fwd')
+        ctx.shape = (n, c, h, w, oh, ow)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, c, h, w, oh, ow = ctx.shape
+        dy, ld = as_nhwc(dy)
+        if ld != c:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = empty_nhwc(n, c, h, w, dy.device)
+        _native.check(_native.lib().semseg_adaptive_avgpool_bwd(_p(dy), _p(dx), c, 0, n, h, w, c, oh, ow, _st()),
+                      'adaptive_avgpool_bwd')
+        return dx, None, None
+
+
+def adaptive_avg_pool(x, size):
+    oh, ow = (size, size) if isinstance(size, int) else size
+    return AdaptiveAvgPoolFn.apply(x, int(oh), int(ow))
+
+
+class BilinearFn(Function):
+    """F.interpolate(mode='bilinear', align_corners=False); optional fused `+ base` (FPN / HRNet sums)
+    and trailing ReLU (hrnet.py:248)."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow, base, relu):
+        L = _native.lib()
+        x, ld = as_nhwc(x.detach())
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, oh, ow, x.device)
+        acc = 0
+        if base is not None:
+            b, b_ld = as_nhwc(base.detach())
+            _native.check(L.semseg_copy2d(_p(b), b_ld, _p(y), c, n * oh * ow, c, 0, _st()), 'copy2d')
+            acc = 1
+        _native.check(L.semseg_bilinear_fwd(_p(x), ld, _p(y), c, acc, int(relu), n, h, w, oh, ow, c, _st()),
+                      'bilinear_fwd')
+        ctx.shape = (n, c, h, w, oh, ow)
+        ctx.has_base = base is not None
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        L = _native.lib()
+        n, c, h, w, oh, ow = ctx.shape
+        dy, ld = as_nhwc(dy)
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            g = empty_nhwc(n, c, oh, ow, dy.device)
+            _native.check(L.semseg_relu_bwd(_p(dy), ld, _p(y), c, _p(g), c, n * oh * ow, c, _st()), 'relu_bwd')
+            dy, ld = g, c
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_nhwc(n, c, h, w, dy.device)
+            _native.check(L.semseg_bilinear_bwd(_p(dy), ld, _p(dx), c, 0, n, h, w, oh, ow, c, _st()), 'bilinear_bwd')
+        return dx, None, None, (dy if ctx.has_base else None), None
+
+
+def interpolate_bilinear(x, size, base=None, relu=False):
+    oh, ow = int(size[0]), int(size[1])
+    if base is None and not relu and x.shape[2] == oh and x.shape[3] == ow:
+        return x                                            # identity resize (scale 1): exact copy in torch too
+    return BilinearFn.apply(x, oh, ow, base, bool(relu))
+
+
+# ------------------------------------------------------------------------------------------------
+# head
+# ------------------------------------------------------------------------------------------------
+def _rows(x):
+    """logical [N,C,H,W] NHWC-dense tensor -> (dense tensor, P, C)."""
+    x, ld = as_nhwc(x)
+    n, c, h, w = x.shape
+    if ld != c:
+        x = x.contiguous(memory_format=torch.channels_last)
+    return x, n * h * w, c
+
+
+class LogSoftmaxFn(Function):
+    @staticmethod
+    def forward(ctx, z):
+        z, P, c = _rows(z.detach())
+        out = empty_nhwc(z.shape[0], c, z.shape[2], z.shape[3], z.device)
+        _native.check(_native.lib().semseg_log_softmax_fwd(_p(z), _p(out), P, c, _st()), 'log_softmax_fwd')
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g, P, c = _rows(g)
+        dz = empty_nhwc(out.shape[0], c, out.shape[2], out.shape[3], out.device)
+        _native.check(_native.lib().semseg_log_softmax_bwd(_p(g), _p(out), _p(dz), P, c, _st()), 'log_softmax_bwd')
+        return dz
+
+
+def log_softmax(z):
+    return LogSoftmaxFn.apply(z)
+
+
+def softmax(z):
+    """Inference-only softmax over the class axis (models.py:482-484)."""
+    z, P, c = _rows(z.detach())
+    out = empty_nhwc(z.shape[0], c, z.shape[2], z.shape[3], z.device)
+    _native.check(_native.lib().semseg_softmax_fwd(_p(z), _p(out), P, c, _st()), 'softmax_fwd')
+    return out
+
+
+class NLLAccFn(Function):
+    """nn.NLLLoss(ignore_index) (train.py:154) + pixel_acc (models.py:12-18) in one pass.
+    Returns (loss, acc) 0-dim tensors; only `loss` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, logp, label, ignore_index):
+        logp, P, c = _rows(logp.detach())
+        _require_cuda(label)
+        label = label.detach().contiguous()
+        if label.dtype != torch.int64:
+            label = label.long()
+        if label.numel() != P:
+            raise ValueError('Expected target size %s, got %s' % ([logp.shape[0], logp.shape[2], logp.shape[3]],
+                                                                 list(label.shape)))
+        out = torch.empty((3,), device=logp.device, dtype=torch.float32)
+        ws = workspace(256 * 3 * 8, logp.device)
+        _native.check(_native.lib().semseg_nll_acc_fwd(_p(logp), _p(label), int(ignore_index), P, c, _p(out), _p(ws),
+                                                       ws.numel(), _st()), 'nll_acc_fwd')
+        ctx.save_for_backward(out, label)
+        ctx.cfg = (int(ignore_index), tuple(logp.shape))
+        loss, acc = out[0].clone(), out[1].clone()      # 0-dim results (4-byte glue copies)
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss, gacc):
+        out, label = ctx.saved_tensors
+        ignore_index, shape = ctx.cfg
+        n, c, h, w = shape
+        gloss = gloss.contiguous().float()
+        dlogp = empty_nhwc(n, c, h, w, out.device)
+        _native.check(_native.lib().semseg_nll_bwd(_p(gloss), _p(out), _p(label), ignore_index, _p(dlogp), n * h * w, c,
+                                                   _st()), 'nll_bwd')
+        return dlogp, None, None
+
+
+def nll_loss_acc(logp, label, ignore_index=-1):
+    return NLLAccFn.apply(logp, label, ignore_index)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------
+def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum=0.9, grad_scale=1.0):
+    """Fused multi-tensor SGD-momentum (train.py:117-126 semantics).  All lists are parallel; `lr_tensor`
+    is a 1-element device tensor (so the poly schedule can change it under hipGraph replay)."""
+    n = len(params)
+    arr = (_native.SgdTensor * n)()
+    for i, (p, g, b) in enumerate(zip(params, grads, bufs)):
+        if p.stride() != g.stride() or p.stride() != b.stride():
+            raise RuntimeError('sgd_step: param/grad/momentum strides differ')
+        arr[i].param = p.data_ptr()
+        arr[i].grad = g.data_ptr()
+        arr[i].momentum_buf = b.data_ptr()
+        arr[i].numel = p.numel()
+        arr[i].weight_decay = float(weight_decays[i])
+        arr[i].first_step = 1 if first_step else 0
+    _native.check(_native.lib().semseg_sgd_step(arr, n, _p(lr_tensor), float(momentum), float(grad_scale), _st()),
+                  'sgd_step')

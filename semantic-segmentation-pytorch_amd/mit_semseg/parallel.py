@@ -1,0 +1,155 @@
+"""One-process-per-GPU data parallelism over RCCL/xGMI -- the MI355X replacement of the reference's
+single-process `UserScatteredDataParallel` + thread-rendezvous SyncBN (lib/nn/parallel/data_parallel.py,
+lib/nn/modules/{batchnorm,comm,replicate}.py, train.py:184-190).
+
+ * weights are resident on every rank (no per-iteration parameter broadcast, reference replicate());
+ * SyncBN statistics: ops.set_sync_bn_group -> all-reduce of [sum, sum^2, n] (fwd) and
+   [sum dy, sum dy*xhat] (bwd), 2C(+1) fp64 per BN layer, on the compute stream;
+ * gradients: flat fp32 buckets filled in reverse parameter order as backward produces them and
+   all-reduced (sum, then /world inside the fused SGD via grad_scale) on a side HIP stream so the
+   transfers overlap the rest of backward; xGMI is point-to-point, so buckets are large (default 64 MiB)
+   to stay bandwidth- rather than latency-bound on the ring.
+ * loss/acc logging mean = mean of per-rank means (train.py:42-43).
+
+Works with any torch.distributed backend: `nccl` (= RCCL) on GPUs, `gloo` in the CPU unit tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ['RANK'])
+    local = int(os.environ.get('LOCAL_RANK', rank))
+    if not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+class GradientBuckets:
+    """Flat gradient buckets + overlapped all-reduce.
+
+    params are taken in REVERSE registration order (the order backward produces gradients).  Each
+    parameter owns a slice of a flat bucket; `reduce_ready()` copies finished gradients into their
+    slice and launches the bucket's all-reduce on `comm_stream` once all its slices are filled.
+    After `finish()`, `p.grad` of every parameter is a VIEW of the reduced bucket (no copy back)."""
+
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, comm_stream=None):
+        self.group = group
+        self.params = [p for p in reversed(list(params)) if p.requires_grad]
+        self.buckets = []          # list of dict(flat, items=[(param, offset, numel)], pending)
+        cur, cur_n = [], 0
+        cap = max(1, bucket_bytes // 4)
+        for p in self.params:
+            n = p.numel()
+            if cur and cur_n + n > cap:
+                self.buckets.append(self._make_bucket(cur, cur_n))
+                cur, cur_n = [], 0
+            cur.append((p, cur_n, n))
+            cur_n += n
+        if cur:
+            self.buckets.append(self._make_bucket(cur, cur_n))
+        self.comm_stream = comm_stream
+        self._works = []
+
+    def _make_bucket(self, items, total):
+        dev = items[0][0].device
+        return dict(flat=torch.zeros(total, device=dev, dtype=torch.float32), items=list(items))
+
+    def bucket_sizes(self):
+        return [b['flat'].numel() * 4 for b in self.buckets]
+
+    def _stage(self, b):
+        """copy p.grad into the bucket slices (physical order), re-point p.grad at the slice"""
+        for p, off, n in b['items']:
+            g = p.grad
+            if g is None:
+                b['flat'][off:off + n].zero_()
+                continue
+            view = b['flat'][off:off + n].as_strided(g.shape, g.stride()) if g.dim() > 0 else b['flat'][off:off + n].view(())
+            if g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+                p.grad = view
+
+    def all_reduce(self):
+        """Stage every bucket and all-reduce it (sum).  With a comm stream the collectives run there and
+        overlap whatever the compute stream does next; `finish()` joins."""
+        if world_size(self.group) <= 1:
+            for b in self.buckets:
+                self._stage(b)
+            return
+        use_side = self.comm_stream is not None and self.buckets[0]['flat'].is_cuda
+        for b in self.buckets:
+            self._stage(b)
+            if use_side:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ev)
+                    dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                self._works.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.comm_stream is not None and self.buckets and self.buckets[0]['flat'].is_cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+class NativeDataParallel(nn.Module):
+    """Reference-compatible wrapper (`UserScatteredDataParallel(module, device_ids=gpus)` /
+    `DataParallelWithCallback`): runs the resident module on this rank's element of the scattered batch.
+
+    forward(batch): `batch` is the reference's list of per-GPU dicts (train.py:170-177,
+    data_parallel.py:54-62) -- this rank consumes element [rank % len(batch)] -- or a single dict.
+    Returns what the wrapped module returns; losses are per-rank means exactly as each DataParallel
+    replica produced them (train.py:42 then averages; `mean_over_ranks` does that across processes)."""
+
+    def __init__(self, module, device_ids=None, output_device=None, dim=0, group=None, sync_bn=True):
+        super().__init__()
+        self.module = module
+        self.device_ids = device_ids
+        self.group = group
+        self.rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+        if sync_bn:
+            ops.set_sync_bn_group(group, enabled=world_size(group) > 1)
+
+    def scatter(self, batch):
+        if isinstance(batch, (list, tuple)):
+            return batch[self.rank % len(batch)]
+        return batch
+
+    def forward(self, batch, **kwargs):
+        item = self.scatter(batch)
+        dev = next(self.module.parameters()).device
+        if isinstance(item, dict):
+            item = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in item.items()}
+        return self.module(item, **kwargs)
+
+
+def mean_over_ranks(*scalars, group=None):
+    """train.py:42-43 `loss.mean(), acc.mean()` across replicas -> across processes (logging only)."""
+    if world_size(group) <= 1:
+        return scalars
+    buf = torch.stack([s.detach().float().reshape(()) for s in scalars])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    buf /= world_size(group)
+    return tuple(buf[i] for i in range(len(scalars)))
