@@ -1,0 +1,168 @@
+"""Benchmark of the MI355X hot path on BASELINE.json's metric: training images/sec at 512x512, bs 2 per GPU,
+ade20k-resnet50dilated-ppm_deepsup (configs[1]), synthetic ADE20K-shaped batches, seeded random-init weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = train.py:34-48: zero_grad, SegmentationModule.forward (loss+acc), backward, 2x SGD (poly LR), fp32.
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch            # noqa: E402
+import torch.nn as nn   # noqa: E402
+
+# SURVEY 8d (hooks on the reference modules): 2*MACs of every Conv2d; train = 3*fwd - fwd(first conv)
+TRAIN_GFLOP_PER_IMG = {'resnet50dilated+ppm_deepsup': 1224.2}
+FWD_GFLOP_CONV_LAST = 309.24          # decoder.conv_last.0: 3x3 4096->512 @64x64, N=2 (per launch, fwd)
+PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def build_model(dev, seed=304):
+    from mit_semseg.models import ModelBuilder, SegmentationModule
+    from mit_semseg.models import resnet
+    from mit_semseg.models.models import ResnetDilated
+    torch.manual_seed(seed)
+    # random init exactly as the reference builds it without a checkpoint (resnet.py:118-124, models.py:52-61)
+    enc = ResnetDilated(resnet.resnet50(pretrained=False), dilate_scale=8)
+    dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=2048, num_class=150)
+    crit = nn.NLLLoss(ignore_index=-1)
+    return SegmentationModule(enc, dec, crit, deep_sup_scale=0.4).to(dev).train()
+
+
+def synth_feed(dev, rank, n=2, h=512, w=512, seg_rate=8):
+    g = torch.Generator().manual_seed(304 + rank)
+    img = torch.randn(n, 3, h, w, generator=g)
+    lab = torch.randint(-1, 150, (n, h // seg_rate, w // seg_rate), generator=g)
+    return {'img_data': img.to(dev), 'seg_label': lab.to(dev)}
+
+
+def time_dominant_kernel(dev, iters=10):
+    """HIP-event timing of the dominant kernel (igemm_conv_kernel on conv_last: 3x3 4096->512 @64x64, N=2)
+    on the stream it is launched on (torch's current stream)."""
+    from mit_semseg import ops
+    x = torch.randn(2, 64, 64, 4096, device=dev).permute(0, 3, 1, 2)
+    w = (torch.randn(512, 3, 3, 4096, device=dev) * 0.01).permute(0, 3, 1, 2)
+    for _ in range(2):
+        ops.conv2d(x, w, None, 1, 1, 1)
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        ops.conv2d(x, w, None, 1, 1, 1)
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters * 1e-3
+
+
+def cpu_baseline():
+    """The CPU oracle (port of the reference path over torch CPU operators) timed on this host: ONE full
+    training step (fwd + loss + bwd + SGD) of the same 2x512x512 workload, all cores."""
+    from oracle import semseg_oracle as O
+    man = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'manifests.json')))
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    enc = O.clone_sd(O.synth_state_dict(man['resnet50dilated'], 0), True)
+    dec = O.clone_sd(O.synth_state_dict(man['ppm_deepsup@2048'], 1), True)
+    img, lab = O.synth_batch(2, 512, 512, 8)
+    masks = {'main': O.synth_dropout_mask(2, 512), 'deepsup': O.synth_dropout_mask(2, 512, seed=1)}
+    t0 = time.perf_counter()
+    res = O.segmentation_forward(enc, dec, 'resnet50dilated', 'ppm_deepsup', img, lab, training=True,
+                                 dropout=masks, deep_sup_scale=0.4)
+    res['loss'].backward()
+    for sd in (enc, dec):
+        params = {k: v for k, v in sd.items() if v.requires_grad}
+        O.sgd_step(params, {k: v.grad for k, v in params.items()}, {}, 0.02)
+    dt = time.perf_counter() - t0
+    return {'value': round(2.0 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '1 training step (fwd+loss+bwd+SGD) of the same 2x512x512 R50dilated+PPM_deepsup batch, '
+                      'torch %s CPU, no warm-up, %.1f s' % (torch.__version__, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import __graft_entry__ as ge
+    ge.build()
+    from mit_semseg.parallel import init_distributed, NativeDataParallel
+    from mit_semseg.engine import TrainStep
+    import torch.distributed as dist
+
+    rank, world, local = init_distributed()
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    sm = build_model(dev)
+    if world > 1:
+        NativeDataParallel(sm)          # enables SyncBN statistics all-reduce over RCCL
+    feed = synth_feed(dev, rank)
+    step = TrainStep(sm, lr_encoder=0.02, lr_decoder=0.02, max_iters=5000 * 20,
+                     graph=(not args.no_graph) and world == 1)
+
+    for _ in range(args.warmup):
+        loss, acc = step.step(feed)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, acc = step.step(feed)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    imgs = 2 * world * args.steps
+    value = imgs / dt
+    lossv = loss.item()
+
+    if rank == 0:
+        kt = time_dominant_kernel(dev)
+        achieved = FWD_GFLOP_CONV_LAST / kt * 1e-3
+        per_gpu = value / world
+        out = {
+            'metric': 'train images/sec (whole job) @512x512 bs2/GPU', 'value': round(value, 3), 'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'ade20k-resnet50dilated-ppm_deepsup (BASELINE configs[1]): full train step '
+                                   '(fwd+NLL loss+bwd+2xSGD), bs 2/GPU 512x512x3, 150 classes, labels 64x64',
+                       'global_batch': 2 * world, 'parallelism': 'dp%d' % world,
+                       'launch': 'eager' if (args.no_graph or world > 1) else 'hipGraph replay',
+                       'images_per_sec_per_gpu': round(per_gpu, 3),
+                       'step_conv_tflops_per_gpu': round(per_gpu * TRAIN_GFLOP_PER_IMG['resnet50dilated+ppm_deepsup'] * 1e-3, 2),
+                       'final_loss': round(lossv, 5)},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'kernel': 'igemm_conv_kernel fwd, decoder.conv_last.0 3x3 4096->512 @64x64 N=2 '
+                                   '(309.24 GFLOP/launch, %.3f ms/launch, HIP events)' % (kt * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

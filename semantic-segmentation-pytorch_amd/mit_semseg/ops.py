@@ -43,7 +43,7 @@ _WS_MIN = 64 << 20
 
 
 def workspace(nbytes, device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, device.index if (device.index is not None or device.type != 'cuda') else torch.cuda.current_device())
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         size = max(_WS_MIN, int(nbytes * 1.25))
