@@ -75,9 +75,11 @@ int semseg_bn_stats(const float* z, int P, int C, double* stats, void* workspace
 /* mean = S/n; var = SS/n - mean^2 (biased); invstd = 1/sqrt(var+eps);
  * scale = gamma*invstd; shift = beta - mean*scale;
  * running_mean = (1-m)*running_mean + m*mean; running_var = (1-m)*running_var + m*var*n/(n-1).
- * running_* may be NULL.  mean/invstd/scale/shift: [C]. */
+ * num_batches_tracked[0] += 1 (int64, torch _BatchNorm buffer).  running_* / num_batches_tracked may be NULL.
+ * mean/invstd/scale/shift: [C]. */
 int semseg_bn_finalize(const double* stats, int C, const float* gamma, const float* beta,
-                       float* running_mean, float* running_var, float momentum, float eps,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                       float momentum, float eps,
                        float* mean, float* invstd, float* scale, float* shift, void* stream);
 
 /* eval mode: scale = gamma/sqrt(running_var+eps); shift = beta - running_mean*scale;

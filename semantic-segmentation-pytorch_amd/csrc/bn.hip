@@ -20,8 +20,8 @@ static ColGeom col_geom(int P, int C) {
     g.cx = quads < 64 ? quads : 64;
     g.py = 256 / g.cx;
     g.gx = ceil_div(quads, g.cx);
-    // ~2048 blocks, strips of <= 64 rows per thread keep fp32 strip sums short
-    int gy = ceil_div(2048, g.gx);
+    // ~512 blocks in total (2 per CU); every thread walks >= 8 rows
+    int gy = ceil_div(512, g.gx);
     const int min_rows = g.py * 8;
     if (gy > ceil_div(P, min_rows)) gy = ceil_div(P, min_rows);
     if (gy < 1) gy = 1;
@@ -45,19 +45,22 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     const int c = quad * 4;
     const int row0 = blockIdx.y * rows_per_block;
     const int row1 = min(P, row0 + rows_per_block);
-    float4 s = f4zero(), ss = f4zero();
+    // fp64 accumulation with EXACT squares: E[x^2]-E[x]^2 must survive var << mean^2 (the PPM scale-1 branch
+    // normalises 2 pooled values per channel, models.py:447-450, where var ~ 1e-5 * mean^2)
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     const bool active = (ty < py) && (c < C);
     if (active) {
         for (int p = row0 + ty; p < row1; p += py) {
             const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + c);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
+            const double x = v.x, y = v.y, zz = v.z, w = v.w;
+            a0 += x; a1 += y; a2 += zz; a3 += w;
+            q0 = fma(x, x, q0); q1 = fma(y, y, q1); q2 = fma(zz, zz, q2); q3 = fma(w, w, q3);
         }
     }
     if (ty < py) {
         double* r = red + ((size_t)ty * cx + tx) * 8;
-        r[0] = s.x; r[1] = s.y; r[2] = s.z; r[3] = s.w;
-        r[4] = ss.x; r[5] = ss.y; r[6] = ss.z; r[7] = ss.w;
+        r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
+        r[4] = q0; r[5] = q1; r[6] = q2; r[7] = q3;
     }
     __syncthreads();
     if (ty == 0 && c < C) {
@@ -76,16 +79,29 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-// out[j] = sum_by partial[by][j] for j in [0,2C); out[2C] = count (if count >= 0)
-__global__ void colsum_finish_kernel(const double* __restrict__ partial, int nparts, int C2, double* __restrict__ out,
-                                     double count) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < C2) {
-        double s = 0.0;
-        for (int b = 0; b < nparts; ++b) s += partial[(size_t)b * C2 + j];
-        out[j] = s;
-    }
-    if (j == 0 && count >= 0.0) out[C2] = count;
+// out[j] = sum_by partial[by][j] for j in [0,2C); out[2C] = count (if count >= 0).
+// block = 16 columns x 16 partial-lanes (a serial loop over hundreds of partials per thread was 80 us per BN layer)
+__device__ __forceinline__ double colsum_block(const double* __restrict__ partial, int nparts, int C2, int j, int lane,
+                                               double (*red)[17]) {
+    double s = 0.0;
+    if (j < C2)
+        for (int b = lane; b < nparts; b += 16) s += partial[(size_t)b * C2 + j];
+    red[lane][threadIdx.x & 15] = s;
+    __syncthreads();
+    double t = 0.0;
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x & 15];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ partial, int nparts, int C2,
+                                                            double* __restrict__ out, double count) {
+    __shared__ double red[16][17];
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int lane = threadIdx.x >> 4;
+    const double t = colsum_block(partial, nparts, C2, j, lane, red);
+    if (lane == 0 && j < C2) out[j] = t;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count >= 0.0) out[C2] = count;
 }
 
 extern "C" int semseg_bn_stats(const float* z, int P, int C, double* stats, void* workspace, size_t workspace_bytes,
@@ -99,7 +115,7 @@ extern "C" int semseg_bn_stats(const float* z, int P, int C, double* stats, void
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
                        g.rows_per_block, (double*)workspace);
     SEMSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(2 * C, 256)), dim3(256), 0, st, (const double*)workspace, g.gy,
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)workspace, g.gy,
                        2 * C, stats, (double)P);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -108,9 +124,11 @@ extern "C" int semseg_bn_stats(const float* z, int P, int C, double* stats, void
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float momentum, float eps, float* __restrict__ mean,
-                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+                                   int64_t* __restrict__ num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
     const double n = stats[2 * C];
     const double mu = stats[c] / n;
     double var = stats[C + c] / n - mu * mu;
@@ -130,11 +148,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, cons
 }
 
 extern "C" int semseg_bn_finalize(const double* stats, int C, const float* gamma, const float* beta, float* running_mean,
-                                  float* running_var, float momentum, float eps, float* mean, float* invstd,
-                                  float* scale, float* shift, void* stream) {
+                                  float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* mean,
+                                  float* invstd, float* scale, float* shift, void* stream) {
     if (!stats || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0) return SEMSEG_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, C, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, num_batches_tracked);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -263,12 +281,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     }
 }
 
-__global__ void bn_bwd_finish_kernel(const double* __restrict__ partial, int nparts, int C, double* __restrict__ sums,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= 2 * C) return;
-    double s = 0.0;
-    for (int b = 0; b < nparts; ++b) s += partial[(size_t)b * 2 * C + j];
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const double* __restrict__ partial, int nparts, int C,
+                                                            double* __restrict__ sums, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+    __shared__ double red[16][17];
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int lane = threadIdx.x >> 4;
+    const double s = colsum_block(partial, nparts, 2 * C, j, lane, red);
+    if (lane != 0 || j >= 2 * C) return;
     sums[j] = s;
     if (j < C) { if (dbeta) dbeta[j] = (float)s; }
     else       { if (dgamma) dgamma[j - C] = (float)s; }
@@ -287,7 +307,7 @@ extern "C" int semseg_bn_bwd_reduce(const float* dy, int dy_ld, const float* y, 
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd, relu,
                        P, C, g.cx, g.py, g.rows_per_block, (double*)workspace);
     SEMSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(ceil_div(2 * C, 256)), dim3(256), 0, st, (const double*)workspace, g.gy, C,
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)workspace, g.gy, C,
                        sums, dgamma, dbeta);
     SEMSEG_LAUNCH_CHECK();
     return 0;

@@ -17,6 +17,7 @@
 // buffering, one barrier per K tile.  Optional split-K (grid.y) writes fp32 partial slabs that
 // splitk_reduce_kernel sums in a fixed order (deterministic).
 #include "common.h"
+#include <stdlib.h>
 
 struct IGemmParams {
     const float* in;
@@ -91,15 +92,27 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const IGemmParams p) {
     }
 
     float4 ra[APASS], rb[BPASS];
-    const size_t w_row = (size_t)p.T * p.Cin;
+    const uint32_t w_row = (uint32_t)p.T * p.Cin;
 
-    auto load_tile = [&](int kt) {
-        const int t = kt / p.chunks;
-        const int c0 = (kt - t * p.chunks) * BK;
+    // Branch-free tile loader.  hipcc turns a per-element `cond ? load : 0` into one basic block per load with its
+    // own s_waitcnt (serialised L2 round trips, ~350 scalar/vector instructions ahead of the MFMA block), so every
+    // load is issued UNCONDITIONALLY from a clamped in-bounds offset and the zero fill is a v_cndmask afterwards.
+    // Offsets are 32-bit element offsets from the tensor base (host checks the tensors are < 2^31 elements); the
+    // gather offsets only change when the tap changes, inside a tap the k-loop adds the channel offset.
+    uint32_t a_off[APASS], b_off[BPASS];
+    uint32_t a_ok = 0, b_ok = 0;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        const int n = n0 + lrow + i * RPP;
+        const bool ok = n < p.Cout;
+        b_off[i] = ok ? (uint32_t)n * w_row + 4u * q : 0u;
+        b_ok |= (ok ? 1u : 0u) << i;
+    }
+    int cur_t = -1;
+    auto set_tap = [&](int t) {
         const int r = t / p.S;
         const int s = t - r * p.S;
-        const int cq = c0 + 4 * q;
-        const int nvalid = max(0, min(4, p.Cin - cq));
+        a_ok = 0;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             int nh = a_ih0[i] + r * p.step;
@@ -111,15 +124,46 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const IGemmParams p) {
                 nw /= p.div;
             }
             ok = ok & (nh < p.Hin) & (nw < p.Win);
-            const size_t addr = (size_t)(a_base[i] + nh * p.Win + nw) * p.in_ld + cq;
-            ra[i] = load4<VEC>(p.in + (ok ? addr : 0), ok ? nvalid : 0);
+            a_off[i] = ok ? (uint32_t)(a_base[i] + nh * p.Win + nw) * (uint32_t)p.in_ld + 4u * q : 0u;
+            a_ok |= (ok ? 1u : 0u) << i;
         }
+    };
+
+    auto load_tile = [&](int kt) {
+        const int t = kt / p.chunks;
+        const int c0 = (kt - t * p.chunks) * BK;
+        if (t != cur_t) {          // wave-uniform
+            set_tap(t);
+            cur_t = t;
+        }
+        const uint32_t koff = (uint32_t)t * p.Cin + c0;
+        if (VEC) {
+            const bool cok = (c0 + 4 * q) < p.Cin;          // only false inside a partial last chunk
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int n = n0 + lrow + i * RPP;
-            const bool ok = n < p.Cout;
-            const size_t addr = (size_t)n * w_row + (size_t)t * p.Cin + cq;
-            rb[i] = load4<VEC>(p.wgt + (ok ? addr : 0), ok ? nvalid : 0);
+            for (int i = 0; i < APASS; ++i) {
+                const bool ok = ((a_ok >> i) & 1u) && cok;
+                const float4 v = *reinterpret_cast<const float4*>(p.in + (ok ? a_off[i] + c0 : 0u));
+                ra[i] = ok ? v : f4zero();
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const bool ok = ((b_ok >> i) & 1u) && cok;
+                const float4 v = *reinterpret_cast<const float4*>(p.wgt + (ok ? b_off[i] + koff : 0u));
+                rb[i] = ok ? v : f4zero();
+            }
+        } else {
+            // scalar path (3-channel stem, 150-class dgrad): tiny layers, conditional loads are fine here
+            const int nvalid = max(0, min(4, p.Cin - (c0 + 4 * q)));
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const bool ok = (a_ok >> i) & 1u;
+                ra[i] = load4<false>(p.in + (ok ? a_off[i] + c0 : 0u), ok ? nvalid : 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const bool ok = (b_ok >> i) & 1u;
+                rb[i] = load4<false>(p.wgt + (ok ? b_off[i] + koff : 0u), ok ? nvalid : 0);
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -246,6 +290,12 @@ struct IGemmPlan {
     bool vec;
 };
 
+// tuning overrides for tools/conv_bench.py: SEMSEG_IGEMM_TILE=0|1|2 (128x128 / 128x64 / 64x64), SEMSEG_IGEMM_SPLITK=n
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 static IGemmPlan plan_igemm(int M, int Cout, int Cin, int T, bool vec) {
     IGemmPlan pl;
     pl.vec = vec;
@@ -257,6 +307,8 @@ static IGemmPlan plan_igemm(int M, int Cout, int Cin, int T, bool vec) {
         if (tiles >= 448) { pick = i; break; }
     }
     if (Cout <= 64 && pick < 2) pick = (M >= 128 * 448) ? 1 : 2;   // never waste a 128-wide N tile on <=64 channels
+    const int force_tile = env_int("SEMSEG_IGEMM_TILE", -1);
+    if (force_tile >= 0 && force_tile <= 2) pick = force_tile;
     pl.BM = cand[pick][0];
     pl.BN = cand[pick][1];
     pl.tiles_m = ceil_div(M, pl.BM);
@@ -269,6 +321,8 @@ static IGemmPlan plan_igemm(int M, int Cout, int Cin, int T, bool vec) {
         splits = min(min(ceil_div(512, tiles), pl.ktiles / 8), 32);
         if (splits < 1) splits = 1;
     }
+    const int force_split = env_int("SEMSEG_IGEMM_SPLITK", 0);
+    if (force_split > 0) splits = min(force_split, pl.ktiles);
     pl.kt_per_split = ceil_div(pl.ktiles, splits);
     pl.splits = ceil_div(pl.ktiles, pl.kt_per_split);
     return pl;
@@ -303,6 +357,9 @@ static int dispatch_igemm(const IGemmPlan& pl, const IGemmParams& p, hipStream_t
 }
 
 static int run_igemm(IGemmParams p, bool vec, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    // the kernel addresses both operands with 32-bit element offsets
+    const size_t in_elems = (size_t)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.in_ld;
+    if (in_elems >= ((size_t)1 << 31) || (size_t)p.Cout * p.T * p.Cin >= ((size_t)1 << 31)) return SEMSEG_EINVAL;
     const IGemmPlan pl = plan_igemm(p.M, p.Cout, p.Cin, p.T, vec);
     p.chunks = pl.chunks;
     p.ktiles = pl.ktiles;

@@ -7,6 +7,7 @@
 // slabs are summed in a fixed order by wgrad_reduce_kernel (deterministic, no atomics).
 // Replaces the autograd weight-gradient of nn.Conv2d (see conv_igemm.hip for call sites).
 #include "common.h"
+#include <stdlib.h>
 
 struct WgradParams {
     const float* x;
@@ -62,29 +63,58 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     const int HWo = p.OH * p.OW;
 
     float4 ra[APASS], rb[BPASS];
+    // branch-free loads (see conv_igemm.hip): unconditional load from a clamped offset, zero fill by select
+    const float inv_hwo = 1.0f / (float)HWo, inv_ow = 1.0f / (float)p.OW;
     auto load_tile = [&](int mt) {
+        if (VEC) {
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) {
-            const int m = mt + rowa + i * RPA;
-            const bool ok = m < m_end;
-            ra[i] = load4<VEC>(p.dy + (ok ? (size_t)m * p.dy_ld + ka : 0), ok ? na_valid : 0);
-        }
+            for (int i = 0; i < APASS; ++i) {
+                const int m = mt + rowa + i * RPA;
+                const bool ok = (m < m_end) && (na_valid > 0);
+                const float4 v = *reinterpret_cast<const float4*>(p.dy + (ok ? (uint32_t)m * (uint32_t)p.dy_ld + ka : 0u));
+                ra[i] = ok ? v : f4zero();
+            }
 #pragma unroll
-        for (int i = 0; i < BPASS; ++i) {
-            const int m = mt + rowb + i * RPB;
-            bool ok = m < m_end;
-            size_t addr = 0;
-            if (ok) {
-                const int n = m / HWo;
-                const int rem = m - n * HWo;
-                const int oh = rem / p.OW;
-                const int ow = rem - oh * p.OW;
+            for (int i = 0; i < BPASS; ++i) {
+                const int m = min(mt + rowb + i * RPB, p.M - 1);
+                // m -> (n, oh, ow) with float-reciprocal division + one correction step (exact for m < 2^24)
+                int n = (int)((float)m * inv_hwo);
+                int rem = m - n * HWo;
+                if (rem < 0) { --n; rem += HWo; } else if (rem >= HWo) { ++n; rem -= HWo; }
+                int oh = (int)((float)rem * inv_ow);
+                int ow = rem - oh * p.OW;
+                if (ow < 0) { --oh; ow += p.OW; } else if (ow >= p.OW) { ++oh; ow -= p.OW; }
                 const int ih = oh * p.stride - p.pad + r * p.dil;
                 const int iw = ow * p.stride - p.pad + s * p.dil;
-                ok = (ih >= 0) & (iw >= 0) & (ih < p.H) & (iw < p.W);
-                addr = ((size_t)(n * p.H + ih) * p.W + iw) * p.x_ld + cb;
+                const bool ok = (mt + rowb + i * RPB < m_end) & (ih >= 0) & (iw >= 0) & (ih < p.H) & (iw < p.W) & (nb_valid > 0);
+                const uint32_t addr = (uint32_t)((n * p.H + ih) * p.W + iw) * (uint32_t)p.x_ld + cb;
+                const float4 v = *reinterpret_cast<const float4*>(p.x + (ok ? addr : 0u));
+                rb[i] = ok ? v : f4zero();
             }
-            rb[i] = load4<VEC>(p.x + (ok ? addr : 0), ok ? nb_valid : 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const int m = mt + rowa + i * RPA;
+                const bool ok = m < m_end;
+                ra[i] = load4<false>(p.dy + (ok ? (size_t)m * p.dy_ld + ka : 0), ok ? na_valid : 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int m = mt + rowb + i * RPB;
+                bool ok = m < m_end;
+                size_t addr = 0;
+                if (ok) {
+                    const int n = m / HWo;
+                    const int rem = m - n * HWo;
+                    const int oh = rem / p.OW;
+                    const int ow = rem - oh * p.OW;
+                    const int ih = oh * p.stride - p.pad + r * p.dil;
+                    const int iw = ow * p.stride - p.pad + s * p.dil;
+                    ok = (ih >= 0) & (iw >= 0) & (ih < p.H) & (iw < p.W);
+                    addr = ((size_t)(n * p.H + ih) * p.W + iw) * p.x_ld + cb;
+                }
+                rb[i] = load4<false>(p.x + (ok ? addr : 0), ok ? nb_valid : 0);
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -184,7 +214,11 @@ struct WgradPlan {
 
 static WgradPlan plan_wgrad(int M, int K, int C, int T) {
     WgradPlan pl;
-    const bool big = (K >= 128 && C >= 128);
+    bool big = (K >= 128 && C >= 128);
+    {   // tuning overrides: SEMSEG_WGRAD_TILE=0 (128x128) | 1 (64x64), SEMSEG_WGRAD_SPLIT=n
+        const char* v = getenv("SEMSEG_WGRAD_TILE");
+        if (v && *v) big = atoi(v) == 0;
+    }
     pl.BM = big ? 128 : 64;
     pl.BN = big ? 128 : 64;
     pl.tiles_k = ceil_div(K, pl.BM);
@@ -194,6 +228,10 @@ static WgradPlan plan_wgrad(int M, int K, int C, int T) {
     int splits = 1;
     if (tiles < 512) splits = (int)min((long)min(mtiles / 4 > 0 ? mtiles / 4 : 1, 64), (512 + tiles - 1) / tiles);
     if (splits < 1) splits = 1;
+    {
+        const char* v = getenv("SEMSEG_WGRAD_SPLIT");
+        if (v && *v && atoi(v) > 0) splits = min(atoi(v), mtiles);
+    }
     int mps = ceil_div(mtiles, splits) * 32;
     pl.m_per_split = mps;
     pl.splits = ceil_div(M, mps);
@@ -240,6 +278,9 @@ extern "C" int semseg_conv2d_wgrad(const float* x, int x_ld, const float* dy, in
     p.M = N * OH * OW;
     p.S = S; p.T = R * S;
     p.stride = stride; p.pad = pad; p.dil = dil;
+    // 32-bit element offsets + float-reciprocal pixel decomposition in the kernel
+    if ((size_t)N * H * W * x_ld >= ((size_t)1 << 31) || (size_t)p.M * dy_ld >= ((size_t)1 << 31) || p.M >= (1 << 24))
+        return SEMSEG_EINVAL;
     const WgradPlan pl = plan_wgrad(p.M, K, C, p.T);
     p.tiles_k = pl.tiles_k; p.tiles_c = pl.tiles_c;
     p.m_per_split = pl.m_per_split; p.splits = pl.splits;

@@ -341,14 +341,21 @@ __device__ __forceinline__ void bl_coord(int d, float scale, int in, int& i0, in
     l0 = 1.f - l1;
 }
 
-template <bool ACC, bool RELU>
+template <int V> struct VecT;
+template <> struct VecT<4> { typedef float4 type; };
+template <> struct VecT<2> { typedef float2 type; };
+template <> struct VecT<1> { typedef float type; };
+
+// V = floats per lane (4 when C % 4 == 0; 2 / 1 for the 150-class logits of the inference branch)
+template <bool ACC, bool RELU, int V>
 __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ y, int y_ld, int N, int IH,
                                     int IW, int OH, int OW, int C, float sh, float sw) {
-    const int qpr = C / 4;
+    typedef typename VecT<V>::type vec;
+    const int qpr = C / V;
     const size_t total = (size_t)N * OH * OW * qpr;
     GRID_STRIDE(i, total) {
         const size_t op = i / qpr;
-        const int c = (int)(i - op * qpr) * 4;
+        const int c = (int)(i - op * qpr) * V;
         const int ow = (int)(op % OW);
         const int oh = (int)((op / OW) % OH);
         const int n = (int)(op / ((size_t)OW * OH));
@@ -357,32 +364,41 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int x_ld, float
         bl_coord(oh, sh, IH, h0, h1, lh0, lh1);
         bl_coord(ow, sw, IW, w0, w1, lw0, lw1);
         const float* b = x + (size_t)n * IH * IW * x_ld + c;
-        const float4 v00 = *reinterpret_cast<const float4*>(b + ((size_t)h0 * IW + w0) * x_ld);
-        const float4 v01 = *reinterpret_cast<const float4*>(b + ((size_t)h0 * IW + w1) * x_ld);
-        const float4 v10 = *reinterpret_cast<const float4*>(b + ((size_t)h1 * IW + w0) * x_ld);
-        const float4 v11 = *reinterpret_cast<const float4*>(b + ((size_t)h1 * IW + w1) * x_ld);
-        float4 o;
+        const vec v00 = *reinterpret_cast<const vec*>(b + ((size_t)h0 * IW + w0) * x_ld);
+        const vec v01 = *reinterpret_cast<const vec*>(b + ((size_t)h0 * IW + w1) * x_ld);
+        const vec v10 = *reinterpret_cast<const vec*>(b + ((size_t)h1 * IW + w0) * x_ld);
+        const vec v11 = *reinterpret_cast<const vec*>(b + ((size_t)h1 * IW + w1) * x_ld);
+        vec* d = reinterpret_cast<vec*>(y + op * y_ld + c);
+        vec prev;
+        if (ACC) prev = *d;
+        vec o;
         // same association as torch upsample_bilinear2d: h0lambda*(w0lambda*v00 + w1lambda*v01) + h1lambda*(...)
-        o.x = lh0 * (lw0 * v00.x + lw1 * v01.x) + lh1 * (lw0 * v10.x + lw1 * v11.x);
-        o.y = lh0 * (lw0 * v00.y + lw1 * v01.y) + lh1 * (lw0 * v10.y + lw1 * v11.y);
-        o.z = lh0 * (lw0 * v00.z + lw1 * v01.z) + lh1 * (lw0 * v10.z + lw1 * v11.z);
-        o.w = lh0 * (lw0 * v00.w + lw1 * v01.w) + lh1 * (lw0 * v10.w + lw1 * v11.w);
-        float4* d = reinterpret_cast<float4*>(y + op * y_ld + c);
-        if (ACC) { const float4 p = *d; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-        if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float a00 = reinterpret_cast<const float*>(&v00)[e], a01 = reinterpret_cast<const float*>(&v01)[e];
+            const float a10 = reinterpret_cast<const float*>(&v10)[e], a11 = reinterpret_cast<const float*>(&v11)[e];
+            float r = lh0 * (lw0 * a00 + lw1 * a01) + lh1 * (lw0 * a10 + lw1 * a11);
+            if (ACC) r += reinterpret_cast<const float*>(&prev)[e];
+            if (RELU) r = fmaxf(r, 0.f);
+            reinterpret_cast<float*>(&o)[e] = r;
+        }
         *d = o;
     }
 }
 
 extern "C" int semseg_bilinear_fwd(const float* x, int x_ld, float* y, int y_ld, int accumulate, int relu, int N, int IH, int IW,
                                    int OH, int OW, int C, void* stream) {
-    if (!x || !y || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || (C % 4) || (x_ld % 4) || (y_ld % 4))
-        return SEMSEG_EINVAL;
+    if (!x || !y || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || x_ld < C || y_ld < C) return SEMSEG_EINVAL;
     const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
-    const int blocks = stream_blocks((size_t)N * OH * OW * (C / 4));
-#define LAUNCH(A, R) hipLaunchKernelGGL((bilinear_fwd_kernel<A, R>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, y, y_ld, N, IH, IW, OH, OW, C, sh, sw)
-    if (accumulate) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
-    else            { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
+    int V = 1;
+    if (C % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && aligned16(x) && aligned16(y)) V = 4;
+    else if (C % 2 == 0 && x_ld % 2 == 0 && y_ld % 2 == 0 && (((uintptr_t)x | (uintptr_t)y) & 7) == 0) V = 2;
+    const int blocks = stream_blocks((size_t)N * OH * OW * (C / V));
+#define LAUNCH(A, R, VV) hipLaunchKernelGGL((bilinear_fwd_kernel<A, R, VV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, y, y_ld, N, IH, IW, OH, OW, C, sh, sw)
+#define LAUNCH_V(A, R) do { if (V == 4) LAUNCH(A, R, 4); else if (V == 2) LAUNCH(A, R, 2); else LAUNCH(A, R, 1); } while (0)
+    if (accumulate) { if (relu) LAUNCH_V(true, true); else LAUNCH_V(true, false); }
+    else            { if (relu) LAUNCH_V(false, true); else LAUNCH_V(false, false); }
+#undef LAUNCH_V
 #undef LAUNCH
     SEMSEG_LAUNCH_CHECK();
     return 0;

@@ -30,7 +30,7 @@ SIGNATURES = {
     'semseg_weight_krsc_to_crsk': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     'semseg_bn_workspace_bytes': (c_sz, [c_int, c_int]),
     'semseg_bn_stats': (c_int, [vp, c_int, c_int, vp, vp, c_sz, vp]),
-    'semseg_bn_finalize': (c_int, [vp, c_int, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp]),
+    'semseg_bn_finalize': (c_int, [vp, c_int, vp, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp]),
     'semseg_bn_eval_coeffs': (c_int, [vp, vp, vp, vp, c_f, c_int, vp, vp, vp, vp, vp]),
     'semseg_bn_apply': (c_int, [vp, vp, vp, vp, c_int, c_int, vp, c_int, c_int, c_int, vp]),
     'semseg_bn_bwd_reduce': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_sz, vp]),

@@ -43,11 +43,9 @@ class _SynchronizedBatchNorm(nn.Module):
     def forward(self, input, residual=None, relu=False):
         """y = BN(input); the fused form y = relu(BN(input) + residual) is what the blocks call."""
         x, shape = self._as4d(input)
-        if self.training:
-            self.num_batches_tracked.add_(1)
         y = ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                residual=residual, training=self.training, momentum=self.momentum,
-                               eps=self.eps, relu=relu)
+                               eps=self.eps, relu=relu, num_batches_tracked=self.num_batches_tracked)
         return y if shape is None else y.reshape(shape)
 
     def extra_repr(self):

@@ -105,6 +105,8 @@ class ConvBNReLU(nn.Sequential):
         super().__init__()
         self.add_module(str(first_index), conv)
         self.add_module(str(first_index + 1), bn)
+        if relu:
+            self.add_module(str(first_index + 2), ReLU(inplace=True))   # executes fused in the BN kernel
         self._relu = relu
         self._conv, self._bn = str(first_index), str(first_index + 1)
 

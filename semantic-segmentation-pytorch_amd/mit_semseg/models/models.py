@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import ops
 from . import resnet, hrnet
-from .layers import (Conv2d, BatchNorm2d, AdaptiveAvgPool2d, Dropout2d, ConvBNReLU, conv3x3_bn_relu)
+from .layers import (Conv2d, BatchNorm2d, AdaptiveAvgPool2d, Dropout2d, ConvBNReLU, ReLU, conv3x3_bn_relu)
 
 
 class SegmentationModuleBase(nn.Module):
@@ -197,6 +197,7 @@ class _PoolBranch(nn.Sequential):
         self.add_module('0', AdaptiveAvgPool2d(scale))
         self.add_module('1', Conv2d(fc_dim, 512, kernel_size=1, bias=False))
         self.add_module('2', BatchNorm2d(512))
+        self.add_module('3', ReLU(inplace=True))      # fused into the BN kernel; kept so indices match the reference
 
     def forward(self, x):
         m = self._modules
@@ -210,6 +211,7 @@ class _ClassifierHead(nn.Sequential):
         super().__init__()
         self.add_module('0', Conv2d(in_dim, 512, kernel_size=3, padding=1, bias=False))
         self.add_module('1', BatchNorm2d(512))
+        self.add_module('2', ReLU(inplace=True))      # fused into the BN kernel; kept so conv_last[3] is the Dropout2d
         self.add_module('3', Dropout2d(0.1))
         self.add_module('4', Conv2d(512, num_class, kernel_size=1))
 

@@ -197,7 +197,7 @@ class BatchNormActFn(Function):
     """y = act(BN(z) [+ residual]); training: batch statistics + running-stat EMA; eval: running stats."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, nbt):
         L = _native.lib()
         z, z_ld = as_nhwc(z.detach())
         n, c, h, w = z.shape
@@ -217,7 +217,7 @@ class BatchNormActFn(Function):
             ws = workspace(L.semseg_bn_workspace_bytes(P, c), dev)
             _native.check(L.semseg_bn_stats(_p(z), P, c, _p(stats), _p(ws), ws.numel(), _st()), 'bn_stats')
             _maybe_allreduce(stats)
-            _native.check(L.semseg_bn_finalize(_p(stats), c, _p(g), _p(b), _p(running_mean), _p(running_var),
+            _native.check(L.semseg_bn_finalize(_p(stats), c, _p(g), _p(b), _p(running_mean), _p(running_var), _p(nbt),
                                                float(momentum), float(eps), _p(coef[0]), _p(coef[1]), _p(coef[2]),
                                                _p(coef[3]), _st()), 'bn_finalize')
         else:
@@ -262,13 +262,14 @@ class BatchNormActFn(Function):
                                             _p(sums), _p(count), int(training), int(relu), _p(dz), _p(dres), P, c,
                                             _st()), 'bn_bwd_apply')
         return (dz, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, dres, None, None, None, None)
+                None, None, dres, None, None, None, None, None)
 
 
 def batch_norm_act(z, gamma, beta, running_mean, running_var, residual=None, training=False, momentum=0.1,
-                   eps=1e-5, relu=False):
+                   eps=1e-5, relu=False, num_batches_tracked=None):
+    """`num_batches_tracked` (int64 0-dim buffer) is incremented by the finalize kernel in training mode."""
     return BatchNormActFn.apply(z, gamma, beta, running_mean, running_var, residual, bool(training),
-                                float(momentum), float(eps), bool(relu))
+                                float(momentum), float(eps), bool(relu), num_batches_tracked)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -118,7 +118,8 @@ def test_batch_norm_act(shape, training, relu, res):
     torch.cuda.synchronize()
     tol = 2e-5
     assert rel_err(y, yr) < tol
-    assert rel_err(xg.grad, xr.grad) < 1e-4
+    # 2 values per channel: xhat = +-1 and dx is pure cancellation (|dx| ~ eps/var * |dy|): compare loosely there
+    assert rel_err(xg.grad, xr.grad) < (1e-4 if n * h * w > 2 else 2e-3)
     assert rel_err(gg.grad, gr.grad) < 1e-4 and rel_err(bg.grad, br.grad) < 1e-4
     if res:
         assert rel_err(rg.grad, rr.grad) < tol
@@ -179,8 +180,21 @@ def test_bilinear(ih, iw, oh, ow):
     xg = cl(x).requires_grad_(True)
     y = ops.interpolate_bilinear(xg, (oh, ow))
     y.backward(cl(gy))
-    assert rel_err(y, yr) < 2e-6
-    assert rel_err(xg.grad, xr.grad) < 1e-5
+    # source coordinates are computed in fp32 (as torch does for fp32 tensors); the fp64 reference differs by that
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(xg.grad, xr.grad) < 2e-5
+    y32 = F.interpolate(x, size=(oh, ow), mode='bilinear', align_corners=False)
+    assert rel_err(y, y32) < 1e-6
+
+
+def test_bilinear_150_classes():
+    """inference branch (models.py:480-484): logits with C=150 (not a multiple of 4) are up-sampled to segSize"""
+    from mit_semseg import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 150, 8, 10, generator=g)
+    yr = F.interpolate(x, size=(35, 45), mode='bilinear', align_corners=False)
+    y = ops.interpolate_bilinear(cl(x), (35, 45))
+    assert rel_err(y, yr) < 1e-6
 
 
 def test_bilinear_accumulate_relu():

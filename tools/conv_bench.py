@@ -1,0 +1,121 @@
+"""Micro-benchmark of the conv kernels through the C ABI on the layer shapes of
+ade20k-resnet50dilated-ppm_deepsup (bs 2, 512x512): per layer and per pass (fwd / dgrad / wgrad), HIP-event
+timing and achieved TFLOP/s for a list of forced tile / split configurations (env overrides read by the
+library).  Used to set the launch heuristics and to produce the PMC profiles under profiles/.
+
+    python tools/conv_bench.py [--layers conv_last,l4_conv2_d4,...] [--passes fwd,dgrad,wgrad] [--sweep]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd'))
+import torch  # noqa: E402
+from mit_semseg import _native  # noqa: E402
+
+vp = ctypes.c_void_p
+#            name            N  C     H   W   K     ks st pad dil   count/step
+LAYERS = [
+    ('conv_last',     2, 4096, 64, 64, 512,  3, 1, 1, 1, 1),
+    ('deepsup',       2, 1024, 64, 64, 512,  3, 1, 1, 1, 1),
+    ('l4_conv2_d4',   2, 512,  64, 64, 512,  3, 1, 4, 4, 2),
+    ('l4_conv3',      2, 512,  64, 64, 2048, 1, 1, 0, 1, 3),
+    ('l3_conv2_d2',   2, 256,  64, 64, 256,  3, 1, 2, 2, 5),
+    ('l4_conv1',      2, 2048, 64, 64, 512,  1, 1, 0, 1, 2),
+    ('l4_down',       2, 1024, 64, 64, 2048, 1, 1, 0, 1, 1),
+    ('l3_conv3',      2, 256,  64, 64, 1024, 1, 1, 0, 1, 6),
+    ('l3_conv1',      2, 1024, 64, 64, 256,  1, 1, 0, 1, 5),
+    ('stem_conv3',    2, 64,  256, 256, 128, 3, 1, 1, 1, 1),
+    ('stem_conv2',    2, 64,  256, 256, 64,  3, 1, 1, 1, 1),
+    ('l1_conv2',      2, 64,  128, 128, 64,  3, 1, 1, 1, 3),
+    ('l2_conv2',      2, 128, 64, 64, 128,   3, 1, 1, 1, 3),
+    ('ppm_1x1_s6',    2, 2048, 6, 6, 512,    1, 1, 0, 1, 1),
+    ('cls',           2, 512, 64, 64, 150,   1, 1, 0, 1, 2),
+]
+
+
+def run(layer, which, iters, L, ws):
+    name, n, c, h, w, k, ks, st, pad, dil, _ = layer
+    dev = torch.device('cuda:0')
+    oh = (h + 2 * pad - dil * (ks - 1) - 1) // st + 1
+    ow = (w + 2 * pad - dil * (ks - 1) - 1) // st + 1
+    x = torch.randn(n, h, w, c, device=dev)
+    wt = torch.randn(k, ks, ks, c, device=dev) * 0.02
+    wtt = torch.randn(c, ks, ks, k, device=dev) * 0.02
+    y = torch.empty(n, oh, ow, k, device=dev)
+    dy = torch.randn(n, oh, ow, k, device=dev)
+    dx = torch.empty(n, h, w, c, device=dev)
+    dw = torch.empty(k, ks, ks, c, device=dev)
+    s = vp(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: vp(t.data_ptr())  # noqa: E731
+
+    def call():
+        if which == 'fwd':
+            rc = L.semseg_conv2d_fwd(P(x), c, P(wt), vp(0), P(y), k, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
+        elif which == 'dgrad':
+            rc = L.semseg_conv2d_dgrad(P(dy), k, P(wtt), P(dx), c, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
+        else:
+            rc = L.semseg_conv2d_wgrad(P(x), c, P(dy), k, P(dw), vp(0), n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
+        _native.check(rc, which)
+    for _ in range(2):
+        call()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        call()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    gflop = 2.0 * n * oh * ow * k * c * ks * ks * 1e-9
+    return ms, gflop / ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--layers', default='')
+    ap.add_argument('--passes', default='fwd,dgrad,wgrad')
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--sweep', action='store_true', help='also try forced tile/split configurations')
+    args = ap.parse_args()
+    L = _native.lib()
+    ws = torch.empty(1 << 30, dtype=torch.uint8, device='cuda:0')
+    sel = [l for l in LAYERS if not args.layers or l[0] in args.layers.split(',')]
+    tot = {}
+    for layer in sel:
+        for which in args.passes.split(','):
+            cfgs = [('default', {})]
+            if args.sweep:
+                if which == 'wgrad':
+                    cfgs += [('t%d_s%d' % (t, sp), {'SEMSEG_WGRAD_TILE': str(t), 'SEMSEG_WGRAD_SPLIT': str(sp)})
+                             for t in (0, 1) for sp in (1, 2, 4, 8, 16)]
+                else:
+                    cfgs += [('t%d_s%d' % (t, sp), {'SEMSEG_IGEMM_TILE': str(t), 'SEMSEG_IGEMM_SPLITK': str(sp)})
+                             for t in (0, 1, 2) for sp in (1, 2, 4)]
+            res = []
+            for cname, env in cfgs:
+                for k in ('SEMSEG_IGEMM_TILE', 'SEMSEG_IGEMM_SPLITK', 'SEMSEG_WGRAD_TILE', 'SEMSEG_WGRAD_SPLIT'):
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                try:
+                    ms, tf = run(layer, which, args.iters, L, ws)
+                    res.append((cname, ms, tf))
+                except RuntimeError as e:
+                    res.append((cname, float('nan'), 0.0))
+            d = res[0]
+            best = max(res, key=lambda r: r[2])
+            tot.setdefault(which, [0.0, 0.0])
+            tot[which][0] += d[1] * layer[-1]
+            tot[which][1] += best[1] * layer[-1]
+            line = '%-12s %-5s default %8.3f ms %6.1f TF' % (layer[0], which, d[1], d[2])
+            if args.sweep:
+                line += ' | best %-8s %8.3f ms %6.1f TF | ' % best + ' '.join('%s:%.0f' % (r[0], r[2]) for r in res[1:])
+            print(line, flush=True)
+    for k, v in tot.items():
+        print('sum over listed layers x count: %-5s default %.2f ms  best-of-sweep %.2f ms' % (k, v[0], v[1]))
+
+
+if __name__ == '__main__':
+    main()
