@@ -296,34 +296,61 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+static inline double partial_wave_cost(int blocks_on_cu, int cu_slots) {
+    if (blocks_on_cu >= cu_slots) return 1.0;
+    if (cu_slots == 2) return 0.567;
+    const double g4[4] = {0.0, 0.40, 0.65, 0.85};
+    return g4[blocks_on_cu];
+}
+
+// Launch plan.  Measured on MI355X (tools/conv_bench.py --sweep, profiles/conv_bench_sweep_r1.txt): the 128x128
+// tile is the most efficient per MFMA (least L2 traffic, most MFMAs per barrier), but only if the grid fills the
+// 512 resident-workgroup slots (2 per CU) in whole waves -- a 1152-block grid runs 3 waves for 2.25 waves of work.
+// So: enumerate tile x split-K candidates and take the one with the smallest modelled time
+//     time = ceil(blocks / slots) * (ktiles_per_block * tile_cost + fixed) + split-K reduction traffic.
 static IGemmPlan plan_igemm(int M, int Cout, int Cin, int T, bool vec) {
     IGemmPlan pl;
     pl.vec = vec;
     pl.BK = (Cin % 32 == 0) ? 32 : 16;
-    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    int pick = 2;
-    for (int i = 0; i < 3; ++i) {
-        const long tiles = (long)ceil_div(M, cand[i][0]) * ceil_div(Cout, cand[i][1]);
-        if (tiles >= 448) { pick = i; break; }
-    }
-    if (Cout <= 64 && pick < 2) pick = (M >= 128 * 448) ? 1 : 2;   // never waste a 128-wide N tile on <=64 channels
-    const int force_tile = env_int("SEMSEG_IGEMM_TILE", -1);
-    if (force_tile >= 0 && force_tile <= 2) pick = force_tile;
-    pl.BM = cand[pick][0];
-    pl.BN = cand[pick][1];
-    pl.tiles_m = ceil_div(M, pl.BM);
-    pl.tiles_n = ceil_div(Cout, pl.BN);
+    const int force_bk = env_int("SEMSEG_IGEMM_BK", 0);
+    if (force_bk == 16 || (force_bk == 32 && Cin % 32 == 0)) pl.BK = force_bk;
     pl.chunks = ceil_div(Cin, pl.BK);
     pl.ktiles = T * pl.chunks;
-    const int tiles = pl.tiles_m * pl.tiles_n;
-    int splits = 1;
-    if (tiles < 256 && pl.ktiles >= 16) {
-        splits = min(min(ceil_div(512, tiles), pl.ktiles / 8), 32);
-        if (splits < 1) splits = 1;
+    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    // CU time of one k-tile for a full set of resident blocks (2 / 2 / 4 per CU), relative to 128x128x32 at ~127 TF:
+    // fitted to the sweep (conv_last fwd: 127 / 112 / 107 TF for the three tiles at equal wave counts)
+    const double tile_cost[3] = {1.0, 0.56, 0.59};
+    const int slots[3] = {512, 512, 1024};
+    const double kscale = pl.BK / 32.0;
+    double best = 1e30;
+    int best_t = 2, best_s = 1;
+    for (int t = 0; t < 3; ++t) {
+        if (Cout <= 64 && cand[t][1] > 64) continue;          // never waste a 128-wide N tile on <=64 channels
+        const long tiles = (long)ceil_div(M, cand[t][0]) * ceil_div(Cout, cand[t][1]);
+        for (int sp = 1; sp <= 16; ++sp) {
+            if (sp > 1 && pl.ktiles / sp < 8) break;
+            const int kps = ceil_div(pl.ktiles, sp);
+            const int nsp = ceil_div(pl.ktiles, kps);
+            if (nsp != sp) continue;
+            const long blocks = tiles * sp;
+            // whole waves cost 1.  A partial last wave costs as much as its most loaded CU: b = ceil(rem / 256) blocks
+            // on a CU that could hold slots/256; measured: one 128x128 block alone on a CU runs 1.76x faster than two.
+            const long rem = blocks % slots[t];
+            const double waves = (double)(blocks / slots[t]) + (rem ? partial_wave_cost((int)((rem + 255) / 256), slots[t] / 256) : 0.0);
+            double time = waves * (kps * tile_cost[t] * kscale + 4.0 * tile_cost[t]);
+            if (sp > 1) time += (double)(sp + 1) * M * Cout * 4.0 / 5.0e12 / 4.2e-6;   // slab write + reduce, in tile units (4.2 us)
+            if (time < best) { best = time; best_t = t; best_s = sp; }
+        }
     }
+    const int force_tile = env_int("SEMSEG_IGEMM_TILE", -1);
+    if (force_tile >= 0 && force_tile <= 2) { best_t = force_tile; best_s = 1; }
     const int force_split = env_int("SEMSEG_IGEMM_SPLITK", 0);
-    if (force_split > 0) splits = min(force_split, pl.ktiles);
-    pl.kt_per_split = ceil_div(pl.ktiles, splits);
+    if (force_split > 0) best_s = min(force_split, pl.ktiles);
+    pl.BM = cand[best_t][0];
+    pl.BN = cand[best_t][1];
+    pl.tiles_m = ceil_div(M, pl.BM);
+    pl.tiles_n = ceil_div(Cout, pl.BN);
+    pl.kt_per_split = ceil_div(pl.ktiles, best_s);
     pl.splits = ceil_div(pl.ktiles, pl.kt_per_split);
     return pl;
 }

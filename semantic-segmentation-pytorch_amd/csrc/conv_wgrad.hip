@@ -212,29 +212,51 @@ struct WgradPlan {
     int BM, BN, tiles_k, tiles_c, splits, m_per_split;
 };
 
+// Same wave-quantisation model as plan_igemm: 128x128 tiles (2 blocks per CU -> 512 slots) or 64x64 (4 per CU),
+// the pixel range split so that the grid is a whole number of waves and every block still loops >= 8 pixel tiles.
 static WgradPlan plan_wgrad(int M, int K, int C, int T) {
     WgradPlan pl;
-    bool big = (K >= 128 && C >= 128);
+    const int mtiles = ceil_div(M, 32);
+    const int cand[2] = {128, 64};
+    const double tile_cost[2] = {1.0, 0.59};
+    const int slots[2] = {512, 1024};
+    int force_tile = -1, force_split = 0;
     {   // tuning overrides: SEMSEG_WGRAD_TILE=0 (128x128) | 1 (64x64), SEMSEG_WGRAD_SPLIT=n
         const char* v = getenv("SEMSEG_WGRAD_TILE");
-        if (v && *v) big = atoi(v) == 0;
+        if (v && *v) force_tile = atoi(v);
+        v = getenv("SEMSEG_WGRAD_SPLIT");
+        if (v && *v) force_split = atoi(v);
     }
-    pl.BM = big ? 128 : 64;
-    pl.BN = big ? 128 : 64;
+    double best = 1e30;
+    int best_t = 1, best_s = 1;
+    for (int t = 0; t < 2; ++t) {
+        if (force_tile >= 0 && t != force_tile) continue;
+        if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
+        const long tiles = (long)ceil_div(K, cand[t]) * ceil_div(C, cand[t]) * T;
+        for (int sp = 1; sp <= 64; ++sp) {
+            if (force_split > 0 && sp != min(force_split, mtiles)) continue;
+            if (force_split <= 0 && sp > 1 && mtiles / sp < 8) break;
+            const int mps = ceil_div(mtiles, sp);
+            if (ceil_div(mtiles, mps) != sp) continue;
+            const long blocks = tiles * sp;
+            const long rem = blocks % slots[t];
+            double pw = 0.0;
+            if (rem) {
+                const int b = (int)((rem + 255) / 256), cs = slots[t] / 256;
+                const double g4[4] = {0.0, 0.40, 0.65, 0.85};
+                pw = b >= cs ? 1.0 : (cs == 2 ? 0.567 : g4[b]);
+            }
+            const double waves = (double)(blocks / slots[t]) + pw;
+            double time = waves * (mps * tile_cost[t] + 4.0 * tile_cost[t]);
+            if (sp > 1) time += (double)(sp + 1) * K * T * C * 4.0 / 5.0e12 / 4.2e-6;
+            if (time < best) { best = time; best_t = t; best_s = sp; }
+        }
+    }
+    pl.BM = pl.BN = cand[best_t];
     pl.tiles_k = ceil_div(K, pl.BM);
     pl.tiles_c = ceil_div(C, pl.BN);
-    const long tiles = (long)pl.tiles_k * pl.tiles_c * T;
-    const int mtiles = ceil_div(M, 32);
-    int splits = 1;
-    if (tiles < 512) splits = (int)min((long)min(mtiles / 4 > 0 ? mtiles / 4 : 1, 64), (512 + tiles - 1) / tiles);
-    if (splits < 1) splits = 1;
-    {
-        const char* v = getenv("SEMSEG_WGRAD_SPLIT");
-        if (v && *v && atoi(v) > 0) splits = min(atoi(v), mtiles);
-    }
-    int mps = ceil_div(mtiles, splits) * 32;
-    pl.m_per_split = mps;
-    pl.splits = ceil_div(M, mps);
+    pl.m_per_split = ceil_div(mtiles, best_s) * 32;
+    pl.splits = ceil_div(M, pl.m_per_split);
     return pl;
 }
 
