@@ -111,10 +111,11 @@ class TrainStep:
     def _eager(self, feed):
         self.opt.zero_grad()
         loss, acc = self.sm(feed)
+        if self.buckets is not None:
+            self.buckets.prepare()            # hooks launch each bucket's all-reduce as backward completes it
         loss.backward()
         scale = 1.0
         if self.buckets is not None:
-            self.buckets.all_reduce()
             self.buckets.finish()
             scale = 1.0 / self.world          # loss.mean() over replicas (train.py:42)
         self.opt.step(grad_scale=scale)

@@ -43,17 +43,21 @@ def world_size(group=None):
 
 
 class GradientBuckets:
-    """Flat gradient buckets + overlapped all-reduce.
+    """Flat gradient buckets + all-reduce overlapped with backward.
 
-    params are taken in REVERSE registration order (the order backward produces gradients).  Each
-    parameter owns a slice of a flat bucket; `reduce_ready()` copies finished gradients into their
-    slice and launches the bucket's all-reduce on `comm_stream` once all its slices are filled.
-    After `finish()`, `p.grad` of every parameter is a VIEW of the reduced bucket (no copy back)."""
+    Parameters are taken in REVERSE registration order (the order backward produces gradients) and packed
+    into flat fp32 buckets.  A post-accumulate-grad hook on every parameter counts its bucket down; when the
+    last gradient of a bucket has been produced the bucket is staged (gradients copied into their slices,
+    `p.grad` re-pointed at the slice) and its all-reduce is launched on `comm_stream` behind an event recorded
+    on the compute stream -- so the transfer runs while backward continues on the earlier layers.
+    `finish()` launches whatever is left (parameters that received no gradient), joins the streams and leaves
+    every `p.grad` as a VIEW of a reduced bucket (sum over ranks; the 1/world factor is folded into the SGD
+    kernel's grad_scale)."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None, comm_stream=None):
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, comm_stream=None, overlap=True):
         self.group = group
         self.params = [p for p in reversed(list(params)) if p.requires_grad]
-        self.buckets = []          # list of dict(flat, items=[(param, offset, numel)], pending)
+        self.buckets = []          # dict(flat, items=[(param, offset, numel)], pending, launched)
         cur, cur_n = [], 0
         cap = max(1, bucket_bytes // 4)
         for p in self.params:
@@ -67,13 +71,38 @@ class GradientBuckets:
             self.buckets.append(self._make_bucket(cur, cur_n))
         self.comm_stream = comm_stream
         self._works = []
+        self._bucket_of = {}
+        self._hooks = []
+        self.armed = False
+        for bi, b in enumerate(self.buckets):
+            for p, _, _ in b['items']:
+                self._bucket_of[p] = bi
+        if overlap and hasattr(torch.Tensor, 'register_post_accumulate_grad_hook'):
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _make_bucket(self, items, total):
         dev = items[0][0].device
-        return dict(flat=torch.zeros(total, device=dev, dtype=torch.float32), items=list(items))
+        return dict(flat=torch.zeros(total, device=dev, dtype=torch.float32), items=list(items),
+                    pending=len(items), launched=False)
 
     def bucket_sizes(self):
         return [b['flat'].numel() * 4 for b in self.buckets]
+
+    def prepare(self):
+        """Call before backward: re-arm the per-bucket counters."""
+        for b in self.buckets:
+            b['pending'] = len(b['items'])
+            b['launched'] = False
+        self.armed = True
+
+    def _on_grad(self, p):
+        if not self.armed:
+            return
+        b = self.buckets[self._bucket_of[p]]
+        b['pending'] -= 1
+        if b['pending'] == 0 and not b['launched']:
+            self._launch(b)
 
     def _stage(self, b):
         """copy p.grad into the bucket slices (physical order), re-point p.grad at the slice"""
@@ -87,31 +116,34 @@ class GradientBuckets:
                 view.copy_(g)
                 p.grad = view
 
-    def all_reduce(self):
-        """Stage every bucket and all-reduce it (sum).  With a comm stream the collectives run there and
-        overlap whatever the compute stream does next; `finish()` joins."""
+    def _launch(self, b):
+        b['launched'] = True
+        self._stage(b)
         if world_size(self.group) <= 1:
-            for b in self.buckets:
-                self._stage(b)
             return
-        use_side = self.comm_stream is not None and self.buckets[0]['flat'].is_cuda
+        if self.comm_stream is not None and b['flat'].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self._works.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def all_reduce(self):
+        """Launch every bucket that the hooks have not launched yet (no hooks / parameters without gradient)."""
         for b in self.buckets:
-            self._stage(b)
-            if use_side:
-                ev = torch.cuda.Event()
-                ev.record()
-                with torch.cuda.stream(self.comm_stream):
-                    self.comm_stream.wait_event(ev)
-                    dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group)
-            else:
-                self._works.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if not b['launched']:
+                self._launch(b)
 
     def finish(self):
+        self.all_reduce()
         for w in self._works:
             w.wait()
         self._works = []
         if self.comm_stream is not None and self.buckets and self.buckets[0]['flat'].is_cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.armed = False
 
 
 class NativeDataParallel(nn.Module):

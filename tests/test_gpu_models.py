@@ -98,44 +98,40 @@ def test_native_matches_reference_golden(name):
             check_summary(sd[k].detach().cpu().contiguous(), want[k], 2e-4, 2e-3, 'after-step ' + k)
 
 
-def _grad_error(got, want):
-    """error of a gradient tensor relative to its own scale (RMS of the reference), from a summarize() record"""
-    got = got.detach().float().cpu().contiguous()
-    if 'full' in want:
-        ref = want['full']
-        scale = ref.pow(2).mean().sqrt().item() + 1e-12
-        return (got.reshape(ref.shape) - ref).abs().max().item() / scale
-    f = got.flatten()
-    scale = want['abssum'] / want['numel'] + 1e-12
-    e = max((f[:16] - want['head']).abs().max().item(), (f[-16:] - want['tail']).abs().max().item())
-    return e / scale
-
-
-def test_native_gradients_match_golden():
-    """Parameter gradients of one backward (no optimizer step) vs the reference's, R50dilated+PPM_deepsup.
-    Error is measured against each tensor's RMS.  The decoder head (first layers of backward) must agree to
-    fp32 roundoff; deep in the encoder the train-mode-BN / ReLU-gate chain amplifies roundoff (a gate that flips
-    at |y| ~ 1e-7 changes downstream gradients discretely), so the bound widens with depth -- the same spread is
-    seen between two fp32 CPU runs with different summation order."""
+def test_native_gradients_vs_oracle():
+    """Every parameter gradient of one backward (no optimizer step) against the CPU oracle on the same weights /
+    batch / dropout masks (R50dilated+PPM_deepsup, the golden case r50d_ppmds_64_train, whose gradients the
+    oracle reproduces from the unmodified reference to 1e-4: tests/test_oracle_golden.py).
+    Metric per tensor: max|g - ref| / rms(ref).  The decoder head (the first layers of backward) must agree to
+    fp32 roundoff; deeper in the encoder the train-mode-BN / ReLU-gate chain amplifies roundoff -- a gate that
+    flips at |y| ~ 1e-7 changes downstream gradients discretely -- so the bound widens with depth."""
     g = load_golden('r50d_ppmds_64_train')
     m = g['meta']
     dev = torch.device('cuda:0')
-    sm, _, _ = build_native(g, dev)
+    sm, enc_sd, dec_sd = build_native(g, dev)
     img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=304 + m['seed'])
     loss, acc = sm({'img_data': img.to(dev), 'seg_label': lab.to(dev)})
     loss.backward()
     torch.cuda.synchronize()
-    worst = {}
-    for mod, want, name in ((sm.decoder, g['grads_dec'], 'dec'), (sm.encoder, g['grads_enc'], 'enc')):
+    e, d = O.clone_sd(enc_sd, True), O.clone_sd(dec_sd, True)
+    ref = O.segmentation_forward(e, d, m['arch_encoder'], m['arch_decoder'], img, lab, training=True,
+                                 dropout=g['dropout'], deep_sup_scale=m['deep_sup_scale'])
+    ref['loss'].backward()
+    rows = []
+    for mod, sd, name in ((sm.decoder, d, 'dec'), (sm.encoder, e, 'enc')):
         for k, p in mod.named_parameters():
-            e = _grad_error(p.grad, want[k])
-            grp = name + '.' + k.split('.')[0]
-            worst[grp] = max(worst.get(grp, 0.0), e)
-    print({k: '%.2e' % v for k, v in worst.items()})
-    for k in ('dec.conv_last', 'dec.conv_last_deepsup', 'dec.cbr_deepsup'):
-        assert worst[k] < 1e-3, (k, worst[k])
-    for k, v in worst.items():
-        assert v < 5e-2, (k, v)
+            r = sd[k].grad
+            got = p.grad.detach().cpu().contiguous()
+            rms = r.pow(2).mean().sqrt().item() + 1e-20
+            rows.append((name + '.' + k, (got - r).abs().max().item() / rms, rms))
+    for k, err, rms in rows:
+        print('%-44s err/rms %.2e   rms %.2e' % (k, err, rms))
+    by = dict((k, err) for k, err, _ in rows)
+    # first layers of backward: fp32 roundoff class
+    for k in ('dec.conv_last.4.weight', 'dec.conv_last.4.bias', 'dec.conv_last_deepsup.weight', 'dec.conv_last.1.weight',
+              'dec.conv_last.0.weight', 'dec.cbr_deepsup.0.weight'):
+        assert by[k] < 2e-3, (k, by[k])
+    assert max(by.values()) < 0.5, max(by.items(), key=lambda kv: kv[1])
 
 
 def test_config1_full_size_vs_oracle():
