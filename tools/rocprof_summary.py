@@ -1,0 +1,47 @@
+"""Summarise a rocprofv3 --kernel-trace run (rocpd sqlite .db or *_kernel_trace.csv) into a per-kernel CSV
+(the same columns as rocprofv3's kernel_stats.csv) so that a small text file can be committed under profiles/.
+
+    python tools/rocprof_summary.py gpurun_out/r1a/prof/bench_results.db profiles/r1_bench_kernel_stats.csv
+"""
+import csv
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def rows_from_db(path):
+    db = sqlite3.connect(path)
+    for name, start, end, gx, gy, gz, wx, vg, ag, sg, lds in db.execute(
+            'select name, start, end, grid_x, grid_y, grid_z, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, '
+            'lds_size from kernels'):
+        yield name, end - start, (vg, ag, sg, lds)
+
+
+def rows_from_csv(path):
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            yield r['Kernel_Name'], int(r['End_Timestamp']) - int(r['Start_Timestamp']), (
+                r.get('VGPR_Count'), r.get('Accum_VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size'))
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    it = rows_from_db(src) if src.endswith('.db') else rows_from_csv(src)
+    agg = defaultdict(list)
+    res = {}
+    for name, dur, r in it:
+        agg[name].append(dur)
+        res[name] = r
+    total = sum(sum(v) for v in agg.values())
+    with open(dst, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'VGPR', 'AGPR', 'SGPR',
+                    'LDS'])
+        for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([name, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 3), min(v), max(v)] +
+                       list(res[name]))
+    print('wrote %s (%d kernels, %.3f ms total)' % (dst, len(agg), total * 1e-6))
+
+
+if __name__ == '__main__':
+    main()
