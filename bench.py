@@ -26,6 +26,19 @@ import torch.nn as nn   # noqa: E402
 TRAIN_GFLOP_PER_IMG = {'resnet50dilated+ppm_deepsup': 1224.2}
 FWD_GFLOP_CONV_LAST = 309.24          # decoder.conv_last.0: 3x3 4096->512 @64x64, N=2 (per launch, fwd)
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the guide's gfx950
+# correction + WRITE_SIZE); measured offline with tools/gpu_pmc.sh, summaries under profiles/ (None = not measured yet)
+F32_CONV_LAST_HBM_BYTES = 1.78e9      # profiles/r1b_pmc_conv_last_fwd_wgrad.txt: 873044 KB x 2 + 32768 KB
+S3_CONV_LAST_HBM_BYTES = None
+
+
+DTYPE = {'s3': 'f32 (fp32 in/out/accumulate; products on the bf16 MFMA via an exact 3-way bf16 split, 6 terms)', 'f32': 'f32'}
+
+
+def ops_mode():
+    from mit_semseg import ops
+    return ops.CONV_MODE
 
 
 def build_model(dev, seed=304):
@@ -48,21 +61,64 @@ def synth_feed(dev, rank, n=2, h=512, w=512, seg_rate=8):
 
 
 def time_dominant_kernel(dev, iters=10):
-    """HIP-event timing of the dominant kernel (igemm_conv_kernel on conv_last: 3x3 4096->512 @64x64, N=2)
-    on the stream it is launched on (torch's current stream)."""
-    from mit_semseg import ops
-    x = torch.randn(2, 64, 64, 4096, device=dev).permute(0, 3, 1, 2)
-    w = (torch.randn(512, 3, 3, 4096, device=dev) * 0.01).permute(0, 3, 1, 2)
+    """HIP-event timing of the dominant kernel of the step -- the implicit-GEMM convolution of decoder.conv_last.0
+    (3x3, 4096->512 @64x64, N=2: 38 % of the step's FLOPs) -- through the C ABI on pre-split operands, i.e. ONLY the
+    conv entry point (igemm_s3_kernel + its split-K reduction; the exact-fp32 igemm_conv_kernel under SEMSEG_CONV=f32)
+    on the stream it is launched on (torch's current stream).  The launch plan is the tuned one."""
+    import ctypes
+    from mit_semseg import ops, _native, tuner
+    L = _native.lib()
+    vp = ctypes.c_void_p
+    n, h, w, c, k = 2, 64, 64, 4096, 512
+    geom = (n, h, w, c, k, 3, 3, 1, 1, 1)
+    x = torch.randn(n, h, w, c, device=dev)
+    wt = torch.randn(k, 3, 3, c, device=dev) * 0.01
+    y = torch.empty(n, h, w, k, device=dev)
+    st = lambda: vp(torch.cuda.current_stream().cuda_stream)   # noqa: E731
+    P = lambda t: vp(t.data_ptr())                              # noqa: E731
+    if ops.CONV_MODE == 's3':
+        xs, wsp = ops.split3(x, n * h * w, c, c), ops.split3(wt, k * 9, c, c)
+
+        def launch():
+            ws = ops.workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), dev)
+            _native.check(L.semseg_conv2d_fwd_s3(P(xs), P(wsp), vp(0), P(y), k, *geom, P(ws), ws.numel(), st()), 'fwd_s3')
+        tuner.ensure(0, geom, launch)
+    else:
+        def launch():
+            ws = ops.workspace(L.semseg_conv2d_workspace_bytes(*geom), dev)
+            _native.check(L.semseg_conv2d_fwd(P(x), c, P(wt), vp(0), P(y), k, *geom, P(ws), ws.numel(), st()), 'fwd')
     for _ in range(2):
-        ops.conv2d(x, w, None, 1, 1, 1)
+        launch()
     torch.cuda.synchronize()
-    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    st.record()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(iters):
-        ops.conv2d(x, w, None, 1, 1, 1)
-    en.record()
+        launch()
+    e1.record()
     torch.cuda.synchronize()
-    return st.elapsed_time(en) / iters * 1e-3
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def roofline_entry(kt):
+    """bound = MFMA.  `achieved` is ALGORITHMIC conv TFLOP/s (2*MACs of the layer / kernel time)."""
+    from mit_semseg import ops
+    achieved = FWD_GFLOP_CONV_LAST / kt * 1e-3
+    if ops.CONV_MODE == 's3':
+        # the kernel issues v_mfma_f32_32x32x16_bf16 (dense peak 2.5 PF); each fp32-accurate MAC costs 6 bf16 MACs, so the
+        # path's own ceiling is 2500/6 = 416.7 algorithmic TFLOP/s and its MFMA-pipe utilisation is 6*achieved/2500
+        return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': S3_CONV_LAST_HBM_BYTES,
+                'executed_bf16_mfma_tflops': round(6 * achieved, 1),
+                'mfma_pipe_utilisation': round(6 * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
+                'path_ceiling_tflops': round(PEAK_BF16_MFMA_TFLOPS / 6, 1),
+                'frac_of_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                'kernel': 'igemm_s3_kernel fwd (3-way bf16 split, 6 bf16 MFMAs per fp32-accurate MAC block), '
+                          'decoder.conv_last.0 3x3 4096->512 @64x64 N=2 (309.24 GFLOP/launch algorithmic, %.3f ms/launch, '
+                          'HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE from profiles/, bytes/launch)' % (kt * 1e3)}
+    return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': F32_CONV_LAST_HBM_BYTES,
+            'kernel': 'igemm_conv_kernel fwd (exact fp32 MFMA), decoder.conv_last.0 3x3 4096->512 @64x64 N=2 '
+                      '(309.24 GFLOP/launch, %.3f ms/launch, HIP events)' % (kt * 1e3)}
 
 
 def cpu_baseline():
@@ -140,23 +196,20 @@ def main():
 
     if rank == 0:
         kt = time_dominant_kernel(dev)
-        achieved = FWD_GFLOP_CONV_LAST / kt * 1e-3
         per_gpu = value / world
         out = {
             'metric': 'train images/sec (whole job) @512x512 bs2/GPU', 'value': round(value, 3), 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[ops_mode()], 'data': 'synthetic',
             'config': {'workload': 'ade20k-resnet50dilated-ppm_deepsup (BASELINE configs[1]): full train step '
                                    '(fwd+NLL loss+bwd+2xSGD), bs 2/GPU 512x512x3, 150 classes, labels 64x64',
                        'global_batch': 2 * world, 'parallelism': 'dp%d' % world,
                        'launch': 'eager' if (args.no_graph or world > 1) else 'hipGraph replay',
+                       'conv_path': ops_mode(),
                        'images_per_sec_per_gpu': round(per_gpu, 3),
                        'step_conv_tflops_per_gpu': round(per_gpu * TRAIN_GFLOP_PER_IMG['resnet50dilated+ppm_deepsup'] * 1e-3, 2),
                        'final_loss': round(lossv, 5)},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
-                         'kernel': 'igemm_conv_kernel fwd, decoder.conv_last.0 3x3 4096->512 @64x64 N=2 '
-                                   '(309.24 GFLOP/launch, %.3f ms/launch, HIP events)' % (kt * 1e3)},
+            'roofline': roofline_entry(kt),
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -61,6 +61,41 @@ int semseg_conv2d_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, fl
 /* [K,R,S,C] -> [C,R,S,K] (T = R*S taps) */
 int semseg_weight_krsc_to_crsk(const float* w, float* wt, int K, int T, int C, void* stream);
 
+/* ---------------- convolution, fp32-accurate on the bf16 MFMA ("s3": 3-way bf16 split, 6 products) -------------
+ * Same call sites as above.  Every fp32 operand is first split into three bf16 planes
+ *     v = v0 + v1 + v2,  v0 = bf16(v), v1 = bf16(v - v0), v2 = bf16(v - v0 - v1)
+ * by semseg_split3; the conv entry points consume ONLY split operands and accumulate the six products of weight
+ * >= 2^-16 in fp32 (error ~2^-23 per product: fp32 class, see csrc/conv_s3.hip).
+ * Split layout: `xs` = bf16 [3][rows][pitch] holding Cp = C rounded up to 32 channels per row (zero filled);
+ * pitch = Cp, or Cp + 128 when Cp*2 bytes is a multiple of 2 KB (L2-channel skew); size = semseg_split3_bytes; 16-byte aligned.
+ *   activations : rows = N*H*W pixels (NHWC)
+ *   weights fwd : rows = K*R*S of the KRSC tensor;  dgrad: rows = C*R*S of the CRSK tensor (semseg_weight_krsc_to_crsk) */
+size_t semseg_split3_bytes(int rows, int C);
+int semseg_split3(const float* x, int x_ld, void* xs, int rows, int C, void* stream);
+/* scratch (bytes) for the three *_s3 conv entry points */
+size_t semseg_conv2d_s3_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
+/* y = conv(x, w) + bias.  xs: split of x [N*H*W][C]; ws: split of w [K*R*S][C]. */
+int semseg_conv2d_fwd_s3(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
+                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* dx = conv^T(dy).  dys: split of dy [N*OH*OW][K]; wts: split of the CRSK weights [C*R*S][K]. */
+int semseg_conv2d_dgrad_s3(const void* dys, const void* wts, float* dx, int dx_ld,
+                           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* dw[k,r,s,c] = sum_m dy[m,k] * x[pix(m,r,s),c].  xs: split of x [N*H*W][C]; dys: split of dy [N*OH*OW][K]. */
+int semseg_conv2d_wgrad_s3(const void* xs, const void* dys, float* dw,
+                           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* Pin the launch plan of one conv geometry (host-side tuner, mit_semseg/tuner.py).  pass: 0 fwd, 1 dgrad, 2 wgrad;
+ * tile: fwd/dgrad 0 = 128x128, 1 = 128x64, 2 = 64x64; wgrad 0 = 128x128, 1 = 64x64; split >= 1 (split-K / split-M factor,
+ * clamped to the k-tile count).  tile < 0 removes the pin (the built-in wave-quantisation heuristic then applies).
+ * semseg_conv2d_s3_workspace_bytes reflects the pinned plans. */
+int semseg_conv2d_s3_set_plan(int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                              int tile, int split);
+/* db[k] = sum_m dy[m,k]  (bias gradient of the classifier convs, models.py:461,463,540) */
+int semseg_bias_grad(const float* dy, int dy_ld, float* db, int M, int K, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 /* ---------------- batch norm (lib/nn/modules/batchnorm.py:56-61 = F.batch_norm) ---------- */
 
 /* scratch (bytes) for bn_stats / bn_bwd_reduce partial sums */

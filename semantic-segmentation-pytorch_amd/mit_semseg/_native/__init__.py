@@ -28,6 +28,14 @@ SIGNATURES = {
     'semseg_conv2d_dgrad': (c_int, [vp, c_int, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
     'semseg_conv2d_wgrad': (c_int, [vp, c_int, vp, c_int, vp, vp] + [c_int] * 10 + [vp, c_sz, vp]),
     'semseg_weight_krsc_to_crsk': (c_int, [vp, vp, c_int, c_int, c_int, vp]),
+    'semseg_split3_bytes': (c_sz, [c_int, c_int]),
+    'semseg_split3': (c_int, [vp, c_int, vp, c_int, c_int, vp]),
+    'semseg_conv2d_s3_workspace_bytes': (c_sz, [c_int] * 10),
+    'semseg_conv2d_fwd_s3': (c_int, [vp, vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
+    'semseg_conv2d_dgrad_s3': (c_int, [vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
+    'semseg_conv2d_wgrad_s3': (c_int, [vp, vp, vp] + [c_int] * 10 + [vp, c_sz, vp]),
+    'semseg_conv2d_s3_set_plan': (c_int, [c_int] * 13),
+    'semseg_bias_grad': (c_int, [vp, c_int, vp, c_int, c_int, vp, c_sz, vp]),
     'semseg_bn_workspace_bytes': (c_sz, [c_int, c_int]),
     'semseg_bn_stats': (c_int, [vp, c_int, c_int, vp, vp, c_sz, vp]),
     'semseg_bn_finalize': (c_int, [vp, c_int, vp, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp]),

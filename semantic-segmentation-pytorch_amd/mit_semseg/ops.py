@@ -10,12 +10,14 @@ train.py:41) is converted once by the nchw_to_nhwc kernel.
 There is no CPU / eager fallback: non-CUDA tensors raise.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _native
+from . import tuner
 
 vp = ctypes.c_void_p
 
@@ -118,8 +120,22 @@ def conv_out_size(h, k, stride, pad, dil):
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
+CONV_MODE = os.environ.get('SEMSEG_CONV', 's3')      # 's3': split-bf16 MFMA kernels (default); 'f32': exact fp32 MFMA kernels
+if CONV_MODE not in ('s3', 'f32'):
+    raise RuntimeError("SEMSEG_CONV must be 's3' or 'f32', got %r" % CONV_MODE)
+
+
+def split3(t, rows, ch, ld):
+    """fp32 rows [rows][ld] (first `ch` columns) -> three bf16 planes (csrc/conv_s3.hip split3_kernel)."""
+    L = _native.lib()
+    out = torch.empty(L.semseg_split3_bytes(rows, ch), dtype=torch.uint8, device=t.device)
+    _native.check(L.semseg_split3(_p(t), ld, _p(out), rows, ch, _st()), 'split3')
+    return out
+
+
 class Conv2dFn(Function):
-    """nn.Conv2d forward/backward (square stride/pad/dilation) on the MFMA implicit-GEMM kernels."""
+    """nn.Conv2d forward/backward (square stride/pad/dilation), exact-fp32 MFMA implicit-GEMM kernels
+    (SEMSEG_CONV=f32; csrc/conv_igemm.hip, conv_wgrad.hip)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil):
@@ -169,8 +185,84 @@ class Conv2dFn(Function):
         return dx, dw, db, None, None, None
 
 
+class Conv2dS3Fn(Function):
+    """nn.Conv2d forward/backward on the bf16 MFMA with fp32-class accuracy: every operand is split into three
+    bf16 planes once (split3) and the six significant partial products are accumulated in fp32
+    (csrc/conv_s3.hip).  The split of the input is kept for the weight gradient; the split of dy is shared by
+    the data and weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        L = _native.lib()
+        x, x_ld = as_nhwc(x.detach())
+        w = krsc(weight.detach())
+        _require_cuda(w, bias)
+        n, c, h, wd = x.shape
+        k, c2, r, s = w.shape
+        if c2 != c:
+            raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (c, c2))
+        oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
+        geom = (n, h, wd, c, k, r, s, stride, pad, dil)
+        y = empty_nhwc(n, k, oh, ow, x.device)
+        xs = split3(x, n * h * wd, c, x_ld)
+        wsp = split3(w, k * r * s, c, c)
+        b = bias.detach() if bias is not None else None
+
+        def launch():
+            ws = workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), x.device)
+            _native.check(L.semseg_conv2d_fwd_s3(_p(xs), _p(wsp), _p(b), _p(y), k, *geom, _p(ws), ws.numel(), _st()),
+                          'conv2d_fwd_s3')
+        tuner.ensure(0, geom, launch)
+        launch()
+        ctx.save_for_backward(xs, w)
+        ctx.geom = geom
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        L = _native.lib()
+        xs, w = ctx.saved_tensors
+        geom = ctx.geom
+        n, h, wd, c, k, r, s, stride, pad, dil = geom
+        oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
+        dev = w.device
+        dy, dy_ld = as_nhwc(dy)
+        dys = split3(dy, n * oh * ow, k, dy_ld)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty((c, r, s, k), device=dev, dtype=torch.float32)
+            _native.check(L.semseg_weight_krsc_to_crsk(_p(w), _p(wt), k, r * s, c, _st()), 'weight_transpose')
+            wts = split3(wt, c * r * s, k, k)
+            dx = empty_nhwc(n, c, h, wd, dev)
+
+            def launch_d():
+                ws = workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), dev)
+                _native.check(L.semseg_conv2d_dgrad_s3(_p(dys), _p(wts), _p(dx), c, *geom, _p(ws), ws.numel(), _st()),
+                              'conv2d_dgrad_s3')
+            tuner.ensure(1, geom, launch_d)
+            launch_d()
+        if ctx.needs_input_grad[1]:
+            dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
+
+            def launch_w():
+                ws = workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), dev)
+                _native.check(L.semseg_conv2d_wgrad_s3(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
+                              'conv2d_wgrad_s3')
+            tuner.ensure(2, geom, launch_w)
+            launch_w()
+            dw = dwb.permute(0, 3, 1, 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((k,), device=dev, dtype=torch.float32)
+            ws = workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), dev)
+            _native.check(L.semseg_bias_grad(_p(dy), dy_ld, _p(db), n * oh * ow, k, _p(ws), ws.numel(), _st()), 'bias_grad')
+        return dx, dw, db, None, None, None
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
-    return Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+    fn = Conv2dS3Fn if CONV_MODE == 's3' else Conv2dFn
+    return fn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
 
 
 # ------------------------------------------------------------------------------------------------

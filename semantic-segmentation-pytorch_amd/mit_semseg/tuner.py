@@ -1,0 +1,110 @@
+"""Host-side launch-plan tuner for the split-bf16 (s3) convolution kernels.
+
+"Measure, don't guess": the best (tile, split-K) of an implicit-GEMM conv on MI355X depends on how the grid
+quantises over 256 CUs x resident-block slots and on L2 behaviour of the particular geometry; the built-in
+heuristic of the library (csrc/conv_s3.hip plan_s3/plan_w3) is within ~25 % of the best plan on average and
+off by 2x on some layers (profiles/r1c_conv_bench_s3_sweep.txt).  The first time a conv geometry is seen
+OUTSIDE hipGraph capture, every candidate plan is timed with HIP events on the real buffers and the winner is
+pinned in the library with semseg_conv2d_s3_set_plan.  Plans only change the fp32 summation order (split-K),
+never the arithmetic.  Disable with SEMSEG_TUNE=0.
+"""
+import os
+
+import torch
+
+from . import _native
+
+ENABLED = os.environ.get('SEMSEG_TUNE', '1') != '0'
+# optional plan cache (JSON): plans tuned by one process are pinned without re-timing by the next (e.g. a profiled run
+# after a tuned run on the same box).  Unset -> no file is read or written.
+CACHE = os.environ.get('SEMSEG_TUNE_CACHE', '')
+_done = {}          # (pass, geom) -> (tile, split, ms)
+_cache_loaded = False
+
+
+def _load_cache():
+    global _cache_loaded
+    _cache_loaded = True
+    if not CACHE or not os.path.exists(CACHE):
+        return
+    import json
+    L = _native.lib()
+    for k, v in json.load(open(CACHE)).items():
+        key = tuple(int(t) for t in k.split(','))
+        _done[key] = tuple(v)
+        if v[0] >= 0:
+            _native.check(L.semseg_conv2d_s3_set_plan(key[0], *key[1:], int(v[0]), int(v[1])), 'set_plan')
+
+
+def _save_cache():
+    if not CACHE:
+        return
+    import json
+    tmp = CACHE + '.tmp.%d' % os.getpid()
+    with open(tmp, 'w') as f:
+        json.dump({','.join(map(str, k)): list(v) for k, v in _done.items()}, f)
+    os.replace(tmp, CACHE)
+_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
+
+
+def _time(launch, reps):
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(reps):
+        launch()
+    en.record()
+    en.synchronize()
+    return st.elapsed_time(en) / reps
+
+
+def tuned_plans():
+    return dict(_done)
+
+
+def ensure(pass_id, geom, launch):
+    """geom = (N,H,W,C,K,R,S,stride,pad,dil); launch() issues the conv of this pass on the current stream."""
+    key = (pass_id,) + tuple(geom)
+    if ENABLED and not _cache_loaded:
+        _load_cache()
+    if not ENABLED or key in _done:
+        return
+    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return                                  # host-logic dry runs (CPU, stubbed ABI) and graph capture: never time
+    L = _native.lib()
+    n, h, w, c, k, r, s, stride, pad, dil = geom
+    oh = (h + 2 * pad - dil * (r - 1) - 1) // stride + 1
+    ow = (w + 2 * pad - dil * (s - 1) - 1) // stride + 1
+    # reduction length in k-tiles (fwd/dgrad: taps x 32-channel chunks; wgrad: 32-pixel chunks)
+    if pass_id == 0:
+        kt = r * s * ((c + 31) // 32)
+    elif pass_id == 1:
+        kt = r * s * ((k + 31) // 32)
+    else:
+        kt = (n * oh * ow + 31) // 32
+    tiles = (0, 1) if pass_id == 2 else (0, 1, 2)
+    best = None
+    try:
+        launch()                                    # heuristic plan first (also warms caches / sizes the workspace)
+        base = _time(launch, 2)
+        best = (-1, 0, base)
+        for tile in tiles:
+            for split in _SPLITS:
+                if split > 1 and kt // split < 4:
+                    break
+                _native.check(L.semseg_conv2d_s3_set_plan(pass_id, *geom, tile, split), 'set_plan')
+                try:
+                    launch()
+                    ms = _time(launch, 2)
+                except RuntimeError:
+                    continue
+                if ms < best[2]:
+                    best = (tile, split, ms)
+                if ms > 3.0 * best[2] and split >= 4:
+                    break
+    finally:
+        if best is None or best[0] < 0:
+            L.semseg_conv2d_s3_set_plan(pass_id, *geom, -1, 0)
+        else:
+            L.semseg_conv2d_s3_set_plan(pass_id, *geom, best[0], best[1])
+    _done[key] = best
+    _save_cache()

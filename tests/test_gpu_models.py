@@ -170,7 +170,7 @@ def test_config1_full_size_vs_oracle():
     torch.cuda.synchronize()
     pred = cap['out'][0].detach().cpu().contiguous()
 
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 32))    # torch CPU convs thrash beyond ~32 threads (203 s at 256)
     e, d = O.clone_sd(enc_sd, True), O.clone_sd(dec_sd, True)
     ref = O.segmentation_forward(e, d, 'resnet50dilated', 'ppm_deepsup', img, lab, training=True, dropout=g['dropout'],
                                  deep_sup_scale=0.4)

@@ -45,9 +45,13 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize('mode', ['s3', 'f32'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
-def test_conv2d_fwd_bwd(case):
+def test_conv2d_fwd_bwd(case, mode, monkeypatch):
+    """both conv families through the autograd op: split-bf16 MFMA (s3, default) and exact-fp32 MFMA (f32),
+    same fp32-class tolerance against a float64 CPU convolution"""
     from mit_semseg import ops
+    monkeypatch.setattr(ops, 'CONV_MODE', mode)
     n, c, h, w, k, ks, stride, pad, dil, bias = case
     g = torch.Generator().manual_seed(hash(case) & 0xffff)
     x = torch.randn(n, c, h, w, generator=g)
@@ -72,9 +76,11 @@ def test_conv2d_fwd_bwd(case):
         assert rel_err(bg.grad, br.grad) < REL, ('bgrad', rel_err(bg.grad, br.grad))
 
 
-def test_conv2d_reads_channel_slice():
+@pytest.mark.parametrize('mode', ['s3', 'f32'])
+def test_conv2d_reads_channel_slice(mode, monkeypatch):
     """x given as a channel slice of a wider NHWC buffer (ld > C), as the concat consumers do"""
     from mit_semseg import ops
+    monkeypatch.setattr(ops, 'CONV_MODE', mode)
     g = torch.Generator().manual_seed(1)
     big = torch.randn(2, 96, 10, 10, generator=g)
     wt = torch.randn(32, 64, 3, 3, generator=g) / 24

@@ -36,7 +36,7 @@ LAYERS = [
 ]
 
 
-def run(layer, which, iters, L, ws):
+def run(layer, which, iters, L, ws, mode='f32'):
     name, n, c, h, w, k, ks, st, pad, dil, _ = layer
     dev = torch.device('cuda:0')
     oh = (h + 2 * pad - dil * (ks - 1) - 1) // st + 1
@@ -51,8 +51,25 @@ def run(layer, which, iters, L, ws):
     s = vp(torch.cuda.current_stream().cuda_stream)
     P = lambda t: vp(t.data_ptr())  # noqa: E731
 
+    if mode == 's3':
+        def split(t, rows, ch):
+            out = torch.empty(L.semseg_split3_bytes(rows, ch), dtype=torch.uint8, device=dev)
+            _native.check(L.semseg_split3(P(t), ch, P(out), rows, ch, s), 'split3')
+            return out
+        xs, wss, wts, dys = split(x, n * h * w, c), split(wt, k * ks * ks, c), split(wtt, c * ks * ks, k), split(dy, n * oh * ow, k)
+
     def call():
-        if which == 'fwd':
+        if mode == 's3':
+            if which == 'fwd':
+                rc = L.semseg_conv2d_fwd_s3(P(xs), P(wss), vp(0), P(y), k, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
+            elif which == 'dgrad':
+                rc = L.semseg_conv2d_dgrad_s3(P(dys), P(wts), P(dx), c, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
+            elif which == 'wgrad':
+                rc = L.semseg_conv2d_wgrad_s3(P(xs), P(dys), P(dw), n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
+            else:   # 'split': the per-conv split traffic of one training step (x once, dy once, w twice)
+                rc = L.semseg_split3(P(x), c, P(xs), n * h * w, c, s) or L.semseg_split3(P(dy), k, P(dys), n * oh * ow, k, s) \
+                    or L.semseg_split3(P(wt), c, P(wss), k * ks * ks, c, s) or L.semseg_split3(P(wtt), k, P(wts), c * ks * ks, k, s)
+        elif which == 'fwd':
             rc = L.semseg_conv2d_fwd(P(x), c, P(wt), vp(0), P(y), k, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
         elif which == 'dgrad':
             rc = L.semseg_conv2d_dgrad(P(dy), k, P(wtt), P(dx), c, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
@@ -79,6 +96,7 @@ def main():
     ap.add_argument('--passes', default='fwd,dgrad,wgrad')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--sweep', action='store_true', help='also try forced tile/split configurations')
+    ap.add_argument('--mode', default='f32', choices=['f32', 's3'], help='exact-fp32 MFMA kernels or the split-bf16 (s3) kernels')
     args = ap.parse_args()
     L = _native.lib()
     ws = torch.empty(1 << 30, dtype=torch.uint8, device='cuda:0')
@@ -88,19 +106,22 @@ def main():
         for which in args.passes.split(','):
             cfgs = [('default', {})]
             if args.sweep:
+                pre = 'SEMSEG_W3' if args.mode == 's3' else 'SEMSEG_WGRAD'
+                pre2 = 'SEMSEG_S3' if args.mode == 's3' else 'SEMSEG_IGEMM'
                 if which == 'wgrad':
-                    cfgs += [('t%d_s%d' % (t, sp), {'SEMSEG_WGRAD_TILE': str(t), 'SEMSEG_WGRAD_SPLIT': str(sp)})
+                    cfgs += [('t%d_s%d' % (t, sp), {pre + '_TILE': str(t), pre + '_SPLIT': str(sp)})
                              for t in (0, 1) for sp in (1, 2, 4, 8, 16)]
-                else:
-                    cfgs += [('t%d_s%d' % (t, sp), {'SEMSEG_IGEMM_TILE': str(t), 'SEMSEG_IGEMM_SPLITK': str(sp)})
+                elif which != 'split':
+                    cfgs += [('t%d_s%d' % (t, sp), {pre2 + '_TILE': str(t), pre2 + '_SPLITK': str(sp)})
                              for t in (0, 1, 2) for sp in (1, 2, 4)]
             res = []
             for cname, env in cfgs:
-                for k in ('SEMSEG_IGEMM_TILE', 'SEMSEG_IGEMM_SPLITK', 'SEMSEG_WGRAD_TILE', 'SEMSEG_WGRAD_SPLIT'):
+                for k in ('SEMSEG_IGEMM_TILE', 'SEMSEG_IGEMM_SPLITK', 'SEMSEG_WGRAD_TILE', 'SEMSEG_WGRAD_SPLIT',
+                          'SEMSEG_S3_TILE', 'SEMSEG_S3_SPLITK', 'SEMSEG_W3_TILE', 'SEMSEG_W3_SPLIT'):
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 try:
-                    ms, tf = run(layer, which, args.iters, L, ws)
+                    ms, tf = run(layer, which, args.iters, L, ws, args.mode)
                     res.append((cname, ms, tf))
                 except RuntimeError as e:
                     res.append((cname, float('nan'), 0.0))

@@ -1,0 +1,117 @@
+"""Correctness sweep of the split-bf16 (s3) convolution entry points through the C ABI against a float64 CPU
+convolution, next to the exact-fp32 MFMA kernels on the same inputs (error unit: max|err| / rms(ref)).
+
+    python tools/s3_check.py            # on the GPU box
+"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd'))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from mit_semseg import _native  # noqa: E402
+
+vp = ctypes.c_void_p
+P = lambda t: vp(t.data_ptr()) if t is not None else vp(0)  # noqa: E731
+
+#        N  C    H   W   K    ks st pad dil bias
+CASES = [
+    (2, 64, 16, 16, 64, 3, 1, 1, 1, False),
+    (2, 256, 16, 16, 256, 3, 1, 2, 2, False),
+    (1, 512, 24, 24, 512, 3, 1, 4, 4, False),
+    (2, 128, 17, 19, 96, 3, 2, 1, 1, False),      # stride 2, odd size, K not multiple of 32
+    (2, 3, 32, 32, 64, 3, 2, 1, 1, False),        # stem
+    (2, 512, 16, 16, 150, 1, 1, 0, 1, True),      # classifier (+bias)
+    (2, 2048, 6, 6, 512, 1, 1, 0, 1, False),      # PPM branch, tiny M
+    (2, 2048, 1, 1, 512, 1, 1, 0, 1, False),
+    (2, 48, 20, 20, 48, 3, 1, 1, 1, False),       # HRNet widths
+    (2, 720, 12, 12, 180, 3, 1, 1, 1, False),
+    (2, 1024, 32, 32, 512, 3, 1, 1, 1, False),    # long K (9216) -> split-K
+]
+
+
+def run_case(L, case, dev):
+    n, c, h, w, k, ks, st, pad, dil, has_bias = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(n, c, h, w, generator=g).relu() * 1.5
+    wt = torch.randn(k, c, ks, ks, generator=g) * (2.0 / (c * ks * ks)) ** 0.5
+    b = torch.randn(k, generator=g) if has_bias else None
+    oh = (h + 2 * pad - dil * (ks - 1) - 1) // st + 1
+    ow = (w + 2 * pad - dil * (ks - 1) - 1) // st + 1
+    dy = torch.randn(n, k, oh, ow, generator=g)
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True) if has_bias else None
+    yd = F.conv2d(xd, wd, bd, st, pad, dil)
+    yd.backward(dy.double())
+    ref = dict(y=yd.detach(), dx=xd.grad, dw=wd.grad, db=bd.grad if has_bias else None)
+
+    s = vp(torch.cuda.current_stream().cuda_stream)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)            # NHWC
+    wg = wt.permute(0, 2, 3, 1).contiguous().to(dev)           # KRSC
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    bg = b.to(dev) if has_bias else None
+    wtg = torch.empty(c, ks, ks, k, device=dev)
+    _native.check(L.semseg_weight_krsc_to_crsk(P(wg), P(wtg), k, ks * ks, c, s), 'transpose')
+    wsb = max(L.semseg_conv2d_s3_workspace_bytes(n, h, w, c, k, ks, ks, st, pad, dil),
+              L.semseg_conv2d_workspace_bytes(n, h, w, c, k, ks, ks, st, pad, dil), 1 << 20)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+
+    def split(t, rows, ch):
+        out = torch.empty(L.semseg_split3_bytes(rows, ch), dtype=torch.uint8, device=dev)
+        _native.check(L.semseg_split3(P(t), ch, P(out), rows, ch, s), 'split3')
+        return out
+
+    xs = split(xg, n * h * w, c)
+    wss = split(wg, k * ks * ks, c)
+    wts = split(wtg, c * ks * ks, k)
+    dys = split(dyg, n * oh * ow, k)
+    res = {}
+    for mode in ('s3', 'f32'):
+        y = torch.full((n, oh, ow, k), float('nan'), device=dev)
+        dx = torch.full((n, h, w, c), float('nan'), device=dev)
+        dw = torch.full((k, ks, ks, c), float('nan'), device=dev)
+        db = torch.full((k,), float('nan'), device=dev) if has_bias else None
+        geo = (n, h, w, c, k, ks, ks, st, pad, dil)
+        if mode == 's3':
+            _native.check(L.semseg_conv2d_fwd_s3(P(xs), P(wss), P(bg), P(y), k, *geo, P(ws), ws.numel(), s), 'fwd_s3')
+            _native.check(L.semseg_conv2d_dgrad_s3(P(dys), P(wts), P(dx), c, *geo, P(ws), ws.numel(), s), 'dgrad_s3')
+            _native.check(L.semseg_conv2d_wgrad_s3(P(xs), P(dys), P(dw), *geo, P(ws), ws.numel(), s), 'wgrad_s3')
+            if has_bias:
+                _native.check(L.semseg_bias_grad(P(dyg), k, P(db), n * oh * ow, k, P(ws), ws.numel(), s), 'bias_grad')
+        else:
+            _native.check(L.semseg_conv2d_fwd(P(xg), c, P(wg), P(bg), P(y), k, *geo, P(ws), ws.numel(), s), 'fwd')
+            _native.check(L.semseg_conv2d_dgrad(P(dyg), k, P(wtg), P(dx), c, *geo, P(ws), ws.numel(), s), 'dgrad')
+            _native.check(L.semseg_conv2d_wgrad(P(xg), c, P(dyg), k, P(dw), P(db), *geo, P(ws), ws.numel(), s), 'wgrad')
+        torch.cuda.synchronize()
+        got = dict(y=y.permute(0, 3, 1, 2), dx=dx.permute(0, 3, 1, 2), dw=dw.permute(0, 3, 1, 2), db=db)
+        for key in ('y', 'dx', 'dw', 'db'):
+            if ref[key] is None:
+                continue
+            r = ref[key]
+            e = (got[key].cpu().double() - r).abs().max().item() / (r.pow(2).mean().sqrt().item() + 1e-30)
+            res[(mode, key)] = e
+    return res
+
+
+def main():
+    L = _native.lib()
+    dev = torch.device('cuda:0')
+    bad = 0
+    for case in CASES:
+        res = run_case(L, case, dev)
+        line = 'N%d C%-4d %2dx%-2d K%-4d k%d s%d p%d d%d b%d |' % case
+        for key in ('y', 'dx', 'dw', 'db'):
+            if ('s3', key) in res:
+                a, b = res[('s3', key)], res[('f32', key)]
+                ok = (a == a) and a < max(4 * b, 3e-6)          # NaN-safe; s3 must be in the fp32 error class
+                bad += 0 if ok else 1
+                line += ' %s s3 %.1e f32 %.1e%s |' % (key, a, b, '' if ok else ' <-- BAD')
+        print(line, flush=True)
+    print('s3_check: %s' % ('OK' if bad == 0 else '%d FAILURES' % bad))
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
