@@ -51,7 +51,7 @@ static bool s3_lookup_plan(int pass, int N, int H, int W, int C, int K, int R, i
 
 extern "C" int semseg_conv2d_s3_set_plan(int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                          int tile, int split) {
-    if (pass < 0 || pass > 2 || tile > 2 || (pass == 2 && tile > 1) || split > 64) return SEMSEG_EINVAL;
+    if (pass < 0 || pass > 2 || tile > 3 || (pass == 2 && tile > 1) || split > 64) return SEMSEG_EINVAL;
     std::lock_guard<std::mutex> lk(g_s3_plans_mu);
     const S3Key key{pass, N, H, W, C, K, R, S, stride, pad, dil};
     if (tile < 0 || split < 1) g_s3_plans.erase(key);
@@ -92,12 +92,18 @@ __device__ __forceinline__ void split3_of(float v, __bf16& h0, __bf16& h1, __bf1
     h2 = (__bf16)r2;
 }
 
+// The three planes are followed by S3_ZERO_TAIL_BYTES of zeros: the LDS-DMA conv kernel points the lanes of padded /
+// out-of-range rows at it (a direct-to-LDS load cannot select a zero afterwards).
+#define S3_ZERO_TAIL_BYTES 256
+
 // one thread = one group of 8 channels of one row: reads 32 B, writes 3 x 16 B
 template <bool VEC>
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int x_ld, uint16_t* __restrict__ out,
                                                      int rows, int C, int Cp, int pitch, size_t plane) {
     const int G = Cp >> 3;
     const size_t total = (size_t)rows * G;
+    if (blockIdx.x == 0 && threadIdx.x < S3_ZERO_TAIL_BYTES / 16)
+        reinterpret_cast<uint4*>(out + 3 * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int row = (int)(idx / G);
         const int g = (int)(idx - (size_t)row * G);
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
 
 extern "C" size_t semseg_split3_bytes(int rows, int C) {
     if (rows <= 0 || C <= 0) return 0;
-    return (size_t)3 * rows * s3_pitch(C) * sizeof(uint16_t);
+    return (size_t)3 * rows * s3_pitch(C) * sizeof(uint16_t) + S3_ZERO_TAIL_BYTES;
 }
 
 extern "C" int semseg_split3(const float* x, int x_ld, void* xs, int rows, int C, void* stream) {
@@ -385,6 +391,233 @@ __global__ __launch_bounds__(256) void igemm_s3_kernel(const S3Params p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the large layers: 256 x 128 x 32 block tile, 8 waves (4 x 2, 64 x 64 each), TWO LDS buffers
+// (2 x 72 KiB) filled by buffer_load_dwordx4 ... lds -- no staging registers, no ds_write pass, and the loads of tile
+// t+1 stay in flight across the barriers while tile t is multiplied (counted s_waitcnt vmcnt, raw s_barrier).
+// The DMA writes M0 + lane*16, i.e. a lane-linear image: one instruction = 16 rows x 64 B of one part, and the XOR
+// swizzle of s3_slot is applied on the SOURCE side (lane l of a 16-row group fetches channel group
+// (l&3) ^ ((l>>4)&3)).  Padded / out-of-range rows fetch the zero tail of the split buffer.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(512) void igemm_s3g_kernel(const S3Params p) {
+    constexpr int NW = 8;                              // waves
+    constexpr int WGN = 2, WGM = NW / WGN;             // wave grid
+    constexpr int WM = BM / WGM, WN = BN / WGN;        // wave tile
+    constexpr int FM = WM / 32, FN = WN / 32;
+    constexpr int AG = BM / 16 / NW;                   // 16-row groups of A per wave
+    constexpr int BG = BN / 16 / NW;
+    constexpr int LPT = 3 * (AG + BG);                 // DMA instructions per wave per tile
+    constexpr int A_BYTES = 3 * BM * 64, B_BYTES = 3 * BN * 64, BUF_BYTES = A_BYTES + B_BYTES;
+    static_assert(AG >= 1 && BG >= 1 && FM >= 1 && FN >= 1, "tile");
+
+    extern __shared__ __align__(16) uint4 smem4[];
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tn = tile % p.tiles_n;
+    const int tm = tile / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int kt_begin = z * p.kt_per_split;
+    const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
+    const int nk = kt_end - kt_begin;
+
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)(6u * p.in_plane + S3_ZERO_TAIL_BYTES),
+                                                                   0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (int)(6u * p.w_plane + S3_ZERO_TAIL_BYTES),
+                                                                   0x00020000);
+    const uint32_t a_zero = 6u * p.in_plane, b_zero = 6u * p.w_plane;      // byte offsets of the zero tails
+    const uint32_t a_plane_b = 2u * p.in_plane, b_plane_b = 2u * p.w_plane;
+
+    // this lane's row inside a 16-row group and its source channel group (pre-swizzled)
+    const int lrow = lane >> 2;
+    const int q = (lane & 3) ^ ((lane >> 4) & 3);
+
+    int a_ih0[AG], a_iw0[AG], a_base[AG];
+    const int HWout = p.Hout * p.Wout;
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        const int m = m0 + (wave + NW * i) * 16 + lrow;
+        if (m < p.M) {
+            const int n = m / HWout;
+            const int rem = m - n * HWout;
+            const int oh = rem / p.Wout;
+            const int ow = rem - oh * p.Wout;
+            a_ih0[i] = oh * p.a + p.off;
+            a_iw0[i] = ow * p.a + p.off;
+            a_base[i] = n * p.Hin * p.Win;
+        } else {
+            a_ih0[i] = -(1 << 28);
+            a_iw0[i] = -(1 << 28);
+            a_base[i] = 0;
+        }
+    }
+    uint32_t b_off[BG];        // byte offset of (row n, tap 0, channel group q) in plane 0, or the zero tail
+    bool b_okv[BG];
+    const uint32_t w_row_b = 2u * (uint32_t)p.T * p.pitch;
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int n = n0 + (wave + NW * i) * 16 + lrow;
+        b_okv[i] = n < p.Cout;
+        b_off[i] = b_okv[i] ? (uint32_t)n * w_row_b + 16u * q : 0u;
+    }
+    uint32_t a_off[AG];
+    bool a_okv[AG];
+    int cur_t = -1;
+    auto set_tap = [&](int t) {
+        const int r = t / p.S;
+        const int s = t - r * p.S;
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            int nh = a_ih0[i] + r * p.step;
+            int nw = a_iw0[i] + s * p.step;
+            bool ok = (nh >= 0) & (nw >= 0);
+            if (p.div > 1) {
+                ok = ok & ((nh % p.div) == 0) & ((nw % p.div) == 0);
+                nh /= p.div;
+                nw /= p.div;
+            }
+            ok = ok & (nh < p.Hin) & (nw < p.Win);
+            a_okv[i] = ok;
+            a_off[i] = ok ? 2u * ((uint32_t)(a_base[i] + nh * p.Win + nw) * (uint32_t)p.pitch) + 16u * q : 0u;
+        }
+    };
+
+    // issue the DMA of k-tile `kt` into LDS buffer `buf` (all lanes fetch the zero tail when kt is out of range)
+    auto issue = [&](int kt, int buf) {
+        const bool live = kt < kt_end;
+        const int ktc = live ? kt : kt_begin;
+        const int t = ktc / p.chunks;
+        const int c0 = (ktc - t * p.chunks) * 32;
+        if (t != cur_t) {          // wave-uniform
+            set_tap(t);
+            cur_t = t;
+        }
+        unsigned char* abuf = smem + buf * BUF_BYTES;
+        unsigned char* bbuf = abuf + A_BYTES;
+        const uint32_t kb_b = 2u * ((uint32_t)t * p.pitch + c0);
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            const bool ok = a_okv[i] && live;
+            const uint32_t o = a_off[i] + 2u * c0;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const uint32_t vo = ok ? o + s * a_plane_b : a_zero;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(abuf + (s * BM + (wave + NW * i) * 16) * 64), 16, vo, 0,
+                                                         0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BG; ++i) {
+            const bool ok = b_okv[i] && live;
+            const uint32_t o = b_off[i] + kb_b;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const uint32_t vo = ok ? o + s * b_plane_b : b_zero;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(bbuf + (s * BN + (wave + NW * i) * 16) * 64), 16, vo, 0,
+                                                         0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31;
+    const int kb = lane >> 5;
+
+    auto compute_tile = [&](int buf) {
+        const uint4* As = reinterpret_cast<const uint4*>(smem + buf * BUF_BYTES);
+        const uint4* Bs = reinterpret_cast<const uint4*>(smem + buf * BUF_BYTES + A_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = 2 * ks + kb;
+            bf16x8 av[FM][3], bv[FN][3];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = wm * WM + i * 32 + frow;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) av[i][s] = *reinterpret_cast<const bf16x8*>(&As[s * BM * 4 + s3_slot(r, ch)]);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = wn * WN + j * 32 + frow;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) bv[j][s] = *reinterpret_cast<const bf16x8*>(&Bs[s * BN * 4 + s3_slot(r, ch)]);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][2], bv[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // pipeline: two tiles in flight.  Every iteration issues exactly LPT DMA instructions per wave (dummy zero-tail
+    // fetches past the end), so "all but the newest LPT have landed" == "tile `it` has landed" for every iteration.
+    issue(kt_begin, 0);
+    issue(kt_begin + 1, 1);
+    for (int it = 0; it < nk; ++it) {
+        const int buf = it & 1;
+        if constexpr (LPT == 9) asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+        else if constexpr (LPT == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        compute_tile(buf);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading `buf`
+        issue(kt_begin + it + 2, buf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S3_MFMA_DRAIN();
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    float* dst;
+    int dst_ld;
+    const bool direct = p.splits == 1;
+    if (direct) {
+        dst = p.out;
+        dst_ld = p.out_ld;
+    } else {
+        dst = p.partial + (size_t)z * p.M * p.Cout;
+        dst_ld = p.Cout;
+    }
+    const int col_l = lane & 31;
+    const int row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + col_l;
+        if (col >= p.Cout) continue;
+        const float bvl = (direct && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
+                if (row < p.M) dst[(size_t)row * dst_ld + col] = acc[i][j][e] + bvl;
+            }
+        }
+    }
+}
+
 // out[m*out_ld + n] = bias[n] + sum_z partial[z][m*Cout + n]   (fixed order => deterministic)
 __global__ void s3_splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                         float* __restrict__ out, int out_ld, int M, int Cout, int splits) {
@@ -416,7 +649,7 @@ static S3Plan plan_s3(int M, int Cout, int Cp, int T, int ov_tile = -1, int ov_s
     S3Plan pl;
     pl.chunks = Cp / 32;
     pl.ktiles = T * pl.chunks;
-    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}};   // the last one is the LDS-DMA kernel (tuner / override only)
     const double tile_cost[3] = {1.0, 0.52, 0.36};  // fitted to the MI355X sweep (profiles/r1c_conv_bench_s3_sweep.txt)
     const int slots[3] = {512, 768, 1280};          // resident blocks: 2 / 3 / 5 per CU
     double best = 1e30;
@@ -440,7 +673,7 @@ static S3Plan plan_s3(int M, int Cout, int Cp, int T, int ov_tile = -1, int ov_s
         }
     }
     const int force_tile = ov_tile >= 0 ? ov_tile : s3_env_int("SEMSEG_S3_TILE", -1);
-    if (force_tile >= 0 && force_tile <= 2) { best_t = force_tile; best_s = 1; }
+    if (force_tile >= 0 && force_tile <= 3) { best_t = force_tile; best_s = 1; }
     const int force_split = ov_split > 0 ? ov_split : s3_env_int("SEMSEG_S3_SPLITK", 0);
     if (force_split > 0) best_s = min(force_split, pl.ktiles);
     pl.BM = cand[best_t][0];
@@ -468,10 +701,27 @@ static int launch_s3(const S3Params& p, hipStream_t st) {
     return 0;
 }
 
+template <int BM, int BN>
+static int launch_s3g(const S3Params& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)2 * 3 * (BM + BN) * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_s3g_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits);
+    hipLaunchKernelGGL((igemm_s3g_kernel<BM, BN>), grid, dim3(512), smem, st, p);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 static int run_s3(S3Params p, size_t in_rows, int ov_tile, int ov_split, void* workspace, size_t workspace_bytes,
                   hipStream_t st) {
     const size_t in_plane = in_rows * p.pitch, w_plane = (size_t)p.Cout * p.T * p.pitch;
-    if (in_plane >= ((size_t)1 << 31) || w_plane >= ((size_t)1 << 31)) return SEMSEG_EINVAL;
+    if (6 * in_plane + S3_ZERO_TAIL_BYTES >= ((size_t)1 << 31) || 6 * w_plane + S3_ZERO_TAIL_BYTES >= ((size_t)1 << 31))
+        return SEMSEG_EINVAL;      // 32-bit byte offsets (buffer descriptors of the LDS-DMA kernel)
     p.in_plane = (uint32_t)in_plane;
     p.w_plane = (uint32_t)w_plane;
     const S3Plan pl = plan_s3(p.M, p.Cout, p.Cp, p.T, ov_tile, ov_split);
@@ -488,7 +738,8 @@ static int run_s3(S3Params p, size_t in_rows, int ov_tile, int ov_split, void* w
         p.partial = (float*)workspace;
     }
     int rc;
-    if (pl.BM == 128 && pl.BN == 128) rc = launch_s3<128, 128>(p, st);
+    if (pl.BM == 256) rc = launch_s3g<256, 128>(p, st);
+    else if (pl.BM == 128 && pl.BN == 128) rc = launch_s3<128, 128>(p, st);
     else if (pl.BM == 128 && pl.BN == 64) rc = launch_s3<128, 64>(p, st);
     else rc = launch_s3<64, 64>(p, st);
     if (rc) return rc;

@@ -81,7 +81,7 @@ def ensure(pass_id, geom, launch):
         kt = r * s * ((k + 31) // 32)
     else:
         kt = (n * oh * ow + 31) // 32
-    tiles = (0, 1) if pass_id == 2 else (0, 1, 2)
+    tiles = (0, 1) if pass_id == 2 else (0, 1, 2, 3)
     best = None
     try:
         launch()                                    # heuristic plan first (also warms caches / sizes the workspace)

@@ -113,7 +113,7 @@ def main():
                              for t in (0, 1) for sp in (1, 2, 4, 8, 16)]
                 elif which != 'split':
                     cfgs += [('t%d_s%d' % (t, sp), {pre2 + '_TILE': str(t), pre2 + '_SPLITK': str(sp)})
-                             for t in (0, 1, 2) for sp in (1, 2, 4)]
+                             for t in (0, 1, 2, 3) for sp in (1, 2, 4)]
             res = []
             for cname, env in cfgs:
                 for k in ('SEMSEG_IGEMM_TILE', 'SEMSEG_IGEMM_SPLITK', 'SEMSEG_WGRAD_TILE', 'SEMSEG_WGRAD_SPLIT',
