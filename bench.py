@@ -33,7 +33,12 @@ F32_CONV_LAST_HBM_BYTES = 1.78e9      # profiles/r1b_pmc_conv_last_fwd_wgrad.txt
 S3_CONV_LAST_HBM_BYTES = None
 
 
-DTYPE = {'s3': 'f32 (fp32 in/out/accumulate; products on the bf16 MFMA via an exact 3-way bf16 split, 6 terms)', 'f32': 'f32'}
+H2_CONV_LAST_HBM_BYTES = None
+DTYPE = {'h2': 'f32 (fp32 in/out/accumulate; products on the fp16 MFMA via a scaled 2-way fp16 split, 3 terms, 2^-22 per product)',
+         's3': 'f32 (fp32 in/out/accumulate; products on the bf16 MFMA via an exact 3-way bf16 split, 6 terms)', 'f32': 'f32'}
+# MFMA products per fp32-accurate MAC block and the issued instruction, per split scheme
+SPLIT_TERMS = {'h2': (3, 'v_mfma_f32_32x32x16_f16', '2-way fp16 split, 3 fp16 MFMAs'),
+               's3': (6, 'v_mfma_f32_32x32x16_bf16', '3-way bf16 split, 6 bf16 MFMAs')}
 
 
 def ops_mode():
@@ -76,13 +81,14 @@ def time_dominant_kernel(dev, iters=10):
     y = torch.empty(n, h, w, k, device=dev)
     st = lambda: vp(torch.cuda.current_stream().cuda_stream)   # noqa: E731
     P = lambda t: vp(t.data_ptr())                              # noqa: E731
-    if ops.CONV_MODE == 's3':
-        xs, wsp = ops.split3(x, n * h * w, c, c), ops.split3(wt, k * 9, c, c)
+    if ops.CONV_MODE in ops.SCHEMES:
+        sch = ops.SCHEMES[ops.CONV_MODE]
+        xs, wsp = sch.split(x, n * h * w, c, c), sch.split(wt, k * 9, c, c)
 
         def launch():
-            ws = ops.workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), dev)
-            _native.check(L.semseg_conv2d_fwd_s3(P(xs), P(wsp), vp(0), P(y), k, *geom, P(ws), ws.numel(), st()), 'fwd_s3')
-        tuner.ensure(0, geom, launch)
+            ws = ops.workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
+            _native.check(sch.fn(L, 'fwd')(P(xs), P(wsp), vp(0), P(y), k, *geom, P(ws), ws.numel(), st()), 'fwd_split')
+        tuner.ensure(ops.CONV_MODE, 0, geom, launch)
     else:
         def launch():
             ws = ops.workspace(L.semseg_conv2d_workspace_bytes(*geom), dev)
@@ -103,18 +109,21 @@ def roofline_entry(kt):
     """bound = MFMA.  `achieved` is ALGORITHMIC conv TFLOP/s (2*MACs of the layer / kernel time)."""
     from mit_semseg import ops
     achieved = FWD_GFLOP_CONV_LAST / kt * 1e-3
-    if ops.CONV_MODE == 's3':
-        # the kernel issues v_mfma_f32_32x32x16_bf16 (dense peak 2.5 PF); each fp32-accurate MAC costs 6 bf16 MACs, so the
-        # path's own ceiling is 2500/6 = 416.7 algorithmic TFLOP/s and its MFMA-pipe utilisation is 6*achieved/2500
+    if ops.CONV_MODE in SPLIT_TERMS:
+        # the kernel issues 16-bit MFMAs (dense peak 2.5 PF); each fp32-accurate MAC costs `terms` 16-bit MACs, so the
+        # path's own ceiling is 2500/terms algorithmic TFLOP/s and its MFMA-pipe utilisation is terms*achieved/2500
+        terms, inst, what = SPLIT_TERMS[ops.CONV_MODE]
+        traffic = H2_CONV_LAST_HBM_BYTES if ops.CONV_MODE == 'h2' else S3_CONV_LAST_HBM_BYTES
         return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': S3_CONV_LAST_HBM_BYTES,
-                'executed_bf16_mfma_tflops': round(6 * achieved, 1),
-                'mfma_pipe_utilisation': round(6 * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
-                'path_ceiling_tflops': round(PEAK_BF16_MFMA_TFLOPS / 6, 1),
+                'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic,
+                'executed_16bit_mfma_tflops': round(terms * achieved, 1),
+                'mfma_pipe_utilisation': round(terms * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
+                'path_ceiling_tflops': round(PEAK_BF16_MFMA_TFLOPS / terms, 1),
                 'frac_of_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                'kernel': 'igemm_s3_kernel fwd (3-way bf16 split, 6 bf16 MFMAs per fp32-accurate MAC block), '
+                'kernel': 'igemm_dma/rs_kernel<%s> fwd (%s per fp32-accurate MAC block, %s), '
                           'decoder.conv_last.0 3x3 4096->512 @64x64 N=2 (309.24 GFLOP/launch algorithmic, %.3f ms/launch, '
-                          'HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE from profiles/, bytes/launch)' % (kt * 1e3)}
+                          'HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE from profiles/, bytes/launch)'
+                          % (ops.CONV_MODE, what, inst, kt * 1e3)}
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': F32_CONV_LAST_HBM_BYTES,
             'kernel': 'igemm_conv_kernel fwd (exact fp32 MFMA), decoder.conv_last.0 3x3 4096->512 @64x64 N=2 '

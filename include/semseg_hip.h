@@ -87,10 +87,33 @@ int semseg_conv2d_wgrad_s3(const void* xs, const void* dys, float* dw,
                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                            void* workspace, size_t workspace_bytes, void* stream);
 /* Pin the launch plan of one conv geometry (host-side tuner, mit_semseg/tuner.py).  pass: 0 fwd, 1 dgrad, 2 wgrad;
- * tile: fwd/dgrad 0 = 128x128, 1 = 128x64, 2 = 64x64; wgrad 0 = 128x128, 1 = 64x64; split >= 1 (split-K / split-M factor,
+ * tile: fwd/dgrad 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 256x128 LDS-DMA; wgrad 0 = 128x128, 1 = 64x64; split >= 1 (split-K / split-M factor,
  * clamped to the k-tile count).  tile < 0 removes the pin (the built-in wave-quantisation heuristic then applies).
  * semseg_conv2d_s3_workspace_bytes reflects the pinned plans. */
 int semseg_conv2d_s3_set_plan(int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                              int tile, int split);
+/* ---------------- convolution, fp32-accurate on the fp16 MFMA ("h2": 2-way fp16 split, 3 products) --------------
+ * Same call sites and argument meaning as the *_s3 family; half the MFMA work.  semseg_split_h2 first finds the
+ * tensor's max |x| (one extra read pass), picks the exponent e with 2^e * max in [2^14, 2^15), and stores
+ *     X = 2^e x = X0 + X1 (+ rho),  X0 = fp16(X), X1 = fp16(X - X0)      |rho| <= max(2^-22 |X|, 2^-40 max|X|)
+ * The conv entry points accumulate X0 W0 + X0 W1 + X1 W0 in fp32 and descale by 2^-(ex+ew) in their epilogue
+ * (per-product error ~2^-21: below the fp32 accumulation noise of any reduction >= 27 terms; csrc/conv_split.hip).
+ * Split layout: fp16 [2][rows][pitch] (pitch as for s3) + 256 B of zeros + a 4352-byte header (int32 e, partial maxima);
+ * size = semseg_split_h2_bytes; 16-byte aligned.  fwd/dgrad tiles for set_plan: 0..3 as s3, 4 = 256x128 LDS-DMA 3-slot
+ * ring, 5 = 256x256 LDS-DMA. */
+size_t semseg_split_h2_bytes(int rows, int C);
+int semseg_split_h2(const float* x, int x_ld, void* xs, int rows, int C, void* stream);
+size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
+int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
+                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int semseg_conv2d_dgrad_h2(const void* dys, const void* wts, float* dx, int dx_ld,
+                           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int semseg_conv2d_wgrad_h2(const void* xs, const void* dys, float* dw,
+                           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int semseg_conv2d_h2_set_plan(int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                               int tile, int split);
 /* db[k] = sum_m dy[m,k]  (bias gradient of the classifier convs, models.py:461,463,540) */
 int semseg_bias_grad(const float* dy, int dy_ld, float* db, int M, int K, void* workspace, size_t workspace_bytes,

@@ -1,0 +1,1455 @@
+// fp32-accurate convolution on the 16-bit MFMA of gfx950 by operand splitting.
+//
+// Why: v_mfma_f32_32x32x2_f32 (exact fp32, conv_igemm.hip) runs at the fp32 VECTOR rate, 157 TFLOP/s --
+// 1/16 of v_mfma_f32_32x32x16_{bf16,f16} (2.5 PFLOP/s).  Two split schemes share every kernel in this file:
+//
+//  s3  (3 x bf16, 6 products; scale free)
+//      a = a0 + a1 + a2,  a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)          (8 + 8 + 8 mantissa bits)
+//      a*b ~ a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0)     dropped terms <= 2^-24 |ab|
+//      ceiling 2.5 PF / 6 = 417 TFLOP/s of fp32-equivalent convolution.
+//
+//  h2  (2 x fp16, 3 products; per-tensor power-of-two scale)
+//      A = 2^e a with e chosen per TENSOR so that max|A| lies in [2^14, 2^15)   (absmax pass, exact scaling)
+//      A = A0 + A1 + rho,  A0 = fp16(A), A1 = fp16(A - A0)                                  (11 + 11 mantissa bits)
+//      |rho| <= 2^-22 |A| for every element >= 2^-18 max|A| (A1 normal); below that A1 is an fp16 subnormal and
+//      |rho| <= 2^-25 = 2^-40 max|A| ABSOLUTE -- error relative to the tensor's large elements, which is what a
+//      dot product sees.
+//      A*B ~ A0 B0 + A0 B1 + A1 B0     dropped A1 B1 <= 2^-22 |AB|; the fp32 accumulator is descaled by
+//      2^-(ea+eb) in the epilogue (exact).  Per-product error <= ~3 * 2^-22, rms ~2e-7: below the ~sqrt(K) 2^-24
+//      rounding noise every fp32 accumulation of K >= 27 products carries (measured: tools/s3_check.py).
+//      ceiling 2.5 PF / 3 = 833 TFLOP/s of fp32-equivalent convolution.
+//
+// Operands are split ONCE per tensor into dense 16-bit planes [NP][rows][pitch] (channels rounded up to 32, zero
+// filled) -- the conv kernels then stream 16-bit data with no conversion work in their main loops.
+// Activations: rows = pixels (NHWC); weights: rows = (k, tap) (KRSC) or (c, tap) (CRSK, for the data gradient).
+//
+// Kernels
+//   split3_kernel / absmax_partial_kernel + split_h2_kernel     fp32 rows -> planes, HBM-bound streaming passes
+//   igemm_rs_kernel     forward AND data-gradient implicit GEMM (tap algebra of conv_igemm.hip), 4 waves,
+//                       register-staged global loads, one LDS buffer; small / odd layers
+//   igemm_dma_kernel    same GEMM for the large layers: 8 waves, LDS filled by buffer_load_dwordx4 ... lds (no
+//                       staging VGPRs, no ds_write), 2-slot (two barriers per k-tile) or 3-slot ring (one barrier
+//                       per k-tile, two tiles in flight)
+//   wgrad_kernel        weight gradient: reduction over pixels = the slow axis of both NHWC operands; tiles are
+//                       staged pixel-major and the MFMA fragments (8 consecutive pixels per lane) are produced by
+//                       the LDS transpose read ds_read_b64_tr_b16
+// Replaces nn.Conv2d at reference resnet.py:18-21,61-66,130; models.py:163,406,448,456-463,519-540;
+// hrnet.py:26-29,188-205,316-338 and its autograd backward.
+#include "common.h"
+#include <stdlib.h>
+#include <array>
+#include <map>
+#include <mutex>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------
+// split schemes
+// ------------------------------------------------------------------------------------------------
+struct SchS3 {
+    static constexpr int ID = 0;
+    static constexpr int NP = 3;
+    static constexpr bool SCALED = false;
+    typedef bf16x8 frag;
+    // smallest terms first
+    static __device__ __forceinline__ void mac(const frag (&a)[3], const frag (&b)[3], f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    }
+};
+
+struct SchH2 {
+    static constexpr int ID = 1;
+    static constexpr int NP = 2;
+    static constexpr bool SCALED = true;
+    typedef f16x8 frag;
+    static __device__ __forceinline__ void mac(const frag (&a)[2], const frag (&b)[2], f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// launch-plan overrides (set by the host-side tuner, mit_semseg/tuner.py): scheme + conv geometry + pass -> (tile, split)
+// ------------------------------------------------------------------------------------------------
+typedef std::array<int, 12> SKey;     // scheme, pass, N, H, W, C, K, R, S, stride, pad, dil
+static std::map<SKey, std::pair<int, int>> g_plans;
+static std::mutex g_plans_mu;
+
+static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                        int* tile, int* split) {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    if (g_plans.empty()) return false;
+    auto it = g_plans.find(SKey{sch, pass, N, H, W, C, K, R, S, stride, pad, dil});
+    if (it == g_plans.end()) return false;
+    *tile = it->second.first;
+    *split = it->second.second;
+    return true;
+}
+
+// fwd/dgrad tiles: 0 = 128x128, 1 = 128x64, 2 = 64x64 (register staged); 3 = 256x128 LDS-DMA 2-slot;
+// h2 only: 4 = 256x128 LDS-DMA 3-slot ring, 5 = 256x256 LDS-DMA 2-slot.  wgrad tiles: 0 = 128x128, 1 = 64x64.
+static int max_tile(int sch, int pass) { return pass == 2 ? 1 : (sch == SchH2::ID ? 5 : 3); }
+
+static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
+                    int split) {
+    if (pass < 0 || pass > 2 || tile > max_tile(sch, pass) || split > 64) return SEMSEG_EINVAL;
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    const SKey key{sch, pass, N, H, W, C, K, R, S, stride, pad, dil};
+    if (tile < 0 || split < 1) g_plans.erase(key);
+    else g_plans[key] = std::make_pair(tile, split);
+    return 0;
+}
+
+extern "C" int semseg_conv2d_s3_set_plan(int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                         int tile, int split) {
+    return set_plan(SchS3::ID, pass, N, H, W, C, K, R, S, stride, pad, dil, tile, split);
+}
+extern "C" int semseg_conv2d_h2_set_plan(int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                         int tile, int split) {
+    return set_plan(SchH2::ID, pass, N, H, W, C, K, R, S, stride, pad, dil, tile, split);
+}
+
+static inline int round_up32(int c) { return (c + 31) & ~31; }
+
+// Row pitch (16-bit elements) of a split plane.  A power-of-two pitch of >= 2 KB walks the gathered rows of an operand
+// tile (128 rows x 64 B) over a fraction of the L2 channels only, so such pitches are skewed by 256 B.
+// SEMSEG_S3_PITCH_PAD overrides the skew (elements; tools/conv_bench.py).
+static int split_pitch(int C) {
+    static int pad = -1;
+    if (pad < 0) {
+        const char* v = getenv("SEMSEG_S3_PITCH_PAD");
+        pad = (v && *v) ? atoi(v) : 128;
+    }
+    const int Cp = round_up32(C);
+    return ((Cp * 2) % 2048 == 0) ? Cp + pad : Cp;
+}
+
+// Wait for the MFMA pipe to retire the last accumulator writes before the epilogue reads them (belt and braces on top of
+// the compiler's own hazard nops: 2 x 16 wait states > the 8-pass latency of v_mfma_f32_32x32x16_*).
+#define S_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+
+// The planes are followed by SPLIT_ZERO_TAIL_BYTES of zeros: the LDS-DMA conv kernel points the lanes of padded /
+// out-of-range rows at it (a direct-to-LDS load cannot select a zero afterwards).  h2 buffers continue with a header:
+// int32 exponent e (the planes hold 2^e * x), then H2_MAX_PARTIALS uint32 partial |x| maxima (bit patterns).
+#define SPLIT_ZERO_TAIL_BYTES 256
+#define H2_MAX_PARTIALS 1024
+#define H2_HDR_BYTES (256 + 4 * H2_MAX_PARTIALS)
+
+template <class SCH>
+static size_t split_bytes(int rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    return (size_t)SCH::NP * rows * split_pitch(C) * sizeof(uint16_t) + SPLIT_ZERO_TAIL_BYTES + (SCH::SCALED ? H2_HDR_BYTES : 0);
+}
+// device address of the exponent word of an h2 split buffer
+static inline const int* h2_exp_ptr(const void* xs, size_t rows, int C) {
+    return reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(xs) +
+                                        (size_t)SchH2::NP * rows * split_pitch(C) * sizeof(uint16_t) + SPLIT_ZERO_TAIL_BYTES);
+}
+
+__device__ __forceinline__ float pow2i(int e) { return __int_as_float((127 + e) << 23); }     // -126 <= e <= 127
+
+// ------------------------------------------------------------------------------------------------
+// split: s3
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split3_of(float v, __bf16& h0, __bf16& h1, __bf16& h2) {
+    h0 = (__bf16)v;
+    const float r1 = v - (float)h0;      // exact
+    h1 = (__bf16)r1;
+    const float r2 = r1 - (float)h1;     // exact
+    h2 = (__bf16)r2;
+}
+
+// one thread = one group of 8 channels of one row: reads 32 B, writes 3 x 16 B
+template <bool VEC>
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int x_ld, uint16_t* __restrict__ out,
+                                                     int rows, int C, int Cp, int pitch, size_t plane) {
+    const int G = Cp >> 3;
+    const size_t total = (size_t)rows * G;
+    if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
+        reinterpret_cast<uint4*>(out + 3 * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int row = (int)(idx / G);
+        const int g = (int)(idx - (size_t)row * G);
+        const int c = g << 3;
+        float v[8];
+        const float* src = x + (size_t)row * x_ld + c;
+        if (VEC && c + 8 <= C) {
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 b = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (c + e < C) ? src[e] : 0.f;
+        }
+        bf16x8 p0, p1, p2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 h0, h1, h2;
+            split3_of(v[e], h0, h1, h2);
+            p0[e] = h0; p1[e] = h1; p2[e] = h2;
+        }
+        const size_t o = (size_t)row * pitch + c;
+        *reinterpret_cast<bf16x8*>(out + o) = p0;
+        *reinterpret_cast<bf16x8*>(out + plane + o) = p1;
+        *reinterpret_cast<bf16x8*>(out + 2 * plane + o) = p2;
+    }
+}
+
+extern "C" size_t semseg_split3_bytes(int rows, int C) { return split_bytes<SchS3>(rows, C); }
+
+extern "C" int semseg_split3(const float* x, int x_ld, void* xs, int rows, int C, void* stream) {
+    if (!x || !xs || rows <= 0 || C <= 0 || x_ld < C) return SEMSEG_EINVAL;
+    const int Cp = round_up32(C), pitch = split_pitch(C);
+    const size_t plane = (size_t)rows * pitch;
+    const size_t total = (size_t)rows * (Cp >> 3);
+    const int blocks = (int)min((size_t)16384, ceil_div_sz(total, 256));
+    const bool vec = (x_ld % 4 == 0) && aligned16(x);
+    if (vec)
+        hipLaunchKernelGGL(split3_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs,
+                           rows, C, Cp, pitch, plane);
+    else
+        hipLaunchKernelGGL(split3_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs,
+                           rows, C, Cp, pitch, plane);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// split: h2 (absmax pass + scaled 2 x fp16 split)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t m) {
+    __shared__ uint32_t red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+// partial[b] = max |x| over the rows x C window, as fp32 bit patterns (monotone for non-negative floats; a NaN sorts
+// above +inf and is handled by h2_exponent)
+template <bool VEC>
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ x, int x_ld, int rows, int C,
+                                                             uint32_t* __restrict__ partial) {
+    const int G = (C + 7) >> 3;
+    const size_t total = (size_t)rows * G;
+    uint32_t m = 0;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int row = (int)(idx / G);
+        const int c = (int)(idx - (size_t)row * G) << 3;
+        const float* src = x + (size_t)row * x_ld + c;
+        if (VEC && c + 8 <= C) {
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 b = *reinterpret_cast<const float4*>(src + 4);
+            m = max(m, max(max(absbits(a.x), absbits(a.y)), max(absbits(a.z), absbits(a.w))));
+            m = max(m, max(max(absbits(b.x), absbits(b.y)), max(absbits(b.z), absbits(b.w))));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c + e < C) m = max(m, absbits(src[e]));
+        }
+    }
+    m = block_max_u32(m);
+    if (threadIdx.x == 0) partial[blockIdx.x] = m;
+}
+
+// exponent e with 2^e * max in [2^14, 2^15); clamped to +-100 (tensors whose max is below 2^-86 keep fewer bits);
+// inf / NaN maxima: e = 0 (they propagate through fp16 as inf / NaN)
+__device__ __forceinline__ int h2_exponent(uint32_t maxbits) {
+    const int ef = (int)(maxbits >> 23);
+    if (ef == 255) return 0;
+    return max(-100, min(100, 141 - ef));
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ x, int x_ld, uint16_t* __restrict__ out,
+                                                       int rows, int C, int Cp, int pitch, size_t plane,
+                                                       const uint32_t* __restrict__ partial, int npartial,
+                                                       int* __restrict__ hdr) {
+    uint32_t m = 0;
+    for (int i = threadIdx.x; i < npartial; i += 256) m = max(m, partial[i]);
+    m = block_max_u32(m);
+    const int ex = h2_exponent(m);
+    const float sc = pow2i(ex);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16) reinterpret_cast<uint4*>(out + 2 * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) hdr[0] = ex;
+    }
+    const int G = Cp >> 3;
+    const size_t total = (size_t)rows * G;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int row = (int)(idx / G);
+        const int c = (int)(idx - (size_t)row * G) << 3;
+        float v[8];
+        const float* src = x + (size_t)row * x_ld + c;
+        if (VEC && c + 8 <= C) {
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 b = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (c + e < C) ? src[e] : 0.f;
+        }
+        f16x8 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float s = v[e] * sc;                  // exact (power of two)
+            const _Float16 h0 = (_Float16)s;
+            const float r = s - (float)h0;              // exact
+            p0[e] = h0;
+            p1[e] = (_Float16)r;
+        }
+        const size_t o = (size_t)row * pitch + c;
+        *reinterpret_cast<f16x8*>(out + o) = p0;
+        *reinterpret_cast<f16x8*>(out + plane + o) = p1;
+    }
+}
+
+extern "C" size_t semseg_split_h2_bytes(int rows, int C) { return split_bytes<SchH2>(rows, C); }
+
+extern "C" int semseg_split_h2(const float* x, int x_ld, void* xs, int rows, int C, void* stream) {
+    if (!x || !xs || rows <= 0 || C <= 0 || x_ld < C) return SEMSEG_EINVAL;
+    const int Cp = round_up32(C), pitch = split_pitch(C);
+    const size_t plane = (size_t)rows * pitch;
+    int* hdr = const_cast<int*>(h2_exp_ptr(xs, (size_t)rows, C));
+    uint32_t* partial = reinterpret_cast<uint32_t*>(hdr) + 64;        // 256 B after the exponent word
+    const bool vec = (x_ld % 4 == 0) && aligned16(x);
+    const size_t total_c = (size_t)rows * ((C + 7) >> 3);
+    const int nb = (int)min((size_t)H2_MAX_PARTIALS, ceil_div_sz(total_c, 1024));     // >= 4 groups per thread
+    if (vec)
+        hipLaunchKernelGGL(absmax_partial_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, x_ld, rows, C, partial);
+    else
+        hipLaunchKernelGGL(absmax_partial_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, x_ld, rows, C, partial);
+    SEMSEG_LAUNCH_CHECK();
+    const size_t total = (size_t)rows * (Cp >> 3);
+    const int blocks = (int)min((size_t)16384, ceil_div_sz(total, 256));
+    if (vec)
+        hipLaunchKernelGGL(split_h2_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs, rows,
+                           C, Cp, pitch, plane, partial, nb, hdr);
+    else
+        hipLaunchKernelGGL(split_h2_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs, rows,
+                           C, Cp, pitch, plane, partial, nb, hdr);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient implicit GEMM on split operands
+// ------------------------------------------------------------------------------------------------
+struct SParams {
+    const uint16_t* in;    // [NP][in_rows][pitch]
+    const uint16_t* wgt;   // [NP][Cout*T][pitch]
+    const int* in_exp;     // h2: exponent words of the two operands
+    const int* w_exp;
+    uint32_t in_plane, w_plane;   // elements per plane (host checks the byte size < 2^31)
+    const float* bias;
+    float* out;
+    float* partial;
+    int Cp, pitch, out_ld;   // Cp: channels padded to 32; pitch: row stride of the split planes (elements)
+    int Hin, Win;
+    int Hout, Wout, Cout;
+    int M;
+    int S, T;
+    int a, off, step, div;
+    int chunks, ktiles, kt_per_split;
+    int tiles_m, tiles_n, splits;
+};
+
+// 2^-(ea+eb) as two factors (each within the normal range; see the header comment of the h2 scheme)
+template <class SCH>
+__device__ __forceinline__ void descale_factors(const int* ea, const int* eb, float& f1, float& f2) {
+    if constexpr (SCH::SCALED) {
+        const int s = *ea + *eb;           // |s| <= 200
+        const int h = s / 2;
+        f1 = pow2i(-h);
+        f2 = pow2i(-(s - h));
+    } else {
+        f1 = 1.f;
+        f2 = 1.f;
+    }
+}
+
+// LDS image of one operand tile: [part][row][4 x 16 B], the 16-byte slot of channel group q of row r stored at
+// q ^ ((r >> 2) & 3): a ds_read_b128 lane group (16 lanes = 16 rows that are distinct mod 16, one q) then covers
+// all 64 banks exactly once, and a ds_write_b128 lane group (8 lanes = 2 whole rows) covers 128 contiguous bytes.
+__device__ __forceinline__ int s_slot(int row, int q) { return row * 4 + (q ^ ((row >> 2) & 3)); }
+
+// epilogue shared by both GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+template <class SCH, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM][FN], int row0, int col0, int z, int lane) {
+    float* dst;
+    int dst_ld;
+    const bool direct = p.splits == 1;
+    if (direct) {
+        dst = p.out;
+        dst_ld = p.out_ld;
+    } else {
+        dst = p.partial + (size_t)z * p.M * p.Cout;
+        dst_ld = p.Cout;
+    }
+    float f1, f2;
+    descale_factors<SCH>(p.in_exp, p.w_exp, f1, f2);
+    const int col_l = lane & 31;
+    const int row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = col0 + j * 32 + col_l;
+        if (col >= p.Cout) continue;
+        const float bvl = (direct && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
+                float v = acc[i][j][e];
+                if constexpr (SCH::SCALED) v = (v * f1) * f2;
+                if (row < p.M) dst[(size_t)row * dst_ld + col] = v + bvl;
+            }
+        }
+    }
+}
+
+template <class SCH, int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
+    constexpr int NP = SCH::NP;
+    typedef typename SCH::frag frag;
+    constexpr int RPP = 64;                 // rows per load pass (256 threads x 16 B = 64 rows x 64 B)
+    constexpr int APASS = BM / RPP, BPASS = BN / RPP;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 32, FN = WN / 32;
+    static_assert(APASS >= 1 && BPASS >= 1 && FM >= 1 && FN >= 1, "tile too small");
+
+    extern __shared__ __align__(16) uint4 smem4[];
+    uint4* As = smem4;                       // [NP][BM][4]
+    uint4* Bs = smem4 + NP * BM * 4;         // [NP][BN][4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tn = tile % p.tiles_n;
+    const int tm = tile / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int kt_begin = z * p.kt_per_split;
+    const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
+
+    const int q = tid & 3;
+    const int lrow = tid >> 2;
+
+    int a_ih0[APASS], a_iw0[APASS], a_base[APASS];
+    const int HWout = p.Hout * p.Wout;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+        const int m = m0 + lrow + i * RPP;
+        if (m < p.M) {
+            const int n = m / HWout;
+            const int rem = m - n * HWout;
+            const int oh = rem / p.Wout;
+            const int ow = rem - oh * p.Wout;
+            a_ih0[i] = oh * p.a + p.off;
+            a_iw0[i] = ow * p.a + p.off;
+            a_base[i] = n * p.Hin * p.Win;
+        } else {
+            a_ih0[i] = -(1 << 28);
+            a_iw0[i] = -(1 << 28);
+            a_base[i] = 0;
+        }
+    }
+
+    uint4 ra[APASS][NP], rb[BPASS][NP];
+    const uint32_t w_row = (uint32_t)p.T * p.pitch;
+    uint32_t a_off[APASS], b_off[BPASS];
+    uint32_t a_ok = 0, b_ok = 0;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        const int n = n0 + lrow + i * RPP;
+        const bool ok = n < p.Cout;
+        b_off[i] = ok ? (uint32_t)n * w_row + 8u * q : 0u;
+        b_ok |= (ok ? 1u : 0u) << i;
+    }
+    int cur_t = -1;
+    auto set_tap = [&](int t) {
+        const int r = t / p.S;
+        const int s = t - r * p.S;
+        a_ok = 0;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            int nh = a_ih0[i] + r * p.step;
+            int nw = a_iw0[i] + s * p.step;
+            bool ok = (nh >= 0) & (nw >= 0);
+            if (p.div > 1) {
+                ok = ok & ((nh % p.div) == 0) & ((nw % p.div) == 0);
+                nh /= p.div;
+                nw /= p.div;
+            }
+            ok = ok & (nh < p.Hin) & (nw < p.Win);
+            a_off[i] = ok ? (uint32_t)(a_base[i] + nh * p.Win + nw) * (uint32_t)p.pitch + 8u * q : 0u;
+            a_ok |= (ok ? 1u : 0u) << i;
+        }
+    };
+
+    // unconditional loads from clamped in-bounds offsets + select (see conv_igemm.hip on why not `cond ? load : 0`)
+    auto load_tile = [&](int kt) {
+        const int t = kt / p.chunks;
+        const int c0 = (kt - t * p.chunks) * 32;
+        if (t != cur_t) {          // wave-uniform
+            set_tap(t);
+            cur_t = t;
+        }
+        const uint32_t koff = (uint32_t)t * p.pitch + c0;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const bool ok = (a_ok >> i) & 1u;
+            const uint32_t o = ok ? a_off[i] + c0 : 0u;
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p.in + (size_t)s * p.in_plane + o);
+                ra[i][s] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            const bool ok = (b_ok >> i) & 1u;
+            const uint32_t o = ok ? b_off[i] + koff : 0u;
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p.wgt + (size_t)s * p.w_plane + o);
+                rb[i][s] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i)
+#pragma unroll
+            for (int s = 0; s < NP; ++s) As[s * BM * 4 + s_slot(lrow + i * RPP, q)] = ra[i][s];
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i)
+#pragma unroll
+            for (int s = 0; s < NP; ++s) Bs[s * BN * 4 + s_slot(lrow + i * RPP, q)] = rb[i][s];
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31;
+    const int kb = lane >> 5;
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile();
+    }
+    __syncthreads();
+
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = 2 * ks + kb;
+            frag av[FM][NP], bv[FN][NP];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = wm * WM + i * 32 + frow;
+#pragma unroll
+                for (int s = 0; s < NP; ++s) av[i][s] = *reinterpret_cast<const frag*>(&As[s * BM * 4 + s_slot(r, ch)]);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = wn * WN + j * 32 + frow;
+#pragma unroll
+                for (int s = 0; s < NP; ++s) bv[j][s] = *reinterpret_cast<const frag*>(&Bs[s * BN * 4 + s_slot(r, ch)]);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) SCH::mac(av[i], bv[j], acc[i][j]);
+        }
+    };
+
+    // steady state: tile kt is in LDS, tile kt+1 travels global -> registers behind the MFMAs of tile kt;
+    // the last tile is peeled so that the loop body is branch free (keeps the accumulators in AGPRs)
+    for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {
+        load_tile(kt + 1);
+        compute_tile();
+        __syncthreads();                        // every wave is done reading tile kt
+        store_tile();
+        __syncthreads();
+    }
+    if (kt_begin < kt_end) compute_tile();
+    S_MFMA_DRAIN();
+    gemm_epilogue<SCH, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant for the large layers: BM x BN x 32 block tile, 8 waves (WGM x WGN), NSLOT LDS buffers filled by
+// buffer_load_dwordx4 ... lds -- no staging registers, no ds_write pass; the loads of the next tile(s) stay in flight
+// across the barriers while the current tile is multiplied (counted s_waitcnt vmcnt, raw s_barrier).
+// The DMA writes M0 + lane*16, i.e. a lane-linear image: one instruction = 16 rows x 64 B of one part, and the XOR
+// swizzle of s_slot is applied on the SOURCE side (lane l of a 16-row group fetches channel group
+// (l&3) ^ ((l>>4)&3)).  Padded / out-of-range rows fetch the zero tail of the split buffer.
+//   NSLOT == 2: wait(tile it) | barrier | multiply slot it&1 | barrier | issue tile it+2 into the slot just read
+//   NSLOT == 3: wait(tile it) | barrier | issue tile it+2 into the slot read in iteration it-1 | multiply slot it%3
+//               (one barrier per k-tile: it proves both "tile it has landed for every wave" and "every wave has
+//                finished reading the slot that is about to be overwritten")
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    // lgkmcnt(0): this wave's LDS reads of the previous tile have returned (free: the MFMAs consumed them) -- the WAR
+    // condition for re-staging that slot right after the barrier (3-slot ring)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
+__global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
+    constexpr int NP = SCH::NP;
+    typedef typename SCH::frag frag;
+    constexpr int NW = 8;                              // waves
+    static_assert(WGM * WGN == NW, "wave grid");
+    constexpr int WM = BM / WGM, WN = BN / WGN;        // wave tile
+    constexpr int FM = WM / 32, FN = WN / 32;
+    constexpr int AG = BM / 16 / NW;                   // 16-row groups of A per wave
+    constexpr int BG = BN / 16 / NW;
+    constexpr int LPT = NP * (AG + BG);                // DMA instructions per wave per tile
+    constexpr int A_BYTES = NP * BM * 64, B_BYTES = NP * BN * 64, BUF_BYTES = A_BYTES + B_BYTES;
+    static_assert(AG >= 1 && BG >= 1 && FM >= 1 && FN >= 1, "tile");
+    static_assert(NSLOT == 2 || NSLOT == 3, "slots");
+    static_assert(2 * LPT < 64, "vmcnt range");
+
+    extern __shared__ __align__(16) uint4 smem4[];
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tn = tile % p.tiles_n;
+    const int tm = tile / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int kt_begin = z * p.kt_per_split;
+    const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
+    const int nk = kt_end - kt_begin;
+
+    const uint32_t a_zero = 2u * NP * p.in_plane, b_zero = 2u * NP * p.w_plane;      // byte offsets of the zero tails
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)(a_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (int)(b_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+    const uint32_t a_plane_b = 2u * p.in_plane, b_plane_b = 2u * p.w_plane;
+
+    // this lane's row inside a 16-row group and its source channel group (pre-swizzled)
+    const int lrow = lane >> 2;
+    const int q = (lane & 3) ^ ((lane >> 4) & 3);
+
+    int a_ih0[AG], a_iw0[AG], a_base[AG];
+    const int HWout = p.Hout * p.Wout;
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        const int m = m0 + (wave + NW * i) * 16 + lrow;
+        if (m < p.M) {
+            const int n = m / HWout;
+            const int rem = m - n * HWout;
+            const int oh = rem / p.Wout;
+            const int ow = rem - oh * p.Wout;
+            a_ih0[i] = oh * p.a + p.off;
+            a_iw0[i] = ow * p.a + p.off;
+            a_base[i] = n * p.Hin * p.Win;
+        } else {
+            a_ih0[i] = -(1 << 28);
+            a_iw0[i] = -(1 << 28);
+            a_base[i] = 0;
+        }
+    }
+    // Per-lane DMA source state.  Every load is issued by all 64 lanes with a plain VGPR offset -- no per-lane branch,
+    // so each wave issues exactly LPT VMEM instructions per tile (the vmcnt accounting below depends on it):
+    //   src = byte offset of (row, tap, channel group q) in plane 0, or the zero tail for padded / out-of-range rows
+    //   msk = all ones for live rows, 0 for dead rows (turns the per-tile / per-plane increments off)
+    uint32_t b_src[BG], b_msk[BG];
+    const uint32_t w_row_b = 2u * (uint32_t)p.T * p.pitch;
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int n = n0 + (wave + NW * i) * 16 + lrow;
+        const bool ok = n < p.Cout;
+        b_src[i] = ok ? (uint32_t)n * w_row_b + 16u * q : b_zero;
+        b_msk[i] = ok ? 0xffffffffu : 0u;
+    }
+    uint32_t a_src[AG], a_msk[AG];
+    int cur_t = -1;
+    auto set_tap = [&](int t) {
+        const int r = t / p.S;
+        const int s = t - r * p.S;
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            int nh = a_ih0[i] + r * p.step;
+            int nw = a_iw0[i] + s * p.step;
+            bool ok = (nh >= 0) & (nw >= 0);
+            if (p.div > 1) {
+                ok = ok & ((nh % p.div) == 0) & ((nw % p.div) == 0);
+                nh /= p.div;
+                nw /= p.div;
+            }
+            ok = ok & (nh < p.Hin) & (nw < p.Win);
+            a_src[i] = ok ? 2u * ((uint32_t)(a_base[i] + nh * p.Win + nw) * (uint32_t)p.pitch) + 16u * q : a_zero;
+            a_msk[i] = ok ? 0xffffffffu : 0u;
+        }
+    };
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem + (uint32_t)wave * 1024u;   // this wave's first 16-row group
+    // issue the DMA of k-tile `kt` into LDS slot `slot` (every lane fetches the zero tail when kt is out of range)
+    auto issue = [&](int kt, int slot) {
+        const uint32_t abuf = lds0 + (uint32_t)slot * BUF_BYTES;
+        const uint32_t bbuf = abuf + A_BYTES;
+        if (kt < kt_end) {                  // wave-uniform
+            const int t = kt / p.chunks;
+            const int c0 = (kt - t * p.chunks) * 32;
+            if (t != cur_t) {               // wave-uniform
+                set_tap(t);
+                cur_t = t;
+            }
+            const uint32_t ka_b = 2u * (uint32_t)c0;
+            const uint32_t kb_b = 2u * ((uint32_t)t * p.pitch + c0);
+#pragma unroll
+            for (int i = 0; i < AG; ++i)
+#pragma unroll
+                for (int s = 0; s < NP; ++s) {
+                    const uint32_t vo = a_src[i] + ((ka_b + s * a_plane_b) & a_msk[i]);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)(abuf + (s * BM + NW * i * 16) * 64), 16, vo,
+                                                             0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < BG; ++i)
+#pragma unroll
+                for (int s = 0; s < NP; ++s) {
+                    const uint32_t vo = b_src[i] + ((kb_b + s * b_plane_b) & b_msk[i]);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)(bbuf + (s * BN + NW * i * 16) * 64), 16, vo,
+                                                             0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AG; ++i)
+#pragma unroll
+                for (int s = 0; s < NP; ++s)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)(abuf + (s * BM + NW * i * 16) * 64), 16,
+                                                             a_zero, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < BG; ++i)
+#pragma unroll
+                for (int s = 0; s < NP; ++s)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)(bbuf + (s * BN + NW * i * 16) * 64), 16,
+                                                             b_zero, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31;
+    const int kb = lane >> 5;
+
+    auto compute_tile = [&](int slot) {
+        const uint4* As = reinterpret_cast<const uint4*>(smem + slot * BUF_BYTES);
+        const uint4* Bs = reinterpret_cast<const uint4*>(smem + slot * BUF_BYTES + A_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = 2 * ks + kb;
+            frag av[FM][NP], bv[FN][NP];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = wn * WN + j * 32 + frow;
+#pragma unroll
+                for (int s = 0; s < NP; ++s) bv[j][s] = *reinterpret_cast<const frag*>(&Bs[s * BN * 4 + s_slot(r, ch)]);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = wm * WM + i * 32 + frow;
+#pragma unroll
+                for (int s = 0; s < NP; ++s) av[i][s] = *reinterpret_cast<const frag*>(&As[s * BM * 4 + s_slot(r, ch)]);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) SCH::mac(av[i], bv[j], acc[i][j]);
+        }
+    };
+
+    // Every iteration issues exactly LPT DMA instructions per wave (dummy zero-tail fetches past the end), so "all but
+    // the newest LPT have landed" == "tile `it` has landed" at the top of every iteration.
+    issue(kt_begin, 0);
+    issue(kt_begin + 1, 1);
+    if constexpr (NSLOT == 2) {
+        for (int it = 0; it < nk; ++it) {
+            const int slot = it & 1;
+            wait_vm_barrier<LPT>();
+            compute_tile(slot);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading `slot`
+            issue(kt_begin + it + 2, slot);
+        }
+    } else {
+        int slot = 0, fill = 2;
+        for (int it = 0; it < nk; ++it) {
+            wait_vm_barrier<LPT>();
+            issue(kt_begin + it + 2, fill);
+            compute_tile(slot);
+            slot = (slot == 2) ? 0 : slot + 1;
+            fill = (fill == 2) ? 0 : fill + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S_MFMA_DRAIN();
+    gemm_epilogue<SCH, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane);
+}
+
+// out[m*out_ld + n] = bias[n] + sum_z partial[z][m*Cout + n]   (fixed order => deterministic)
+__global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                     float* __restrict__ out, int out_ld, int M, int Cout, int splits) {
+    const size_t total = (size_t)M * Cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / Cout);
+        const int n = (int)(i - (size_t)m * Cout);
+        float s = partial[i];
+        for (int zz = 1; zz < splits; ++zz) s += partial[(size_t)zz * total + i];
+        if (bias) s += bias[n];
+        out[(size_t)m * out_ld + n] = s;
+    }
+}
+
+struct SPlan {
+    int tile, BM, BN;
+    int tiles_m, tiles_n, chunks, ktiles, splits, kt_per_split;
+};
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static const int kTiles[6][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}};
+
+// Launch plan: same wave-quantisation model as plan_igemm (conv_igemm.hip) -- tile x split-K candidates, cost =
+// waves * (k-tiles per block * tile cost + fixed) + split-K slab traffic.  The LDS-DMA tiles (3..5) are chosen by the
+// tuner / overrides only.  Tuning overrides for tools/conv_bench.py: SEMSEG_S3_TILE=0..5, SEMSEG_S3_SPLITK=n
+static SPlan plan_gemm(int sch, int M, int Cout, int Cp, int T, int ov_tile = -1, int ov_split = 0) {
+    SPlan pl;
+    pl.chunks = Cp / 32;
+    pl.ktiles = T * pl.chunks;
+    const double tile_cost[3] = {1.0, 0.52, 0.36};  // fitted to the MI355X sweep (profiles/r1c_conv_bench_s3_sweep.txt)
+    const int slots[3] = {512, 768, 1280};          // resident blocks: 2 / 3 / 5 per CU
+    double best = 1e30;
+    int best_t = 2, best_s = 1;
+    for (int t = 0; t < 3; ++t) {
+        if (Cout <= 64 && kTiles[t][1] > 64) continue;
+        const long tiles = (long)ceil_div(M, kTiles[t][0]) * ceil_div(Cout, kTiles[t][1]);
+        for (int sp = 1; sp <= 16; ++sp) {
+            if (sp > 1 && pl.ktiles / sp < 8) break;
+            const int kps = ceil_div(pl.ktiles, sp);
+            if (ceil_div(pl.ktiles, kps) != sp) continue;
+            const long blocks = tiles * sp;
+            const long rem = blocks % slots[t];
+            const int per_cu = slots[t] / 256;
+            const double frac = rem ? (double)min((long)per_cu, (rem + 255) / 256) / per_cu : 0.0;
+            const double waves = (double)(blocks / slots[t]) + (rem ? 0.35 + 0.65 * frac : 0.0);
+            double time = waves * (kps * tile_cost[t] + 6.0 * tile_cost[t]);
+            // slab write + reduce, in units of one 128x128x32 k-tile on a full chip (~1.6 us)
+            if (sp > 1) time += (double)(sp + 1) * M * Cout * 4.0 / 4.0e12 / 1.6e-6;
+            if (time < best) { best = time; best_t = t; best_s = sp; }
+        }
+    }
+    const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_S3_TILE", -1);
+    if (force_tile >= 0 && force_tile <= max_tile(sch, 0)) { best_t = force_tile; best_s = 1; }
+    const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_S3_SPLITK", 0);
+    if (force_split > 0) best_s = min(force_split, pl.ktiles);
+    pl.tile = best_t;
+    pl.BM = kTiles[best_t][0];
+    pl.BN = kTiles[best_t][1];
+    pl.tiles_m = ceil_div(M, pl.BM);
+    pl.tiles_n = ceil_div(Cout, pl.BN);
+    pl.kt_per_split = ceil_div(pl.ktiles, best_s);
+    pl.splits = ceil_div(pl.ktiles, pl.kt_per_split);
+    return pl;
+}
+
+template <class SCH, int BM, int BN>
+static int launch_rs(const SParams& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)SCH::NP * (BM + BN) * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_rs_kernel<SCH, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits);
+    hipLaunchKernelGGL((igemm_rs_kernel<SCH, BM, BN>), grid, dim3(256), smem, st, p);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
+static int launch_dma(const SParams& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)NSLOT * SCH::NP * (BM + BN) * 64;
+    static_assert(smem <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits);
+    hipLaunchKernelGGL((igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(512), smem, st, p);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <class SCH>
+static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* workspace, size_t workspace_bytes,
+                    hipStream_t st) {
+    const size_t in_plane = in_rows * p.pitch, w_plane = (size_t)p.Cout * p.T * p.pitch;
+    if (2 * SCH::NP * in_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
+        2 * SCH::NP * w_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31))
+        return SEMSEG_EINVAL;      // 32-bit byte offsets (buffer descriptors of the LDS-DMA kernel)
+    p.in_plane = (uint32_t)in_plane;
+    p.w_plane = (uint32_t)w_plane;
+    const SPlan pl = plan_gemm(SCH::ID, p.M, p.Cout, p.Cp, p.T, ov_tile, ov_split);
+    p.chunks = pl.chunks;
+    p.ktiles = pl.ktiles;
+    p.kt_per_split = pl.kt_per_split;
+    p.tiles_m = pl.tiles_m;
+    p.tiles_n = pl.tiles_n;
+    p.splits = pl.splits;
+    p.partial = nullptr;
+    if (pl.splits > 1) {
+        const size_t need = (size_t)pl.splits * p.M * p.Cout * sizeof(float);
+        if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
+        p.partial = (float*)workspace;
+    }
+    int rc = SEMSEG_EINVAL;
+    switch (pl.tile) {
+        case 0: rc = launch_rs<SCH, 128, 128>(p, st); break;
+        case 1: rc = launch_rs<SCH, 128, 64>(p, st); break;
+        case 2: rc = launch_rs<SCH, 64, 64>(p, st); break;
+        case 3: rc = launch_dma<SCH, 256, 128, 4, 2, 2>(p, st); break;
+        case 4:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 128, 4, 2, 3>(p, st);
+            break;
+        case 5:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 256, 2, 4, 2>(p, st);
+            break;
+    }
+    if (rc) return rc;
+    if (pl.splits > 1) {
+        const size_t total = (size_t)p.M * p.Cout;
+        const int blocks = (int)min((size_t)2048, ceil_div_sz(total, 256));
+        hipLaunchKernelGGL(split_gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.out, p.out_ld, p.M,
+                           p.Cout, pl.splits);
+        SEMSEG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+static size_t gemm_workspace_bytes(int sch, int M, int Cout, int Cin, int T, int ov_tile, int ov_split) {
+    const SPlan pl = plan_gemm(sch, M, Cout, round_up32(Cin), T, ov_tile, ov_split);
+    return pl.splits > 1 ? (size_t)pl.splits * M * Cout * sizeof(float) : 0;
+}
+
+static inline int out_dim(int in, int k, int stride, int pad, int dil) {
+    return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+}
+
+template <class SCH>
+static int conv_fwd(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
+                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!xs || !ws || !y || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0 || y_ld < K) return SEMSEG_EINVAL;
+    if (!aligned16(xs) || !aligned16(ws)) return SEMSEG_EINVAL;
+    const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
+    if (OH <= 0 || OW <= 0) return SEMSEG_EINVAL;
+    SParams p = {};
+    p.in = (const uint16_t*)xs; p.wgt = (const uint16_t*)ws; p.bias = bias; p.out = y;
+    p.Cp = round_up32(C); p.pitch = split_pitch(C); p.out_ld = y_ld;
+    p.Hin = H; p.Win = W;
+    p.Hout = OH; p.Wout = OW; p.Cout = K;
+    p.M = N * OH * OW;
+    p.S = S; p.T = R * S;
+    p.a = stride; p.off = -pad; p.step = dil; p.div = 1;
+    if (SCH::SCALED) {
+        p.in_exp = h2_exp_ptr(xs, (size_t)N * H * W, C);
+        p.w_exp = h2_exp_ptr(ws, (size_t)K * R * S, C);
+    }
+    int ov_tile = -1, ov_split = 0;
+    lookup_plan(SCH::ID, 0, N, H, W, C, K, R, S, stride, pad, dil, &ov_tile, &ov_split);
+    return run_gemm<SCH>(p, (size_t)N * H * W, ov_tile, ov_split, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+template <class SCH>
+static int conv_dgrad(const void* dys, const void* wts, float* dx, int dx_ld,
+                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dys || !wts || !dx || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0 || dx_ld < C) return SEMSEG_EINVAL;
+    if (!aligned16(dys) || !aligned16(wts)) return SEMSEG_EINVAL;
+    const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
+    if (OH <= 0 || OW <= 0) return SEMSEG_EINVAL;
+    SParams p = {};
+    p.in = (const uint16_t*)dys; p.wgt = (const uint16_t*)wts; p.bias = nullptr; p.out = dx;
+    p.Cp = round_up32(K); p.pitch = split_pitch(K); p.out_ld = dx_ld;
+    p.Hin = OH; p.Win = OW;
+    p.Hout = H; p.Wout = W; p.Cout = C;
+    p.M = N * H * W;
+    p.S = S; p.T = R * S;
+    p.a = 1; p.off = pad; p.step = -dil; p.div = stride;
+    if (SCH::SCALED) {
+        p.in_exp = h2_exp_ptr(dys, (size_t)N * OH * OW, K);
+        p.w_exp = h2_exp_ptr(wts, (size_t)C * R * S, K);
+    }
+    int ov_tile = -1, ov_split = 0;
+    lookup_plan(SCH::ID, 1, N, H, W, C, K, R, S, stride, pad, dil, &ov_tile, &ov_split);
+    return run_gemm<SCH>(p, (size_t)N * OH * OW, ov_tile, ov_split, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int semseg_conv2d_fwd_s3(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
+                                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_fwd<SchS3>(xs, ws, bias, y, y_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
+}
+extern "C" int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
+                                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_fwd<SchH2>(xs, ws, bias, y, y_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
+}
+extern "C" int semseg_conv2d_dgrad_s3(const void* dys, const void* wts, float* dx, int dx_ld,
+                                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_dgrad<SchS3>(dys, wts, dx, dx_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
+}
+extern "C" int semseg_conv2d_dgrad_h2(const void* dys, const void* wts, float* dx, int dx_ld,
+                                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_dgrad<SchH2>(dys, wts, dx, dx_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bias gradient: db[k] = sum_m dy[m][k]   (two deterministic passes, fp64 combine)
+// ------------------------------------------------------------------------------------------------
+// block = 64 channels x 4 row lanes; grid = (channel groups, row chunks); partial[chunk][k] (fp64)
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, int dy_ld, int M, int K,
+                                                                int rows_per_chunk, double* __restrict__ partial) {
+    __shared__ double red[4][64];
+    const int kx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kx;
+    const int m_begin = blockIdx.y * rows_per_chunk;
+    const int m_end = min(M, m_begin + rows_per_chunk);
+    float s = 0.f;
+    if (k < K)
+        for (int m = m_begin + ry; m < m_end; m += 4) s += dy[(size_t)m * dy_ld + k];
+    red[ry][kx] = (double)s;
+    __syncthreads();
+    if (ry == 0 && k < K) partial[(size_t)blockIdx.y * K + k] = red[0][kx] + red[1][kx] + red[2][kx] + red[3][kx];
+}
+
+__global__ void bias_grad_finish_kernel(const double* __restrict__ partial, int nchunks, int K, float* __restrict__ db) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (int i = 0; i < nchunks; ++i) s += partial[(size_t)i * K + k];
+    db[k] = (float)s;
+}
+
+extern "C" int semseg_bias_grad(const float* dy, int dy_ld, float* db, int M, int K, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    if (!dy || !db || M <= 0 || K <= 0 || dy_ld < K) return SEMSEG_EINVAL;
+    const int nchunks = min(256, ceil_div(M, 64));
+    const int rows_per_chunk = ceil_div(M, nchunks);
+    if (!workspace || workspace_bytes < (size_t)nchunks * K * sizeof(double)) return SEMSEG_EWORKSPACE;
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(ceil_div(K, 64), nchunks), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
+                       M, K, rows_per_chunk, (double*)workspace);
+    SEMSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)workspace, nchunks, K, db);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient on split operands
+//   dw[k][t][c] = sum_m dy[m][k] * x[pix(m,t)][c]
+// One block = one (tap, 128/64 k, 128/64 c) tile over a range of pixels.  Both operand tiles are staged
+// pixel-major ([32 pixels][channels], the HBM layout -> coalesced 16-byte loads); the MFMA wants 8 consecutive
+// PIXELS per lane, which ds_read_b64_tr_b16 delivers: within a 16-lane group lane 4j+q addresses the 4 channels
+// 4q..4q+3 of pixel j, and lane i receives channel i of pixels 0..3 (a 4x16 -> 16x4 transpose in the LDS crossbar).
+// LDS row stride = channels*2 + 64 B: (row j, 16-channel half g, chunk q) -> bank 16j + 8g + 2q, all distinct for
+// the 32 lanes of a half wave.
+// ------------------------------------------------------------------------------------------------
+struct WParams {
+    const uint16_t* xs;    // [NP][N*H*W][xpitch]
+    const uint16_t* dys;   // [NP][M][dypitch]
+    const int* x_exp;      // h2: exponent words
+    const int* dy_exp;
+    uint32_t x_plane, dy_plane;
+    float* dw;             // [K][T][C]
+    float* partial;        // [splits][K*T*C]
+    int Cp, Kp, xpitch, dypitch;
+    int H, W, C;
+    int OH, OW, K;
+    int M;
+    int S, T;
+    int stride, pad, dil;
+    int tiles_k, tiles_c;
+    int m_per_split, splits;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int NP, int BT>
+struct WTile {
+    static constexpr int CPR = BT / 8;            // 16-byte chunks per pixel row
+    static constexpr int RPP = 256 / CPR;         // pixel rows per load pass
+    static constexpr int PASS = 32 / RPP;
+    static constexpr int STRIDE = BT * 2 + 64;    // bytes
+    static constexpr int BYTES = NP * 32 * STRIDE;
+};
+
+template <class SCH, int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
+    constexpr int NP = SCH::NP;
+    typedef typename SCH::frag frag;
+    using TA = WTile<NP, BM>;
+    using TB = WTile<NP, BN>;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 32, FN = WN / 32;
+    static_assert(TA::PASS >= 1 && TB::PASS >= 1 && FM >= 1 && FN >= 1, "tile");
+
+    extern __shared__ __align__(16) unsigned char smem_w[];
+    unsigned char* As = smem_w;                  // dy tile  [NP][32][STRIDE_A]
+    unsigned char* Bs = smem_w + TA::BYTES;      // x tile   [NP][32][STRIDE_B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntiles = p.tiles_k * p.tiles_c * p.T;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int t = tile % p.T;
+    const int tc = (tile / p.T) % p.tiles_c;
+    const int tk = tile / (p.T * p.tiles_c);
+    const int k0 = tk * BM, c0 = tc * BN;
+    const int r = t / p.S, s = t - r * p.S;
+    const int z = blockIdx.y;
+    const int m_begin = z * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+
+    const int qa = tid % TA::CPR, rowa = tid / TA::CPR;
+    const int qb = tid % TB::CPR, rowb = tid / TB::CPR;
+    const bool ka_ok = (k0 + 8 * qa) < p.Kp;
+    const bool cb_ok = (c0 + 8 * qb) < p.Cp;
+    const int HWo = p.OH * p.OW;
+    const float inv_hwo = 1.0f / (float)HWo, inv_ow = 1.0f / (float)p.OW;
+
+    uint4 ra[TA::PASS][NP], rb[TB::PASS][NP];
+    auto load_tile = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < TA::PASS; ++i) {
+            const int m = mt + rowa + i * TA::RPP;
+            const bool ok = (m < m_end) && ka_ok;
+            const uint32_t o = ok ? (uint32_t)m * (uint32_t)p.dypitch + k0 + 8 * qa : 0u;
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p.dys + (size_t)h * p.dy_plane + o);
+                ra[i][h] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TB::PASS; ++i) {
+            const int mr = mt + rowb + i * TB::RPP;
+            const int m = min(mr, p.M - 1);
+            // m -> (n, oh, ow): float-reciprocal division + one correction step (exact for m < 2^24)
+            int n = (int)((float)m * inv_hwo);
+            int rem = m - n * HWo;
+            if (rem < 0) { --n; rem += HWo; } else if (rem >= HWo) { ++n; rem -= HWo; }
+            int oh = (int)((float)rem * inv_ow);
+            int ow = rem - oh * p.OW;
+            if (ow < 0) { --oh; ow += p.OW; } else if (ow >= p.OW) { ++oh; ow -= p.OW; }
+            const int ih = oh * p.stride - p.pad + r * p.dil;
+            const int iw = ow * p.stride - p.pad + s * p.dil;
+            const bool ok = (mr < m_end) & (ih >= 0) & (iw >= 0) & (ih < p.H) & (iw < p.W) & cb_ok;
+            const uint32_t o = ok ? (uint32_t)((n * p.H + ih) * p.W + iw) * (uint32_t)p.xpitch + c0 + 8 * qb : 0u;
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p.xs + (size_t)h * p.x_plane + o);
+                rb[i][h] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < TA::PASS; ++i)
+#pragma unroll
+            for (int h = 0; h < NP; ++h)
+                *reinterpret_cast<uint4*>(As + (h * 32 + rowa + i * TA::RPP) * TA::STRIDE + 16 * qa) = ra[i][h];
+#pragma unroll
+        for (int i = 0; i < TB::PASS; ++i)
+#pragma unroll
+            for (int h = 0; h < NP; ++h)
+                *reinterpret_cast<uint4*>(Bs + (h * 32 + rowb + i * TB::RPP) * TB::STRIDE + 16 * qb) = rb[i][h];
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // transpose-read addressing: lane -> (pixel row within an 8-pixel block, channel offset)
+    const int G = lane >> 4, i16 = lane & 15;
+    const int tr_row = 8 * (G >> 1) + (i16 >> 2);            // + 16*ks + 4*half
+    const int tr_col = 16 * (G & 1) + 4 * (i16 & 3);         // + fragment base channel
+    const unsigned char* a_base = As + tr_row * TA::STRIDE + (wm * WM + tr_col) * 2;
+    const unsigned char* b_base = Bs + tr_row * TB::STRIDE + (wn * WN + tr_col) * 2;
+
+    if (m_begin < m_end) {
+        load_tile(m_begin);
+        store_tile();
+    }
+    __syncthreads();
+
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            frag av[FM][NP], bv[FN][NP];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int h = 0; h < NP; ++h) {
+                    const unsigned char* q0 = a_base + ((h * 32 + 16 * ks) * TA::STRIDE) + i * 64;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * TA::STRIDE));
+                    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    av[i][h] = __builtin_bit_cast(frag, v);
+                }
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int h = 0; h < NP; ++h) {
+                    const unsigned char* q0 = b_base + ((h * 32 + 16 * ks) * TB::STRIDE) + j * 64;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * TB::STRIDE));
+                    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bv[j][h] = __builtin_bit_cast(frag, v);
+                }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) SCH::mac(av[i], bv[j], acc[i][j]);
+        }
+    };
+
+    for (int mt = m_begin; mt + 32 < m_end; mt += 32) {
+        load_tile(mt + 32);
+        compute_tile();
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+    }
+    if (m_begin < m_end) compute_tile();
+    S_MFMA_DRAIN();
+
+    float f1 = 1.f, f2 = 1.f;
+    descale_factors<SCH>(p.x_exp, p.dy_exp, f1, f2);
+    float* dst = (p.splits == 1) ? p.dw : p.partial + (size_t)z * p.K * p.T * p.C;
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int c = c0 + wn * WN + j * 32 + col_l;
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
+                float v = acc[i][j][e];
+                if constexpr (SCH::SCALED) v = (v * f1) * f2;
+                if (k < p.K) dst[((size_t)k * p.T + t) * p.C + c] = v;
+            }
+        }
+    }
+}
+
+__global__ void split_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t total, int splits) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float s = partial[i];
+        for (int z = 1; z < splits; ++z) s += partial[(size_t)z * total + i];
+        dw[i] = s;
+    }
+}
+
+struct WPlan {
+    int BT, tiles_k, tiles_c, splits, m_per_split;
+};
+
+// tuning overrides: SEMSEG_W3_TILE=0 (128x128) | 1 (64x64), SEMSEG_W3_SPLIT=n
+static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_split = 0) {
+    WPlan pl;
+    const int mtiles = ceil_div(M, 32);
+    const int cand[2] = {128, 64};
+    const double tile_cost[2] = {1.0, 0.32};
+    const int slots[2] = {512, 1024};
+    const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_W3_TILE", -1);
+    const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_W3_SPLIT", 0);
+    double best = 1e30;
+    int best_t = 1, best_s = 1;
+    for (int t = 0; t < 2; ++t) {
+        if (force_tile >= 0 && t != force_tile) continue;
+        if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
+        const long tiles = (long)ceil_div(K, cand[t]) * ceil_div(C, cand[t]) * T;
+        for (int sp = 1; sp <= 64; ++sp) {
+            if (force_split > 0 && sp != min(force_split, mtiles)) continue;
+            if (force_split <= 0 && sp > 1 && mtiles / sp < 8) break;
+            const int mps = ceil_div(mtiles, sp);
+            if (ceil_div(mtiles, mps) != sp) continue;
+            const long blocks = tiles * sp;
+            const long rem = blocks % slots[t];
+            const int per_cu = slots[t] / 256;
+            const double frac = rem ? (double)min((long)per_cu, (rem + 255) / 256) / per_cu : 0.0;
+            const double waves = (double)(blocks / slots[t]) + (rem ? 0.35 + 0.65 * frac : 0.0);
+            double time = waves * (mps * tile_cost[t] + 6.0 * tile_cost[t]);
+            if (sp > 1) time += (double)(sp + 1) * K * T * C * 4.0 / 4.0e12 / 1.6e-6;
+            if (time < best) { best = time; best_t = t; best_s = sp; }
+        }
+    }
+    pl.BT = cand[best_t];
+    pl.tiles_k = ceil_div(K, pl.BT);
+    pl.tiles_c = ceil_div(C, pl.BT);
+    pl.m_per_split = ceil_div(mtiles, best_s) * 32;
+    pl.splits = ceil_div(M, pl.m_per_split);
+    return pl;
+}
+
+static size_t wgrad_split_workspace_bytes(int M, int K, int C, int T, int ov_tile, int ov_split) {
+    const WPlan pl = plan_wgrad(M, K, C, T, ov_tile, ov_split);
+    return pl.splits > 1 ? (size_t)pl.splits * K * T * C * sizeof(float) : 0;
+}
+
+template <class SCH, int BT>
+static int launch_wgrad(const WParams& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)2 * WTile<SCH::NP, BT>::BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<SCH, BT, BT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits);
+    hipLaunchKernelGGL((wgrad_kernel<SCH, BT, BT>), grid, dim3(256), smem, st, p);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <class SCH>
+static int conv_wgrad(const void* xs, const void* dys, float* dw,
+                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!xs || !dys || !dw || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0) return SEMSEG_EINVAL;
+    if (!aligned16(xs) || !aligned16(dys)) return SEMSEG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
+    if (OH <= 0 || OW <= 0) return SEMSEG_EINVAL;
+    WParams p = {};
+    p.xs = (const uint16_t*)xs; p.dys = (const uint16_t*)dys; p.dw = dw;
+    p.Cp = round_up32(C); p.Kp = round_up32(K); p.xpitch = split_pitch(C); p.dypitch = split_pitch(K);
+    p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
+    p.M = N * OH * OW;
+    p.S = S; p.T = R * S;
+    p.stride = stride; p.pad = pad; p.dil = dil;
+    const size_t x_plane = (size_t)N * H * W * p.xpitch, dy_plane = (size_t)p.M * p.dypitch;
+    if (x_plane >= ((size_t)1 << 31) || dy_plane >= ((size_t)1 << 31) || p.M >= (1 << 24)) return SEMSEG_EINVAL;
+    p.x_plane = (uint32_t)x_plane; p.dy_plane = (uint32_t)dy_plane;
+    if (SCH::SCALED) {
+        p.x_exp = h2_exp_ptr(xs, (size_t)N * H * W, C);
+        p.dy_exp = h2_exp_ptr(dys, (size_t)p.M, K);
+    }
+    int ov_tile = -1, ov_split = 0;
+    lookup_plan(SCH::ID, 2, N, H, W, C, K, R, S, stride, pad, dil, &ov_tile, &ov_split);
+    const WPlan pl = plan_wgrad(p.M, K, C, p.T, ov_tile, ov_split);
+    p.tiles_k = pl.tiles_k; p.tiles_c = pl.tiles_c;
+    p.m_per_split = pl.m_per_split; p.splits = pl.splits;
+    if (pl.splits > 1) {
+        const size_t need = (size_t)pl.splits * K * p.T * C * sizeof(float);
+        if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
+        p.partial = (float*)workspace;
+    }
+    const int rc = pl.BT == 128 ? launch_wgrad<SCH, 128>(p, st) : launch_wgrad<SCH, 64>(p, st);
+    if (rc) return rc;
+    if (pl.splits > 1) {
+        const size_t total = (size_t)K * p.T * C;
+        const int blocks = (int)min((size_t)2048, ceil_div_sz(total, 256));
+        hipLaunchKernelGGL(split_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, total, pl.splits);
+        SEMSEG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int semseg_conv2d_wgrad_s3(const void* xs, const void* dys, float* dw,
+                                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_wgrad<SchS3>(xs, dys, dw, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
+}
+extern "C" int semseg_conv2d_wgrad_h2(const void* xs, const void* dys, float* dw,
+                                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_wgrad<SchH2>(xs, dys, dw, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
+}
+
+static size_t split_conv_workspace_bytes(int sch, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || dil <= 0) return 0;
+    const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
+    if (OH <= 0 || OW <= 0) return 0;
+    const int T = R * S;
+    int t0 = -1, s0 = 0, t1 = -1, s1 = 0, t2 = -1, s2 = 0;
+    lookup_plan(sch, 0, N, H, W, C, K, R, S, stride, pad, dil, &t0, &s0);
+    lookup_plan(sch, 1, N, H, W, C, K, R, S, stride, pad, dil, &t1, &s1);
+    lookup_plan(sch, 2, N, H, W, C, K, R, S, stride, pad, dil, &t2, &s2);
+    const size_t a = gemm_workspace_bytes(sch, N * OH * OW, K, C, T, t0, s0);      // forward
+    const size_t b = gemm_workspace_bytes(sch, N * H * W, C, K, T, t1, s1);        // dgrad
+    const size_t c = wgrad_split_workspace_bytes(N * OH * OW, K, C, T, t2, s2);    // wgrad
+    const size_t d = (size_t)256 * K * sizeof(double);                    // bias gradient partials
+    size_t m = a > b ? a : b;
+    m = m > c ? m : c;
+    return m > d ? m : d;
+}
+
+extern "C" size_t semseg_conv2d_s3_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                                   int dil) {
+    return split_conv_workspace_bytes(SchS3::ID, N, H, W, C, K, R, S, stride, pad, dil);
+}
+extern "C" size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                                   int dil) {
+    return split_conv_workspace_bytes(SchH2::ID, N, H, W, C, K, R, S, stride, pad, dil);
+}

@@ -120,17 +120,38 @@ def conv_out_size(h, k, stride, pad, dil):
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
-CONV_MODE = os.environ.get('SEMSEG_CONV', 's3')      # 's3': split-bf16 MFMA kernels (default); 'f32': exact fp32 MFMA kernels
-if CONV_MODE not in ('s3', 'f32'):
-    raise RuntimeError("SEMSEG_CONV must be 's3' or 'f32', got %r" % CONV_MODE)
+# 'h2': 2-way fp16 split, 3 MFMA products (default); 's3': 3-way bf16 split, 6 products; 'f32': exact fp32 MFMA kernels
+CONV_MODE = os.environ.get('SEMSEG_CONV', 'h2')
+if CONV_MODE not in ('h2', 's3', 'f32'):
+    raise RuntimeError("SEMSEG_CONV must be 'h2', 's3' or 'f32', got %r" % CONV_MODE)
+
+
+class SplitScheme:
+    """Entry points of one operand-split convolution family of the C ABI (csrc/conv_split.hip)."""
+
+    def __init__(self, name, split, tag):
+        self.name, self._split, self._tag = name, split, tag
+
+    def fn(self, L, what):
+        if what in ('bytes', 'split'):
+            return getattr(L, 'semseg_%s%s' % (self._split, '_bytes' if what == 'bytes' else ''))
+        if what in ('workspace_bytes', 'set_plan'):
+            return getattr(L, 'semseg_conv2d_%s_%s' % (self._tag, what))
+        return getattr(L, 'semseg_conv2d_%s_%s' % (what, self._tag))          # fwd / dgrad / wgrad
+
+    def split(self, t, rows, ch, ld):
+        """fp32 rows [rows][ld] (first `ch` columns) -> 16-bit planes of this scheme."""
+        L = _native.lib()
+        out = torch.empty(self.fn(L, 'bytes')(rows, ch), dtype=torch.uint8, device=t.device)
+        _native.check(self.fn(L, 'split')(_p(t), ld, _p(out), rows, ch, _st()), self._split)
+        return out
+
+
+SCHEMES = {'s3': SplitScheme('s3', 'split3', 's3'), 'h2': SplitScheme('h2', 'split_h2', 'h2')}
 
 
 def split3(t, rows, ch, ld):
-    """fp32 rows [rows][ld] (first `ch` columns) -> three bf16 planes (csrc/conv_s3.hip split3_kernel)."""
-    L = _native.lib()
-    out = torch.empty(L.semseg_split3_bytes(rows, ch), dtype=torch.uint8, device=t.device)
-    _native.check(L.semseg_split3(_p(t), ld, _p(out), rows, ch, _st()), 'split3')
-    return out
+    return SCHEMES['s3'].split(t, rows, ch, ld)
 
 
 class Conv2dFn(Function):
@@ -185,15 +206,16 @@ class Conv2dFn(Function):
         return dx, dw, db, None, None, None
 
 
-class Conv2dS3Fn(Function):
-    """nn.Conv2d forward/backward on the bf16 MFMA with fp32-class accuracy: every operand is split into three
-    bf16 planes once (split3) and the six significant partial products are accumulated in fp32
-    (csrc/conv_s3.hip).  The split of the input is kept for the weight gradient; the split of dy is shared by
-    the data and weight gradients."""
+class Conv2dSplitFn(Function):
+    """nn.Conv2d forward/backward on the 16-bit MFMA with fp32-class accuracy: every operand is split into 16-bit
+    planes once (h2: 2 x fp16 with a per-tensor power-of-two scale, 3 products; s3: 3 x bf16, 6 products) and the
+    significant partial products are accumulated in fp32 (csrc/conv_split.hip).  The split of the input is kept
+    for the weight gradient; the split of dy is shared by the data and weight gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil):
+    def forward(ctx, x, weight, bias, stride, pad, dil, scheme):
         L = _native.lib()
+        sch = SCHEMES[scheme]
         x, x_ld = as_nhwc(x.detach())
         w = krsc(weight.detach())
         _require_cuda(w, bias)
@@ -204,19 +226,20 @@ class Conv2dS3Fn(Function):
         oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
         geom = (n, h, wd, c, k, r, s, stride, pad, dil)
         y = empty_nhwc(n, k, oh, ow, x.device)
-        xs = split3(x, n * h * wd, c, x_ld)
-        wsp = split3(w, k * r * s, c, c)
+        xs = sch.split(x, n * h * wd, c, x_ld)
+        wsp = sch.split(w, k * r * s, c, c)
         b = bias.detach() if bias is not None else None
 
         def launch():
-            ws = workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), x.device)
-            _native.check(L.semseg_conv2d_fwd_s3(_p(xs), _p(wsp), _p(b), _p(y), k, *geom, _p(ws), ws.numel(), _st()),
-                          'conv2d_fwd_s3')
-        tuner.ensure(0, geom, launch)
+            ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), x.device)
+            _native.check(sch.fn(L, 'fwd')(_p(xs), _p(wsp), _p(b), _p(y), k, *geom, _p(ws), ws.numel(), _st()),
+                          'conv2d_fwd_' + scheme)
+        tuner.ensure(scheme, 0, geom, launch)
         launch()
         ctx.save_for_backward(xs, w)
         ctx.geom = geom
         ctx.has_bias = bias is not None
+        ctx.scheme = scheme
         return y
 
     @staticmethod
@@ -225,44 +248,47 @@ class Conv2dS3Fn(Function):
         L = _native.lib()
         xs, w = ctx.saved_tensors
         geom = ctx.geom
+        scheme = ctx.scheme
+        sch = SCHEMES[scheme]
         n, h, wd, c, k, r, s, stride, pad, dil = geom
         oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
         dev = w.device
         dy, dy_ld = as_nhwc(dy)
-        dys = split3(dy, n * oh * ow, k, dy_ld)
+        dys = sch.split(dy, n * oh * ow, k, dy_ld)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = torch.empty((c, r, s, k), device=dev, dtype=torch.float32)
             _native.check(L.semseg_weight_krsc_to_crsk(_p(w), _p(wt), k, r * s, c, _st()), 'weight_transpose')
-            wts = split3(wt, c * r * s, k, k)
+            wts = sch.split(wt, c * r * s, k, k)
             dx = empty_nhwc(n, c, h, wd, dev)
 
             def launch_d():
-                ws = workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), dev)
-                _native.check(L.semseg_conv2d_dgrad_s3(_p(dys), _p(wts), _p(dx), c, *geom, _p(ws), ws.numel(), _st()),
-                              'conv2d_dgrad_s3')
-            tuner.ensure(1, geom, launch_d)
+                ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
+                _native.check(sch.fn(L, 'dgrad')(_p(dys), _p(wts), _p(dx), c, *geom, _p(ws), ws.numel(), _st()),
+                              'conv2d_dgrad_' + scheme)
+            tuner.ensure(scheme, 1, geom, launch_d)
             launch_d()
         if ctx.needs_input_grad[1]:
             dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
 
             def launch_w():
-                ws = workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), dev)
-                _native.check(L.semseg_conv2d_wgrad_s3(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
-                              'conv2d_wgrad_s3')
-            tuner.ensure(2, geom, launch_w)
+                ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
+                _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
+                              'conv2d_wgrad_' + scheme)
+            tuner.ensure(scheme, 2, geom, launch_w)
             launch_w()
             dw = dwb.permute(0, 3, 1, 2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty((k,), device=dev, dtype=torch.float32)
-            ws = workspace(L.semseg_conv2d_s3_workspace_bytes(*geom), dev)
+            ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
             _native.check(L.semseg_bias_grad(_p(dy), dy_ld, _p(db), n * oh * ow, k, _p(ws), ws.numel(), _st()), 'bias_grad')
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
-    fn = Conv2dS3Fn if CONV_MODE == 's3' else Conv2dFn
-    return fn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+    if CONV_MODE == 'f32':
+        return Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+    return Conv2dSplitFn.apply(x, weight, bias, int(stride), int(padding), int(dilation), CONV_MODE)
 
 
 # ------------------------------------------------------------------------------------------------

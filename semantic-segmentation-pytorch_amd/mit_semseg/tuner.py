@@ -1,11 +1,11 @@
-"""Host-side launch-plan tuner for the split-bf16 (s3) convolution kernels.
+"""Host-side launch-plan tuner for the operand-split (h2 / s3) convolution kernels.
 
 "Measure, don't guess": the best (tile, split-K) of an implicit-GEMM conv on MI355X depends on how the grid
 quantises over 256 CUs x resident-block slots and on L2 behaviour of the particular geometry; the built-in
-heuristic of the library (csrc/conv_s3.hip plan_s3/plan_w3) is within ~25 % of the best plan on average and
+heuristic of the library (csrc/conv_split.hip plan_gemm/plan_wgrad) is within ~25 % of the best plan on average and
 off by 2x on some layers (profiles/r1c_conv_bench_s3_sweep.txt).  The first time a conv geometry is seen
 OUTSIDE hipGraph capture, every candidate plan is timed with HIP events on the real buffers and the winner is
-pinned in the library with semseg_conv2d_s3_set_plan.  Plans only change the fp32 summation order (split-K),
+pinned in the library with semseg_conv2d_{h2,s3}_set_plan.  Plans only change the fp32 summation order (split-K),
 never the arithmetic.  Disable with SEMSEG_TUNE=0.
 """
 import os
@@ -18,7 +18,7 @@ ENABLED = os.environ.get('SEMSEG_TUNE', '1') != '0'
 # optional plan cache (JSON): plans tuned by one process are pinned without re-timing by the next (e.g. a profiled run
 # after a tuned run on the same box).  Unset -> no file is read or written.
 CACHE = os.environ.get('SEMSEG_TUNE_CACHE', '')
-_done = {}          # (pass, geom) -> (tile, split, ms)
+_done = {}          # (scheme, pass, geom) -> (tile, split, ms)
 _cache_loaded = False
 
 
@@ -30,10 +30,11 @@ def _load_cache():
     import json
     L = _native.lib()
     for k, v in json.load(open(CACHE)).items():
-        key = tuple(int(t) for t in k.split(','))
+        parts = k.split(',')
+        key = (parts[0],) + tuple(int(t) for t in parts[1:])
         _done[key] = tuple(v)
         if v[0] >= 0:
-            _native.check(L.semseg_conv2d_s3_set_plan(key[0], *key[1:], int(v[0]), int(v[1])), 'set_plan')
+            _native.check(_set_plan(L, key[0])(key[1], *key[2:], int(v[0]), int(v[1])), 'set_plan')
 
 
 def _save_cache():
@@ -45,6 +46,17 @@ def _save_cache():
         json.dump({','.join(map(str, k)): list(v) for k, v in _done.items()}, f)
     os.replace(tmp, CACHE)
 _SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
+# fwd/dgrad tile ids per scheme (csrc/conv_split.hip): 0..2 register staged, 3 = 256x128 LDS-DMA, h2 only: 4 = 256x128
+# 3-slot ring, 5 = 256x256.  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).
+_TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5)}
+_ALLOW = os.environ.get('SEMSEG_TUNE_TILES', '')
+if _ALLOW:
+    _allow = tuple(int(t) for t in _ALLOW.split(','))
+    _TILES = {k: tuple(t for t in v if t in _allow) for k, v in _TILES.items()}
+
+
+def _set_plan(L, scheme):
+    return getattr(L, 'semseg_conv2d_%s_set_plan' % scheme)
 
 
 def _time(launch, reps):
@@ -61,9 +73,10 @@ def tuned_plans():
     return dict(_done)
 
 
-def ensure(pass_id, geom, launch):
-    """geom = (N,H,W,C,K,R,S,stride,pad,dil); launch() issues the conv of this pass on the current stream."""
-    key = (pass_id,) + tuple(geom)
+def ensure(scheme, pass_id, geom, launch):
+    """scheme = 'h2' | 's3'; geom = (N,H,W,C,K,R,S,stride,pad,dil); launch() issues the conv of this pass on the
+    current stream."""
+    key = (scheme, pass_id) + tuple(geom)
     if ENABLED and not _cache_loaded:
         _load_cache()
     if not ENABLED or key in _done:
@@ -81,7 +94,8 @@ def ensure(pass_id, geom, launch):
         kt = r * s * ((k + 31) // 32)
     else:
         kt = (n * oh * ow + 31) // 32
-    tiles = (0, 1) if pass_id == 2 else (0, 1, 2, 3)
+    tiles = (0, 1) if pass_id == 2 else _TILES[scheme]
+    set_plan = _set_plan(L, scheme)
     best = None
     try:
         launch()                                    # heuristic plan first (also warms caches / sizes the workspace)
@@ -91,7 +105,7 @@ def ensure(pass_id, geom, launch):
             for split in _SPLITS:
                 if split > 1 and kt // split < 4:
                     break
-                _native.check(L.semseg_conv2d_s3_set_plan(pass_id, *geom, tile, split), 'set_plan')
+                _native.check(set_plan(pass_id, *geom, tile, split), 'set_plan')
                 try:
                     launch()
                     ms = _time(launch, 2)
@@ -103,8 +117,8 @@ def ensure(pass_id, geom, launch):
                     break
     finally:
         if best is None or best[0] < 0:
-            L.semseg_conv2d_s3_set_plan(pass_id, *geom, -1, 0)
+            set_plan(pass_id, *geom, -1, 0)
         else:
-            L.semseg_conv2d_s3_set_plan(pass_id, *geom, best[0], best[1])
+            set_plan(pass_id, *geom, best[0], best[1])
     _done[key] = best
     _save_cache()

@@ -45,11 +45,11 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('mode', ['s3', 'f32'])
+@pytest.mark.parametrize('mode', ['h2', 's3', 'f32'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
 def test_conv2d_fwd_bwd(case, mode, monkeypatch):
-    """both conv families through the autograd op: split-bf16 MFMA (s3, default) and exact-fp32 MFMA (f32),
-    same fp32-class tolerance against a float64 CPU convolution"""
+    """all conv families through the autograd op: split-fp16 MFMA (h2, default), split-bf16 MFMA (s3) and exact-fp32
+    MFMA (f32), same fp32-class tolerance against a float64 CPU convolution"""
     from mit_semseg import ops
     monkeypatch.setattr(ops, 'CONV_MODE', mode)
     n, c, h, w, k, ks, stride, pad, dil, bias = case
@@ -76,7 +76,7 @@ def test_conv2d_fwd_bwd(case, mode, monkeypatch):
         assert rel_err(bg.grad, br.grad) < REL, ('bgrad', rel_err(bg.grad, br.grad))
 
 
-@pytest.mark.parametrize('mode', ['s3', 'f32'])
+@pytest.mark.parametrize('mode', ['h2', 's3', 'f32'])
 def test_conv2d_reads_channel_slice(mode, monkeypatch):
     """x given as a channel slice of a wider NHWC buffer (ld > C), as the concat consumers do"""
     from mit_semseg import ops

@@ -45,7 +45,7 @@ CONFIGS = [('resnet18dilated', 'ppm_deepsup', 512, 0.4, 8, 64), ('resnet50dilate
            ('resnet18dilated', 'c1_deepsup', 512, 0.4, 8, 64), ('resnet18dilated', 'ppm', 512, None, 8, 64)]
 
 
-@pytest.mark.parametrize('mode', ['s3', 'f32'])
+@pytest.mark.parametrize('mode', ['h2', 's3', 'f32'])
 @pytest.mark.parametrize('cfg', CONFIGS, ids=lambda c: c[0] + '+' + c[1])
 def test_train_step_host_logic(stub, cfg, mode, monkeypatch):
     from mit_semseg import ops
@@ -70,8 +70,10 @@ def test_train_step_host_logic(stub, cfg, mode, monkeypatch):
         assert p.grad is not None, n
         assert p.grad.shape == p.shape and p.grad.stride() == p.stride(), n
     names = set(stub.calls)
-    conv = ('semseg_conv2d_fwd', 'semseg_conv2d_dgrad', 'semseg_conv2d_wgrad') if mode == 'f32' else \
-        ('semseg_split3', 'semseg_conv2d_fwd_s3', 'semseg_conv2d_dgrad_s3', 'semseg_conv2d_wgrad_s3', 'semseg_bias_grad')
+    conv = {'f32': ('semseg_conv2d_fwd', 'semseg_conv2d_dgrad', 'semseg_conv2d_wgrad'),
+            's3': ('semseg_split3', 'semseg_conv2d_fwd_s3', 'semseg_conv2d_dgrad_s3', 'semseg_conv2d_wgrad_s3', 'semseg_bias_grad'),
+            'h2': ('semseg_split_h2', 'semseg_conv2d_fwd_h2', 'semseg_conv2d_dgrad_h2', 'semseg_conv2d_wgrad_h2',
+                   'semseg_bias_grad')}[mode]
     for must in conv + ('semseg_bn_stats', 'semseg_bn_apply',
                  'semseg_bn_bwd_reduce', 'semseg_bn_bwd_apply', 'semseg_log_softmax_fwd', 'semseg_nll_acc_fwd',
                  'semseg_nll_bwd', 'semseg_sgd_step'):

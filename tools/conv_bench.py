@@ -41,34 +41,40 @@ def run(layer, which, iters, L, ws, mode='f32'):
     dev = torch.device('cuda:0')
     oh = (h + 2 * pad - dil * (ks - 1) - 1) // st + 1
     ow = (w + 2 * pad - dil * (ks - 1) - 1) // st + 1
+    torch.manual_seed(7)
     x = torch.randn(n, h, w, c, device=dev)
     wt = torch.randn(k, ks, ks, c, device=dev) * 0.02
     wtt = torch.randn(c, ks, ks, k, device=dev) * 0.02
     y = torch.empty(n, oh, ow, k, device=dev)
-    dy = torch.randn(n, oh, ow, k, device=dev)
+    dy = torch.randn(n, oh, ow, k, device=dev) * 1e-3
     dx = torch.empty(n, h, w, c, device=dev)
     dw = torch.empty(k, ks, ks, c, device=dev)
     s = vp(torch.cuda.current_stream().cuda_stream)
     P = lambda t: vp(t.data_ptr())  # noqa: E731
 
-    if mode == 's3':
+    if mode in ('s3', 'h2'):
+        tag = mode
+        f_bytes = getattr(L, 'semseg_split3_bytes' if mode == 's3' else 'semseg_split_h2_bytes')
+        f_split = getattr(L, 'semseg_split3' if mode == 's3' else 'semseg_split_h2')
+        f_fwd, f_dgrad, f_wgrad = (getattr(L, 'semseg_conv2d_%s_%s' % (w_, tag)) for w_ in ('fwd', 'dgrad', 'wgrad'))
+
         def split(t, rows, ch):
-            out = torch.empty(L.semseg_split3_bytes(rows, ch), dtype=torch.uint8, device=dev)
-            _native.check(L.semseg_split3(P(t), ch, P(out), rows, ch, s), 'split3')
+            out = torch.empty(f_bytes(rows, ch), dtype=torch.uint8, device=dev)
+            _native.check(f_split(P(t), ch, P(out), rows, ch, s), 'split')
             return out
         xs, wss, wts, dys = split(x, n * h * w, c), split(wt, k * ks * ks, c), split(wtt, c * ks * ks, k), split(dy, n * oh * ow, k)
 
     def call():
-        if mode == 's3':
+        if mode in ('s3', 'h2'):
             if which == 'fwd':
-                rc = L.semseg_conv2d_fwd_s3(P(xs), P(wss), vp(0), P(y), k, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
+                rc = f_fwd(P(xs), P(wss), vp(0), P(y), k, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
             elif which == 'dgrad':
-                rc = L.semseg_conv2d_dgrad_s3(P(dys), P(wts), P(dx), c, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
+                rc = f_dgrad(P(dys), P(wts), P(dx), c, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
             elif which == 'wgrad':
-                rc = L.semseg_conv2d_wgrad_s3(P(xs), P(dys), P(dw), n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
+                rc = f_wgrad(P(xs), P(dys), P(dw), n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
             else:   # 'split': the per-conv split traffic of one training step (x once, dy once, w twice)
-                rc = L.semseg_split3(P(x), c, P(xs), n * h * w, c, s) or L.semseg_split3(P(dy), k, P(dys), n * oh * ow, k, s) \
-                    or L.semseg_split3(P(wt), c, P(wss), k * ks * ks, c, s) or L.semseg_split3(P(wtt), k, P(wts), c * ks * ks, k, s)
+                rc = f_split(P(x), c, P(xs), n * h * w, c, s) or f_split(P(dy), k, P(dys), n * oh * ow, k, s) \
+                    or f_split(P(wt), c, P(wss), k * ks * ks, c, s) or f_split(P(wtt), k, P(wts), c * ks * ks, k, s)
         elif which == 'fwd':
             rc = L.semseg_conv2d_fwd(P(x), c, P(wt), vp(0), P(y), k, n, h, w, c, k, ks, ks, st, pad, dil, P(ws), ws.numel(), s)
         elif which == 'dgrad':
@@ -87,7 +93,8 @@ def run(layer, which, iters, L, ws, mode='f32'):
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / iters
     gflop = 2.0 * n * oh * ow * k * c * ks * ks * 1e-9
-    return ms, gflop / ms
+    out = {'fwd': y, 'dgrad': dx, 'wgrad': dw}.get(which)
+    return ms, gflop / ms, out
 
 
 def main():
@@ -96,7 +103,10 @@ def main():
     ap.add_argument('--passes', default='fwd,dgrad,wgrad')
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--sweep', action='store_true', help='also try forced tile/split configurations')
-    ap.add_argument('--mode', default='f32', choices=['f32', 's3'], help='exact-fp32 MFMA kernels or the split-bf16 (s3) kernels')
+    ap.add_argument('--mode', default='f32', choices=['f32', 's3', 'h2'],
+                    help='exact-fp32 MFMA kernels, the split-bf16 (s3) or the split-fp16 (h2) kernels')
+    ap.add_argument('--verify', action='store_true',
+                    help='compare every configuration with the exact-fp32 MFMA kernel on the same (seeded) inputs: max|err|/rms')
     args = ap.parse_args()
     L = _native.lib()
     ws = torch.empty(1 << 30, dtype=torch.uint8, device='cuda:0')
@@ -105,23 +115,39 @@ def main():
     for layer in sel:
         for which in args.passes.split(','):
             cfgs = [('default', {})]
+            split_mode = args.mode in ('s3', 'h2')
             if args.sweep:
-                pre = 'SEMSEG_W3' if args.mode == 's3' else 'SEMSEG_WGRAD'
-                pre2 = 'SEMSEG_S3' if args.mode == 's3' else 'SEMSEG_IGEMM'
+                pre = 'SEMSEG_W3' if split_mode else 'SEMSEG_WGRAD'
+                pre2 = 'SEMSEG_S3' if split_mode else 'SEMSEG_IGEMM'
                 if which == 'wgrad':
                     cfgs += [('t%d_s%d' % (t, sp), {pre + '_TILE': str(t), pre + '_SPLIT': str(sp)})
                              for t in (0, 1) for sp in (1, 2, 4, 8, 16)]
                 elif which != 'split':
+                    tiles = (0, 1, 2, 3, 4, 5) if args.mode == 'h2' else (0, 1, 2, 3)
                     cfgs += [('t%d_s%d' % (t, sp), {pre2 + '_TILE': str(t), pre2 + '_SPLITK': str(sp)})
-                             for t in (0, 1, 2, 3) for sp in (1, 2, 4)]
+                             for t in tiles for sp in (1, 2, 4, 8)]
+            ref = None
+            if args.verify and which != 'split':
+                for kk in list(os.environ):
+                    if kk.startswith('SEMSEG_') and kk.endswith(('_TILE', '_SPLITK', '_SPLIT')):
+                        os.environ.pop(kk)
+                ref = run(layer, which, 1, L, ws, 'f32')[2].double()
+                ref_rms = ref.pow(2).mean().sqrt().item() + 1e-30
             res = []
+            worst_err = 0.0
             for cname, env in cfgs:
                 for k in ('SEMSEG_IGEMM_TILE', 'SEMSEG_IGEMM_SPLITK', 'SEMSEG_WGRAD_TILE', 'SEMSEG_WGRAD_SPLIT',
                           'SEMSEG_S3_TILE', 'SEMSEG_S3_SPLITK', 'SEMSEG_W3_TILE', 'SEMSEG_W3_SPLIT'):
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 try:
-                    ms, tf = run(layer, which, args.iters, L, ws, args.mode)
+                    ms, tf, out = run(layer, which, args.iters, L, ws, args.mode)
+                    if ref is not None:
+                        err = (out.double() - ref).abs().max().item() / ref_rms
+                        if not err < 1e-4:           # NaN-safe
+                            print('  VERIFY FAIL %s %s %s: max|err|/rms = %.3e' % (layer[0], which, cname, err), flush=True)
+                            tf = -tf                  # a wrong kernel never wins the sweep
+                        worst_err = max(worst_err, err) if err == err else float('nan')
                     res.append((cname, ms, tf))
                 except RuntimeError as e:
                     res.append((cname, float('nan'), 0.0))
@@ -133,6 +159,8 @@ def main():
             line = '%-12s %-5s default %8.3f ms %6.1f TF' % (layer[0], which, d[1], d[2])
             if args.sweep:
                 line += ' | best %-8s %8.3f ms %6.1f TF | ' % best + ' '.join('%s:%.0f' % (r[0], r[2]) for r in res[1:])
+            if ref is not None:
+                line += ' | verify max|err|/rms %.1e' % worst_err
             print(line, flush=True)
     for k, v in tot.items():
         print('sum over listed layers x count: %-5s default %.2f ms  best-of-sweep %.2f ms' % (k, v[0], v[1]))

@@ -1,6 +1,7 @@
-"""Correctness sweep of the split-bf16 (s3) convolution entry points through the C ABI against a float64 CPU
-convolution, next to the exact-fp32 MFMA kernels and torch's CPU fp32 convolution on the same inputs
-(error unit: max|err| / rms(ref); s3 must stay within 3x of the worse of the two fp32 implementations).
+"""Correctness sweep of the operand-split convolution entry points (h2: 2 x fp16, s3: 3 x bf16) through the C ABI
+against a float64 CPU convolution, next to the exact-fp32 MFMA kernels and torch's CPU fp32 convolution on the same
+inputs (error unit: max|err| / rms(ref); h2 and s3 must stay within 3x of the worse of the two fp32 implementations).
+Also runs every case with operands rescaled by 2^-20 / 2^+12 (gradient-like and large magnitudes: the h2 scale).
 
     python tools/s3_check.py            # on the GPU box
 """
@@ -33,15 +34,18 @@ CASES = [
 ]
 
 
-def run_case(L, case, dev):
+def run_case(L, case, dev, xscale=1.0, dyscale=1.0):
     n, c, h, w, k, ks, st, pad, dil, has_bias = case
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
-    x = torch.randn(n, c, h, w, generator=g).relu() * 1.5
+    x = torch.randn(n, c, h, w, generator=g).relu() * 1.5 * xscale
     wt = torch.randn(k, c, ks, ks, generator=g) * (2.0 / (c * ks * ks)) ** 0.5
-    b = torch.randn(k, generator=g) if has_bias else None
+    b = torch.randn(k, generator=g) * xscale if has_bias else None
     oh = (h + 2 * pad - dil * (ks - 1) - 1) // st + 1
     ow = (w + 2 * pad - dil * (ks - 1) - 1) // st + 1
-    dy = torch.randn(n, k, oh, ow, generator=g)
+    dy = torch.randn(n, k, oh, ow, generator=g) * dyscale
+    # a few outliers 200x the bulk, as ReLU'd activations / sparse gradients have (the h2 scale follows the max)
+    x.view(-1)[::9973] *= 200.0
+    dy.view(-1)[::7919] *= 200.0
     xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
     bd = b.double().requires_grad_(True) if has_bias else None
     yd = F.conv2d(xd, wd, bd, st, pad, dil)
@@ -63,32 +67,36 @@ def run_case(L, case, dev):
     _native.check(L.semseg_weight_krsc_to_crsk(P(wg), P(wtg), k, ks * ks, c, s), 'transpose')
     wsb = max(L.semseg_conv2d_s3_workspace_bytes(n, h, w, c, k, ks, ks, st, pad, dil),
               L.semseg_conv2d_workspace_bytes(n, h, w, c, k, ks, ks, st, pad, dil), 1 << 20)
+    wsb = max(wsb, L.semseg_conv2d_h2_workspace_bytes(n, h, w, c, k, ks, ks, st, pad, dil))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 
-    def split(t, rows, ch):
-        out = torch.empty(L.semseg_split3_bytes(rows, ch), dtype=torch.uint8, device=dev)
-        _native.check(L.semseg_split3(P(t), ch, P(out), rows, ch, s), 'split3')
+    def split(mode, t, rows, ch):
+        fb = L.semseg_split3_bytes if mode == 's3' else L.semseg_split_h2_bytes
+        fs = L.semseg_split3 if mode == 's3' else L.semseg_split_h2
+        out = torch.empty(fb(rows, ch), dtype=torch.uint8, device=dev)
+        _native.check(fs(P(t), ch, P(out), rows, ch, s), 'split')
         return out
 
-    xs = split(xg, n * h * w, c)
-    wss = split(wg, k * ks * ks, c)
-    wts = split(wtg, c * ks * ks, k)
-    dys = split(dyg, n * oh * ow, k)
     res = {}
     for key in ('y', 'dx', 'dw', 'db'):
         if ref[key] is not None:
             r = ref[key]
             res[('cpu', key)] = (cpu32[key].double() - r).abs().max().item() / (r.pow(2).mean().sqrt().item() + 1e-30)
-    for mode in ('s3', 'f32'):
+    for mode in ('h2', 's3', 'f32'):
         y = torch.full((n, oh, ow, k), float('nan'), device=dev)
         dx = torch.full((n, h, w, c), float('nan'), device=dev)
         dw = torch.full((k, ks, ks, c), float('nan'), device=dev)
         db = torch.full((k,), float('nan'), device=dev) if has_bias else None
         geo = (n, h, w, c, k, ks, ks, st, pad, dil)
-        if mode == 's3':
-            _native.check(L.semseg_conv2d_fwd_s3(P(xs), P(wss), P(bg), P(y), k, *geo, P(ws), ws.numel(), s), 'fwd_s3')
-            _native.check(L.semseg_conv2d_dgrad_s3(P(dys), P(wts), P(dx), c, *geo, P(ws), ws.numel(), s), 'dgrad_s3')
-            _native.check(L.semseg_conv2d_wgrad_s3(P(xs), P(dys), P(dw), *geo, P(ws), ws.numel(), s), 'wgrad_s3')
+        if mode in ('s3', 'h2'):
+            xs = split(mode, xg, n * h * w, c)
+            wss = split(mode, wg, k * ks * ks, c)
+            wts = split(mode, wtg, c * ks * ks, k)
+            dys = split(mode, dyg, n * oh * ow, k)
+            f = lambda w_: getattr(L, 'semseg_conv2d_%s_%s' % (w_, mode))  # noqa: E731
+            _native.check(f('fwd')(P(xs), P(wss), P(bg), P(y), k, *geo, P(ws), ws.numel(), s), 'fwd_' + mode)
+            _native.check(f('dgrad')(P(dys), P(wts), P(dx), c, *geo, P(ws), ws.numel(), s), 'dgrad_' + mode)
+            _native.check(f('wgrad')(P(xs), P(dys), P(dw), *geo, P(ws), ws.numel(), s), 'wgrad_' + mode)
             if has_bias:
                 _native.check(L.semseg_bias_grad(P(dyg), k, P(db), n * oh * ow, k, P(ws), ws.numel(), s), 'bias_grad')
         else:
@@ -110,16 +118,19 @@ def main():
     L = _native.lib()
     dev = torch.device('cuda:0')
     bad = 0
-    for case in CASES:
-        res = run_case(L, case, dev)
-        line = 'N%d C%-4d %2dx%-2d K%-4d k%d s%d p%d d%d b%d |' % case
-        for key in ('y', 'dx', 'dw', 'db'):
-            if ('s3', key) in res:
-                a, b, cpu = res[('s3', key)], res[('f32', key)], res[('cpu', key)]
-                ok = (a == a) and a < max(3 * max(b, cpu), 3e-6)    # NaN-safe; s3 must be in the fp32 error class
-                bad += 0 if ok else 1
-                line += ' %s s3 %.1e f32 %.1e cpu32 %.1e%s |' % (key, a, b, cpu, '' if ok else ' <-- BAD')
-        print(line, flush=True)
+    for xscale, dyscale in ((1.0, 1.0), (2.0 ** 12, 2.0 ** -20)):
+        print('--- operand scales: x * %g, dy * %g' % (xscale, dyscale))
+        for case in CASES:
+            res = run_case(L, case, dev, xscale, dyscale)
+            line = 'N%d C%-4d %2dx%-2d K%-4d k%d s%d p%d d%d b%d |' % case
+            for key in ('y', 'dx', 'dw', 'db'):
+                if ('s3', key) in res:
+                    h2, a, b, cpu = res[('h2', key)], res[('s3', key)], res[('f32', key)], res[('cpu', key)]
+                    lim = max(3 * max(b, cpu), 3e-6)
+                    ok = (a == a) and a < lim and (h2 == h2) and h2 < lim   # NaN-safe; split paths must be in the fp32 error class
+                    bad += 0 if ok else 1
+                    line += ' %s h2 %.1e s3 %.1e f32 %.1e cpu32 %.1e%s |' % (key, h2, a, b, cpu, '' if ok else ' <-- BAD')
+            print(line, flush=True)
     print('s3_check: %s' % ('OK' if bad == 0 else '%d FAILURES' % bad))
     return 1 if bad else 0
 
