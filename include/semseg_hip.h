@@ -167,6 +167,42 @@ int semseg_bn_bwd_apply(const float* dy, int dy_ld, const float* y, int y_ld, co
                         const double* sums, const double* stats_count, int training, int relu,
                         float* dz, float* dres, int P, int C, void* stream);
 
+/* ---------------- BN kernels of the fused conv -> BN -> (ReLU) -> conv chain on the h2 path --------------------
+ * The h2 split of a BN result does not need a pass over the result to find its exponent: per-channel min/max of z
+ * (gathered by the statistics pass) bound |y| rigorously, and the backward sums bound |dz| (csrc/bn.hip).
+ * Same reference call sites as the plain BN entry points above (batchnorm.py:56-61 and its autograd backward). */
+size_t semseg_bn_mm_workspace_bytes(int P, int C);
+/* semseg_bn_stats + zmm[0..C) = min_p z[p,c], zmm[C..2C) = max_p z[p,c] (fp32; local to this rank) */
+int semseg_bn_stats_mm(const float* z, int P, int C, double* stats, float* zmm, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* semseg_bn_finalize + absmax_out[0] = an upper bound of max |act(BN(z) + residual)| given |residual| <= res_absmax[0]
+ * (device scalars; res_absmax NULL = no residual; absmax_out may be NULL) and, if y_planes != NULL, the exponent word
+ * of that h2 split buffer (P rows x C channels) derived from the bound. */
+int semseg_bn_finalize_mm(const double* stats, const float* zmm, int C, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          float momentum, float eps, int relu, const float* res_absmax,
+                          float* mean, float* invstd, float* scale, float* shift,
+                          float* absmax_out, void* y_planes, int P, void* stream);
+/* semseg_bn_apply (y dense, ld C) that ALSO writes the h2 split planes of y into y_planes (semseg_split_h2_bytes(P, C);
+ * exponent word set by semseg_bn_finalize_mm).  C % 8 == 0. */
+int semseg_bn_apply_h2(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
+                       int relu, float* y, void* y_planes, int P, int C, void* stream);
+/* semseg_bn_bwd_reduce + gmax[c] = max_p |g[p,c]| */
+int semseg_bn_bwd_reduce_mm(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                            const float* mean, const float* invstd, int relu, int P, int C,
+                            double* sums, float* gmax, float* dgamma, float* dbeta,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* exponent word of dz_planes from |dz| <= |gamma| invstd (gmax + |sums[c]|/n + max|xhat| |sums[C+c]|/n)
+ * (after the data-parallel all-reduce of `sums`) */
+int semseg_bn_bwd_bound(const double* sums, const double* stats_count, const float* gmax, const float* zmm,
+                        const float* mean, const float* invstd, const float* gamma, int C, int training,
+                        void* dz_planes, int P, void* stream);
+/* semseg_bn_bwd_apply writing dz ONLY as h2 split planes (P rows x C channels; C % 8 == 0); dres stays fp32 */
+int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                           const float* mean, const float* invstd, const float* gamma,
+                           const double* sums, const double* stats_count, int training, int relu,
+                           void* dz_planes, float* dres, int P, int C, void* stream);
+
 /* ---------------- elementwise helpers ------------------------------------------------------ */
 /* out = act(a + b) (hrnet.py:231-248 fuse sums); a,b,out [P,C] with their own ld */
 int semseg_add_act(const float* a, int a_ld, const float* b, int b_ld, int relu, float* out, int out_ld,
@@ -216,6 +252,17 @@ int semseg_nll_acc_fwd(const float* logp, const int64_t* label, int ignore_index
 /* dlogp[p,c] = -(gloss[0]/n_valid) if c==label[p] (valid) else 0 */
 int semseg_nll_bwd(const float* gloss, const float* nll_out, const int64_t* label, int ignore_index,
                    float* dlogp, int P, int C, void* stream);
+
+/* ---------------- weight preparation for the h2 convolutions (multi-tensor) ------------------
+ * For every conv weight w [K][T][C] (KRSC, T = R*S): the h2 split of w (rows K*T, channels C: operand of fwd) and of
+ * its CRSK transpose (rows C*T, channels K: operand of dgrad), sharing one exponent -- bit-identical to
+ * semseg_split_h2(w) and semseg_split_h2(semseg_weight_krsc_to_crsk(w)), in 2 launches per 64 tensors instead of 5 per
+ * tensor.  The weights change only in the optimiser step (train.py:117-126): call once after semseg_sgd_step.
+ * krsc / crsk: buffers of semseg_split_h2_bytes(K*T, C) / semseg_split_h2_bytes(C*T, K) bytes. */
+typedef struct {
+    const float* w; void* krsc; void* crsk; int K, T, C;
+} semseg_wprep_tensor;
+int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host, int n, void* stream);
 
 /* ---------------- optimiser (torch.optim.SGD, train.py:117-126) ----------------------------- */
 typedef struct {

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'mit_semseg', '_native')
 LIB = os.path.join(OUT_DIR, 'libsemseg_hip.so')
-SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'conv_split.hip', 'bn.hip', 'pool_resize.hip', 'head.hip', 'api.hip']
+SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'conv_split.hip', 'weights_prep.hip', 'bn.hip', 'pool_resize.hip', 'head.hip', 'api.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC,
          '-Wno-unused-result']
@@ -22,7 +22,7 @@ def _newer(a, b):
 
 def build(force=False, verbose=True):
     os.makedirs(OUT_DIR, exist_ok=True)
-    deps = [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'semseg_hip.h')]
+    deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'split_layout.h'), os.path.join(ROOT, 'include', 'semseg_hip.h')]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -381,3 +381,520 @@ extern "C" int semseg_bn_bwd_apply(const float* dy, int dy_ld, const float* y, i
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
+
+// ================================================================================================
+// BN kernels of the fused conv -> BN -> (ReLU) -> conv chain on the h2 path (ops.ConvBNActFn).
+//
+// The h2 split of a tensor needs a per-tensor exponent BEFORE the first element is written.  For tensors that BN
+// produces the exponent does not need a pass over the result: BN is a per-channel affine map, so the per-channel
+// min/max of z (gathered by the statistics pass that reads z anyway) give a RIGOROUS bound of |y|, and the sums of the
+// backward reduction bound |dz|.  h2_exponent accepts any upper bound (split_layout.h), hence
+//   forward : stats(+min/max) -> finalize(+bound -> exponent) -> apply writes y AND its split planes
+//   backward: reduce(+max|g|) -> bound -> apply writes the split planes of dz ONLY (dz feeds nothing but the conv
+//             gradients, which read planes)
+// which removes the absmax + split passes (2 launches, 12 B/element) on both sides of every conv -> BN pair.
+// ================================================================================================
+#include "split_layout.h"
+
+extern "C" size_t semseg_bn_mm_workspace_bytes(int P, int C) {
+    if (C % 4) return 0;
+    const ColGeom g = col_geom(P, C);
+    return (size_t)g.gy * 2 * C * (sizeof(double) + sizeof(float));
+}
+
+// as bn_stats_partial_kernel + per-channel min / max of z:  mm[by][0][c] = min, mm[by][1][c] = max
+__global__ __launch_bounds__(256) void bn_stats_mm_partial_kernel(const float* __restrict__ z, int P, int C, int cx, int py,
+                                                                  int rows_per_block, double* __restrict__ partial,
+                                                                  float* __restrict__ mm) {
+    extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][8] floats
+    float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
+    const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
+    const int quad = blockIdx.x * cx + tx;
+    const int c = quad * 4;
+    const int row0 = blockIdx.y * rows_per_block;
+    const int row1 = min(P, row0 + rows_per_block);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    float4 hi = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const bool active = (ty < py) && (c < C);
+    if (active) {
+        for (int p = row0 + ty; p < row1; p += py) {
+            const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + c);
+            const double x = v.x, y = v.y, zz = v.z, w = v.w;
+            a0 += x; a1 += y; a2 += zz; a3 += w;
+            q0 = fma(x, x, q0); q1 = fma(y, y, q1); q2 = fma(zz, zz, q2); q3 = fma(w, w, q3);
+            lo.x = fminf(lo.x, v.x); lo.y = fminf(lo.y, v.y); lo.z = fminf(lo.z, v.z); lo.w = fminf(lo.w, v.w);
+            hi.x = fmaxf(hi.x, v.x); hi.y = fmaxf(hi.y, v.y); hi.z = fmaxf(hi.z, v.z); hi.w = fmaxf(hi.w, v.w);
+        }
+    }
+    if (ty < py) {
+        double* r = red + ((size_t)ty * cx + tx) * 8;
+        r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
+        r[4] = q0; r[5] = q1; r[6] = q2; r[7] = q3;
+        float* f = redf + ((size_t)ty * cx + tx) * 8;
+        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
+        f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+    }
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int y = 0; y < py; ++y) {
+            const double* r = red + ((size_t)y * cx + tx) * 8;
+            const float* f = redf + ((size_t)y * cx + tx) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += r[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mn[e] = fminf(mn[e], f[e]);
+                mx[e] = fmaxf(mx[e], f[4 + e]);
+            }
+        }
+        double* o = partial + (size_t)blockIdx.y * 2 * C;
+        float* of = mm + (size_t)blockIdx.y * 2 * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[c + e] = a[e];
+            o[C + c + e] = a[4 + e];
+            of[c + e] = mn[e];
+            of[C + c + e] = mx[e];
+        }
+    }
+}
+
+// column sums of the fp64 partials (as colsum_finish_kernel) + column min (j < C) / max (j >= C) of the float partials
+__global__ __launch_bounds__(256) void bn_stats_mm_finish_kernel(const double* __restrict__ partial,
+                                                                 const float* __restrict__ mm, int nparts, int C,
+                                                                 double* __restrict__ out, float* __restrict__ zmm,
+                                                                 double count) {
+    __shared__ double red[16][17];
+    __shared__ float redf[16][17];
+    const int C2 = 2 * C;
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int lane = threadIdx.x >> 4;
+    const bool is_min = j < C;
+    float m = is_min ? INFINITY : -INFINITY;
+    if (j < C2)
+        for (int b = lane; b < nparts; b += 16) {
+            const float v = mm[(size_t)b * C2 + j];
+            m = is_min ? fminf(m, v) : fmaxf(m, v);
+        }
+    redf[lane][threadIdx.x & 15] = m;
+    const double t = colsum_block(partial, nparts, C2, j, lane, red);     // contains the __syncthreads
+    if (lane == 0 && j < C2) {
+        out[j] = t;
+        float r = redf[0][threadIdx.x & 15];
+        for (int i = 1; i < 16; ++i) {
+            const float v = redf[i][threadIdx.x & 15];
+            r = is_min ? fminf(r, v) : fmaxf(r, v);
+        }
+        zmm[j] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count >= 0.0) out[C2] = count;
+}
+
+extern "C" int semseg_bn_stats_mm(const float* z, int P, int C, double* stats, float* zmm, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!z || !stats || !zmm || P <= 0 || C <= 0 || (C % 4) || !aligned16(z)) return SEMSEG_EINVAL;
+    const ColGeom g = col_geom(P, C);
+    const size_t need = (size_t)g.gy * 2 * C * (sizeof(double) + sizeof(float));
+    if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = (double*)workspace;
+    float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
+    const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
+    hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
+                       g.rows_per_block, partial, mm);
+    SEMSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_mm_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)partial,
+                       (const float*)mm, g.gy, C, stats, zmm, (double)P);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// bn_finalize_kernel + the bound of |y| and the exponent of y's h2 planes.  One block (C <= a few thousand).
+//   y = act(fmaf(z, scale, shift) (+ res)): fmaf and the fp32 add are monotone, so per channel the extremes of the BN
+//   part are attained at zmin / zmax EXACTLY as bn_apply computes them, and |res| <= res_absmax.
+__global__ __launch_bounds__(256) void bn_finalize_mm_kernel(const double* __restrict__ stats, const float* __restrict__ zmm,
+                                                             int C, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float momentum, float eps,
+                                                             int relu, const float* __restrict__ res_absmax,
+                                                             float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ scale, float* __restrict__ shift,
+                                                             int64_t* __restrict__ num_batches_tracked,
+                                                             float* __restrict__ absmax_out, int* __restrict__ planes_hdr) {
+    if (threadIdx.x == 0 && num_batches_tracked) num_batches_tracked[0] += 1;
+    const double n = stats[2 * C];
+    const float rmax = res_absmax ? res_absmax[0] : 0.f;
+    float bound = 0.f;
+    bool bad = false;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double mu = stats[c] / n;
+        double var = stats[C + c] / n - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float muf = (float)mu;
+        mean[c] = muf;
+        invstd[c] = is;
+        const float sc = gamma[c] * is;
+        const float sh = beta[c] - muf * sc;
+        scale[c] = sc;
+        shift[c] = sh;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
+        if (running_var) {
+            const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+        const float e0 = fmaf(zmm[c], sc, sh), e1 = fmaf(zmm[C + c], sc, sh);
+        const float hi = fmaxf(e0, e1) + rmax, lo = fminf(e0, e1) - rmax;
+        const float b = relu ? fmaxf(hi, 0.f) : fmaxf(fabsf(hi), fabsf(lo));
+        bad = bad || !(b == b) || !(e0 == e0) || !(e1 == e1);
+        bound = fmaxf(bound, b);
+    }
+    uint32_t bits = bad ? 0x7fc00000u : __float_as_uint(bound);       // a NaN anywhere: NaN bound -> exponent 0
+    bits = block_max_u32(bits);
+    if (threadIdx.x == 0) {
+        if (absmax_out) absmax_out[0] = __uint_as_float(bits);
+        if (planes_hdr) planes_hdr[0] = h2_exponent(bits);
+    }
+}
+
+extern "C" int semseg_bn_finalize_mm(const double* stats, const float* zmm, int C, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                     float eps, int relu, const float* res_absmax, float* mean, float* invstd, float* scale,
+                                     float* shift, float* absmax_out, void* y_planes, int P, void* stream) {
+    if (!stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || P <= 0) return SEMSEG_EINVAL;
+    int* hdr = y_planes ? const_cast<int*>(h2_exp_ptr(y_planes, (size_t)P, C)) : nullptr;
+    hipLaunchKernelGGL(bn_finalize_mm_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, zmm, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, relu, res_absmax, mean, invstd, scale, shift,
+                       num_batches_tracked, absmax_out, hdr);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = act(z*scale + shift (+res)) written as fp32 AND as h2 split planes (exponent from the header, set by
+// bn_finalize_mm).  One thread = 8 channels of one pixel: 2 x 16 B fp32 stores + 2 x 16 B plane stores.
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ res,
+                                                          int res_ld, float* __restrict__ y, uint16_t* __restrict__ planes,
+                                                          size_t plane, int pitch, const int* __restrict__ hdr, int P, int C,
+                                                          int Cp) {
+    const float sc2 = pow2i(hdr[0]);
+    if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
+        reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    const int G = Cp >> 3;
+    const size_t total = (size_t)P * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / G);
+        const int c = (int)(i - (size_t)p * G) << 3;
+        f16x8 p0, p1;
+        if (c < C) {                               // C % 8 == 0: the 8 channels are all real
+            float o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + c + 4 * h);
+                const float4 sc = *reinterpret_cast<const float4*>(scale + c + 4 * h);
+                const float4 sh = *reinterpret_cast<const float4*>(shift + c + 4 * h);
+                float4 t;
+                t.x = fmaf(v.x, sc.x, sh.x); t.y = fmaf(v.y, sc.y, sh.y);
+                t.z = fmaf(v.z, sc.z, sh.z); t.w = fmaf(v.w, sc.w, sh.w);
+                if (RES) {
+                    const float4 r = *reinterpret_cast<const float4*>(res + (size_t)p * res_ld + c + 4 * h);
+                    t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+                }
+                if (RELU) {
+                    t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+                }
+                *reinterpret_cast<float4*>(y + (size_t)p * C + c + 4 * h) = t;
+                o[4 * h] = t.x; o[4 * h + 1] = t.y; o[4 * h + 2] = t.z; o[4 * h + 3] = t.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 a, r;
+                h2_split_of(o[e] * sc2, a, r);
+                p0[e] = a;
+                p1[e] = r;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { p0[e] = (_Float16)0.f; p1[e] = (_Float16)0.f; }
+        }
+        const size_t po = (size_t)p * pitch + c;
+        *reinterpret_cast<f16x8*>(planes + po) = p0;
+        *reinterpret_cast<f16x8*>(planes + plane + po) = p1;
+    }
+}
+
+extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
+                                  int relu, float* y, void* y_planes, int P, int C, void* stream) {
+    if (!z || !scale || !shift || !y || !y_planes || P <= 0 || C <= 0 || (C % 8) || !aligned16(z) || !aligned16(y) ||
+        !aligned16(y_planes))
+        return SEMSEG_EINVAL;
+    if (residual && ((res_ld % 4) || res_ld < C || !aligned16(residual))) return SEMSEG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int Cp = round_up32(C), pitch = split_pitch(C);
+    const size_t plane = h2_plane_elems((size_t)P, C);
+    const int* hdr = h2_exp_ptr(y_planes, (size_t)P, C);
+    const int blocks = stream_blocks((size_t)P * (Cp / 8));
+#define LAUNCH(R, A) hipLaunchKernelGGL((bn_apply_h2_kernel<R, A>), dim3(blocks), dim3(256), 0, st, z, scale, shift, residual, res_ld, y, (uint16_t*)y_planes, plane, pitch, hdr, P, C, Cp)
+    if (residual) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
+    else          { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- backward ----------------------------------------------------------------------------------
+// as bn_bwd_partial_kernel + per-channel max |g|:  gm[by][c]
+__global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __restrict__ dy, int dy_ld,
+                                                                const float* __restrict__ y, int y_ld,
+                                                                const float* __restrict__ z, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int relu, int P, int C,
+                                                                int cx, int py, int rows_per_block,
+                                                                double* __restrict__ partial, float* __restrict__ gm) {
+    extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][4] floats
+    float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
+    const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
+    const int c = (blockIdx.x * cx + tx) * 4;
+    const int row0 = blockIdx.y * rows_per_block;
+    const int row1 = min(P, row0 + rows_per_block);
+    float4 s = f4zero(), sx = f4zero(), gx = f4zero();
+    if (ty < py && c < C) {
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        for (int p = row0 + ty; p < row1; p += py) {
+            float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c);
+            if (relu) {
+                const float4 yy = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c);
+                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+            }
+            const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + c);
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            sx.x += g.x * ((v.x - mu.x) * is.x); sx.y += g.y * ((v.y - mu.y) * is.y);
+            sx.z += g.z * ((v.z - mu.z) * is.z); sx.w += g.w * ((v.w - mu.w) * is.w);
+            // NaN-propagating max (fmaxf would drop a NaN gradient)
+            gx.x = (fabsf(g.x) > gx.x || g.x != g.x) ? fabsf(g.x) : gx.x;
+            gx.y = (fabsf(g.y) > gx.y || g.y != g.y) ? fabsf(g.y) : gx.y;
+            gx.z = (fabsf(g.z) > gx.z || g.z != g.z) ? fabsf(g.z) : gx.z;
+            gx.w = (fabsf(g.w) > gx.w || g.w != g.w) ? fabsf(g.w) : gx.w;
+        }
+    }
+    if (ty < py) {
+        double* r = red + ((size_t)ty * cx + tx) * 8;
+        r[0] = s.x; r[1] = s.y; r[2] = s.z; r[3] = s.w;
+        r[4] = sx.x; r[5] = sx.y; r[6] = sx.z; r[7] = sx.w;
+        float* f = redf + ((size_t)ty * cx + tx) * 4;
+        f[0] = gx.x; f[1] = gx.y; f[2] = gx.z; f[3] = gx.w;
+    }
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t m[4] = {0, 0, 0, 0};             // bit patterns: monotone for |g| >= 0, NaN sorts above inf
+        for (int yy = 0; yy < py; ++yy) {
+            const double* r = red + ((size_t)yy * cx + tx) * 8;
+            const float* f = redf + ((size_t)yy * cx + tx) * 4;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += r[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = max(m[e], absbits(f[e]));
+        }
+        double* o = partial + (size_t)blockIdx.y * 2 * C;
+        float* of = gm + (size_t)blockIdx.y * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[c + e] = a[e];
+            o[C + c + e] = a[4 + e];
+            of[c + e] = __uint_as_float(m[e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_mm_finish_kernel(const double* __restrict__ partial, const float* __restrict__ gm,
+                                                               int nparts, int C, double* __restrict__ sums,
+                                                               float* __restrict__ gmax, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    __shared__ double red[16][17];
+    __shared__ uint32_t redu[16][17];
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int lane = threadIdx.x >> 4;
+    uint32_t m = 0;
+    if (j < C)
+        for (int b = lane; b < nparts; b += 16) m = max(m, absbits(gm[(size_t)b * C + j]));
+    redu[lane][threadIdx.x & 15] = m;
+    const double s = colsum_block(partial, nparts, 2 * C, j, lane, red);   // contains the __syncthreads
+    if (lane != 0 || j >= 2 * C) return;
+    sums[j] = s;
+    if (j < C) {
+        if (dbeta) dbeta[j] = (float)s;
+        uint32_t r = 0;
+        for (int i = 0; i < 16; ++i) r = max(r, redu[i][threadIdx.x & 15]);
+        gmax[j] = __uint_as_float(r);
+    } else if (dgamma) {
+        dgamma[j - C] = (float)s;
+    }
+}
+
+extern "C" int semseg_bn_bwd_reduce_mm(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                                       const float* mean, const float* invstd, int relu, int P, int C, double* sums,
+                                       float* gmax, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    if (!dy || !z || !mean || !invstd || !sums || !gmax || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) || dy_ld < C)
+        return SEMSEG_EINVAL;
+    if (relu && (!y || (y_ld % 4) || y_ld < C)) return SEMSEG_EINVAL;
+    const ColGeom g = col_geom(P, C);
+    const size_t need = (size_t)g.gy * 2 * C * (sizeof(double) + sizeof(float));
+    if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = (double*)workspace;
+    float* gm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
+    const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
+    hipLaunchKernelGGL(bn_bwd_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
+                       relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm);
+    SEMSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_mm_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)partial,
+                       (const float*)gm, g.gy, C, sums, gmax, dgamma, dbeta);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// exponent of the dz planes from a bound of |dz| = |gamma*invstd*(g - m - xhat*x)|:
+//   |dz| <= |gamma| invstd (max|g| + |m| + max|xhat| |x|),  m = sums[c]/n, x = sums[C+c]/n,
+//   max|xhat| = max(|zmin-mean|, |zmax-mean|) invstd.   The bound is evaluated in fp32 with a 2^-10 margin for the
+//   roundings of bn_bwd_apply (the exponent leaves a further factor 2 of headroom below the fp16 maximum).
+__global__ __launch_bounds__(256) void bn_bwd_bound_kernel(const double* __restrict__ sums, const double* __restrict__ count,
+                                                           const float* __restrict__ gmax, const float* __restrict__ zmm,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, int C, int training,
+                                                           int* __restrict__ planes_hdr) {
+    const float inv_n = training ? (float)(1.0 / count[0]) : 0.f;
+    uint32_t bits = 0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float is = invstd[c];
+        float b = gmax[c];
+        if (training) {
+            const float m = fabsf((float)sums[c] * inv_n), x = fabsf((float)sums[C + c] * inv_n);
+            const float xh = fmaxf(fabsf(zmm[c] - mean[c]), fabsf(zmm[C + c] - mean[c])) * is;
+            b = b + m + xh * x;
+        }
+        b = fabsf(gamma[c]) * is * b * 1.0009765625f;
+        bits = max(bits, absbits(b));             // NaN sorts above inf -> exponent 0
+    }
+    bits = block_max_u32(bits);
+    if (threadIdx.x == 0) planes_hdr[0] = h2_exponent(bits);
+}
+
+extern "C" int semseg_bn_bwd_bound(const double* sums, const double* stats_count, const float* gmax, const float* zmm,
+                                   const float* mean, const float* invstd, const float* gamma, int C, int training,
+                                   void* dz_planes, int P, void* stream) {
+    if (!gmax || !invstd || !gamma || !dz_planes || C <= 0 || P <= 0) return SEMSEG_EINVAL;
+    if (training && (!sums || !stats_count || !zmm || !mean)) return SEMSEG_EINVAL;
+    int* hdr = const_cast<int*>(h2_exp_ptr(dz_planes, (size_t)P, C));
+    hipLaunchKernelGGL(bn_bwd_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, stats_count, gmax, zmm, mean,
+                       invstd, gamma, C, training, hdr);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// bn_bwd_apply_kernel writing the h2 split planes of dz instead of fp32 dz (dres stays fp32)
+template <bool TRAIN, bool RELU, bool DRES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __restrict__ dy, int dy_ld,
+                                                              const float* __restrict__ y, int y_ld,
+                                                              const float* __restrict__ z, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const double* __restrict__ sums,
+                                                              const double* __restrict__ count,
+                                                              uint16_t* __restrict__ planes, size_t plane, int pitch,
+                                                              const int* __restrict__ hdr, float* __restrict__ dres, int P,
+                                                              int C, int Cp) {
+    const float sc2 = pow2i(hdr[0]);
+    if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
+        reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    const float inv_n = TRAIN ? (float)(1.0 / count[0]) : 0.f;
+    const int G = Cp >> 3;
+    const size_t total = (size_t)P * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / G);
+        const int c = (int)(i - (size_t)p * G) << 3;
+        f16x8 p0, p1;
+        if (c < C) {
+            float o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cc = c + 4 * h;
+                float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + cc);
+                if (RELU) {
+                    const float4 yy = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + cc);
+                    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                    g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+                }
+                if (DRES) *reinterpret_cast<float4*>(dres + (size_t)p * C + cc) = g;
+                const float4 is = *reinterpret_cast<const float4*>(invstd + cc);
+                const float4 ga = *reinterpret_cast<const float4*>(gamma + cc);
+                float4 t;
+                if (TRAIN) {
+                    const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + cc);
+                    const float4 mu = *reinterpret_cast<const float4*>(mean + cc);
+                    const float m0 = (float)sums[cc] * inv_n, m1 = (float)sums[cc + 1] * inv_n;
+                    const float m2 = (float)sums[cc + 2] * inv_n, m3 = (float)sums[cc + 3] * inv_n;
+                    const float x0 = (float)sums[C + cc] * inv_n, x1 = (float)sums[C + cc + 1] * inv_n;
+                    const float x2 = (float)sums[C + cc + 2] * inv_n, x3 = (float)sums[C + cc + 3] * inv_n;
+                    t.x = ga.x * is.x * (g.x - m0 - (v.x - mu.x) * is.x * x0);
+                    t.y = ga.y * is.y * (g.y - m1 - (v.y - mu.y) * is.y * x1);
+                    t.z = ga.z * is.z * (g.z - m2 - (v.z - mu.z) * is.z * x2);
+                    t.w = ga.w * is.w * (g.w - m3 - (v.w - mu.w) * is.w * x3);
+                } else {
+                    t.x = ga.x * is.x * g.x; t.y = ga.y * is.y * g.y; t.z = ga.z * is.z * g.z; t.w = ga.w * is.w * g.w;
+                }
+                o[4 * h] = t.x; o[4 * h + 1] = t.y; o[4 * h + 2] = t.z; o[4 * h + 3] = t.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 a, r;
+                h2_split_of(o[e] * sc2, a, r);
+                p0[e] = a;
+                p1[e] = r;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { p0[e] = (_Float16)0.f; p1[e] = (_Float16)0.f; }
+        }
+        const size_t po = (size_t)p * pitch + c;
+        *reinterpret_cast<f16x8*>(planes + po) = p0;
+        *reinterpret_cast<f16x8*>(planes + plane + po) = p1;
+    }
+}
+
+extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                                      const float* mean, const float* invstd, const float* gamma, const double* sums,
+                                      const double* stats_count, int training, int relu, void* dz_planes, float* dres, int P,
+                                      int C, void* stream) {
+    if (!dy || !invstd || !gamma || !dz_planes || P <= 0 || C <= 0 || (C % 8) || (dy_ld % 4) || dy_ld < C ||
+        !aligned16(dy) || !aligned16(dz_planes))
+        return SEMSEG_EINVAL;
+    if (training && (!z || !mean || !sums || !stats_count)) return SEMSEG_EINVAL;
+    if (relu && (!y || (y_ld % 4) || y_ld < C)) return SEMSEG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int Cp = round_up32(C), pitch = split_pitch(C);
+    const size_t plane = h2_plane_elems((size_t)P, C);
+    const int* hdr = h2_exp_ptr(dz_planes, (size_t)P, C);
+    const int blocks = stream_blocks((size_t)P * (Cp / 8));
+#define LAUNCH(T, R, D) hipLaunchKernelGGL((bn_bwd_apply_h2_kernel<T, R, D>), dim3(blocks), dim3(256), 0, st, dy, dy_ld, y, y_ld, z, mean, invstd, gamma, sums, stats_count, (uint16_t*)dz_planes, plane, pitch, hdr, dres, P, C, Cp)
+    const int key = (training ? 4 : 0) | (relu ? 2 : 0) | (dres ? 1 : 0);
+    switch (key) {
+        case 0: LAUNCH(false, false, false); break;
+        case 1: LAUNCH(false, false, true); break;
+        case 2: LAUNCH(false, true, false); break;
+        case 3: LAUNCH(false, true, true); break;
+        case 4: LAUNCH(true, false, false); break;
+        case 5: LAUNCH(true, false, true); break;
+        case 6: LAUNCH(true, true, false); break;
+        default: LAUNCH(true, true, true); break;
+    }
+#undef LAUNCH
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}

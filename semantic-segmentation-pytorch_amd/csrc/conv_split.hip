@@ -36,13 +36,13 @@
 // Replaces nn.Conv2d at reference resnet.py:18-21,61-66,130; models.py:163,406,448,456-463,519-540;
 // hrnet.py:26-29,188-205,316-338 and its autograd backward.
 #include "common.h"
+#include "split_layout.h"
 #include <stdlib.h>
 #include <array>
 #include <map>
 #include <mutex>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -118,44 +118,16 @@ extern "C" int semseg_conv2d_h2_set_plan(int pass, int N, int H, int W, int C, i
     return set_plan(SchH2::ID, pass, N, H, W, C, K, R, S, stride, pad, dil, tile, split);
 }
 
-static inline int round_up32(int c) { return (c + 31) & ~31; }
-
-// Row pitch (16-bit elements) of a split plane.  A power-of-two pitch of >= 2 KB walks the gathered rows of an operand
-// tile (128 rows x 64 B) over a fraction of the L2 channels only, so such pitches are skewed by 256 B.
-// SEMSEG_S3_PITCH_PAD overrides the skew (elements; tools/conv_bench.py).
-static int split_pitch(int C) {
-    static int pad = -1;
-    if (pad < 0) {
-        const char* v = getenv("SEMSEG_S3_PITCH_PAD");
-        pad = (v && *v) ? atoi(v) : 128;
-    }
-    const int Cp = round_up32(C);
-    return ((Cp * 2) % 2048 == 0) ? Cp + pad : Cp;
-}
-
 // Wait for the MFMA pipe to retire the last accumulator writes before the epilogue reads them (belt and braces on top of
 // the compiler's own hazard nops: 2 x 16 wait states > the 8-pass latency of v_mfma_f32_32x32x16_*).
 #define S_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
-// The planes are followed by SPLIT_ZERO_TAIL_BYTES of zeros: the LDS-DMA conv kernel points the lanes of padded /
-// out-of-range rows at it (a direct-to-LDS load cannot select a zero afterwards).  h2 buffers continue with a header:
-// int32 exponent e (the planes hold 2^e * x), then H2_MAX_PARTIALS uint32 partial |x| maxima (bit patterns).
-#define SPLIT_ZERO_TAIL_BYTES 256
-#define H2_MAX_PARTIALS 1024
-#define H2_HDR_BYTES (256 + 4 * H2_MAX_PARTIALS)
-
+// plane layout, pitch, zero tail and the h2 header: split_layout.h
 template <class SCH>
 static size_t split_bytes(int rows, int C) {
     if (rows <= 0 || C <= 0) return 0;
     return (size_t)SCH::NP * rows * split_pitch(C) * sizeof(uint16_t) + SPLIT_ZERO_TAIL_BYTES + (SCH::SCALED ? H2_HDR_BYTES : 0);
 }
-// device address of the exponent word of an h2 split buffer
-static inline const int* h2_exp_ptr(const void* xs, size_t rows, int C) {
-    return reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(xs) +
-                                        (size_t)SchH2::NP * rows * split_pitch(C) * sizeof(uint16_t) + SPLIT_ZERO_TAIL_BYTES);
-}
-
-__device__ __forceinline__ float pow2i(int e) { return __int_as_float((127 + e) << 23); }     // -126 <= e <= 127
 
 // ------------------------------------------------------------------------------------------------
 // split: s3
@@ -226,17 +198,6 @@ extern "C" int semseg_split3(const float* x, int x_ld, void* xs, int rows, int C
 // ------------------------------------------------------------------------------------------------
 // split: h2 (absmax pass + scaled 2 x fp16 split)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
-
-__device__ __forceinline__ uint32_t block_max_u32(uint32_t m) {
-    __shared__ uint32_t red[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    return max(max(red[0], red[1]), max(red[2], red[3]));
-}
-
 // partial[b] = max |x| over the rows x C window, as fp32 bit patterns (monotone for non-negative floats; a NaN sorts
 // above +inf and is handled by h2_exponent)
 template <bool VEC>
@@ -262,14 +223,6 @@ __global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __rest
     }
     m = block_max_u32(m);
     if (threadIdx.x == 0) partial[blockIdx.x] = m;
-}
-
-// exponent e with 2^e * max in [2^14, 2^15); clamped to +-100 (tensors whose max is below 2^-86 keep fewer bits);
-// inf / NaN maxima: e = 0 (they propagate through fp16 as inf / NaN)
-__device__ __forceinline__ int h2_exponent(uint32_t maxbits) {
-    const int ef = (int)(maxbits >> 23);
-    if (ef == 255) return 0;
-    return max(-100, min(100, 141 - ef));
 }
 
 template <bool VEC>

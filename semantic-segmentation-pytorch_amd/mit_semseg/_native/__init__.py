@@ -20,6 +20,10 @@ class SgdTensor(ctypes.Structure):
                 ('weight_decay', c_f), ('first_step', c_int)]
 
 
+class WPrepTensor(ctypes.Structure):
+    _fields_ = [('w', vp), ('krsc', vp), ('crsk', vp), ('K', c_int), ('T', c_int), ('C', c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/semseg_hip.h one to one
 SIGNATURES = {
     'semseg_abi_version': (c_int, []),
@@ -50,6 +54,17 @@ SIGNATURES = {
     'semseg_bn_apply': (c_int, [vp, vp, vp, vp, c_int, c_int, vp, c_int, c_int, c_int, vp]),
     'semseg_bn_bwd_reduce': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_sz, vp]),
     'semseg_bn_bwd_apply': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int, vp]),
+    'semseg_bn_mm_workspace_bytes': (c_sz, [c_int, c_int]),
+    'semseg_bn_stats_mm': (c_int, [vp, c_int, c_int, vp, vp, vp, c_sz, vp]),
+    'semseg_bn_finalize_mm': (c_int, [vp, vp, c_int, vp, vp, vp, vp, vp, c_f, c_f, c_int, vp, vp, vp, vp, vp, vp, vp,
+                                      c_int, vp]),
+    'semseg_bn_apply_h2': (c_int, [vp, vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int, vp]),
+    'semseg_bn_bwd_reduce_mm': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, vp, c_sz,
+                                        vp]),
+    'semseg_bn_bwd_bound': (c_int, [vp, vp, vp, vp, vp, vp, vp, c_int, c_int, vp, c_int, vp]),
+    'semseg_bn_bwd_apply_h2': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int,
+                                       vp]),
+    'semseg_weights_prepare_h2': (c_int, [ctypes.POINTER(WPrepTensor), c_int, vp]),
     'semseg_add_act': (c_int, [vp, c_int, vp, c_int, c_int, vp, c_int, c_int, c_int, vp]),
     'semseg_relu_bwd': (c_int, [vp, c_int, vp, c_int, vp, c_int, c_int, c_int, vp]),
     'semseg_copy2d': (c_int, [vp, c_int, vp, c_int, c_int, c_int, c_int, vp]),

@@ -96,6 +96,10 @@ class TrainStep:
             dev = next(segmentation_module.parameters()).device
             side = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
             self.buckets = GradientBuckets(list(enc.parameters()) + list(dec.parameters()), bucket_bytes, group, side)
+        # h2 path: the split planes of every conv weight are rebuilt by ONE multi-tensor launch after each optimiser
+        # step (csrc/weights_prep.hip) instead of 5 small launches per conv inside forward/backward
+        self._conv_weights = [m.weight for m in segmentation_module.modules() if isinstance(m, Conv2d)]
+        self._weights_ready = False
         self.use_graph = graph
         self._graph = None
         self._static = None
@@ -108,7 +112,14 @@ class TrainStep:
         for i, g in enumerate(self.opt.groups):
             self.opt.set_lr(i, g['base_lr'] * scale)
 
+    def _prepare_weights(self):
+        if ops.CONV_MODE == 'h2' and ops.FUSE:
+            ops.prepare_conv_weights(self._conv_weights)
+            self._weights_ready = True
+
     def _eager(self, feed):
+        if not self._weights_ready:
+            self._prepare_weights()
         self.opt.zero_grad()
         loss, acc = self.sm(feed)
         if self.buckets is not None:
@@ -119,6 +130,7 @@ class TrainStep:
             self.buckets.finish()
             scale = 1.0 / self.world          # loss.mean() over replicas (train.py:42)
         self.opt.step(grad_scale=scale)
+        self._prepare_weights()               # planes of the UPDATED weights, for the next step
         return loss.detach(), acc.detach()
 
     def step(self, feed):

@@ -8,7 +8,7 @@ kernel's accumulate form so no separate add pass is made for the up-sampled term
 import torch.nn as nn
 
 from .. import ops
-from .layers import Conv2d, BatchNorm2d, ReLU, ConvBNReLU
+from .layers import Conv2d, BatchNorm2d, ReLU, ConvBNReLU, conv_bn
 from .utils import load_url
 
 BN_MOMENTUM = 0.1
@@ -44,8 +44,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         residual = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), residual=residual, relu=True)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        return conv_bn(self.conv2, self.bn2, out, residual=residual, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -66,9 +66,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         residual = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=residual, relu=True)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        return conv_bn(self.conv3, self.bn3, out, residual=residual, relu=True)
 
 
 class HighResolutionModule(nn.Module):
@@ -198,8 +198,8 @@ class HRNetV2(nn.Module):
         return nn.Sequential(*mods), num_inchannels
 
     def forward(self, x, return_feature_maps=False):
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.bn2(self.conv2(x), relu=True)
+        x = conv_bn(self.conv1, self.bn1, x, relu=True)
+        x = conv_bn(self.conv2, self.bn2, x, relu=True)
         x = self.layer1(x)
         xs = [t(x) if t is not None else x for t in self.transition1]
         ys = self.stage2(xs)

@@ -49,6 +49,18 @@ class Conv2d(nn.Module):
                'dilation={dilation}'.format(**self.__dict__) + (', bias=False' if self.bias is None else '')
 
 
+def conv_bn(conv, bn, x, residual=None, relu=False):
+    """bn(conv(x), residual=..., relu=...) -- the conv -> BN [-> +residual] [-> ReLU] unit every block of the reference
+    is made of (resnet.py:72-92, models.py:160-167, hrnet.py:45-61) -- dispatched as ONE fused autograd node when the
+    h2 path can run it (ops.conv_bn_act), else as the two modules."""
+    if conv.bias is None and x.dim() == 4 and type(conv) is Conv2d and isinstance(bn, SynchronizedBatchNorm2d):
+        return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                               bn.num_batches_tracked, residual=residual, stride=conv.stride[0],
+                               padding=conv.padding[0], dilation=conv.dilation[0], training=bn.training,
+                               momentum=bn.momentum, eps=bn.eps, relu=relu)
+    return bn(conv(x), residual=residual, relu=relu)
+
+
 class ReLU(nn.Module):
     """Standalone ReLU (only used where the reference applies it outside a conv-BN pair)."""
 
@@ -111,7 +123,7 @@ class ConvBNReLU(nn.Sequential):
         self._conv, self._bn = str(first_index), str(first_index + 1)
 
     def forward(self, x, residual=None):
-        return self._modules[self._bn](self._modules[self._conv](x), residual=residual, relu=self._relu)
+        return conv_bn(self._modules[self._conv], self._modules[self._bn], x, residual=residual, relu=self._relu)
 
 
 def conv3x3_bn_relu(in_planes, out_planes, stride=1):

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import ops
 from . import resnet, hrnet
-from .layers import (Conv2d, BatchNorm2d, AdaptiveAvgPool2d, Dropout2d, ConvBNReLU, ReLU, conv3x3_bn_relu)
+from .layers import (Conv2d, BatchNorm2d, AdaptiveAvgPool2d, Dropout2d, ConvBNReLU, ReLU, conv3x3_bn_relu, conv_bn)
 
 
 class SegmentationModuleBase(nn.Module):
@@ -135,9 +135,9 @@ class Resnet(nn.Module):
             setattr(self, name, getattr(orig_resnet, name))
 
     def forward(self, x, return_feature_maps=False):
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.bn2(self.conv2(x), relu=True)
-        x = self.bn3(self.conv3(x), relu=True)
+        x = conv_bn(self.conv1, self.bn1, x, relu=True)
+        x = conv_bn(self.conv2, self.bn2, x, relu=True)
+        x = conv_bn(self.conv3, self.bn3, x, relu=True)
         x = self.maxpool(x)
         conv_out = []
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -201,7 +201,7 @@ class _PoolBranch(nn.Sequential):
 
     def forward(self, x):
         m = self._modules
-        return m['2'](m['1'](m['0'](x)), relu=True)
+        return conv_bn(m['1'], m['2'], m['0'](x), relu=True)
 
 
 class _ClassifierHead(nn.Sequential):
@@ -217,7 +217,7 @@ class _ClassifierHead(nn.Sequential):
 
     def forward(self, x):
         m = self._modules
-        x = m['1'](m['0'](x), relu=True)
+        x = conv_bn(m['0'], m['1'], x, relu=True)
         return m['4'](m['3'](x))
 
 

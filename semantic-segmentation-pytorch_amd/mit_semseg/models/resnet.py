@@ -6,7 +6,7 @@ import math
 
 import torch.nn as nn
 
-from .layers import Conv2d, BatchNorm2d, ReLU, MaxPool3x3s2, ConvBNReLU
+from .layers import Conv2d, BatchNorm2d, ReLU, MaxPool3x3s2, ConvBNReLU, conv_bn
 from .utils import load_url
 
 __all__ = ['ResNet', 'resnet18', 'resnet50', 'resnet101']
@@ -41,8 +41,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         residual = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), residual=residual, relu=True)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        return conv_bn(self.conv2, self.bn2, out, residual=residual, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -63,9 +63,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         residual = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=residual, relu=True)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        return conv_bn(self.conv3, self.bn3, out, residual=residual, relu=True)
 
 
 class ResNet(nn.Module):
@@ -107,9 +107,9 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def stem(self, x):
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.bn2(self.conv2(x), relu=True)
-        x = self.bn3(self.conv3(x), relu=True)
+        x = conv_bn(self.conv1, self.bn1, x, relu=True)
+        x = conv_bn(self.conv2, self.bn2, x, relu=True)
+        x = conv_bn(self.conv3, self.bn3, x, relu=True)
         return self.maxpool(x)
 
     def forward(self, x):

@@ -206,17 +206,110 @@ class Conv2dFn(Function):
         return dx, dw, db, None, None, None
 
 
+# SEMSEG_FUSE=0 turns the plane hand-over between producers and consumers off (every conv then splits its own operands)
+FUSE = os.environ.get('SEMSEG_FUSE', '1') != '0'
+
+
+def attach_planes(t, buf, scheme, rows, ch):
+    """Remember the split planes of activation `t` on the tensor object: the next conv that consumes this very object
+    (unchanged: same version counter, same storage) reads them instead of splitting again."""
+    t._semseg_planes = (buf, scheme, rows, ch, t._version, t.data_ptr())
+
+
+def planes_of(t, scheme, rows, ch):
+    rec = getattr(t, '_semseg_planes', None) if FUSE else None
+    if rec is not None and rec[1:4] == (scheme, rows, ch) and rec[4] == t._version and rec[5] == t.data_ptr():
+        return rec[0]
+    return None
+
+
+def input_planes(x, scheme):
+    """Split planes of conv input `x` (logical NCHW): handed over by the producer (BN kernels of the fused path), left by
+    an earlier consumer of the same tensor (block inputs feed two convs), or computed now."""
+    n, c, h, w = x.shape
+    xp = planes_of(x, scheme, n * h * w, c)
+    if xp is None:
+        xn, ld = as_nhwc(x.detach())
+        xp = SCHEMES[scheme].split(xn, n * h * w, c, ld)
+        if FUSE:
+            attach_planes(x, xp, scheme, n * h * w, c)
+    return xp
+
+
+def attach_absmax(t, absmax):
+    """`absmax`: 1-element device tensor holding an upper bound of max|t| (BN kernels of the fused path)."""
+    t._semseg_absmax = (absmax, t._version, t.data_ptr())
+
+
+def absmax_of(t):
+    rec = getattr(t, '_semseg_absmax', None) if (FUSE and t is not None) else None
+    if rec is not None and rec[1] == t._version and rec[2] == t.data_ptr():
+        return rec[0]
+    return None
+
+
+# ---- conv weights: split planes prepared for ALL convs in one multi-tensor launch (engine calls it after the SGD step)
+_WPLANES = {}       # id(param) -> (weakref, version, data_ptr, krsc planes, crsk planes)
+
+
+def prepare_conv_weights(weights):
+    """h2 split planes (KRSC for fwd, CRSK for dgrad) of every 4-D conv weight in `weights`, csrc/weights_prep.hip.
+    The planes stay valid until the parameter changes through torch (version counter) -- the fused SGD kernel updates
+    parameters behind torch's back, so the engine calls this again right after it."""
+    import weakref
+    L = _native.lib()
+    todo = []
+    for w in weights:
+        if w.dim() != 4 or not w.permute(0, 2, 3, 1).is_contiguous():
+            continue
+        _require_cuda(w)
+        k, c, r, s = w.shape
+        rec = _WPLANES.get(id(w))
+        if rec is None or rec[0]() is not w or rec[2] != w.data_ptr():
+            kb = torch.empty(L.semseg_split_h2_bytes(k * r * s, c), dtype=torch.uint8, device=w.device)
+            cb = torch.empty(L.semseg_split_h2_bytes(c * r * s, k), dtype=torch.uint8, device=w.device)
+            rec = (weakref.ref(w), w._version, w.data_ptr(), kb, cb)
+        else:
+            rec = (rec[0], w._version, rec[2], rec[3], rec[4])
+        _WPLANES[id(w)] = rec
+        todo.append((w, rec))
+    if not todo:
+        return 0
+    arr = (_native.WPrepTensor * len(todo))()
+    for i, (w, rec) in enumerate(todo):
+        k, c, r, s = w.shape
+        arr[i].w, arr[i].krsc, arr[i].crsk = w.data_ptr(), rec[3].data_ptr(), rec[4].data_ptr()
+        arr[i].K, arr[i].T, arr[i].C = k, r * s, c
+    _native.check(L.semseg_weights_prepare_h2(arr, len(todo), _st()), 'weights_prepare_h2')
+    return len(todo)
+
+
+def weight_planes(w, scheme):
+    """(KRSC planes, CRSK planes) prepared by prepare_conv_weights for this exact parameter state, else (None, None)."""
+    rec = _WPLANES.get(id(w)) if (FUSE and scheme == 'h2') else None
+    if rec is not None and rec[0]() is w and rec[1] == w._version and rec[2] == w.data_ptr():
+        return rec[3], rec[4]
+    return None, None
+
+
+def _weight_crsk_planes(L, sch, w, dev):
+    k, c, r, s = w.shape
+    wt = torch.empty((c, r, s, k), device=dev, dtype=torch.float32)
+    _native.check(L.semseg_weight_krsc_to_crsk(_p(w), _p(wt), k, r * s, c, _st()), 'weight_transpose')
+    return sch.split(wt, c * r * s, k, k)
+
+
 class Conv2dSplitFn(Function):
     """nn.Conv2d forward/backward on the 16-bit MFMA with fp32-class accuracy: every operand is split into 16-bit
     planes once (h2: 2 x fp16 with a per-tensor power-of-two scale, 3 products; s3: 3 x bf16, 6 products) and the
-    significant partial products are accumulated in fp32 (csrc/conv_split.hip).  The split of the input is kept
-    for the weight gradient; the split of dy is shared by the data and weight gradients."""
+    significant partial products are accumulated in fp32 (csrc/conv_split.hip).  The planes of the input (`xp`) are
+    kept for the weight gradient; the split of dy is shared by the data and weight gradients; `wp` / `wtp` are the
+    prepared weight planes (None: split here)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, scheme):
+    def forward(ctx, x, weight, bias, xp, wp, wtp, stride, pad, dil, scheme):
         L = _native.lib()
         sch = SCHEMES[scheme]
-        x, x_ld = as_nhwc(x.detach())
         w = krsc(weight.detach())
         _require_cuda(w, bias)
         n, c, h, wd = x.shape
@@ -226,17 +319,16 @@ class Conv2dSplitFn(Function):
         oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
         geom = (n, h, wd, c, k, r, s, stride, pad, dil)
         y = empty_nhwc(n, k, oh, ow, x.device)
-        xs = sch.split(x, n * h * wd, c, x_ld)
-        wsp = sch.split(w, k * r * s, c, c)
+        wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
         b = bias.detach() if bias is not None else None
 
         def launch():
             ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), x.device)
-            _native.check(sch.fn(L, 'fwd')(_p(xs), _p(wsp), _p(b), _p(y), k, *geom, _p(ws), ws.numel(), _st()),
+            _native.check(sch.fn(L, 'fwd')(_p(xp), _p(wsp), _p(b), _p(y), k, *geom, _p(ws), ws.numel(), _st()),
                           'conv2d_fwd_' + scheme)
         tuner.ensure(scheme, 0, geom, launch)
         launch()
-        ctx.save_for_backward(xs, w)
+        ctx.save_for_backward(xp, w, wtp)
         ctx.geom = geom
         ctx.has_bias = bias is not None
         ctx.scheme = scheme
@@ -246,7 +338,7 @@ class Conv2dSplitFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         L = _native.lib()
-        xs, w = ctx.saved_tensors
+        xs, w, wtp = ctx.saved_tensors
         geom = ctx.geom
         scheme = ctx.scheme
         sch = SCHEMES[scheme]
@@ -255,40 +347,50 @@ class Conv2dSplitFn(Function):
         dev = w.device
         dy, dy_ld = as_nhwc(dy)
         dys = sch.split(dy, n * oh * ow, k, dy_ld)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt = torch.empty((c, r, s, k), device=dev, dtype=torch.float32)
-            _native.check(L.semseg_weight_krsc_to_crsk(_p(w), _p(wt), k, r * s, c, _st()), 'weight_transpose')
-            wts = sch.split(wt, c * r * s, k, k)
-            dx = empty_nhwc(n, c, h, wd, dev)
-
-            def launch_d():
-                ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
-                _native.check(sch.fn(L, 'dgrad')(_p(dys), _p(wts), _p(dx), c, *geom, _p(ws), ws.numel(), _st()),
-                              'conv2d_dgrad_' + scheme)
-            tuner.ensure(scheme, 1, geom, launch_d)
-            launch_d()
-        if ctx.needs_input_grad[1]:
-            dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
-
-            def launch_w():
-                ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
-                _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
-                              'conv2d_wgrad_' + scheme)
-            tuner.ensure(scheme, 2, geom, launch_w)
-            launch_w()
-            dw = dwb.permute(0, 3, 1, 2)
+        dx, dw = _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty((k,), device=dev, dtype=torch.float32)
             ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
             _native.check(L.semseg_bias_grad(_p(dy), dy_ld, _p(db), n * oh * ow, k, _p(ws), ws.numel(), _st()), 'bias_grad')
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
+
+
+def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
+    """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys)."""
+    n, h, wd, c, k, r, s, stride, pad, dil = geom
+    dev = w.device
+    dx = dw = None
+    if need_dx:
+        wts = wtp if wtp is not None else _weight_crsk_planes(L, sch, w, dev)
+        dx = empty_nhwc(n, c, h, wd, dev)
+
+        def launch_d():
+            ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
+            _native.check(sch.fn(L, 'dgrad')(_p(dys), _p(wts), _p(dx), c, *geom, _p(ws), ws.numel(), _st()),
+                          'conv2d_dgrad_' + scheme)
+        tuner.ensure(scheme, 1, geom, launch_d)
+        launch_d()
+    if need_dw:
+        dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
+
+        def launch_w():
+            ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
+            _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
+                          'conv2d_wgrad_' + scheme)
+        tuner.ensure(scheme, 2, geom, launch_w)
+        launch_w()
+        dw = dwb.permute(0, 3, 1, 2)
+    return dx, dw
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     if CONV_MODE == 'f32':
         return Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
-    return Conv2dSplitFn.apply(x, weight, bias, int(stride), int(padding), int(dilation), CONV_MODE)
+    _require_cuda(x)
+    xp = input_planes(x, CONV_MODE)
+    wp, wtp = weight_planes(weight, CONV_MODE)
+    return Conv2dSplitFn.apply(x, weight, bias, xp, wp, wtp, int(stride), int(padding), int(dilation), CONV_MODE)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -388,6 +490,130 @@ def batch_norm_act(z, gamma, beta, running_mean, running_var, residual=None, tra
     """`num_batches_tracked` (int64 0-dim buffer) is incremented by the finalize kernel in training mode."""
     return BatchNormActFn.apply(z, gamma, beta, running_mean, running_var, residual, bool(training),
                                 float(momentum), float(eps), bool(relu), num_batches_tracked)
+
+
+class ConvBNActFn(Function):
+    """y = act(BN_train(conv(x)) [+ residual]) as ONE autograd node on the h2 path (resnet.py:72-92 blocks,
+    models.py:160-167 conv3x3_bn_relu, hrnet.py).  Versus Conv2dSplitFn + BatchNormActFn:
+      * the BN statistics pass also gathers per-channel min/max of z, which bound |y| rigorously -> the exponent of y's
+        split planes is known before y is written and bn_apply emits y's planes itself (no absmax + split passes in the
+        next conv);
+      * backward: the BN gradient is written ONLY as split planes (its sole consumers are the conv gradients), with the
+        exponent bounded from the reduction sums (csrc/bn.hip, second half).
+    Returns (y, planes of y or None, |y| bound or None)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg):
+        stride, pad, dil, momentum, eps, relu, emit = cfg
+        L = _native.lib()
+        sch = SCHEMES['h2']
+        w = krsc(weight.detach())
+        g, b = gamma.detach(), beta.detach()
+        _require_cuda(w, g, b, running_mean, running_var)
+        n, c, h, wd = x.shape
+        k, c2, r, s = w.shape
+        if c2 != c:
+            raise RuntimeError('conv2d: input has %d channels, weight expects %d' % (c, c2))
+        oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
+        P = n * oh * ow
+        if P <= 1:
+            raise ValueError('Expected more than 1 value per channel when training, got input size %s'
+                             % str([n, k, oh, ow]))
+        geom = (n, h, wd, c, k, r, s, stride, pad, dil)
+        dev = x.device
+        wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
+        z = empty_nhwc(n, k, oh, ow, dev)
+
+        def launch():
+            ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
+            _native.check(sch.fn(L, 'fwd')(_p(xp), _p(wsp), _p(None), _p(z), k, *geom, _p(ws), ws.numel(), _st()),
+                          'conv2d_fwd_h2')
+        tuner.ensure('h2', 0, geom, launch)
+        launch()
+        stats = torch.empty((2 * k + 1,), device=dev, dtype=torch.float64)
+        zmm = torch.empty((2 * k,), device=dev, dtype=torch.float32)
+        ws = workspace(L.semseg_bn_mm_workspace_bytes(P, k), dev)
+        _native.check(L.semseg_bn_stats_mm(_p(z), P, k, _p(stats), _p(zmm), _p(ws), ws.numel(), _st()), 'bn_stats_mm')
+        _maybe_allreduce(stats)
+        coef = torch.empty((4, k), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
+        res, res_ld = (None, 0)
+        if residual is not None:
+            res, res_ld = as_nhwc(residual.detach())
+        bound_ok = residual is None or res_absmax is not None
+        absmax = torch.empty((1,), device=dev, dtype=torch.float32) if bound_ok else None
+        yp = torch.empty(L.semseg_split_h2_bytes(P, k), dtype=torch.uint8, device=dev) if (emit and bound_ok) else None
+        _native.check(L.semseg_bn_finalize_mm(_p(stats), _p(zmm), k, _p(g), _p(b), _p(running_mean), _p(running_var),
+                                              _p(nbt), float(momentum), float(eps), int(relu), _p(res_absmax),
+                                              _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(absmax), _p(yp), P,
+                                              _st()), 'bn_finalize_mm')
+        y = empty_nhwc(n, k, oh, ow, dev)
+        if yp is not None:
+            _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), _p(yp),
+                                               P, k, _st()), 'bn_apply_h2')
+        else:
+            _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), k, P, k,
+                                            _st()), 'bn_apply')
+        ctx.save_for_backward(xp, w, wtp, z, y if relu else None, coef, g, stats, zmm)
+        ctx.geom = geom
+        ctx.cfg = (bool(relu), residual is not None)
+        if absmax is not None:
+            ctx.mark_non_differentiable(absmax)
+        return y, yp, absmax
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _gyp, _gabs):
+        L = _native.lib()
+        sch = SCHEMES['h2']
+        xp, w, wtp, z, y, coef, gamma, stats, zmm = ctx.saved_tensors
+        relu, has_res = ctx.cfg
+        geom = ctx.geom
+        n, h, wd, c, k, r, s, stride, pad, dil = geom
+        oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
+        P = n * oh * ow
+        dev = w.device
+        dy, dy_ld = as_nhwc(dy)
+        sums = torch.empty((2 * k,), device=dev, dtype=torch.float64)
+        gmax = torch.empty((k,), device=dev, dtype=torch.float32)
+        dgamma = torch.empty((k,), device=dev, dtype=torch.float32)
+        dbeta = torch.empty((k,), device=dev, dtype=torch.float32)
+        ws = workspace(L.semseg_bn_mm_workspace_bytes(P, k), dev)
+        _native.check(L.semseg_bn_bwd_reduce_mm(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), int(relu), P, k,
+                                                _p(sums), _p(gmax), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _st()),
+                      'bn_bwd_reduce_mm')
+        _maybe_allreduce(sums)
+        count = stats[2 * k:]
+        dzp = torch.empty(L.semseg_split_h2_bytes(P, k), dtype=torch.uint8, device=dev)
+        _native.check(L.semseg_bn_bwd_bound(_p(sums), _p(count), _p(gmax), _p(zmm), _p(coef[0]), _p(coef[1]), _p(gamma), k,
+                                            1, _p(dzp), P, _st()), 'bn_bwd_bound')
+        dres = empty_nhwc(n, k, oh, ow, dev) if (has_res and ctx.needs_input_grad[4]) else None
+        _native.check(L.semseg_bn_bwd_apply_h2(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gamma),
+                                               _p(sums), _p(count), 1, int(relu), _p(dzp), _p(dres), P, k, _st()),
+                      'bn_bwd_apply_h2')
+        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
+                None, None, None, None, None, None, None, None)
+
+
+def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, residual=None, stride=1,
+                padding=0, dilation=1, training=False, momentum=0.1, eps=1e-5, relu=False):
+    """act(BN(conv(x)) + residual) for a bias-free conv.  Training on the h2 path with K % 8 == 0 runs the fused node
+    (ConvBNActFn); everything else composes conv2d + batch_norm_act."""
+    if not (FUSE and CONV_MODE == 'h2' and training and weight.shape[0] % 8 == 0):
+        z = conv2d(x, weight, None, stride, padding, dilation)
+        return batch_norm_act(z, gamma, beta, running_mean, running_var, residual=residual, training=training,
+                              momentum=momentum, eps=eps, relu=relu, num_batches_tracked=num_batches_tracked)
+    _require_cuda(x)
+    xp = input_planes(x, 'h2')
+    wp, wtp = weight_planes(weight, 'h2')
+    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu))
+    y, yp, absmax = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean,
+                                      running_var, num_batches_tracked, cfg)
+    if yp is not None:
+        attach_planes(y, yp, 'h2', y.shape[0] * y.shape[2] * y.shape[3], y.shape[1])
+    if absmax is not None:
+        attach_absmax(y, absmax)
+    return y
 
 
 # ------------------------------------------------------------------------------------------------
@@ -522,7 +748,11 @@ class MaxPool3x3s2Fn(Function):
 
 
 def max_pool_3x3_s2(x):
-    return MaxPool3x3s2Fn.apply(x)
+    y = MaxPool3x3s2Fn.apply(x)
+    bound = absmax_of(x)
+    if bound is not None:
+        attach_absmax(y, bound)          # max over windows of x: the bound of |x| holds for |y|
+    return y
 
 
 class AdaptiveAvgPoolFn(Function):

@@ -287,3 +287,239 @@ def test_sgd_step_matches_torch():
         ops.sgd_step(gp, [x.to(dev()) for x in grads], bufs, it == 0, wds, lr, 0.9, 1.0)
     for p, r in zip(gp, ref):
         torch.testing.assert_close(p.cpu(), r.detach(), atol=1e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# h2 plane producers outside the split kernels: multi-tensor weight preparation, BN kernels that emit planes, and the
+# fused conv -> BN node built on them
+# ------------------------------------------------------------------------------------------------
+def _h2_decode(buf, rows, ch):
+    """h2 split buffer -> (float64 [rows, ch] reconstruction (p0 + p1) * 2^-e, exponent e, raw planes [2, rows, pitch],
+    zero tail bytes)."""
+    from mit_semseg import _native
+    L = _native.lib()
+    total = L.semseg_split_h2_bytes(rows, ch)
+    assert buf.numel() == total
+    plane_bytes = (total - 256 - (256 + 4 * 1024)) // 2
+    pitch = plane_bytes // 2 // rows
+    raw = buf[:2 * plane_bytes].view(torch.float16).reshape(2, rows, pitch)
+    tail = buf[2 * plane_bytes:2 * plane_bytes + 256]
+    e = int(buf[2 * plane_bytes + 256:2 * plane_bytes + 260].view(torch.int32).item())
+    val = (raw[0, :, :ch].double() + raw[1, :, :ch].double()) * 2.0 ** (-e)
+    return val.cpu(), e, raw, tail
+
+
+@pytest.mark.parametrize('k,c,r', [(64, 3, 3), (64, 64, 3), (150, 512, 1), (512, 1024, 3), (48, 48, 3), (180, 720, 3),
+                                   (2048, 1024, 1), (96, 48, 3), (512, 4096, 3)], ids=str)
+def test_weights_prepare_h2_matches_split(k, c, r):
+    """csrc/weights_prep.hip == semseg_split_h2 of the KRSC weight and of its CRSK transpose, bit for bit (planes incl.
+    channel padding, zero tail, exponent word)"""
+    from mit_semseg import ops, _native
+    L = _native.lib()
+    g = torch.Generator().manual_seed(k * 7 + c)
+    w = (torch.randn(k, c, r, r, generator=g) * 0.05).to(dev()).contiguous(memory_format=torch.channels_last)
+    if r == 1:
+        w = w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    w2 = (torch.randn(32, 16, 1, 1, generator=g)).to(dev()).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    wp = torch.nn.Parameter(w)
+    wp2 = torch.nn.Parameter(w2)
+    assert ops.prepare_conv_weights([wp2, wp]) == 2          # two tensors in one launch (tile_base bookkeeping)
+    krsc, crsk = ops.weight_planes(wp, 'h2')
+    assert krsc is not None
+    sch = ops.SCHEMES['h2']
+    t = r * r
+    ref_k = sch.split(ops.krsc(w), k * t, c, c)
+    wt = torch.empty((c, r, r, k), device=dev())
+    _native.check(L.semseg_weight_krsc_to_crsk(ops._p(ops.krsc(w)), ops._p(wt), k, t, c, ops._st()), 'transpose')
+    ref_c = sch.split(wt, c * t, k, k)
+    torch.cuda.synchronize()
+    for got, ref, rows, ch in ((krsc, ref_k, k * t, c), (crsk, ref_c, c * t, k)):
+        gv, ge, graw, gtail = _h2_decode(got, rows, ch)
+        rv, re_, rraw, rtail = _h2_decode(ref, rows, ch)
+        assert ge == re_
+        chp = (ch + 31) // 32 * 32
+        assert torch.equal(graw[:, :, :chp].view(torch.int16), rraw[:, :, :chp].view(torch.int16))
+        assert int(gtail.max()) == 0
+    # the version counter invalidates the planes when the parameter is changed through torch
+    with torch.no_grad():
+        wp.mul_(2.0)
+    assert ops.weight_planes(wp, 'h2') == (None, None)
+
+
+@pytest.mark.parametrize('n,c,h,w', [(2, 64, 16, 16), (2, 512, 8, 8), (1, 48, 9, 7), (2, 2048, 2, 2), (2, 40, 5, 5)], ids=str)
+@pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True), (False, True)])
+def test_bn_h2_forward_kernels(n, c, h, w, relu, res):
+    """stats_mm / finalize_mm / apply_h2: y identical to the plain BN kernels, planes reconstruct y to 2^-21, the
+    exponent comes from a valid (and, without residual, exact) bound"""
+    from mit_semseg import ops, _native
+    L = _native.lib()
+    d = dev()
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    P = n * h * w
+    z = (torch.randn(P, c, generator=g) * 3 + 1).to(d)
+    z[::7] *= 40.0                                             # outliers: exercise the subnormal floor of the low part
+    gamma = (torch.rand(c, generator=g) + 0.5).to(d)
+    gamma[::3] *= -1                                            # negative scale: min/max swap roles
+    beta = torch.randn(c, generator=g).to(d)
+    r = (torch.randn(P, c, generator=g) * 2).to(d) if res else None
+    rabs = r.abs().max().reshape(1) * 1.5 if res else None     # any upper bound of |res|
+    rm, rv = torch.zeros(c, device=d), torch.ones(c, device=d)
+    rm2, rv2 = torch.zeros(c, device=d), torch.ones(c, device=d)
+    st = ops._st()
+    # plain path
+    stats0 = torch.empty(2 * c + 1, dtype=torch.float64, device=d)
+    ws = torch.empty(max(L.semseg_bn_workspace_bytes(P, c), L.semseg_bn_mm_workspace_bytes(P, c)), dtype=torch.uint8, device=d)
+    coef0 = torch.empty(4, c, device=d)
+    _native.check(L.semseg_bn_stats(ops._p(z), P, c, ops._p(stats0), ops._p(ws), ws.numel(), st), 'stats')
+    _native.check(L.semseg_bn_finalize(ops._p(stats0), c, ops._p(gamma), ops._p(beta), ops._p(rm), ops._p(rv), ops._p(None),
+                                       0.1, 1e-5, ops._p(coef0[0]), ops._p(coef0[1]), ops._p(coef0[2]), ops._p(coef0[3]), st), 'fin')
+    y0 = torch.empty(P, c, device=d)
+    _native.check(L.semseg_bn_apply(ops._p(z), ops._p(coef0[2]), ops._p(coef0[3]), ops._p(r), c, int(relu), ops._p(y0), c, P, c, st), 'apply')
+    # mm path
+    stats = torch.empty(2 * c + 1, dtype=torch.float64, device=d)
+    zmm = torch.empty(2 * c, device=d)
+    coef = torch.empty(4, c, device=d)
+    absmax = torch.empty(1, device=d)
+    yp = torch.full((L.semseg_split_h2_bytes(P, c),), 0x5a, dtype=torch.uint8, device=d)
+    y = torch.empty(P, c, device=d)
+    _native.check(L.semseg_bn_stats_mm(ops._p(z), P, c, ops._p(stats), ops._p(zmm), ops._p(ws), ws.numel(), st), 'stats_mm')
+    _native.check(L.semseg_bn_finalize_mm(ops._p(stats), ops._p(zmm), c, ops._p(gamma), ops._p(beta), ops._p(rm2), ops._p(rv2),
+                                          ops._p(None), 0.1, 1e-5, int(relu), ops._p(rabs), ops._p(coef[0]), ops._p(coef[1]),
+                                          ops._p(coef[2]), ops._p(coef[3]), ops._p(absmax), ops._p(yp), P, st), 'fin_mm')
+    _native.check(L.semseg_bn_apply_h2(ops._p(z), ops._p(coef[2]), ops._p(coef[3]), ops._p(r), c, int(relu), ops._p(y), ops._p(yp),
+                                       P, c, st), 'apply_h2')
+    torch.cuda.synchronize()
+    assert torch.equal(stats, stats0)
+    for a, b in ((coef, coef0), (rm, rm2), (rv, rv2), (y, y0)):     # same formulas, separately compiled kernels
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+    assert torch.equal(zmm[:c], z.min(0).values) and torch.equal(zmm[c:], z.max(0).values)
+    val, e, raw, tail = _h2_decode(yp, P, c)
+    ymax = y.abs().max().item()
+    assert absmax.item() >= ymax
+    if not res:
+        assert absmax.item() == ymax                               # exact without a residual
+    assert ymax * 2.0 ** e < 2.0 ** 15 and absmax.item() * 2.0 ** e >= 2.0 ** 14
+    yd = y.double().cpu()
+    err = (val - yd).abs()
+    assert (err <= 2.0 ** -21 * yd.abs() + 2.0 ** (-25 - e)).all(), err.max()
+    assert int(tail.max()) == 0
+    chp = (c + 31) // 32 * 32
+    assert (raw[:, :, c:chp] == 0).all()
+
+
+@pytest.mark.parametrize('n,c,h,w', [(2, 64, 16, 16), (2, 512, 8, 8), (1, 48, 9, 7), (2, 2048, 2, 2)], ids=str)
+@pytest.mark.parametrize('relu,dres', [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('training', [True, False])
+def test_bn_h2_backward_kernels(n, c, h, w, relu, dres, training):
+    """reduce_mm / bound / bwd_apply_h2: sums and parameter gradients identical to the plain kernels, the planes
+    reconstruct the plain fp32 dz to 2^-21, no fp16 overflow"""
+    from mit_semseg import ops, _native
+    L = _native.lib()
+    d = dev()
+    g = torch.Generator().manual_seed(n * 1000 + c + 1)
+    P = n * h * w
+    z = (torch.randn(P, c, generator=g) * 2 + 0.5).to(d)
+    dy = (torch.randn(P, c, generator=g) * 1e-3).to(d)
+    dy[::5] *= 300.0
+    gamma = (torch.rand(c, generator=g) + 0.5).to(d)
+    mean, var = z.mean(0), z.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    y = torch.relu((z - mean) * invstd * gamma) if relu else None
+    count = torch.tensor([float(P)], dtype=torch.float64, device=d)
+    zmm = torch.cat([z.min(0).values, z.max(0).values])
+    st = ops._st()
+    ws = torch.empty(max(L.semseg_bn_workspace_bytes(P, c), L.semseg_bn_mm_workspace_bytes(P, c)), dtype=torch.uint8, device=d)
+    sums0 = torch.empty(2 * c, dtype=torch.float64, device=d)
+    dg0, db0 = torch.empty(c, device=d), torch.empty(c, device=d)
+    _native.check(L.semseg_bn_bwd_reduce(ops._p(dy), c, ops._p(y), c, ops._p(z), ops._p(mean), ops._p(invstd), int(relu), P, c,
+                                         ops._p(sums0), ops._p(dg0), ops._p(db0), ops._p(ws), ws.numel(), st), 'reduce')
+    dz0 = torch.empty(P, c, device=d)
+    dres0 = torch.empty(P, c, device=d) if dres else None
+    _native.check(L.semseg_bn_bwd_apply(ops._p(dy), c, ops._p(y), c, ops._p(z), ops._p(mean), ops._p(invstd), ops._p(gamma),
+                                        ops._p(sums0), ops._p(count), int(training), int(relu), ops._p(dz0), ops._p(dres0), P, c, st), 'apply')
+    sums = torch.empty(2 * c, dtype=torch.float64, device=d)
+    gmax = torch.empty(c, device=d)
+    dg, db = torch.empty(c, device=d), torch.empty(c, device=d)
+    _native.check(L.semseg_bn_bwd_reduce_mm(ops._p(dy), c, ops._p(y), c, ops._p(z), ops._p(mean), ops._p(invstd), int(relu), P, c,
+                                            ops._p(sums), ops._p(gmax), ops._p(dg), ops._p(db), ops._p(ws), ws.numel(), st), 'reduce_mm')
+    dzp = torch.full((L.semseg_split_h2_bytes(P, c),), 0x5a, dtype=torch.uint8, device=d)
+    dres1 = torch.empty(P, c, device=d) if dres else None
+    _native.check(L.semseg_bn_bwd_bound(ops._p(sums), ops._p(count), ops._p(gmax), ops._p(zmm), ops._p(mean), ops._p(invstd),
+                                        ops._p(gamma), c, int(training), ops._p(dzp), P, st), 'bound')
+    _native.check(L.semseg_bn_bwd_apply_h2(ops._p(dy), c, ops._p(y), c, ops._p(z), ops._p(mean), ops._p(invstd), ops._p(gamma),
+                                           ops._p(sums), ops._p(count), int(training), int(relu), ops._p(dzp), ops._p(dres1), P, c, st),
+                  'apply_h2')
+    torch.cuda.synchronize()
+    assert torch.equal(sums, sums0) and torch.equal(dg, dg0) and torch.equal(db, db0)
+    gg = dy * (y > 0) if relu else dy
+    assert torch.equal(gmax, gg.abs().max(0).values)
+    if dres:
+        assert torch.equal(dres1, dres0)
+    val, e, raw, tail = _h2_decode(dzp, P, c)
+    dzd = dz0.double().cpu()
+    dmax = dzd.abs().max().item()
+    assert dmax * 2.0 ** e < 2.0 ** 15                        # the bound holds
+    assert dmax * 2.0 ** e >= 2.0 ** 10, (dmax, e)            # ... and is not absurdly loose
+    err = (val - dzd).abs()
+    # 1e-6 * max: the two apply kernels are compiled separately (fma contraction of g - m - xhat*x may differ)
+    assert (err <= 2.0 ** -21 * dzd.abs() + 2.0 ** (-25 - e) + 1e-6 * dmax).all(), err.max()
+    assert int(tail.max()) == 0
+
+
+@pytest.mark.parametrize('case', [(2, 64, 24, 24, 128, 3, 1, 1, 1), (2, 256, 16, 16, 256, 3, 1, 2, 2), (2, 128, 17, 19, 64, 1, 2, 0, 1),
+                                  (2, 3, 32, 32, 64, 3, 2, 1, 1)], ids=str)
+@pytest.mark.parametrize('relu,res', [(True, False), (True, True), (False, False)])
+def test_conv_bn_act_fused_vs_float64(case, relu, res, monkeypatch):
+    """ops.conv_bn_act (fused node: planes from the BN kernels, dz only as planes, prepared weights) followed by a second
+    fused unit that CONSUMES the emitted planes, against float64 conv + batch_norm on the CPU"""
+    from mit_semseg import ops
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    n, c, h, w, k, ks, stride, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(n, c, h, w, generator=g)
+    w1 = torch.randn(k, c, ks, ks, generator=g) / (c * ks * ks) ** 0.5
+    w2 = torch.randn(k, k, 3, 3, generator=g) / (k * 9) ** 0.5
+    g1, b1 = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g) * 0.1
+    g2, b2 = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g) * 0.1
+    oh = (h + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+    ow = (w + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+    r = torch.randn(n, k, oh, ow, generator=g) if res else None
+    gy = torch.randn(n, k, oh, ow, generator=g)
+
+    def ref():
+        ts = [t.double().requires_grad_(True) for t in (x, w1, w2, g1, b1, g2, b2)] + [r.double().requires_grad_(True) if res else None]
+        xd, w1d, w2d, g1d, b1d, g2d, b2d, rd = ts
+        t = F.batch_norm(F.conv2d(xd, w1d, None, stride, pad, dil), None, None, g1d, b1d, True, 0.1, 1e-5)
+        if res:
+            t = t + rd
+        if relu:
+            t = torch.relu(t)
+        u = torch.relu(F.batch_norm(F.conv2d(t, w2d, None, 1, 1, 1), None, None, g2d, b2d, True, 0.1, 1e-5))
+        u.backward(gy.double())
+        return u.detach(), [p.grad for p in ts if p is not None]
+
+    def run():
+        ts = [cl(x).requires_grad_(True), torch.nn.Parameter(cl(w1)), torch.nn.Parameter(cl(w2))] + \
+             [torch.nn.Parameter(t.to(dev())) for t in (g1, b1, g2, b2)] + [cl(r).requires_grad_(True) if res else None]
+        xg, w1g, w2g, g1g, b1g, g2g, b2g, rg = ts
+        ops.prepare_conv_weights([w1g, w2g])
+        bufs = [torch.zeros(k, device=dev()), torch.ones(k, device=dev()), torch.zeros((), dtype=torch.long, device=dev())]
+        if rg is not None:
+            ops.attach_absmax(rg, rg.detach().abs().max().reshape(1))
+        t = ops.conv_bn_act(xg, w1g, g1g, b1g, bufs[0], bufs[1], bufs[2], residual=rg, stride=stride, padding=pad,
+                            dilation=dil, training=True, relu=relu)
+        assert (ops.planes_of(t, 'h2', n * oh * ow, k) is not None) == bool(relu)
+        u = ops.conv_bn_act(t, w2g, g2g, b2g, torch.zeros(k, device=dev()), torch.ones(k, device=dev()),
+                            torch.zeros((), dtype=torch.long, device=dev()), stride=1, padding=1, dilation=1, training=True, relu=True)
+        u.backward(cl(gy))
+        torch.cuda.synchronize()
+        assert int(bufs[2].item()) == 1
+        return u.detach(), [p.grad for p in ts if p is not None]
+
+    ur, gr = ref()
+    ug, gg = run()
+    assert rel_err(ug, ur) < 5e-5, rel_err(ug, ur)
+    names = ['x', 'w1', 'w2', 'g1', 'b1', 'g2', 'b2', 'res']
+    for nm, a, b in zip(names, gg, gr):
+        e = ((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()
+        assert e < 3e-3, (nm, e)      # relative L2; a ReLU gate flipped by a 1e-6 difference moves it by ~1e-3

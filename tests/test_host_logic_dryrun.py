@@ -74,9 +74,11 @@ def test_train_step_host_logic(stub, cfg, mode, monkeypatch):
             's3': ('semseg_split3', 'semseg_conv2d_fwd_s3', 'semseg_conv2d_dgrad_s3', 'semseg_conv2d_wgrad_s3', 'semseg_bias_grad'),
             'h2': ('semseg_split_h2', 'semseg_conv2d_fwd_h2', 'semseg_conv2d_dgrad_h2', 'semseg_conv2d_wgrad_h2',
                    'semseg_bias_grad')}[mode]
-    for must in conv + ('semseg_bn_stats', 'semseg_bn_apply',
-                 'semseg_bn_bwd_reduce', 'semseg_bn_bwd_apply', 'semseg_log_softmax_fwd', 'semseg_nll_acc_fwd',
-                 'semseg_nll_bwd', 'semseg_sgd_step'):
+    # h2: conv -> BN pairs run as the fused node (BN kernels that emit / consume split planes, multi-tensor weight prep)
+    bn = ('semseg_bn_stats_mm', 'semseg_bn_finalize_mm', 'semseg_bn_apply_h2', 'semseg_bn_bwd_reduce_mm',
+          'semseg_bn_bwd_bound', 'semseg_bn_bwd_apply_h2', 'semseg_weights_prepare_h2') if mode == 'h2' else \
+         ('semseg_bn_stats', 'semseg_bn_apply', 'semseg_bn_bwd_reduce', 'semseg_bn_bwd_apply')
+    for must in conv + bn + ('semseg_log_softmax_fwd', 'semseg_nll_acc_fwd', 'semseg_nll_bwd', 'semseg_sgd_step'):
         assert must in names, must
     # second step exercises momentum buffers / grad re-allocation
     ts.step(feed)
