@@ -184,12 +184,14 @@ def main():
 
     for _ in range(args.warmup):
         loss, acc = step.step(feed)
+    step.flush()                     # multi-step graphs: no staged step crosses into the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, acc = step.step(feed)
+    step.flush()                     # ... and every one of the K timed steps has run before the clock stops
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

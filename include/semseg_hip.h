@@ -183,10 +183,13 @@ int semseg_bn_finalize_mm(const double* stats, const float* zmm, int C, const fl
                           float momentum, float eps, int relu, const float* res_absmax,
                           float* mean, float* invstd, float* scale, float* shift,
                           float* absmax_out, void* y_planes, int P, void* stream);
-/* semseg_bn_apply (y dense, ld C) that ALSO writes the h2 split planes of y into y_planes (semseg_split_h2_bytes(P, C);
- * exponent word set by semseg_bn_finalize_mm).  C % 8 == 0. */
+/* semseg_bn_apply (y dense, ld C) that ALSO writes the h2 split planes of y into y_planes (semseg_split_h2_bytes(P, C)).
+ * C % 8 == 0.  Exponent: blockbound == NULL -> the header word set by semseg_bn_finalize_mm; else the maximum of the
+ * ceil(C/16) per-block bounds left by semseg_bn_fwd_stats_fused (the kernel then also publishes the header word and, if
+ * absmax_out != NULL, the bound itself). */
 int semseg_bn_apply_h2(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
-                       int relu, float* y, void* y_planes, int P, int C, void* stream);
+                       int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
+                       void* stream);
 /* semseg_bn_bwd_reduce + gmax[c] = max_p |g[p,c]| */
 int semseg_bn_bwd_reduce_mm(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
                             const float* mean, const float* invstd, int relu, int P, int C,
@@ -197,11 +200,28 @@ int semseg_bn_bwd_reduce_mm(const float* dy, int dy_ld, const float* y, int y_ld
 int semseg_bn_bwd_bound(const double* sums, const double* stats_count, const float* gmax, const float* zmm,
                         const float* mean, const float* invstd, const float* gamma, int C, int training,
                         void* dz_planes, int P, void* stream);
-/* semseg_bn_bwd_apply writing dz ONLY as h2 split planes (P rows x C channels; C % 8 == 0); dres stays fp32 */
+/* semseg_bn_bwd_apply writing dz ONLY as h2 split planes (P rows x C channels; C % 8 == 0); dres stays fp32.
+ * gate_scale/gate_shift != NULL (BN without residual): the ReLU gate is recomputed as fmaf(z, scale, shift) > 0 -- the
+ * forward's own decision -- and y is not read.  blockbound: as semseg_bn_apply_h2 (from semseg_bn_bwd_reduce_fused). */
 int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
                            const float* mean, const float* invstd, const float* gamma,
                            const double* sums, const double* stats_count, int training, int relu,
-                           void* dz_planes, float* dres, int P, int C, void* stream);
+                           void* dz_planes, float* dres, int P, int C,
+                           const float* gate_scale, const float* gate_shift, const void* blockbound, void* stream);
+/* Single-rank fused forms (no all-reduce between the partial sums and their use): 3 launches per BN pass instead of 4.
+ * semseg_bn_fwd_stats_fused = semseg_bn_stats_mm + semseg_bn_finalize_mm, leaving ceil(C/16) per-block bounds (uint32 bit
+ * patterns) in `blockbound` for semseg_bn_apply_h2.  semseg_bn_bwd_reduce_fused = semseg_bn_bwd_reduce_mm + the per-channel
+ * part of semseg_bn_bwd_bound, leaving the bounds for semseg_bn_bwd_apply_h2. */
+int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                              float momentum, float eps, int relu, const float* res_absmax,
+                              float* mean, float* invstd, float* scale, float* shift, void* blockbound,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                               const float* mean, const float* invstd, const float* gate_scale, const float* gate_shift,
+                               int relu, int P, int C, const double* stats_count, const float* zmm, const float* gamma,
+                               int training, double* sums, float* dgamma, float* dbeta, void* blockbound,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------- elementwise helpers ------------------------------------------------------ */
 /* out = act(a + b) (hrnet.py:231-248 fuse sums); a,b,out [P,C] with their own ld */

@@ -396,6 +396,15 @@ extern "C" int semseg_bn_bwd_apply(const float* dy, int dy_ld, const float* y, i
 // ================================================================================================
 #include "split_layout.h"
 
+// ReLU gate of a BN WITHOUT residual recomputed from z: y = max(fmaf(z, scale, shift), 0), so y > 0 <=> the very same fmaf
+// > 0 -- bit-identical to the forward decision; saves the 4 B/element read of y in both backward passes.
+__device__ __forceinline__ float4 relu_gate_from_z(const float4 v, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift) {
+    const float4 sc = *reinterpret_cast<const float4*>(scale);
+    const float4 sh = *reinterpret_cast<const float4*>(shift);
+    return make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+}
+
 extern "C" size_t semseg_bn_mm_workspace_bytes(int P, int C) {
     if (C % 4) return 0;
     const ColGeom g = col_geom(P, C);
@@ -573,15 +582,35 @@ extern "C" int semseg_bn_finalize_mm(const double* stats, const float* zmm, int 
     return 0;
 }
 
+// Exponent of an h2 plane buffer inside the kernel that writes the planes: either the header word (set by an earlier
+// bn_finalize_mm / bn_bwd_bound launch), or -- single-rank fused path -- the maximum of the per-block bounds that the
+// merged finish kernel left in `blockbound` (bit patterns; every block redoes this <= 1 KB reduction, block 0 publishes
+// the exponent word and the bound itself).
+__device__ __forceinline__ int h2_exponent_from(int* __restrict__ hdr, const uint32_t* __restrict__ blockbound, int nbound,
+                                                float* __restrict__ absmax_out) {
+    if (!blockbound) return hdr[0];
+    uint32_t m = 0;
+    for (int i = threadIdx.x; i < nbound; i += blockDim.x) m = max(m, blockbound[i]);
+    m = block_max_u32(m);
+    const int ex = h2_exponent(m);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr[0] = ex;
+        if (absmax_out) absmax_out[0] = __uint_as_float(m);
+    }
+    return ex;
+}
+
 // y = act(z*scale + shift (+res)) written as fp32 AND as h2 split planes (exponent from the header, set by
 // bn_finalize_mm).  One thread = 8 channels of one pixel: 2 x 16 B fp32 stores + 2 x 16 B plane stores.
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ res,
                                                           int res_ld, float* __restrict__ y, uint16_t* __restrict__ planes,
-                                                          size_t plane, int pitch, const int* __restrict__ hdr, int P, int C,
-                                                          int Cp) {
-    const float sc2 = pow2i(hdr[0]);
+                                                          size_t plane, int pitch, int* __restrict__ hdr, int P, int C,
+                                                          int Cp, const uint32_t* __restrict__ blockbound, int nbound,
+                                                          float* __restrict__ absmax_out) {
+    const int ex = h2_exponent_from(hdr, blockbound, nbound, absmax_out);
+    const float sc2 = pow2i(ex);
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
         reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
     const int G = Cp >> 3;
@@ -628,7 +657,8 @@ __global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restric
 }
 
 extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
-                                  int relu, float* y, void* y_planes, int P, int C, void* stream) {
+                                  int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
+                                  void* stream) {
     if (!z || !scale || !shift || !y || !y_planes || P <= 0 || C <= 0 || (C % 8) || !aligned16(z) || !aligned16(y) ||
         !aligned16(y_planes))
         return SEMSEG_EINVAL;
@@ -636,9 +666,11 @@ extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const floa
     hipStream_t st = (hipStream_t)stream;
     const int Cp = round_up32(C), pitch = split_pitch(C);
     const size_t plane = h2_plane_elems((size_t)P, C);
-    const int* hdr = h2_exp_ptr(y_planes, (size_t)P, C);
-    const int blocks = stream_blocks((size_t)P * (Cp / 8));
-#define LAUNCH(R, A) hipLaunchKernelGGL((bn_apply_h2_kernel<R, A>), dim3(blocks), dim3(256), 0, st, z, scale, shift, residual, res_ld, y, (uint16_t*)y_planes, plane, pitch, hdr, P, C, Cp)
+    int* hdr = const_cast<int*>(h2_exp_ptr(y_planes, (size_t)P, C));
+    int blocks = stream_blocks((size_t)P * (Cp / 8));
+    if (blockbound && blocks > 2048) blocks = 2048;      // every block redoes the bound reduction: keep them long-lived
+    const int nbound = ceil_div(C, 16);
+#define LAUNCH(R, A) hipLaunchKernelGGL((bn_apply_h2_kernel<R, A>), dim3(blocks), dim3(256), 0, st, z, scale, shift, residual, res_ld, y, (uint16_t*)y_planes, plane, pitch, hdr, P, C, Cp, (const uint32_t*)blockbound, nbound, absmax_out)
     if (residual) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
     else          { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -653,7 +685,9 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
                                                                 const float* __restrict__ z, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, int relu, int P, int C,
                                                                 int cx, int py, int rows_per_block,
-                                                                double* __restrict__ partial, float* __restrict__ gm) {
+                                                                double* __restrict__ partial, float* __restrict__ gm,
+                                                                const float* __restrict__ gscale,
+                                                                const float* __restrict__ gshift) {
     extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][4] floats
     float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
     const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
@@ -666,12 +700,14 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
         for (int p = row0 + ty; p < row1; p += py) {
             float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c);
+            const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + c);
             if (relu) {
-                const float4 yy = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c);
+                float4 yy;
+                if (gscale) yy = relu_gate_from_z(v, gscale + c, gshift + c);
+                else yy = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c);
                 g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                 g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
             }
-            const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + c);
             s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
             sx.x += g.x * ((v.x - mu.x) * is.x); sx.y += g.y * ((v.y - mu.y) * is.y);
             sx.z += g.z * ((v.z - mu.z) * is.z); sx.w += g.w * ((v.w - mu.w) * is.w);
@@ -752,7 +788,7 @@ extern "C" int semseg_bn_bwd_reduce_mm(const float* dy, int dy_ld, const float* 
     float* gm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
     hipLaunchKernelGGL(bn_bwd_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
-                       relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm);
+                       relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr);
     SEMSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_mm_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)partial,
                        (const float*)gm, g.gy, C, sums, gmax, dgamma, dbeta);
@@ -808,9 +844,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
                                                               const double* __restrict__ sums,
                                                               const double* __restrict__ count,
                                                               uint16_t* __restrict__ planes, size_t plane, int pitch,
-                                                              const int* __restrict__ hdr, float* __restrict__ dres, int P,
-                                                              int C, int Cp) {
-    const float sc2 = pow2i(hdr[0]);
+                                                              int* __restrict__ hdr, float* __restrict__ dres, int P,
+                                                              int C, int Cp, const float* __restrict__ gscale,
+                                                              const float* __restrict__ gshift,
+                                                              const uint32_t* __restrict__ blockbound, int nbound) {
+    const int ex = h2_exponent_from(hdr, blockbound, nbound, nullptr);
+    const float sc2 = pow2i(ex);
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
         reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
     const float inv_n = TRAIN ? (float)(1.0 / count[0]) : 0.f;
@@ -826,8 +865,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
             for (int h = 0; h < 2; ++h) {
                 const int cc = c + 4 * h;
                 float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + cc);
+                float4 v = f4zero();
+                if (TRAIN || (RELU && gscale)) v = *reinterpret_cast<const float4*>(z + (size_t)p * C + cc);
                 if (RELU) {
-                    const float4 yy = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + cc);
+                    float4 yy;
+                    if (gscale) yy = relu_gate_from_z(v, gscale + cc, gshift + cc);
+                    else yy = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + cc);
                     g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                     g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
                 }
@@ -836,7 +879,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
                 const float4 ga = *reinterpret_cast<const float4*>(gamma + cc);
                 float4 t;
                 if (TRAIN) {
-                    const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + cc);
                     const float4 mu = *reinterpret_cast<const float4*>(mean + cc);
                     const float m0 = (float)sums[cc] * inv_n, m1 = (float)sums[cc + 1] * inv_n;
                     const float m2 = (float)sums[cc + 2] * inv_n, m3 = (float)sums[cc + 3] * inv_n;
@@ -871,18 +913,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
 extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
                                       const float* mean, const float* invstd, const float* gamma, const double* sums,
                                       const double* stats_count, int training, int relu, void* dz_planes, float* dres, int P,
-                                      int C, void* stream) {
+                                      int C, const float* gate_scale, const float* gate_shift, const void* blockbound,
+                                      void* stream) {
     if (!dy || !invstd || !gamma || !dz_planes || P <= 0 || C <= 0 || (C % 8) || (dy_ld % 4) || dy_ld < C ||
         !aligned16(dy) || !aligned16(dz_planes))
         return SEMSEG_EINVAL;
     if (training && (!z || !mean || !sums || !stats_count)) return SEMSEG_EINVAL;
-    if (relu && (!y || (y_ld % 4) || y_ld < C)) return SEMSEG_EINVAL;
+    if (relu && gate_scale && (!gate_shift || !z)) return SEMSEG_EINVAL;
+    if (relu && !gate_scale && (!y || (y_ld % 4) || y_ld < C)) return SEMSEG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int Cp = round_up32(C), pitch = split_pitch(C);
     const size_t plane = h2_plane_elems((size_t)P, C);
-    const int* hdr = h2_exp_ptr(dz_planes, (size_t)P, C);
-    const int blocks = stream_blocks((size_t)P * (Cp / 8));
-#define LAUNCH(T, R, D) hipLaunchKernelGGL((bn_bwd_apply_h2_kernel<T, R, D>), dim3(blocks), dim3(256), 0, st, dy, dy_ld, y, y_ld, z, mean, invstd, gamma, sums, stats_count, (uint16_t*)dz_planes, plane, pitch, hdr, dres, P, C, Cp)
+    int* hdr = const_cast<int*>(h2_exp_ptr(dz_planes, (size_t)P, C));
+    int blocks = stream_blocks((size_t)P * (Cp / 8));
+    if (blockbound && blocks > 2048) blocks = 2048;
+    const int nbound = ceil_div(C, 16);
+#define LAUNCH(T, R, D) hipLaunchKernelGGL((bn_bwd_apply_h2_kernel<T, R, D>), dim3(blocks), dim3(256), 0, st, dy, dy_ld, y, y_ld, z, mean, invstd, gamma, sums, stats_count, (uint16_t*)dz_planes, plane, pitch, hdr, dres, P, C, Cp, gate_scale, gate_shift, (const uint32_t*)blockbound, nbound)
     const int key = (training ? 4 : 0) | (relu ? 2 : 0) | (dres ? 1 : 0);
     switch (key) {
         case 0: LAUNCH(false, false, false); break;
@@ -895,6 +941,177 @@ extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y
         default: LAUNCH(true, true, true); break;
     }
 #undef LAUNCH
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ================================================================================================
+// Single-rank fused path: no all-reduce sits between the partial sums and their use, so the finish kernels also do the
+// per-channel finalize / bound work and leave one bound per block (16 channels) for the apply kernel's prologue
+// (h2_exponent_from): 3 launches per BN pass instead of 4.  Block = 16 channels x 16 partial lanes.
+// ================================================================================================
+__global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
+    const double* __restrict__ partial, const float* __restrict__ mm, int nparts, int C, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float momentum, float eps, int relu, const float* __restrict__ res_absmax,
+    double* __restrict__ stats, float* __restrict__ zmm, float* __restrict__ mean, float* __restrict__ invstd,
+    float* __restrict__ scale, float* __restrict__ shift, int64_t* __restrict__ num_batches_tracked,
+    uint32_t* __restrict__ blockbound) {
+    __shared__ double rs[16][17], rq[16][17];
+    __shared__ float rlo[16][17], rhi[16][17];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int C2 = 2 * C;
+    double su = 0.0, sq = 0.0;
+    float lo = INFINITY, hi = -INFINITY;
+    if (c < C)
+        for (int b = lane; b < nparts; b += 16) {
+            su += partial[(size_t)b * C2 + c];
+            sq += partial[(size_t)b * C2 + C + c];
+            lo = fminf(lo, mm[(size_t)b * C2 + c]);
+            hi = fmaxf(hi, mm[(size_t)b * C2 + C + c]);
+        }
+    rs[lane][cl] = su; rq[lane][cl] = sq; rlo[lane][cl] = lo; rhi[lane][cl] = hi;
+    __syncthreads();
+    uint32_t bits = 0;
+    if (lane == 0 && c < C) {
+        su = 0.0; sq = 0.0; lo = INFINITY; hi = -INFINITY;
+        for (int i = 0; i < 16; ++i) {            // same summation order as colsum_block
+            su += rs[i][cl]; sq += rq[i][cl];
+            lo = fminf(lo, rlo[i][cl]); hi = fmaxf(hi, rhi[i][cl]);
+        }
+        stats[c] = su; stats[C + c] = sq;
+        zmm[c] = lo; zmm[C + c] = hi;
+        const double n = count;
+        const double mu = su / n;
+        double var = sq / n - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float muf = (float)mu;
+        mean[c] = muf;
+        invstd[c] = is;
+        const float sc = gamma[c] * is;
+        const float sh = beta[c] - muf * sc;
+        scale[c] = sc;
+        shift[c] = sh;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
+        if (running_var) {
+            const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+        const float rmax = res_absmax ? res_absmax[0] : 0.f;
+        const float e0 = fmaf(lo, sc, sh), e1 = fmaf(hi, sc, sh);
+        const float bh = fmaxf(e0, e1) + rmax, bl = fminf(e0, e1) - rmax;
+        const float b = relu ? fmaxf(bh, 0.f) : fmaxf(fabsf(bh), fabsf(bl));
+        const bool bad = !(b == b) || !(e0 == e0) || !(e1 == e1);
+        bits = bad ? 0x7fc00000u : __float_as_uint(b);
+    }
+    bits = block_max_u32(bits);
+    if (threadIdx.x == 0) {
+        blockbound[blockIdx.x] = bits;
+        if (blockIdx.x == 0) {
+            stats[C2] = count;
+            if (num_batches_tracked) num_batches_tracked[0] += 1;
+        }
+    }
+}
+
+extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var,
+                                         int64_t* num_batches_tracked, float momentum, float eps, int relu,
+                                         const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
+                                         void* blockbound, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!z || !stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || !blockbound || P <= 0 || C <= 0 ||
+        (C % 4) || !aligned16(z))
+        return SEMSEG_EINVAL;
+    const ColGeom g = col_geom(P, C);
+    const size_t need = (size_t)g.gy * 2 * C * (sizeof(double) + sizeof(float));
+    if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = (double*)workspace;
+    float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
+    const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
+    hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
+                       g.rows_per_block, partial, mm);
+    SEMSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_fwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+                       (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
+                       res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
+    const double* __restrict__ partial, const float* __restrict__ gm, int nparts, int C, const double* __restrict__ count,
+    const float* __restrict__ zmm, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, int training, double* __restrict__ sums, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, uint32_t* __restrict__ blockbound) {
+    __shared__ double rs[16][17], rq[16][17];
+    __shared__ uint32_t rg[16][17];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int C2 = 2 * C;
+    double su = 0.0, sq = 0.0;
+    uint32_t gmx = 0;
+    if (c < C)
+        for (int b = lane; b < nparts; b += 16) {
+            su += partial[(size_t)b * C2 + c];
+            sq += partial[(size_t)b * C2 + C + c];
+            gmx = max(gmx, absbits(gm[(size_t)b * C + c]));
+        }
+    rs[lane][cl] = su; rq[lane][cl] = sq; rg[lane][cl] = gmx;
+    __syncthreads();
+    uint32_t bits = 0;
+    if (lane == 0 && c < C) {
+        su = 0.0; sq = 0.0; gmx = 0;
+        for (int i = 0; i < 16; ++i) {
+            su += rs[i][cl]; sq += rq[i][cl];
+            gmx = max(gmx, rg[i][cl]);
+        }
+        sums[c] = su; sums[C + c] = sq;
+        if (dbeta) dbeta[c] = (float)su;
+        if (dgamma) dgamma[c] = (float)sq;
+        const float is = invstd[c];
+        float b = __uint_as_float(gmx);
+        if (training) {
+            const float inv_n = (float)(1.0 / count[0]);
+            const float m = fabsf((float)su * inv_n), x = fabsf((float)sq * inv_n);
+            const float xh = fmaxf(fabsf(zmm[c] - mean[c]), fabsf(zmm[C + c] - mean[c])) * is;
+            b = b + m + xh * x;
+        }
+        b = fabsf(gamma[c]) * is * b * 1.0009765625f;
+        bits = absbits(b);
+    }
+    bits = block_max_u32(bits);
+    if (threadIdx.x == 0) blockbound[blockIdx.x] = bits;
+}
+
+extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                                          const float* mean, const float* invstd, const float* gate_scale,
+                                          const float* gate_shift, int relu, int P, int C, const double* stats_count,
+                                          const float* zmm, const float* gamma, int training, double* sums, float* dgamma,
+                                          float* dbeta, void* blockbound, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    if (!dy || !z || !mean || !invstd || !sums || !gamma || !blockbound || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) ||
+        dy_ld < C)
+        return SEMSEG_EINVAL;
+    if (training && (!stats_count || !zmm)) return SEMSEG_EINVAL;
+    if (relu && gate_scale && !gate_shift) return SEMSEG_EINVAL;
+    if (relu && !gate_scale && (!y || (y_ld % 4) || y_ld < C)) return SEMSEG_EINVAL;
+    const ColGeom g = col_geom(P, C);
+    const size_t need = (size_t)g.gy * 2 * C * (sizeof(double) + sizeof(float));
+    if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = (double*)workspace;
+    float* gm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
+    const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
+    hipLaunchKernelGGL(bn_bwd_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
+                       relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, gate_scale, gate_shift);
+    SEMSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+                       (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
+                       (uint32_t*)blockbound);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -317,6 +317,37 @@ struct SParams {
     int a, off, step, div;
     int chunks, ktiles, kt_per_split;
     int tiles_m, tiles_n, splits;
+    int tap_major;           // k-tile order: 0 = channel chunk major, taps inner (default); 1 = tap major (SEMSEG_TAP_MAJOR=1)
+};
+
+// (chunk, tap) walk of the k loop, shared by both GEMM kernels.  Default order: channel chunk major, taps inner -- the T
+// taps of one 32-channel chunk re-read (shifted) the same pixels in consecutive k-tiles, so only the first tap of a chunk
+// misses L2, and a split-K slice is a channel range (profiles/r1i: HBM-side fetch of conv_last fwd 1.75 GB -> 0.34 GB).
+struct KWalk {
+    int cc, t, r, s;     // channel chunk, tap, tap row / column of the NEXT k-tile
+    bool dirty;          // the tap changed since the last set_tap
+    __device__ __forceinline__ void init(const SParams& p, int kt) {
+        if (p.tap_major) { t = kt / p.chunks; cc = kt - t * p.chunks; }
+        else             { cc = kt / p.T;     t = kt - cc * p.T; }
+        r = t / p.S;
+        s = t - r * p.S;
+        dirty = true;
+    }
+    __device__ __forceinline__ void next_tap(const SParams& p) {
+        dirty = true;
+        if (++s == p.S) { s = 0; ++r; }
+        if (++t == p.T) { t = 0; r = 0; s = 0; }
+    }
+    __device__ __forceinline__ void advance(const SParams& p) {
+        if (p.tap_major) {
+            if (++cc == p.chunks) { cc = 0; next_tap(p); }
+        } else if (p.T > 1) {
+            next_tap(p);
+            if (t == 0) ++cc;
+        } else {
+            ++cc;
+        }
+    }
 };
 
 // 2^-(ea+eb) as two factors (each within the normal range; see the header comment of the h2 scheme)
@@ -392,12 +423,14 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tn = tile % p.tiles_n;
-    const int tm = tile / p.tiles_n;
+    // block -> (tm, tn, z): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
+    // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows)
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, p.tiles_m * p.tiles_n * p.splits);
+    const int tm = lid % p.tiles_m;
+    const int tnz = lid / p.tiles_m;
+    const int tn = tnz % p.tiles_n;
+    const int z = tnz / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
 
@@ -435,11 +468,39 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
         b_off[i] = ok ? (uint32_t)n * w_row + 8u * q : 0u;
         b_ok |= (ok ? 1u : 0u) << i;
     }
-    int cur_t = -1;
-    auto set_tap = [&](int t) {
-        const int r = t / p.S;
-        const int s = t - r * p.S;
+    KWalk kw;
+    kw.init(p, kt_begin);
+    // stride-1 geometry (div == 1; every forward conv and the dgrad of stride-1 convs): the offset of tap (r, s) relative
+    // to tap (0, 0) is the same for every pixel, so a tap switch is one scalar delta + a per-row validity bit
+    const bool fast_tap = (p.div == 1) && (p.T <= 32);          // block-uniform
+    uint32_t a_row[APASS], a_vm[APASS];
+    if (fast_tap) {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            a_row[i] = ((uint32_t)a_base[i] + (uint32_t)a_ih0[i] * (uint32_t)p.Win + (uint32_t)a_iw0[i]) * (uint32_t)p.pitch +
+                       8u * q;                                   // arithmetic mod 2^32 (halo rows are "negative")
+            uint32_t vm = 0;
+            int r = 0, s2 = 0;
+            for (int t = 0; t < p.T; ++t) {
+                const int nh = a_ih0[i] + r * p.step, nw = a_iw0[i] + s2 * p.step;
+                vm |= ((nh >= 0) & (nw >= 0) & (nh < p.Hin) & (nw < p.Win)) ? (1u << t) : 0u;
+                if (++s2 == p.S) { s2 = 0; ++r; }
+            }
+            a_vm[i] = vm;
+        }
+    }
+    auto set_tap = [&](int t, int r, int s) {
         a_ok = 0;
+        if (fast_tap) {
+            const uint32_t delta = (uint32_t)((r * p.Win + s) * p.step) * (uint32_t)p.pitch;      // step < 0 for dgrad: mod 2^32
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const bool ok = (a_vm[i] >> t) & 1u;
+                a_off[i] = ok ? a_row[i] + delta : 0u;
+                a_ok |= (ok ? 1u : 0u) << i;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             int nh = a_ih0[i] + r * p.step;
@@ -457,14 +518,14 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
     };
 
     // unconditional loads from clamped in-bounds offsets + select (see conv_igemm.hip on why not `cond ? load : 0`)
-    auto load_tile = [&](int kt) {
-        const int t = kt / p.chunks;
-        const int c0 = (kt - t * p.chunks) * 32;
-        if (t != cur_t) {          // wave-uniform
-            set_tap(t);
-            cur_t = t;
+    auto load_tile = [&](int) {            // k-tiles are loaded in order: the (chunk, tap) walk advances here
+        const int c0 = kw.cc * 32;
+        if (kw.dirty) {                    // block-uniform
+            set_tap(kw.t, kw.r, kw.s);
+            kw.dirty = false;
         }
-        const uint32_t koff = (uint32_t)t * p.pitch + c0;
+        const uint32_t koff = (uint32_t)kw.t * p.pitch + c0;
+        kw.advance(p);
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const bool ok = (a_ok >> i) & 1u;
@@ -597,12 +658,14 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
 
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tn = tile % p.tiles_n;
-    const int tm = tile / p.tiles_n;
+    // block -> (tm, tn, z): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
+    // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows)
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, p.tiles_m * p.tiles_n * p.splits);
+    const int tm = lid % p.tiles_m;
+    const int tnz = lid / p.tiles_m;
+    const int tn = tnz % p.tiles_n;
+    const int z = tnz / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
     const int nk = kt_end - kt_begin;
@@ -649,10 +712,36 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
         b_msk[i] = ok ? 0xffffffffu : 0u;
     }
     uint32_t a_src[AG], a_msk[AG];
-    int cur_t = -1;
-    auto set_tap = [&](int t) {
-        const int r = t / p.S;
-        const int s = t - r * p.S;
+    KWalk kw;
+    kw.init(p, kt_begin);
+    const bool fast_tap = (p.div == 1) && (p.T <= 32);          // block-uniform, see igemm_rs_kernel
+    uint32_t a_row[AG], a_vm[AG];
+    if (fast_tap) {
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            a_row[i] = 2u * (((uint32_t)a_base[i] + (uint32_t)a_ih0[i] * (uint32_t)p.Win + (uint32_t)a_iw0[i]) *
+                             (uint32_t)p.pitch) + 16u * q;       // arithmetic mod 2^32 (halo rows are "negative")
+            uint32_t vm = 0;
+            int r = 0, s2 = 0;
+            for (int t = 0; t < p.T; ++t) {
+                const int nh = a_ih0[i] + r * p.step, nw = a_iw0[i] + s2 * p.step;
+                vm |= ((nh >= 0) & (nw >= 0) & (nh < p.Hin) & (nw < p.Win)) ? (1u << t) : 0u;
+                if (++s2 == p.S) { s2 = 0; ++r; }
+            }
+            a_vm[i] = vm;
+        }
+    }
+    auto set_tap = [&](int t, int r, int s) {
+        if (fast_tap) {
+            const uint32_t delta = 2u * ((uint32_t)((r * p.Win + s) * p.step) * (uint32_t)p.pitch);
+#pragma unroll
+            for (int i = 0; i < AG; ++i) {
+                const bool ok = (a_vm[i] >> t) & 1u;
+                a_src[i] = ok ? a_row[i] + delta : a_zero;
+                a_msk[i] = ok ? 0xffffffffu : 0u;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AG; ++i) {
             int nh = a_ih0[i] + r * p.step;
@@ -674,15 +763,15 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
     auto issue = [&](int kt, int slot) {
         const uint32_t abuf = lds0 + (uint32_t)slot * BUF_BYTES;
         const uint32_t bbuf = abuf + A_BYTES;
-        if (kt < kt_end) {                  // wave-uniform
-            const int t = kt / p.chunks;
-            const int c0 = (kt - t * p.chunks) * 32;
-            if (t != cur_t) {               // wave-uniform
-                set_tap(t);
-                cur_t = t;
+        if (kt < kt_end) {                  // wave-uniform; tiles are issued in k order: the counters advance here
+            const int c0 = kw.cc * 32;
+            if (kw.dirty) {                 // wave-uniform
+                set_tap(kw.t, kw.r, kw.s);
+                kw.dirty = false;
             }
             const uint32_t ka_b = 2u * (uint32_t)c0;
-            const uint32_t kb_b = 2u * ((uint32_t)t * p.pitch + c0);
+            const uint32_t kb_b = 2u * ((uint32_t)kw.t * p.pitch + c0);
+            kw.advance(p);
 #pragma unroll
             for (int i = 0; i < AG; ++i)
 #pragma unroll
@@ -891,6 +980,8 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
     p.in_plane = (uint32_t)in_plane;
     p.w_plane = (uint32_t)w_plane;
     const SPlan pl = plan_gemm(SCH::ID, p.M, p.Cout, p.Cp, p.T, ov_tile, ov_split);
+    static const int tap_major = env_int("SEMSEG_TAP_MAJOR", 0);
+    p.tap_major = tap_major;
     p.chunks = pl.chunks;
     p.ktiles = pl.ktiles;
     p.kt_per_split = pl.kt_per_split;

@@ -10,7 +10,7 @@
 #include "split_layout.h"
 
 constexpr int WPREP_MAX_TENSORS = 64;
-constexpr int WPREP_CHUNKS = 64;           // absmax partial blocks per tensor (<= H2_MAX_PARTIALS)
+constexpr int WPREP_CHUNKS = 256;          // absmax partial blocks per tensor (<= H2_MAX_PARTIALS)
 
 struct WPrepTensor {
     const float* w;        // [K][T][C] fp32
@@ -33,7 +33,13 @@ __global__ __launch_bounds__(256) void wprep_absmax_kernel(const WPrepBatch b, i
     const WPrepTensor t = b.t[blockIdx.y];
     const size_t total = (size_t)t.K * t.T * t.C;
     uint32_t m = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)WPREP_CHUNKS * 256) m = max(m, absbits(t.w[i]));
+    const size_t quads = total >> 2;                 // t.w is 16-byte aligned (checked on the host)
+    const float4* w4 = reinterpret_cast<const float4*>(t.w);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)WPREP_CHUNKS * 256) {
+        const float4 v = w4[i];
+        m = max(m, max(max(absbits(v.x), absbits(v.y)), max(absbits(v.z), absbits(v.w))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(total & 3)) m = max(m, absbits(t.w[(quads << 2) + threadIdx.x]));
     m = block_max_u32(m);
     const int Cp = (t.C + 31) & ~31;
     const int pitch = ((Cp * 2) % 2048 == 0) ? Cp + pitch_pad : Cp;
@@ -62,6 +68,7 @@ __global__ __launch_bounds__(256) void wprep_split_kernel(const WPrepBatch b, in
 
     // exponent from the partial maxima of wprep_absmax_kernel
     const uint32_t* partial = wprep_partials(t, plane_krsc);
+    static_assert(WPREP_CHUNKS <= 256 && WPREP_CHUNKS <= H2_MAX_PARTIALS, "one partial per thread");
     uint32_t m = threadIdx.x < WPREP_CHUNKS ? partial[threadIdx.x] : 0u;
     m = block_max_u32(m);
     const int ex = h2_exponent(m);
@@ -138,7 +145,7 @@ extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host
         for (int i = 0; i < b.n; ++i) {
             const semseg_wprep_tensor& s = tensors_host[base + i];
             if (!s.w || !s.krsc || !s.crsk || s.K <= 0 || s.T <= 0 || s.C <= 0) return SEMSEG_EINVAL;
-            if (!aligned16(s.krsc) || !aligned16(s.crsk)) return SEMSEG_EINVAL;
+            if (!aligned16(s.krsc) || !aligned16(s.crsk) || !aligned16(s.w)) return SEMSEG_EINVAL;
             b.t[i].w = s.w;
             b.t[i].krsc = (uint16_t*)s.krsc;
             b.t[i].crsk = (uint16_t*)s.crsk;

@@ -2,6 +2,8 @@
 poly LR of train.py:130-139) executed as HIP kernels, optionally captured ONCE into a hipGraph and
 replayed (the whole step is capture-safe: no host sync, no allocation outside torch's graph pool, the
 learning rate lives in device memory)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -32,20 +34,22 @@ class FusedSGD:
     """torch.optim.SGD(momentum=0.9, weight_decay on group 0) for both encoder and decoder groups in one
     multi-tensor HIP kernel (train.py:115-127).  lr per group is a device scalar."""
 
-    def __init__(self, groups, momentum=0.9):
-        """groups: list of dict(params=[...], lr=float, weight_decay=float)"""
+    def __init__(self, groups, momentum=0.9, lr_slots=1):
+        """groups: list of dict(params=[...], lr=float, weight_decay=float).  `lr_slots`: device-resident learning rates
+        per group -- a hipGraph that holds several consecutive steps reads slot i in its i-th step."""
         self.groups = groups
         self.momentum = momentum
         self.state = {}
         self.steps = 0
+        self.lr_slot = 0
         for g in groups:
             dev = g['params'][0].device
-            g['lr_t'] = torch.tensor([g['lr']], device=dev, dtype=torch.float32)
+            g['lr_t'] = torch.full((lr_slots,), float(g['lr']), device=dev, dtype=torch.float32)
 
-    def set_lr(self, group_index, lr):
+    def set_lr(self, group_index, lr, slot=0):
         g = self.groups[group_index]
         g['lr'] = lr
-        g['lr_t'].fill_(lr)
+        g['lr_t'][slot:slot + 1].fill_(lr)
 
     def zero_grad(self):
         for g in self.groups:
@@ -65,8 +69,8 @@ class FusedSGD:
                     b = torch.empty_like(p.grad)
                     self.state[p] = b
                 bufs.append(b)
-            ops.sgd_step(ps, [p.grad for p in ps], bufs, first, [g['weight_decay']] * len(ps), g['lr_t'],
-                         self.momentum, grad_scale)
+            ops.sgd_step(ps, [p.grad for p in ps], bufs, first, [g['weight_decay']] * len(ps),
+                         g['lr_t'][self.lr_slot:self.lr_slot + 1], self.momentum, grad_scale)
         self.steps += 1
 
 
@@ -78,7 +82,7 @@ class TrainStep:
     hipGraph; later calls copy the batch into static buffers and replay."""
 
     def __init__(self, segmentation_module, lr_encoder=0.02, lr_decoder=0.02, momentum=0.9, weight_decay=1e-4,
-                 lr_pow=0.9, max_iters=100000, graph=False, group=None, bucket_bytes=64 << 20):
+                 lr_pow=0.9, max_iters=100000, graph=False, group=None, bucket_bytes=64 << 20, graph_steps=None):
         self.sm = segmentation_module
         enc, dec = segmentation_module.encoder, segmentation_module.decoder
         groups = []
@@ -101,16 +105,24 @@ class TrainStep:
         self._conv_weights = [m.weight for m in segmentation_module.modules() if isinstance(m, Conv2d)]
         self._weights_ready = False
         self.use_graph = graph
+        # hipGraph replay.  `graph_steps` consecutive training steps are captured into ONE graph: every hipGraphLaunch
+        # costs ~1 ms during which the GPU idles (profiles/r1i_trace_gaps_graph.txt: kernels are back to back inside a
+        # replay, the only holes are between replays), so S steps per launch amortise it S-fold.  step() then returns
+        # the (loss, acc) device scalars of its step, which hold their values once the S-th call of the group has
+        # launched the replay.  SEMSEG_GRAPH_STEPS overrides.
+        self.graph_steps = max(1, int(os.environ.get('SEMSEG_GRAPH_STEPS', graph_steps or 1))) if graph else 1
         self._graph = None
-        self._static = None
-        self._out = None
+        self._static = None           # graph_steps feed dicts
+        self._out = None              # graph_steps (loss, acc)
         self.warmup_eager = 2
+        if self.graph_steps > 1:
+            self.opt = FusedSGD(groups, momentum, lr_slots=self.graph_steps)
 
-    def adjust_learning_rate(self):
+    def adjust_learning_rate(self, slot=0):
         """train.py:130-139 poly schedule"""
         scale = (1.0 - float(self.iter) / self.max_iters) ** self.lr_pow
         for i, g in enumerate(self.opt.groups):
-            self.opt.set_lr(i, g['base_lr'] * scale)
+            self.opt.set_lr(i, g['base_lr'] * scale, slot)
 
     def _prepare_weights(self):
         if ops.CONV_MODE == 'h2' and ops.FUSE:
@@ -124,7 +136,9 @@ class TrainStep:
         loss, acc = self.sm(feed)
         if self.buckets is not None:
             self.buckets.prepare()            # hooks launch each bucket's all-reduce as backward completes it
+        ops.side_wgrad_begin(loss.device)     # weight gradients run on a second stream, off backward's critical path
         loss.backward()
+        ops.side_wgrad_join()
         scale = 1.0
         if self.buckets is not None:
             self.buckets.finish()
@@ -134,19 +148,45 @@ class TrainStep:
         return loss.detach(), acc.detach()
 
     def step(self, feed):
-        self.adjust_learning_rate()
-        self.iter += 1
         if not self.use_graph or self.world > 1:
+            self.adjust_learning_rate()
+            self.iter += 1
             return self._eager(feed)
+        if self._graph is None and self.opt.steps < self.warmup_eager:
+            self.adjust_learning_rate()
+            self.iter += 1
+            return self._eager(feed)
+        S = self.graph_steps
         if self._graph is None:
-            if self.opt.steps < self.warmup_eager:
-                return self._eager(feed)
-            self._static = {k: v.clone() for k, v in feed.items() if torch.is_tensor(v)}
+            # capture S consecutive steps; capture records but does not execute, the replays below run them
+            self._static = [{k: v.clone() for k, v in feed.items() if torch.is_tensor(v)} for _ in range(S)]
             self._graph = torch.cuda.CUDAGraph()
+            self._out = []
             with torch.cuda.graph(self._graph):
-                self._out = self._eager(self._static)
-            # capture records but does not execute: fall through to the replay of this very step
-        for k, v in self._static.items():
+                for i in range(S):
+                    self.opt.lr_slot = i
+                    self._out.append(self._eager(self._static[i]))
+            self.opt.lr_slot = 0
+            self._sub = 0
+        i = self._sub
+        self.adjust_learning_rate(slot=i)
+        self.iter += 1
+        for k, v in self._static[i].items():
             v.copy_(feed[k])
-        self._graph.replay()
-        return self._out
+        self._sub = (i + 1) % S
+        if self._sub == 0:
+            self._graph.replay()
+        return self._out[i]
+
+    def flush(self):
+        """graph_steps > 1: a group of steps that has not been replayed yet (fewer than S calls since the last replay) is
+        run eagerly from the staged batches.  Call before reading results / saving weights."""
+        if self._graph is None or self.graph_steps == 1 or self._sub == 0:
+            return
+        n, self._sub = self._sub, 0
+        for i in range(n):
+            self.opt.lr_slot = i
+            loss, acc = self._eager(self._static[i])
+            self._out[i][0].copy_(loss)
+            self._out[i][1].copy_(acc)
+        self.opt.lr_slot = 0

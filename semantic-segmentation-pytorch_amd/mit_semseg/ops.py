@@ -44,8 +44,10 @@ _WS = {}
 _WS_MIN = 64 << 20
 
 
-def workspace(nbytes, device):
-    key = (device.type, device.index if (device.index is not None or device.type != 'cuda') else torch.cuda.current_device())
+def workspace(nbytes, device, tag=''):
+    """`tag`: kernels running concurrently on different streams need disjoint scratch (tag 'side': the weight-gradient
+    stream)."""
+    key = (device.type, device.index if (device.index is not None or device.type != 'cuda') else torch.cuda.current_device(), tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         size = max(_WS_MIN, int(nbytes * 1.25))
@@ -356,11 +358,66 @@ class Conv2dSplitFn(Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
+# ---- weight gradients on a side stream ---------------------------------------------------------------------------
+# dw is consumed only by the optimiser, so the wgrad kernels need not sit on backward's critical path: between
+# side_wgrad_begin() and side_wgrad_join() (TrainStep brackets loss.backward() with them) every wgrad launch goes to a
+# second HIP stream that forks from the main stream once the planes of dy exist.  The main stream carries the
+# dependent chain (BN backward -> dgrad -> BN backward ...), much of it small kernels that leave most of the 256 CUs idle;
+# the wgrad GEMMs fill those CUs.  Under hipGraph capture the fork/join become parallel branches of the graph.
+# Operand buffers are kept alive in `pending` until the join (the caching allocator must not hand them to a later
+# main-stream allocation while the side stream still reads them).  Opt-in (SEMSEG_SIDE_WGRAD=1): on MI355X the overlap
+# did not pay (profiles/r1g: hipGraph replay 18.8 ms with the fork vs 17.9 ms without; the contended kernels slow each other
+# down by about what the overlap saves).
+_SIDE = {'on': False, 'stream': None, 'pending': []}
+SIDE_WGRAD = os.environ.get('SEMSEG_SIDE_WGRAD', '0') == '1'
+
+
+def side_wgrad_begin(device):
+    if not SIDE_WGRAD or device.type != 'cuda':
+        return
+    if _SIDE['stream'] is None or _SIDE['stream'].device != device:
+        _SIDE['stream'] = torch.cuda.Stream(device=device)
+    _SIDE['on'] = True
+
+
+def side_wgrad_sync():
+    """Make the current stream wait for the weight gradients launched so far (before anything reads .grad)."""
+    if _SIDE['on'] and _SIDE['stream'] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE['stream'])
+
+
+def side_wgrad_join():
+    side_wgrad_sync()
+    _SIDE['pending'].clear()
+    _SIDE['on'] = False
+
+
 def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
     """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys)."""
     n, h, wd, c, k, r, s, stride, pad, dil = geom
     dev = w.device
     dx = dw = None
+    if need_dw:
+        side = _SIDE['stream'] if _SIDE['on'] else None
+        tag = 'side' if side is not None else ''
+
+        def run_w():
+            dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
+
+            def launch_w():
+                ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev, tag)
+                _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
+                              'conv2d_wgrad_' + scheme)
+            tuner.ensure(scheme, 2, geom, launch_w)
+            launch_w()
+            return dwb.permute(0, 3, 1, 2)
+        if side is None:
+            dw = run_w()
+        else:
+            side.wait_stream(torch.cuda.current_stream())       # fork: dys / xs are complete on the main stream
+            with torch.cuda.stream(side):
+                dw = run_w()
+            _SIDE['pending'].append((xs, dys))
     if need_dx:
         wts = wtp if wtp is not None else _weight_crsk_planes(L, sch, w, dev)
         dx = empty_nhwc(n, c, h, wd, dev)
@@ -371,16 +428,6 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
                           'conv2d_dgrad_' + scheme)
         tuner.ensure(scheme, 1, geom, launch_d)
         launch_d()
-    if need_dw:
-        dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
-
-        def launch_w():
-            ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
-            _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
-                          'conv2d_wgrad_' + scheme)
-        tuner.ensure(scheme, 2, geom, launch_w)
-        launch_w()
-        dw = dwb.permute(0, 3, 1, 2)
     return dx, dw
 
 
@@ -404,6 +451,14 @@ def set_sync_bn_group(group, enabled=True):
     the one-process-per-GPU replacement of reference batchnorm.py:63-117 / comm.py."""
     _SYNC_GROUP['group'] = group
     _SYNC_GROUP['enabled'] = enabled
+
+
+def _sync_active():
+    """True when BN statistics have to be all-reduced across ranks (SyncBN on a world of more than one rank)."""
+    if not _SYNC_GROUP['enabled']:
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_GROUP['group']) > 1
 
 
 def _maybe_allreduce(buf):
@@ -500,10 +555,11 @@ class ConvBNActFn(Function):
         next conv);
       * backward: the BN gradient is written ONLY as split planes (its sole consumers are the conv gradients), with the
         exponent bounded from the reduction sums (csrc/bn.hip, second half).
-    Returns (y, planes of y or None, |y| bound or None)."""
+    The planes of y and the |y| bound leave forward through `box` (a dict), not as autograd outputs: autograd would
+    materialise a zero gradient of their size in every backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg):
+    def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg, box):
         stride, pad, dil, momentum, eps, relu, emit = cfg
         L = _native.lib()
         sch = SCHEMES['h2']
@@ -533,8 +589,6 @@ class ConvBNActFn(Function):
         stats = torch.empty((2 * k + 1,), device=dev, dtype=torch.float64)
         zmm = torch.empty((2 * k,), device=dev, dtype=torch.float32)
         ws = workspace(L.semseg_bn_mm_workspace_bytes(P, k), dev)
-        _native.check(L.semseg_bn_stats_mm(_p(z), P, k, _p(stats), _p(zmm), _p(ws), ws.numel(), _st()), 'bn_stats_mm')
-        _maybe_allreduce(stats)
         coef = torch.empty((4, k), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
         res, res_ld = (None, 0)
         if residual is not None:
@@ -542,27 +596,41 @@ class ConvBNActFn(Function):
         bound_ok = residual is None or res_absmax is not None
         absmax = torch.empty((1,), device=dev, dtype=torch.float32) if bound_ok else None
         yp = torch.empty(L.semseg_split_h2_bytes(P, k), dtype=torch.uint8, device=dev) if (emit and bound_ok) else None
-        _native.check(L.semseg_bn_finalize_mm(_p(stats), _p(zmm), k, _p(g), _p(b), _p(running_mean), _p(running_var),
-                                              _p(nbt), float(momentum), float(eps), int(relu), _p(res_absmax),
-                                              _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(absmax), _p(yp), P,
-                                              _st()), 'bn_finalize_mm')
         y = empty_nhwc(n, k, oh, ow, dev)
-        if yp is not None:
+        single = not _sync_active()
+        if single and yp is not None:
+            # one rank: finish + finalize in one kernel; the apply kernel derives the exponent from the per-block bounds
+            bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
+            _native.check(L.semseg_bn_fwd_stats_fused(_p(z), P, k, _p(stats), _p(zmm), _p(g), _p(b), _p(running_mean),
+                                                      _p(running_var), _p(nbt), float(momentum), float(eps), int(relu),
+                                                      _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
+                                                      _p(bb), _p(ws), ws.numel(), _st()), 'bn_fwd_stats_fused')
             _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), _p(yp),
-                                               P, k, _st()), 'bn_apply_h2')
+                                               P, k, _p(bb), _p(absmax), _st()), 'bn_apply_h2')
         else:
-            _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), k, P, k,
-                                            _st()), 'bn_apply')
-        ctx.save_for_backward(xp, w, wtp, z, y if relu else None, coef, g, stats, zmm)
+            _native.check(L.semseg_bn_stats_mm(_p(z), P, k, _p(stats), _p(zmm), _p(ws), ws.numel(), _st()), 'bn_stats_mm')
+            _maybe_allreduce(stats)
+            _native.check(L.semseg_bn_finalize_mm(_p(stats), _p(zmm), k, _p(g), _p(b), _p(running_mean), _p(running_var),
+                                                  _p(nbt), float(momentum), float(eps), int(relu), _p(res_absmax),
+                                                  _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(absmax), _p(yp), P,
+                                                  _st()), 'bn_finalize_mm')
+            if yp is not None:
+                _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y),
+                                                   _p(yp), P, k, _p(None), _p(None), _st()), 'bn_apply_h2')
+            else:
+                _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), k, P, k,
+                                                _st()), 'bn_apply')
+        # the ReLU gate of a BN without residual is recomputed from z in backward: y need not be kept for it
+        keep_y = relu and residual is not None
+        ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm)
         ctx.geom = geom
         ctx.cfg = (bool(relu), residual is not None)
-        if absmax is not None:
-            ctx.mark_non_differentiable(absmax)
-        return y, yp, absmax
+        box['planes'], box['absmax'] = yp, absmax
+        return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy, _gyp, _gabs):
+    def backward(ctx, dy):
         L = _native.lib()
         sch = SCHEMES['h2']
         xp, w, wtp, z, y, coef, gamma, stats, zmm = ctx.saved_tensors
@@ -578,21 +646,36 @@ class ConvBNActFn(Function):
         dgamma = torch.empty((k,), device=dev, dtype=torch.float32)
         dbeta = torch.empty((k,), device=dev, dtype=torch.float32)
         ws = workspace(L.semseg_bn_mm_workspace_bytes(P, k), dev)
-        _native.check(L.semseg_bn_bwd_reduce_mm(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), int(relu), P, k,
-                                                _p(sums), _p(gmax), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _st()),
-                      'bn_bwd_reduce_mm')
-        _maybe_allreduce(sums)
         count = stats[2 * k:]
         dzp = torch.empty(L.semseg_split_h2_bytes(P, k), dtype=torch.uint8, device=dev)
-        _native.check(L.semseg_bn_bwd_bound(_p(sums), _p(count), _p(gmax), _p(zmm), _p(coef[0]), _p(coef[1]), _p(gamma), k,
-                                            1, _p(dzp), P, _st()), 'bn_bwd_bound')
         dres = empty_nhwc(n, k, oh, ow, dev) if (has_res and ctx.needs_input_grad[4]) else None
+        gate = relu and not has_res                       # ReLU gate from z (forward's own fmaf), y was not saved
+        gsc, gsh = (coef[2], coef[3]) if gate else (None, None)
+        if not _sync_active():
+            bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
+            _native.check(L.semseg_bn_bwd_reduce_fused(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gsc),
+                                                       _p(gsh), int(relu), P, k, _p(count), _p(zmm), _p(gamma), 1, _p(sums),
+                                                       _p(dgamma), _p(dbeta), _p(bb), _p(ws), ws.numel(), _st()),
+                          'bn_bwd_reduce_fused')
+        else:
+            bb = None
+            if gate:                                      # the unfused reduce reads y: rebuild the gate tensor once
+                y = empty_nhwc(n, k, oh, ow, dev)
+                _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(None), 0, 1, _p(y), k, P, k, _st()),
+                              'bn_apply')
+                gsc = gsh = None
+            _native.check(L.semseg_bn_bwd_reduce_mm(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), int(relu), P,
+                                                    k, _p(sums), _p(gmax), _p(dgamma), _p(dbeta), _p(ws), ws.numel(),
+                                                    _st()), 'bn_bwd_reduce_mm')
+            _maybe_allreduce(sums)
+            _native.check(L.semseg_bn_bwd_bound(_p(sums), _p(count), _p(gmax), _p(zmm), _p(coef[0]), _p(coef[1]), _p(gamma),
+                                                k, 1, _p(dzp), P, _st()), 'bn_bwd_bound')
         _native.check(L.semseg_bn_bwd_apply_h2(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gamma),
-                                               _p(sums), _p(count), 1, int(relu), _p(dzp), _p(dres), P, k, _st()),
-                      'bn_bwd_apply_h2')
+                                               _p(sums), _p(count), 1, int(relu), _p(dzp), _p(dres), P, k, _p(gsc), _p(gsh),
+                                               _p(bb), _st()), 'bn_bwd_apply_h2')
         dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, residual=None, stride=1,
@@ -607,8 +690,10 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
     xp = input_planes(x, 'h2')
     wp, wtp = weight_planes(weight, 'h2')
     cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu))
-    y, yp, absmax = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean,
-                                      running_var, num_batches_tracked, cfg)
+    box = {}
+    y = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean, running_var,
+                          num_batches_tracked, cfg, box)
+    yp, absmax = box['planes'], box['absmax']
     if yp is not None:
         attach_planes(y, yp, 'h2', y.shape[0] * y.shape[2] * y.shape[3], y.shape[1])
     if absmax is not None:

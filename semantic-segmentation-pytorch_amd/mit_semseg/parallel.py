@@ -106,6 +106,7 @@ class GradientBuckets:
 
     def _stage(self, b):
         """copy p.grad into the bucket slices (physical order), re-point p.grad at the slice"""
+        ops.side_wgrad_sync()                 # weight gradients may still be in flight on the wgrad stream
         for p, off, n in b['items']:
             g = p.grad
             if g is None:

@@ -207,8 +207,13 @@ def _w_trainstep_world2(rank, world):
         assert any(lo <= p.grad.data_ptr() < hi for lo, hi in flats), n
     sgd = [a for name, a in lib.calls if name == 'semseg_sgd_step']
     assert sgd and all(abs(a[4] - 1.0 / world) < 1e-12 for a in sgd)
-    nstats = sum(1 for name, _ in lib.calls if name == 'semseg_bn_stats')
+    nstats = sum(1 for name, _ in lib.calls if name in ('semseg_bn_stats', 'semseg_bn_stats_mm'))
     assert nstats > 0
+    # with SyncBN active the statistics are all-reduced between the partial sums and their use: the unfused BN entry
+    # points (stats -> all-reduce -> finalize, reduce -> all-reduce -> bound) must be the ones called
+    names = {name for name, _ in lib.calls}
+    assert {'semseg_bn_finalize_mm', 'semseg_bn_bwd_reduce_mm', 'semseg_bn_bwd_bound'} <= names
+    assert not ({'semseg_bn_fwd_stats_fused', 'semseg_bn_bwd_reduce_fused'} & names)
 
 
 def test_trainstep_host_logic_world2():

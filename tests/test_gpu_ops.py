@@ -387,8 +387,29 @@ def test_bn_h2_forward_kernels(n, c, h, w, relu, res):
                                           ops._p(None), 0.1, 1e-5, int(relu), ops._p(rabs), ops._p(coef[0]), ops._p(coef[1]),
                                           ops._p(coef[2]), ops._p(coef[3]), ops._p(absmax), ops._p(yp), P, st), 'fin_mm')
     _native.check(L.semseg_bn_apply_h2(ops._p(z), ops._p(coef[2]), ops._p(coef[3]), ops._p(r), c, int(relu), ops._p(y), ops._p(yp),
-                                       P, c, st), 'apply_h2')
+                                       P, c, ops._p(None), ops._p(None), st), 'apply_h2')
+    # single-rank fused form: finish + finalize in one kernel, exponent from the per-block bounds inside apply
+    stats_f = torch.empty(2 * c + 1, dtype=torch.float64, device=d)
+    zmm_f, coef_f, absmax_f = torch.empty(2 * c, device=d), torch.empty(4, c, device=d), torch.empty(1, device=d)
+    rm3, rv3 = torch.zeros(c, device=d), torch.ones(c, device=d)
+    nbt = torch.zeros((), dtype=torch.long, device=d)
+    bb = torch.empty((c + 15) // 16, dtype=torch.int32, device=d)
+    yp_f = torch.full((L.semseg_split_h2_bytes(P, c),), 0x5a, dtype=torch.uint8, device=d)
+    y_f = torch.empty(P, c, device=d)
+    _native.check(L.semseg_bn_fwd_stats_fused(ops._p(z), P, c, ops._p(stats_f), ops._p(zmm_f), ops._p(gamma), ops._p(beta),
+                                              ops._p(rm3), ops._p(rv3), ops._p(nbt), 0.1, 1e-5, int(relu), ops._p(rabs),
+                                              ops._p(coef_f[0]), ops._p(coef_f[1]), ops._p(coef_f[2]), ops._p(coef_f[3]),
+                                              ops._p(bb), ops._p(ws), ws.numel(), st), 'fwd_stats_fused')
+    _native.check(L.semseg_bn_apply_h2(ops._p(z), ops._p(coef_f[2]), ops._p(coef_f[3]), ops._p(r), c, int(relu), ops._p(y_f),
+                                       ops._p(yp_f), P, c, ops._p(bb), ops._p(absmax_f), st), 'apply_h2_fused')
     torch.cuda.synchronize()
+    assert torch.equal(stats_f, stats) and torch.equal(zmm_f, zmm) and int(nbt.item()) == 1
+    for a, b in ((coef_f, coef), (rm3, rm2), (rv3, rv2), (y_f, y)):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+    vf, ef, rawf, tailf = _h2_decode(yp_f, P, c)
+    assert ef == _h2_decode(yp, P, c)[1] and absmax_f.item() >= y_f.abs().max().item()
+    assert ((vf - y_f.double().cpu()).abs() <= 2.0 ** -21 * y_f.double().cpu().abs() + 2.0 ** (-25 - ef)).all()
+    assert int(tailf.max()) == 0
     assert torch.equal(stats, stats0)
     for a, b in ((coef, coef0), (rm, rm2), (rv, rv2), (y, y0)):     # same formulas, separately compiled kernels
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
@@ -447,9 +468,47 @@ def test_bn_h2_backward_kernels(n, c, h, w, relu, dres, training):
     _native.check(L.semseg_bn_bwd_bound(ops._p(sums), ops._p(count), ops._p(gmax), ops._p(zmm), ops._p(mean), ops._p(invstd),
                                         ops._p(gamma), c, int(training), ops._p(dzp), P, st), 'bound')
     _native.check(L.semseg_bn_bwd_apply_h2(ops._p(dy), c, ops._p(y), c, ops._p(z), ops._p(mean), ops._p(invstd), ops._p(gamma),
-                                           ops._p(sums), ops._p(count), int(training), int(relu), ops._p(dzp), ops._p(dres1), P, c, st),
-                  'apply_h2')
+                                           ops._p(sums), ops._p(count), int(training), int(relu), ops._p(dzp), ops._p(dres1), P, c,
+                                           ops._p(None), ops._p(None), ops._p(None), st), 'apply_h2')
+    # single-rank fused form (+ ReLU gate recomputed from z when there is no residual gradient, i.e. no residual)
+    gate = relu and not dres
+    gsc = (invstd * gamma) if gate else None
+    gsh = (-mean * invstd * gamma) if gate else None
+    if gate:       # the gate kernel evaluates fmaf(z, scale, shift): build y from exactly that expression
+        y = torch.relu(torch.addcmul(gsh, z, gsc))
+    sums_f = torch.empty(2 * c, dtype=torch.float64, device=d)
+    dg_f, db_f = torch.empty(c, device=d), torch.empty(c, device=d)
+    bb = torch.empty((c + 15) // 16, dtype=torch.int32, device=d)
+    dzp_f = torch.full((L.semseg_split_h2_bytes(P, c),), 0x5a, dtype=torch.uint8, device=d)
+    dres_f = torch.empty(P, c, device=d) if dres else None
+    _native.check(L.semseg_bn_bwd_reduce_fused(ops._p(dy), c, ops._p(None if gate else y), c, ops._p(z), ops._p(mean), ops._p(invstd),
+                                               ops._p(gsc), ops._p(gsh), int(relu), P, c, ops._p(count), ops._p(zmm), ops._p(gamma),
+                                               int(training), ops._p(sums_f), ops._p(dg_f), ops._p(db_f), ops._p(bb), ops._p(ws),
+                                               ws.numel(), st), 'reduce_fused')
+    _native.check(L.semseg_bn_bwd_apply_h2(ops._p(dy), c, ops._p(None if gate else y), c, ops._p(z), ops._p(mean), ops._p(invstd),
+                                           ops._p(gamma), ops._p(sums_f), ops._p(count), int(training), int(relu), ops._p(dzp_f),
+                                           ops._p(dres_f), P, c, ops._p(gsc), ops._p(gsh), ops._p(bb), st), 'apply_h2_fused')
     torch.cuda.synchronize()
+    if gate:       # reference for the gated variant: the plain kernels on the y built from the same fmaf
+        _native.check(L.semseg_bn_bwd_reduce(ops._p(dy), c, ops._p(y), c, ops._p(z), ops._p(mean), ops._p(invstd), 1, P, c,
+                                             ops._p(sums0), ops._p(dg0), ops._p(db0), ops._p(ws), ws.numel(), st), 'reduce')
+        _native.check(L.semseg_bn_bwd_apply(ops._p(dy), c, ops._p(y), c, ops._p(z), ops._p(mean), ops._p(invstd), ops._p(gamma),
+                                            ops._p(sums0), ops._p(count), int(training), 1, ops._p(dz0), ops._p(None), P, c, st), 'apply')
+        torch.cuda.synchronize()
+        dzf_ref = dz0.double().cpu()
+        assert torch.equal(sums_f, sums0) and torch.equal(dg_f, dg0) and torch.equal(db_f, db0)
+    else:
+        dzf_ref = dz0.double().cpu()
+        assert torch.equal(sums_f, sums0) and torch.equal(dg_f, dg0) and torch.equal(db_f, db0)
+        if dres:
+            assert torch.equal(dres_f, dres0)
+    vf, ef, rawf, tailf = _h2_decode(dzp_f, P, c)
+    fmax = dzf_ref.abs().max().item()
+    assert fmax * 2.0 ** ef < 2.0 ** 15 and fmax * 2.0 ** ef >= 2.0 ** 10
+    assert ((vf - dzf_ref).abs() <= 2.0 ** -21 * dzf_ref.abs() + 2.0 ** (-25 - ef) + 1e-6 * fmax).all()
+    assert int(tailf.max()) == 0
+    if gate:
+        return     # the unfused comparisons below used the pre-gate y
     assert torch.equal(sums, sums0) and torch.equal(dg, dg0) and torch.equal(db, db0)
     gg = dy * (y > 0) if relu else dy
     assert torch.equal(gmax, gg.abs().max(0).values)

@@ -105,6 +105,8 @@ def main():
     ap.add_argument('--sweep', action='store_true', help='also try forced tile/split configurations')
     ap.add_argument('--mode', default='f32', choices=['f32', 's3', 'h2'],
                     help='exact-fp32 MFMA kernels, the split-bf16 (s3) or the split-fp16 (h2) kernels')
+    ap.add_argument('--tile', type=int, default=-1, help="force this tile id for the 'default' configuration (split families)")
+    ap.add_argument('--split', type=int, default=0, help="force this split-K / split-M factor for the 'default' configuration")
     ap.add_argument('--verify', action='store_true',
                     help='compare every configuration with the exact-fp32 MFMA kernel on the same (seeded) inputs: max|err|/rms')
     args = ap.parse_args()
@@ -114,8 +116,15 @@ def main():
     tot = {}
     for layer in sel:
         for which in args.passes.split(','):
-            cfgs = [('default', {})]
             split_mode = args.mode in ('s3', 'h2')
+            forced = {}
+            if args.tile >= 0:
+                forced[('SEMSEG_W3' if split_mode else 'SEMSEG_WGRAD') + '_TILE' if which == 'wgrad' else
+                       ('SEMSEG_S3' if split_mode else 'SEMSEG_IGEMM') + '_TILE'] = str(args.tile)
+            if args.split > 0:
+                forced[('SEMSEG_W3' if split_mode else 'SEMSEG_WGRAD') + '_SPLIT' if which == 'wgrad' else
+                       ('SEMSEG_S3' if split_mode else 'SEMSEG_IGEMM') + '_SPLITK'] = str(args.split)
+            cfgs = [('default', forced)]
             if args.sweep:
                 pre = 'SEMSEG_W3' if split_mode else 'SEMSEG_WGRAD'
                 pre2 = 'SEMSEG_S3' if split_mode else 'SEMSEG_IGEMM'

@@ -1,12 +1,13 @@
 #!/bin/bash
 # PMC passes (separate runs, as MI355X_MICROARCH.md prescribes) on the conv microbench.
 #   gpurun --timeout 900 -- 'bash tools/gpu_pmc.sh <tag> <layers> <passes>'
-TAG=${1:-pmc}; LAYERS=${2:-conv_last}; PASSES=${3:-fwd}
+#   MODE=h2 TILE=5 SPLIT=4 bash tools/gpu_pmc.sh ...   (forced tile / split of the measured configuration)
+TAG=${1:-pmc}; LAYERS=${2:-conv_last}; PASSES=${3:-fwd}; MODE=${MODE:-f32}; TILE=${TILE:--1}; SPLIT=${SPLIT:-0}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 python __graft_entry__.py > $OUT/build.log 2>&1
 cd /tmp
-CMD="python $ROOT/tools/conv_bench.py --layers $LAYERS --passes $PASSES --iters 3"
+CMD="python $ROOT/tools/conv_bench.py --mode $MODE --layers $LAYERS --passes $PASSES --iters 3 --tile $TILE --split $SPLIT"
 run() { # name counters...
   n=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o $n -- $CMD > $OUT/$n.log 2>&1

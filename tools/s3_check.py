@@ -1,6 +1,9 @@
 """Correctness sweep of the operand-split convolution entry points (h2: 2 x fp16, s3: 3 x bf16) through the C ABI
 against a float64 CPU convolution, next to the exact-fp32 MFMA kernels and torch's CPU fp32 convolution on the same
-inputs (error unit: max|err| / rms(ref); h2 and s3 must stay within 3x of the worse of the two fp32 implementations).
+inputs.  Two error units per result: max|err| / rms(ref) (printed), and the COMPONENTWISE backward-stable measure
+max_i |err_i| / (sum |a||b|)_i -- the quantity the fp32 error analysis of a dot product bounds (gamma_n ~ n 2^-24),
+insensitive to a few outlier elements dominating rms(ref).  Pass criterion: the componentwise error of h2 / s3 is within
+4x of the worse of the two fp32 implementations (or below 2^-20).
 Also runs every case with operands rescaled by 2^-20 / 2^+12 (gradient-like and large magnitudes: the h2 scale).
 
     python tools/s3_check.py            # on the GPU box
@@ -57,6 +60,12 @@ def run_case(L, case, dev, xscale=1.0, dyscale=1.0):
     y32 = F.conv2d(x32, w32, b32, st, pad, dil)
     y32.backward(dy)
     cpu32 = dict(y=y32.detach(), dx=x32.grad, dw=w32.grad, db=b32.grad if has_bias else None)
+    # sum |a||b| of every output element: the same conv / gradients on the absolute values
+    xa, wa = x.double().abs().requires_grad_(True), wt.double().abs().requires_grad_(True)
+    ba = b.double().abs().requires_grad_(True) if has_bias else None
+    ya = F.conv2d(xa, wa, ba, st, pad, dil)
+    ya.backward(dy.double().abs())
+    mag = dict(y=ya.detach(), dx=xa.grad, dw=wa.grad, db=ba.grad if has_bias else None)
 
     s = vp(torch.cuda.current_stream().cuda_stream)
     xg = x.permute(0, 2, 3, 1).contiguous().to(dev)            # NHWC
@@ -82,6 +91,7 @@ def run_case(L, case, dev, xscale=1.0, dyscale=1.0):
         if ref[key] is not None:
             r = ref[key]
             res[('cpu', key)] = (cpu32[key].double() - r).abs().max().item() / (r.pow(2).mean().sqrt().item() + 1e-30)
+            res[('cpu', key, 'cw')] = ((cpu32[key].double() - r).abs() / (mag[key] + 1e-300)).max().item()
     for mode in ('h2', 's3', 'f32'):
         y = torch.full((n, oh, ow, k), float('nan'), device=dev)
         dx = torch.full((n, h, w, c), float('nan'), device=dev)
@@ -111,6 +121,7 @@ def run_case(L, case, dev, xscale=1.0, dyscale=1.0):
             r = ref[key]
             e = (got[key].cpu().double() - r).abs().max().item() / (r.pow(2).mean().sqrt().item() + 1e-30)
             res[(mode, key)] = e
+            res[(mode, key, 'cw')] = ((got[key].cpu().double() - r).abs() / (mag[key] + 1e-300)).max().item()
     return res
 
 
@@ -126,10 +137,12 @@ def main():
             for key in ('y', 'dx', 'dw', 'db'):
                 if ('s3', key) in res:
                     h2, a, b, cpu = res[('h2', key)], res[('s3', key)], res[('f32', key)], res[('cpu', key)]
-                    lim = max(3 * max(b, cpu), 3e-6)
-                    ok = (a == a) and a < lim and (h2 == h2) and h2 < lim   # NaN-safe; split paths must be in the fp32 error class
+                    cw = [res[(m, key, 'cw')] for m in ('h2', 's3', 'f32', 'cpu')]
+                    lim = max(4 * max(cw[2], cw[3]), 2.0 ** -20)
+                    ok = all((v == v) and v < lim for v in cw[:2]) and (h2 == h2) and (a == a)   # NaN-safe
                     bad += 0 if ok else 1
-                    line += ' %s h2 %.1e s3 %.1e f32 %.1e cpu32 %.1e%s |' % (key, h2, a, b, cpu, '' if ok else ' <-- BAD')
+                    line += ' %s h2 %.1e s3 %.1e f32 %.1e cpu32 %.1e [cw %.1e %.1e %.1e %.1e]%s |' % (
+                        (key, h2, a, b, cpu) + tuple(cw) + ('' if ok else ' <-- BAD',))
             print(line, flush=True)
     print('s3_check: %s' % ('OK' if bad == 0 else '%d FAILURES' % bad))
     return 1 if bad else 0
