@@ -33,7 +33,11 @@ F32_CONV_LAST_HBM_BYTES = 1.78e9      # profiles/r1b_pmc_conv_last_fwd_wgrad.txt
 S3_CONV_LAST_HBM_BYTES = None
 
 
-H2_CONV_LAST_HBM_BYTES = None
+# profiles/r1n_pmc_conv_last_fwd_h2.txt: FETCH_SIZE 170295 KiB x 2 + WRITE_SIZE 65536 KiB (4 split-K slabs of 16 MiB);
+# the algorithmic bytes of this launch are 227 MB (x planes 134 MB + w planes 75.5 MB + 16.8 MB fp32 output)
+H2_CONV_LAST_HBM_BYTES = (2 * 170295 + 65536) * 1024
+H2_CONV_LAST_CLOCK_GHZ = 1.69     # SQ_WAVE_CYCLES x 4 / waves / duration of the same PMC pass: the MFMA-dense kernel runs
+                                  # power-limited well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at
 DTYPE = {'h2': 'f32 (fp32 in/out/accumulate; products on the fp16 MFMA via a scaled 2-way fp16 split, 3 terms, 2^-22 per product)',
          's3': 'f32 (fp32 in/out/accumulate; products on the bf16 MFMA via an exact 3-way bf16 split, 6 terms)', 'f32': 'f32'}
 # MFMA products per fp32-accurate MAC block and the issued instruction, per split scheme
@@ -120,6 +124,10 @@ def roofline_entry(kt):
                 'mfma_pipe_utilisation': round(terms * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
                 'path_ceiling_tflops': round(PEAK_BF16_MFMA_TFLOPS / terms, 1),
                 'frac_of_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                'algorithmic_bytes': 227.0e6 if ops.CONV_MODE == 'h2' else None,
+                'clock_ghz_under_load': H2_CONV_LAST_CLOCK_GHZ if ops.CONV_MODE == 'h2' else None,
+                'mfma_pipe_utilisation_at_measured_clock': round(terms * achieved / (PEAK_BF16_MFMA_TFLOPS * H2_CONV_LAST_CLOCK_GHZ / 2.4), 4)
+                if ops.CONV_MODE == 'h2' else None,
                 'kernel': 'igemm_dma/rs_kernel<%s> fwd (%s per fp32-accurate MAC block, %s), '
                           'decoder.conv_last.0 3x3 4096->512 @64x64 N=2 (309.24 GFLOP/launch algorithmic, %.3f ms/launch, '
                           'HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE from profiles/, bytes/launch)'

@@ -1,7 +1,10 @@
 """Summarise a rocprofv3 --kernel-trace run (rocpd sqlite .db or *_kernel_trace.csv) into a per-kernel CSV
 (the same columns as rocprofv3's kernel_stats.csv) so that a small text file can be committed under profiles/.
 
-    python tools/rocprof_summary.py gpurun_out/r1a/prof/bench_results.db profiles/r1_bench_kernel_stats.csv
+    python tools/rocprof_summary.py gpurun_out/r1a/prof/bench_results.db profiles/r1_bench_kernel_stats.csv [--by-grid]
+
+--by-grid keeps launches of one kernel with different grids apart (name suffix " grid=GX*GY*GZ/WG", .db input only): the
+conv kernels are shared by many layers, the dominant layer (decoder.conv_last.0) is the row with its grid.
 """
 import csv
 import sqlite3
@@ -14,6 +17,8 @@ def rows_from_db(path):
     for name, start, end, gx, gy, gz, wx, vg, ag, sg, lds in db.execute(
             'select name, start, end, grid_x, grid_y, grid_z, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, '
             'lds_size from kernels'):
+        if BY_GRID:
+            name = '%s grid=%d*%d*%d/%d' % (name, gx, gy, gz, wx)
         yield name, end - start, (vg, ag, sg, lds)
 
 
@@ -24,7 +29,12 @@ def rows_from_csv(path):
                 r.get('VGPR_Count'), r.get('Accum_VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size'))
 
 
+BY_GRID = False
+
+
 def main():
+    global BY_GRID
+    BY_GRID = '--by-grid' in sys.argv
     src, dst = sys.argv[1], sys.argv[2]
     it = rows_from_db(src) if src.endswith('.db') else rows_from_csv(src)
     agg = defaultdict(list)
