@@ -42,6 +42,23 @@ def main():
     for name, dur, r in it:
         agg[name].append(dur)
         res[name] = r
+    if BY_GRID:
+        # one kernel + grid can still serve several layers (e.g. two 3x3 convs with 64 tiles x 4 splits): separate the
+        # duration clusters (consecutive sorted durations more than 1.5x apart) so that every row is one launch shape
+        split = {}
+        for name, v in agg.items():
+            v = sorted(v)
+            cl = [[v[0]]]
+            for d in v[1:]:
+                if d > 1.5 * cl[-1][-1]:
+                    cl.append([d])
+                else:
+                    cl[-1].append(d)
+            for c in cl:
+                key = name if len(cl) == 1 else '%s ~%dus' % (name, round(sum(c) / len(c) / 1e3))
+                split[key] = c
+                res[key] = res[name]
+        agg = split
     total = sum(sum(v) for v in agg.values())
     with open(dst, 'w', newline='') as f:
         w = csv.writer(f)
