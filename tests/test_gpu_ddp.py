@@ -1,0 +1,105 @@
+"""The data-parallel path on REAL kernels: two ranks share the one GPU of the test box (gloo carries the collectives --
+RCCL refuses two ranks on one device -- everything else is the production path: NativeDataParallel, SyncBN statistics
+all-reduced between the unfused BN entry points, gradient buckets filled by the post-accumulate hooks, fused SGD with
+1/world folded in).  Rank r trains on images [2r, 2r+2) of a 4-image batch; the CPU oracle trains on the joint batch:
+with SyncBN and all labels valid the two are the same computation (BN statistics over all 4 images, loss = mean of the
+per-rank means, gradient = mean of the per-rank gradients) -- the invariant of the reference's own
+tests/test_sync_batchnorm.py:99-107, here for the whole model and the optimiser step."""
+import json
+import os
+import socket
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LR = 0.02
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _joint_case():
+    from oracle import semseg_oracle as O
+    man = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'manifests.json')))
+    enc_sd = O.synth_state_dict(man['resnet18dilated'], 11)
+    dec_sd = O.synth_state_dict(man['ppm_deepsup@512'], 12)
+    img, lab = O.synth_batch(4, 64, 64, 8, seed=77)
+    lab = lab.clamp_min(0)                       # every pixel valid: equal per-rank pixel counts
+    masks = {'main': O.synth_dropout_mask(4, 512, seed=5), 'deepsup': O.synth_dropout_mask(4, 128, seed=6)}
+    return enc_sd, dec_sd, img, lab, masks
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from mit_semseg.models import ModelBuilder, SegmentationModule
+        from mit_semseg.parallel import NativeDataParallel, mean_over_ranks
+        from mit_semseg.engine import TrainStep
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        enc_sd, dec_sd, img, lab, masks = _joint_case()
+        with tempfile.TemporaryDirectory() as d:
+            pe, pd = os.path.join(d, 'e.pth'), os.path.join(d, 'd.pth')
+            torch.save(enc_sd, pe)
+            torch.save(dec_sd, pd)
+            enc = ModelBuilder.build_encoder('resnet18dilated', fc_dim=512, weights=pe)
+            dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=512, num_class=150, weights=pd)
+        sl = slice(2 * rank, 2 * rank + 2)
+        dec.conv_last[3].mask_override = masks['main'][sl].to(dev)
+        dec.dropout_deepsup.mask_override = masks['deepsup'][sl].to(dev)
+        sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), 0.4).to(dev).train()
+        dp = NativeDataParallel(sm)                      # SyncBN on
+        ts = TrainStep(sm, lr_encoder=LR, lr_decoder=LR, max_iters=10 ** 9, bucket_bytes=8 << 20)
+        assert ts.buckets is not None and len(ts.buckets.buckets) > 1
+        feed = {'img_data': img[sl].to(dev), 'seg_label': lab[sl].to(dev)}
+        loss, acc = ts.step(dp.scatter(feed))
+        mloss, macc = mean_over_ranks(loss, acc)
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu().contiguous() for k, v in sm.state_dict().items()}
+        torch.save(dict(loss=mloss.cpu(), acc=macc.cpu(), sd=sd), os.path.join(out_dir, 'rank%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_oracle_on_joint_batch():
+    from oracle import semseg_oracle as O
+    with tempfile.TemporaryDirectory() as out_dir:
+        mp.spawn(_worker, args=(2, _free_port(), out_dir), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(out_dir, 'rank0.pt'), weights_only=False)
+        r1 = torch.load(os.path.join(out_dir, 'rank1.pt'), weights_only=False)
+    # replicas stay identical: same reduced gradients, same BN statistics on both ranks
+    for k in r0['sd']:
+        assert torch.equal(r0['sd'][k], r1['sd'][k]), k
+    enc_sd, dec_sd, img, lab, masks = _joint_case()
+    e, d = O.clone_sd(enc_sd, True), O.clone_sd(dec_sd, True)
+    ref = O.segmentation_forward(e, d, 'resnet18dilated', 'ppm_deepsup', img, lab, training=True, dropout=masks,
+                                 deep_sup_scale=0.4)
+    ref['loss'].backward()
+    assert abs(r0['loss'].item() - ref['loss'].item()) < 1e-3, (r0['loss'].item(), ref['loss'].item())
+    assert abs(r0['acc'].item() - ref['acc'].item()) < 1e-6
+    for sd, prefix in ((e, 'encoder.'), (d, 'decoder.')):
+        params = {k: v for k, v in sd.items() if v.requires_grad}
+        O.sgd_step(params, {k: v.grad for k, v in params.items()}, {}, LR)
+        for k, v in sd.items():
+            if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
+                continue
+            got = r0['sd'][prefix + k]
+            torch.testing.assert_close(got.reshape(v.shape).float(), v.detach().float(), atol=2e-4, rtol=2e-3,
+                                       msg=lambda m, k=k: prefix + k + ': ' + m)
