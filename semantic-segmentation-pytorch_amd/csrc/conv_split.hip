@@ -96,8 +96,9 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 }
 
 // fwd/dgrad tiles: 0 = 128x128, 1 = 128x64, 2 = 64x64 (register staged); 3 = 256x128 LDS-DMA 2-slot;
-// h2 only: 4 = 256x128 LDS-DMA 3-slot ring, 5 = 256x256 LDS-DMA 2-slot.  wgrad tiles: 0 = 128x128, 1 = 64x64.
-static int max_tile(int sch, int pass) { return pass == 2 ? 1 : (sch == SchH2::ID ? 5 : 3); }
+// h2 only: 4 = 256x128 LDS-DMA 3-slot ring, 5 = 256x256 LDS-DMA 2-slot.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
+// staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot.
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 4 : 1) : (sch == SchH2::ID ? 5 : 3); }
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
@@ -1345,6 +1346,215 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA weight gradient: the same contraction as wgrad_kernel, but the 32-pixel x (BM | BN)-channel operand tiles go
+// global -> LDS by buffer_load_dwordx4 ... lds (no staging VGPRs and, above all, no ds_write_b128: at ~79 B/clk/CU the
+// LDS store path of the register-staged kernel costs more cycles per k-tile than its transposed reads).
+// LDS image per operand: [plane][128-channel column block][32 pixel rows][256 B]; one DMA instruction ("piece") = 4 rows
+// x 256 B = 1 KiB, lane l -> row l>>4, 16-byte chunk l&15.  The 64-byte row padding of wgrad_kernel (which keeps the four
+// rows of a ds_read_b64_tr_b16 lane group on distinct banks) is replaced by an XOR swizzle applied on the DMA SOURCE side:
+// the physical chunk p of row r holds the logical chunk p ^ ((r & 3) << 2).  Rows that are padding / outside the image /
+// past the split fetch the zero tail of the plane buffer; every wave issues exactly LPT pieces per k-tile.
+//   NSLOT == 2: wait(tile it) | barrier | multiply | barrier | issue tile it+2      (4 waves, 2 blocks per CU)
+//   NSLOT == 3: wait(tile it) | barrier | issue tile it+2 | multiply                (8 waves, one barrier per k-tile)
+// ------------------------------------------------------------------------------------------------
+template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
+__global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams p) {
+    constexpr int NP = SCH::NP;
+    typedef typename SCH::frag frag;
+    constexpr int NW = WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int FM = WM / 32, FN = WN / 32;
+    constexpr int CBA = BM / 128, CBB = BN / 128;          // 128-channel column blocks per operand
+    constexpr int GPW = 8 / NW;                            // 4-row groups per wave
+    constexpr int LPT = GPW * NP * (CBA + CBB);            // DMA pieces per wave per k-tile
+    constexpr int A_BYTES = NP * CBA * 32 * 256, B_BYTES = NP * CBB * 32 * 256, BUF_BYTES = A_BYTES + B_BYTES;
+    static_assert(BM % 128 == 0 && BN % 128 == 0 && (NW == 4 || NW == 8) && FM >= 1 && FN >= 1, "tile");
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3) && 2 * LPT < 64, "tile");
+
+    extern __shared__ __align__(16) unsigned char smem_w[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int ntiles = p.tiles_k * p.tiles_c * p.T;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int t = tile % p.T;
+    const int tc = (tile / p.T) % p.tiles_c;
+    const int tk = tile / (p.T * p.tiles_c);
+    const int k0 = tk * BM, c0 = tc * BN;
+    const int r = t / p.S, s = t - r * p.S;
+    const int z = blockIdx.y;
+    const int m_begin = z * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+    const int nk = (m_end - m_begin + 31) >> 5;
+
+    const uint32_t a_plane_b = 2u * p.dy_plane, b_plane_b = 2u * p.x_plane;
+    const uint32_t a_zero = NP * a_plane_b, b_zero = NP * b_plane_b;          // byte offsets of the zero tails
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.dys, 0, (int)(a_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.xs, 0, (int)(b_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+
+    // DMA lane constants: row inside a 4-row piece, logical 16-byte chunk this lane fetches (source-side swizzle)
+    const int lrow = lane >> 4;
+    const int cl = (lane & 15) ^ (lrow << 2);
+    uint32_t a_cb_msk[CBA], b_cb_msk[CBB];                 // all ones: the chunk lies inside the padded channel range
+#pragma unroll
+    for (int cb = 0; cb < CBA; ++cb) a_cb_msk[cb] = (k0 + cb * 128 + 8 * cl) < p.Kp ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int cb = 0; cb < CBB; ++cb) b_cb_msk[cb] = (c0 + cb * 128 + 8 * cl) < p.Cp ? 0xffffffffu : 0u;
+    const uint32_t a_col_b = 2u * (uint32_t)k0 + 16u * cl, b_col_b = 2u * (uint32_t)c0 + 16u * cl;
+    const uint32_t a_row_b = 2u * (uint32_t)p.dypitch, b_row_b = 2u * (uint32_t)p.xpitch;
+    const int HWo = p.OH * p.OW;
+    const float inv_hwo = 1.0f / (float)HWo, inv_ow = 1.0f / (float)p.OW;
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem_w;
+    auto issue = [&](int mt, int slot) {
+        const uint32_t abuf = lds0 + (uint32_t)slot * BUF_BYTES;
+        const uint32_t bbuf = abuf + A_BYTES;
+        const bool live = mt < m_end;                      // wave-uniform
+#pragma unroll
+        for (int gi = 0; gi < GPW; ++gi) {
+            const int g = wave + NW * gi;                  // wave-uniform 4-row group
+            const int mr = mt + 4 * g + lrow;
+            const bool rowok = live && (mr < m_end);
+            const int m = min(mr, p.M - 1);
+            // m -> (n, oh, ow): float-reciprocal division + one correction step (exact for m < 2^24)
+            int n = (int)((float)m * inv_hwo);
+            int rem = m - n * HWo;
+            if (rem < 0) { --n; rem += HWo; } else if (rem >= HWo) { ++n; rem -= HWo; }
+            int oh = (int)((float)rem * inv_ow);
+            int ow = rem - oh * p.OW;
+            if (ow < 0) { --oh; ow += p.OW; } else if (ow >= p.OW) { ++oh; ow -= p.OW; }
+            const int ih = oh * p.stride - p.pad + r * p.dil;
+            const int iw = ow * p.stride - p.pad + s * p.dil;
+            const bool pixok = rowok & (ih >= 0) & (iw >= 0) & (ih < p.H) & (iw < p.W);
+            const uint32_t a_msk = rowok ? 0xffffffffu : 0u, b_msk = pixok ? 0xffffffffu : 0u;
+            const uint32_t a_off = (uint32_t)m * a_row_b + a_col_b;
+            const uint32_t b_off = (uint32_t)((n * p.H + ih) * p.W + iw) * b_row_b + b_col_b;
+#pragma unroll
+            for (int cb = 0; cb < CBA; ++cb)
+#pragma unroll
+                for (int h = 0; h < NP; ++h) {
+                    const uint32_t ok = a_msk & a_cb_msk[cb];
+                    const uint32_t vo = ((a_off + cb * 256u + h * a_plane_b) & ok) | (a_zero & ~ok);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rs_a, (lds_void*)(uintptr_t)(abuf + ((h * CBA + cb) * 32 + 4 * g) * 256), 16, vo, 0, 0, 0);
+                }
+#pragma unroll
+            for (int cb = 0; cb < CBB; ++cb)
+#pragma unroll
+                for (int h = 0; h < NP; ++h) {
+                    const uint32_t ok = b_msk & b_cb_msk[cb];
+                    const uint32_t vo = ((b_off + cb * 256u + h * b_plane_b) & ok) | (b_zero & ~ok);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rs_b, (lds_void*)(uintptr_t)(bbuf + ((h * CBB + cb) * 32 + 4 * g) * 256), 16, vo, 0, 0, 0);
+                }
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // transpose-read addressing (logical mapping of wgrad_kernel): lane -> pixel row 8*(G>>1) + (i16>>2) (+16*ks, +4 for the
+    // second read) and channels 16*(G&1) + 4*(i16&3) .. +3 of the 32-channel fragment
+    const int G = lane >> 4, i16 = lane & 15;
+    const int tr_row = 8 * (G >> 1) + (i16 >> 2);
+    const int swz = (i16 >> 2) << 2;                        // (row & 3) << 2: tr_row, 16*ks and 4*half keep row & 3
+    const int chan_l = 16 * (G & 1) + 4 * (i16 & 3);
+    uint32_t a_foff[FM], b_foff[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int cbase = wm * WM + i * 32, within = (cbase & 127) + chan_l;
+        a_foff[i] = ((cbase >> 7) * 32 + tr_row) * 256 + (((within >> 3) ^ swz) << 4) + ((within & 7) << 1);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int cbase = wn * WN + j * 32, within = (cbase & 127) + chan_l;
+        b_foff[j] = ((cbase >> 7) * 32 + tr_row) * 256 + (((within >> 3) ^ swz) << 4) + ((within & 7) << 1);
+    }
+
+    auto compute_tile = [&](int slot) {
+        const unsigned char* As = smem_w + slot * BUF_BYTES;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            frag av[FM][NP], bv[FN][NP];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int h = 0; h < NP; ++h) {
+                    const unsigned char* q0 = As + a_foff[i] + (h * CBA * 32 + 16 * ks) * 256;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 256));
+                    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    av[i][h] = __builtin_bit_cast(frag, v);
+                }
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int h = 0; h < NP; ++h) {
+                    const unsigned char* q0 = Bs + b_foff[j] + (h * CBB * 32 + 16 * ks) * 256;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 256));
+                    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bv[j][h] = __builtin_bit_cast(frag, v);
+                }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) SCH::mac(av[i], bv[j], acc[i][j]);
+        }
+    };
+
+    issue(m_begin, 0);
+    issue(m_begin + 32, 1);
+    if constexpr (NSLOT == 2) {
+        for (int it = 0; it < nk; ++it) {
+            const int slot = it & 1;
+            wait_vm_barrier<LPT>();
+            compute_tile(slot);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading `slot`
+            issue(m_begin + (it + 2) * 32, slot);
+        }
+    } else {
+        int slot = 0, fill = 2;
+        for (int it = 0; it < nk; ++it) {
+            wait_vm_barrier<LPT>();
+            issue(m_begin + (it + 2) * 32, fill);
+            compute_tile(slot);
+            slot = (slot == 2) ? 0 : slot + 1;
+            fill = (fill == 2) ? 0 : fill + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S_MFMA_DRAIN();
+
+    float f1 = 1.f, f2 = 1.f;
+    descale_factors<SCH>(p.x_exp, p.dy_exp, f1, f2);
+    float* dst = (p.splits == 1) ? p.dw : p.partial + (size_t)z * p.K * p.T * p.C;
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int c = c0 + wn * WN + j * 32 + col_l;
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
+                float v = acc[i][j][e];
+                if constexpr (SCH::SCALED) v = (v * f1) * f2;
+                if (k < p.K) dst[((size_t)k * p.T + t) * p.C + c] = v;
+            }
+        }
+    }
+}
+
 __global__ void split_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t total, int splits) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         float s = partial[i];
@@ -1354,24 +1564,28 @@ __global__ void split_wgrad_reduce_kernel(const float* __restrict__ partial, flo
 }
 
 struct WPlan {
-    int BT, tiles_k, tiles_c, splits, m_per_split;
+    int tile, BM, BN, tiles_k, tiles_c, splits, m_per_split;
 };
 
-// tuning overrides: SEMSEG_W3_TILE=0 (128x128) | 1 (64x64), SEMSEG_W3_SPLIT=n
+// wgrad tiles (k x c): 0 = 128x128, 1 = 64x64 (register staged); h2 only: 2 = 128x128 LDS-DMA 2-slot (4 waves),
+// 3 = 256x128 LDS-DMA 3-slot ring (8 waves), 4 = 256x256 LDS-DMA 2-slot (8 waves) -- chosen by the tuner / overrides only
+static const int kWTiles[5][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}};
+
+// tuning overrides: SEMSEG_W3_TILE=0..3, SEMSEG_W3_SPLIT=n
 static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_split = 0) {
     WPlan pl;
     const int mtiles = ceil_div(M, 32);
-    const int cand[2] = {128, 64};
-    const double tile_cost[2] = {1.0, 0.32};
-    const int slots[2] = {512, 1024};
+    const double tile_cost[5] = {1.0, 0.32, 1.0, 2.0, 4.0};
+    const int slots[5] = {512, 1024, 512, 256, 256};
     const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_W3_TILE", -1);
     const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_W3_SPLIT", 0);
     double best = 1e30;
     int best_t = 1, best_s = 1;
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 5; ++t) {
         if (force_tile >= 0 && t != force_tile) continue;
+        if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
-        const long tiles = (long)ceil_div(K, cand[t]) * ceil_div(C, cand[t]) * T;
+        const long tiles = (long)ceil_div(K, kWTiles[t][0]) * ceil_div(C, kWTiles[t][1]) * T;
         for (int sp = 1; sp <= 64; ++sp) {
             if (force_split > 0 && sp != min(force_split, mtiles)) continue;
             if (force_split <= 0 && sp > 1 && mtiles / sp < 8) break;
@@ -1387,9 +1601,11 @@ static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_spl
             if (time < best) { best = time; best_t = t; best_s = sp; }
         }
     }
-    pl.BT = cand[best_t];
-    pl.tiles_k = ceil_div(K, pl.BT);
-    pl.tiles_c = ceil_div(C, pl.BT);
+    pl.tile = best_t;
+    pl.BM = kWTiles[best_t][0];
+    pl.BN = kWTiles[best_t][1];
+    pl.tiles_k = ceil_div(K, pl.BM);
+    pl.tiles_c = ceil_div(C, pl.BN);
     pl.m_per_split = ceil_div(mtiles, best_s) * 32;
     pl.splits = ceil_div(M, pl.m_per_split);
     return pl;
@@ -1412,6 +1628,27 @@ static int launch_wgrad(const WParams& p, hipStream_t st) {
     }
     dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits);
     hipLaunchKernelGGL((wgrad_kernel<SCH, BT, BT>), grid, dim3(256), smem, st, p);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
+static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)NSLOT * SCH::NP * (BM / 128 + BN / 128) * 32 * 256;
+    static_assert(smem <= 160 * 1024, "LDS");
+    // 32-bit byte offsets in the buffer descriptors
+    if ((size_t)2 * SCH::NP * p.x_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
+        (size_t)2 * SCH::NP * p.dy_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31))
+        return SEMSEG_EINVAL;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits);
+    hipLaunchKernelGGL((wgrad_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(WGM * WGN * 64), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -1449,7 +1686,20 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
         if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
         p.partial = (float*)workspace;
     }
-    const int rc = pl.BT == 128 ? launch_wgrad<SCH, 128>(p, st) : launch_wgrad<SCH, 64>(p, st);
+    int rc = SEMSEG_EINVAL;
+    switch (pl.tile) {
+        case 0: rc = launch_wgrad<SCH, 128>(p, st); break;
+        case 1: rc = launch_wgrad<SCH, 64>(p, st); break;
+        case 2:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 2, 2, 2>(p, st);
+            break;
+        case 3:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 256, 128, 4, 2, 3>(p, st);
+            break;
+        case 4:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 256, 256, 2, 4, 2>(p, st);
+            break;
+    }
     if (rc) return rc;
     if (pl.splits > 1) {
         const size_t total = (size_t)K * p.T * C;

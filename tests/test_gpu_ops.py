@@ -582,3 +582,42 @@ def test_conv_bn_act_fused_vs_float64(case, relu, res, monkeypatch):
     for nm, a, b in zip(names, gg, gr):
         e = ((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()
         assert e < 3e-3, (nm, e)      # relative L2; a ReLU gate flipped by a 1e-6 difference moves it by ~1e-3
+
+
+# every tile variant of the h2 kernels under a PINNED plan (the tuner only ever runs the fastest one): fwd/dgrad tiles
+# 0..5 (register staged 128x128 / 128x64 / 64x64, LDS-DMA 256x128 2-slot / 3-slot ring / 256x256), wgrad tiles 0..3
+# (register staged 128 / 64, LDS-DMA 128x128 2-slot / 256x128 3-slot ring / 256x256 2-slot), with and without split-K / split-M
+PLAN_CASES = [
+    (2, 256, 24, 24, 384, 3, 1, 2, 2),      # dilated 3x3, K not a multiple of 256
+    (2, 160, 17, 19, 96, 3, 2, 1, 1),       # stride 2, odd size, C and K with partial 128-blocks
+    (1, 512, 16, 16, 1024, 1, 1, 0, 1),     # 1x1
+]
+
+
+@pytest.mark.parametrize('case', PLAN_CASES, ids=str)
+@pytest.mark.parametrize('pass_id,tile', [(0, t) for t in range(6)] + [(1, t) for t in range(6)] + [(2, t) for t in range(5)])
+@pytest.mark.parametrize('split', [1, 3])
+def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
+    from mit_semseg import ops, _native, tuner
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    monkeypatch.setattr(tuner, 'ENABLED', False)
+    L = _native.lib()
+    n, c, h, w, k, ks, stride, pad, dil = case
+    geom = (n, h, w, c, k, ks, ks, stride, pad, dil)
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, ks, ks, generator=g) / (c * ks * ks) ** 0.5
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad, dil)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    _native.check(L.semseg_conv2d_h2_set_plan(pass_id, *geom, tile, split), 'set_plan')
+    try:
+        xg, wg = cl(x).requires_grad_(True), cl(wt).requires_grad_(True)
+        y = ops.conv2d(xg, wg, None, stride, pad, dil)
+        y.backward(cl(gy))
+        torch.cuda.synchronize()
+    finally:
+        L.semseg_conv2d_h2_set_plan(pass_id, *geom, -1, 0)
+    got, ref = ((y, yr), (xg.grad, xr.grad), (wg.grad, wr.grad))[pass_id]
+    assert rel_err(got, ref) < (REL * 4 if pass_id == 2 else REL), (pass_id, tile, split, rel_err(got, ref))
