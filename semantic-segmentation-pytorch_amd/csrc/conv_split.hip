@@ -96,9 +96,10 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 }
 
 // fwd/dgrad tiles: 0 = 128x128, 1 = 128x64, 2 = 64x64 (register staged); 3 = 256x128 LDS-DMA 2-slot;
-// h2 only: 4 = 256x128 LDS-DMA 3-slot ring, 5 = 256x256 LDS-DMA 2-slot.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
+// h2 only: 4 = 256x128 LDS-DMA 3-slot ring, 5 = 256x256 LDS-DMA 2-slot, 6 = 128x128 LDS-DMA 2-slot (8 waves, 64 KiB of LDS:
+// two blocks per CU overlap each other's prologue / epilogue on the short-K layers).  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 4 : 1) : (sch == SchH2::ID ? 5 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 4 : 1) : (sch == SchH2::ID ? 6 : 3); }
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
@@ -893,7 +894,7 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[6][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}};
+static const int kTiles[7][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128}};
 
 // Launch plan: same wave-quantisation model as plan_igemm (conv_igemm.hip) -- tile x split-K candidates, cost =
 // waves * (k-tiles per block * tile cost + fixed) + split-K slab traffic.  The LDS-DMA tiles (3..5) are chosen by the
@@ -1006,6 +1007,9 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
         case 5:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 256, 2, 4, 2>(p, st);
+            break;
+        case 6:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 4, 2, 2>(p, st);
             break;
     }
     if (rc) return rc;
