@@ -284,6 +284,17 @@ typedef struct {
 } semseg_wprep_tensor;
 int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host, int n, void* stream);
 
+/* ---------------- evaluation metrics (eval.py:74-84, utils.py:128-156) -----------------------
+ * pred[p] = argmax_c scores[p, c] (first maximum, as torch.max) on [P, C] rows with pixel stride ld; with `label`
+ * (int64 [P], < 0 = unlabeled) the exact integer tallies of accuracy() and intersectionAndUnion() are ADDED to
+ * counts (int64 [2 + 3C]: acc_sum, valid_sum, area_intersection[C], area_pred[C], area_lab[C]; area_union =
+ * area_pred + area_lab - area_intersection).  pred_out may be NULL; label/counts may be NULL (argmax only). */
+int semseg_argmax_metrics(const float* scores, int ld, const int64_t* label, int P, int C, int64_t* pred_out,
+                          int64_t* counts, void* stream);
+
+/* the same tallies from an existing prediction map (pred, label: int64 [P]); counts as above, accumulated */
+int semseg_label_metrics(const int64_t* pred, const int64_t* label, int P, int C, int64_t* counts, void* stream);
+
 /* ---------------- optimiser (torch.optim.SGD, train.py:117-126) ----------------------------- */
 typedef struct {
     float* param; const float* grad; float* momentum_buf; int64_t numel; float weight_decay; int first_step;

@@ -234,3 +234,102 @@ extern "C" int semseg_sgd_step(const semseg_sgd_tensor* tensors_host, int n, con
 }
 
 extern "C" int semseg_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------- evaluation metrics --------------
+// eval.py:74-84 on the device: pred = argmax_c scores (torch.max: first maximum), then utils.py:128-156
+//   accuracy            : acc_sum = #(label >= 0 && pred == label), valid_sum = #(label >= 0)
+//   intersectionAndUnion: area_intersection[c] = #(label >= 0 && pred == c && label == c)
+//                         area_pred[c]         = #(label >= 0 && pred == c)      (predictions on unlabeled pixels dropped)
+//                         area_lab[c]          = #(label == c)                   (0 <= c < C; np.histogram's range drops others)
+// counts (int64, ACCUMULATED so that a caller can sum over images): [acc_sum, valid_sum, inter[C], pred[C], lab[C]].
+// Integer counting: exact and order independent.  One wave per pixel, per-block LDS histograms flushed by atomics.
+__global__ __launch_bounds__(256) void argmax_metrics_kernel(const float* __restrict__ scores, int ld,
+                                                             const int64_t* __restrict__ label, int P, int C,
+                                                             int64_t* __restrict__ pred_out,
+                                                             unsigned long long* __restrict__ counts) {
+    extern __shared__ unsigned int hist[];       // [2 + 3C]
+    const int nh = 2 + 3 * C;
+    for (int i = threadIdx.x; i < nh; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p = blockIdx.x * 4 + wave; p < P; p += gridDim.x * 4) {
+        const float* row = scores + (size_t)p * ld;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float v = row[c];
+            if (v > best || (v == best && c < bi) || bi == 0x7fffffff) { best = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            if (pred_out) pred_out[p] = bi;
+            if (label) {
+                const int64_t l = label[p];
+                if (l >= 0) {
+                    atomicAdd(&hist[1], 1u);
+                    atomicAdd(&hist[2 + C + bi], 1u);
+                    if (l == bi) {
+                        atomicAdd(&hist[0], 1u);
+                        atomicAdd(&hist[2 + bi], 1u);
+                    }
+                    if (l < C) atomicAdd(&hist[2 + 2 * C + (int)l], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (label && counts)
+        for (int i = threadIdx.x; i < nh; i += blockDim.x)
+            if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
+extern "C" int semseg_argmax_metrics(const float* scores, int ld, const int64_t* label, int P, int C, int64_t* pred_out,
+                                     int64_t* counts, void* stream) {
+    if (!scores || P <= 0 || C <= 0 || C > 4096 || ld < C || (label && !counts) || (!label && !pred_out)) return SEMSEG_EINVAL;
+    int blocks = ceil_div(P, 4 * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(argmax_metrics_kernel, dim3(blocks), dim3(256), (size_t)(2 + 3 * C) * sizeof(unsigned int),
+                       (hipStream_t)stream, scores, ld, label, P, C, pred_out, (unsigned long long*)counts);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same tallies from an existing prediction map (utils.py:128-156 called on label maps, eval.py:81-82)
+__global__ __launch_bounds__(256) void label_metrics_kernel(const int64_t* __restrict__ pred, const int64_t* __restrict__ label,
+                                                            int P, int C, unsigned long long* __restrict__ counts) {
+    extern __shared__ unsigned int hist[];       // [2 + 3C]
+    const int nh = 2 + 3 * C;
+    for (int i = threadIdx.x; i < nh; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int64_t l = label[p], q = pred[p];
+        if (l < 0) continue;
+        atomicAdd(&hist[1], 1u);
+        if (q >= 0 && q < C) atomicAdd(&hist[2 + C + (int)q], 1u);
+        if (l == q) {
+            atomicAdd(&hist[0], 1u);
+            if (q < C) atomicAdd(&hist[2 + (int)q], 1u);
+        }
+        if (l < C) atomicAdd(&hist[2 + 2 * C + (int)l], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nh; i += blockDim.x)
+        if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
+extern "C" int semseg_label_metrics(const int64_t* pred, const int64_t* label, int P, int C, int64_t* counts, void* stream) {
+    if (!pred || !label || !counts || P <= 0 || C <= 0 || C > 4096) return SEMSEG_EINVAL;
+    int blocks = ceil_div(P, 256 * 4);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(label_metrics_kernel, dim3(blocks), dim3(256), (size_t)(2 + 3 * C) * sizeof(unsigned int),
+                       (hipStream_t)stream, pred, label, P, C, (unsigned long long*)counts);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}

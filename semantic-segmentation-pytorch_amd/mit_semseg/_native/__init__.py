@@ -86,6 +86,8 @@ SIGNATURES = {
     'semseg_softmax_fwd': (c_int, [vp, vp, c_int, c_int, vp]),
     'semseg_nll_acc_fwd': (c_int, [vp, vp, c_int, c_int, c_int, vp, vp, c_sz, vp]),
     'semseg_nll_bwd': (c_int, [vp, vp, vp, c_int, vp, c_int, c_int, vp]),
+    'semseg_argmax_metrics': (c_int, [vp, c_int, vp, c_int, c_int, vp, vp, vp]),
+    'semseg_label_metrics': (c_int, [vp, vp, c_int, c_int, vp, vp]),
     'semseg_sgd_step': (c_int, [ctypes.POINTER(SgdTensor), c_int, vp, c_f, c_f, vp]),
 }
 

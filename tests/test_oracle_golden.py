@@ -1,5 +1,7 @@
 """Pin oracle/semseg_oracle.py against outputs of the UNMODIFIED reference
 (tests/golden/*.pt, produced by tests/golden/make_golden.py).  CPU only."""
+import os
+
 import pytest
 import torch
 
@@ -36,3 +38,39 @@ def test_oracle_matches_reference(name):
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue   # fork-only DP buffers, untouched on the single-device path (batchnorm.py:50-52)
             check_summary(sd[k], want[k], 1e-4, 1e-3, 'after-step ' + k)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# evaluation metrics: the numpy oracle against outputs of the unmodified reference functions
+# ---------------------------------------------------------------------------------------------------------
+def _metrics_cases():
+    import importlib.util
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    spec = importlib.util.spec_from_file_location('make_metrics_golden', os.path.join(here, 'make_metrics_golden.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = np.load(os.path.join(here, 'metrics_golden.npz'))
+    for name in sorted(k[:-4] for k in gold.files if k.endswith('_cfg')):
+        C, H, W, seed = (int(v) for v in gold[name + '_cfg'])
+        scores, label = gen.synth_case(name, C, H, W, seed)
+        if name == 'perfect':
+            label = gold[name + '_pred'].astype('int64')
+        yield name, C, scores, label, {k: gold[name + '_' + k] for k in ('pred', 'acc', 'pix', 'inter', 'union')}
+
+
+def test_metrics_oracle_matches_reference_golden():
+    import numpy as np
+    from oracle import metrics_oracle as M
+    n = 0
+    for name, C, scores, label, want in _metrics_cases():
+        pred = M.argmax_first(scores)
+        assert np.array_equal(pred, want['pred'].astype(np.int64)), name
+        # torch.max(dim) (eval.py:74) picks the same first maximum on the tie-laden inputs
+        assert np.array_equal(torch.max(torch.from_numpy(scores)[None], dim=1)[1][0].numpy(), pred), name
+        acc, pix = M.accuracy(pred, label)
+        assert pix == int(want['pix']) and acc == float(want['acc']), name
+        inter, union = M.intersection_and_union(pred, label, C)
+        assert np.array_equal(inter, want['inter']) and np.array_equal(union, want['union']), name
+        n += 1
+    assert n == 6
