@@ -181,6 +181,8 @@ def main():
 
     rank, world, local = init_distributed()
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    if os.environ.get('SEMSEG_BENCH_DEVICE'):          # several ranks on one GPU (gloo): functional check of the N>1 path
+        local = int(os.environ['SEMSEG_BENCH_DEVICE'])
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     sm = build_model(dev)

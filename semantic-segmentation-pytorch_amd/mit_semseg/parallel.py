@@ -31,7 +31,9 @@ def init_distributed(backend=None):
     local = int(os.environ.get('LOCAL_RANK', rank))
     if not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # SEMSEG_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses that) -- how the single-GPU test box runs the
+            # multi-rank code path end to end
+            backend = os.environ.get('SEMSEG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
