@@ -110,6 +110,11 @@ int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, floa
 int semseg_conv2d_dgrad_h2(const void* dys, const void* wts, float* dx, int dx_ld,
                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* dx = addend + dgrad: `addend` ([N*H*W][addend_ld] fp32, NHWC) is the gradient another consumer of the same input
+ * already produced (residual branch / downsample conv of a bottleneck, resnet.py:72-92); accumulated in the epilogue. */
+int semseg_conv2d_dgrad_acc_h2(const void* dys, const void* wts, const float* addend, int addend_ld, float* dx, int dx_ld,
+                               int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                               void* workspace, size_t workspace_bytes, void* stream);
 int semseg_conv2d_wgrad_h2(const void* xs, const void* dys, float* dw,
                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                            void* workspace, size_t workspace_bytes, void* stream);

@@ -309,6 +309,8 @@ struct SParams {
     const int* w_exp;
     uint32_t in_plane, w_plane;   // elements per plane (host checks the byte size < 2^31)
     const float* bias;
+    const float* addend;   // optional [M][addend_ld] fp32 added to the result (gradient accumulation in the dgrad epilogue)
+    int addend_ld;
     float* out;
     float* partial;
     int Cp, pitch, out_ld;   // Cp: channels padded to 32; pitch: row stride of the split planes (elements)
@@ -400,7 +402,11 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
                 const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
                 float v = acc[i][j][e];
                 if constexpr (SCH::SCALED) v = (v * f1) * f2;
-                if (row < p.M) dst[(size_t)row * dst_ld + col] = v + bvl;
+                if (row < p.M) {
+                    v += bvl;
+                    if (direct && p.addend) v += p.addend[(size_t)row * p.addend_ld + col];
+                    dst[(size_t)row * dst_ld + col] = v;
+                }
             }
         }
     }
@@ -872,7 +878,8 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
 
 // out[m*out_ld + n] = bias[n] + sum_z partial[z][m*Cout + n]   (fixed order => deterministic)
 __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
-                                     float* __restrict__ out, int out_ld, int M, int Cout, int splits) {
+                                         const float* __restrict__ addend, int addend_ld, float* __restrict__ out, int out_ld,
+                                         int M, int Cout, int splits) {
     const size_t total = (size_t)M * Cout;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / Cout);
@@ -880,6 +887,7 @@ __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, cons
         float s = partial[i];
         for (int zz = 1; zz < splits; ++zz) s += partial[(size_t)zz * total + i];
         if (bias) s += bias[n];
+        if (addend) s += addend[(size_t)m * addend_ld + n];
         out[(size_t)m * out_ld + n] = s;
     }
 }
@@ -1016,7 +1024,7 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
     if (pl.splits > 1) {
         const size_t total = (size_t)p.M * p.Cout;
         const int blocks = (int)min((size_t)2048, ceil_div_sz(total, 256));
-        hipLaunchKernelGGL(split_gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.out, p.out_ld, p.M,
+        hipLaunchKernelGGL(split_gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.addend, p.addend_ld, p.out, p.out_ld, p.M,
                            p.Cout, pl.splits);
         SEMSEG_LAUNCH_CHECK();
     }
@@ -1060,13 +1068,15 @@ static int conv_fwd(const void* xs, const void* ws, const float* bias, float* y,
 template <class SCH>
 static int conv_dgrad(const void* dys, const void* wts, float* dx, int dx_ld,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+                      void* workspace, size_t workspace_bytes, void* stream, const float* addend = nullptr, int addend_ld = 0) {
     if (!dys || !wts || !dx || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0 || dx_ld < C) return SEMSEG_EINVAL;
+    if (addend && addend_ld < C) return SEMSEG_EINVAL;
     if (!aligned16(dys) || !aligned16(wts)) return SEMSEG_EINVAL;
     const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
     if (OH <= 0 || OW <= 0) return SEMSEG_EINVAL;
     SParams p = {};
     p.in = (const uint16_t*)dys; p.wgt = (const uint16_t*)wts; p.bias = nullptr; p.out = dx;
+    p.addend = addend; p.addend_ld = addend_ld;
     p.Cp = round_up32(K); p.pitch = split_pitch(K); p.out_ld = dx_ld;
     p.Hin = OH; p.Win = OW;
     p.Hout = H; p.Wout = W; p.Cout = C;
@@ -1103,6 +1113,15 @@ extern "C" int semseg_conv2d_dgrad_h2(const void* dys, const void* wts, float* d
     return conv_dgrad<SchH2>(dys, wts, dx, dx_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
 }
 
+// dx = addend + dgrad(dys, wts): the gradient another consumer of the same input has already produced is accumulated in the
+// epilogue (no separate add pass); addend may alias dx only element for element (it is read before the write)
+extern "C" int semseg_conv2d_dgrad_acc_h2(const void* dys, const void* wts, const float* addend, int addend_ld, float* dx,
+                                          int dx_ld, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                          int dil, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_dgrad<SchH2>(dys, wts, dx, dx_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream,
+                             addend, addend_ld);
+}
+
 // ------------------------------------------------------------------------------------------------
 // bias gradient: db[k] = sum_m dy[m][k]   (two deterministic passes, fp64 combine)
 // ------------------------------------------------------------------------------------------------
@@ -1122,12 +1141,22 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
     if (ry == 0 && k < K) partial[(size_t)blockIdx.y * K + k] = red[0][kx] + red[1][kx] + red[2][kx] + red[3][kx];
 }
 
-__global__ void bias_grad_finish_kernel(const double* __restrict__ partial, int nchunks, int K, float* __restrict__ db) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
+// 16 channels x 16 partial lanes per block (a serial loop over 128 partials per thread was 30 us)
+__global__ __launch_bounds__(256) void bias_grad_finish_kernel(const double* __restrict__ partial, int nchunks, int K,
+                                                               float* __restrict__ db) {
+    __shared__ double red[16][17];
+    const int kl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kl;
     double s = 0.0;
-    for (int i = 0; i < nchunks; ++i) s += partial[(size_t)i * K + k];
-    db[k] = (float)s;
+    if (k < K)
+        for (int i = lane; i < nchunks; i += 16) s += partial[(size_t)i * K + k];
+    red[lane][kl] = s;
+    __syncthreads();
+    if (lane == 0 && k < K) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i][kl];
+        db[k] = (float)t;
+    }
 }
 
 extern "C" int semseg_bias_grad(const float* dy, int dy_ld, float* db, int M, int K, void* workspace, size_t workspace_bytes,
@@ -1139,7 +1168,7 @@ extern "C" int semseg_bias_grad(const float* dy, int dy_ld, float* db, int M, in
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(ceil_div(K, 64), nchunks), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
                        M, K, rows_per_chunk, (double*)workspace);
     SEMSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(ceil_div(K, 16)), dim3(256), 0, (hipStream_t)stream,
                        (const double*)workspace, nchunks, K, db);
     SEMSEG_LAUNCH_CHECK();
     return 0;

@@ -98,10 +98,10 @@ constexpr int NLL_BLOCKS = 256;
 __global__ __launch_bounds__(256) void nll_acc_partial_kernel(const float* __restrict__ logp, const int64_t* __restrict__ label,
                                                               int ignore_index, int P, int C, double* __restrict__ partial) {
     __shared__ double sl[4];
-    __shared__ int sv[4], sh[4];
+    __shared__ int sv[4], sh[4], sn[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double loss = 0.0;
-    int valid = 0, hits = 0;
+    int valid = 0, hits = 0, nonneg = 0;
     for (int p = blockIdx.x * 4 + w; p < P; p += gridDim.x * 4) {
         const float* row = logp + (size_t)p * C;
         // first-max argmax over C (torch.max(dim=1) returns the first index of the maximum)
@@ -120,32 +120,34 @@ __global__ __launch_bounds__(256) void nll_acc_partial_kernel(const float* __res
         if (lane == 0) {
             const long long lab = label[p];
             // pixel_acc (models.py:12-18): valid = label >= 0 ; NLLLoss: valid = label != ignore_index
-            if (lab >= 0) hits += ((long long)bi == lab) ? 1 : 0;
+            if (lab >= 0) {
+                hits += ((long long)bi == lab) ? 1 : 0;
+                nonneg += 1;
+            }
             if (lab != ignore_index) {
                 valid += 1;
                 if (lab >= 0 && lab < C) loss -= (double)row[lab];
             }
         }
     }
-    if (lane == 0) { sl[w] = loss; sv[w] = valid; sh[w] = hits; }
+    if (lane == 0) { sl[w] = loss; sv[w] = valid; sh[w] = hits; sn[w] = nonneg; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[blockIdx.x * 3 + 0] = sl[0] + sl[1] + sl[2] + sl[3];
-        partial[blockIdx.x * 3 + 1] = (double)(sv[0] + sv[1] + sv[2] + sv[3]);
-        partial[blockIdx.x * 3 + 2] = (double)(sh[0] + sh[1] + sh[2] + sh[3]);
+        partial[blockIdx.x * 4 + 0] = sl[0] + sl[1] + sl[2] + sl[3];
+        partial[blockIdx.x * 4 + 1] = (double)(sv[0] + sv[1] + sv[2] + sv[3]);
+        partial[blockIdx.x * 4 + 2] = (double)(sh[0] + sh[1] + sh[2] + sh[3]);
+        partial[blockIdx.x * 4 + 3] = (double)(sn[0] + sn[1] + sn[2] + sn[3]);      // accuracy denominator: label >= 0
     }
 }
 
-__global__ void nll_acc_finish_kernel(const double* __restrict__ partial, int nblocks, const int64_t* __restrict__ label, int P,
-                                      float* __restrict__ out) {
-    // single wave; also counts label>=0 for the accuracy denominator (== n_valid when ignore_index == -1)
+__global__ void nll_acc_finish_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ out) {
+    // single wave over the <= 256 per-block partials
     const int lane = threadIdx.x;
-    double l = 0.0, v = 0.0, h = 0.0;
-    for (int b = lane; b < nblocks; b += 64) { l += partial[b * 3]; v += partial[b * 3 + 1]; h += partial[b * 3 + 2]; }
-    l = wave_sum_d(l); v = wave_sum_d(v); h = wave_sum_d(h);
-    double nonneg = 0.0;
-    for (int p = lane; p < P; p += 64) nonneg += label[p] >= 0 ? 1.0 : 0.0;
-    nonneg = wave_sum_d(nonneg);
+    double l = 0.0, v = 0.0, h = 0.0, nonneg = 0.0;
+    for (int b = lane; b < nblocks; b += 64) {
+        l += partial[b * 4]; v += partial[b * 4 + 1]; h += partial[b * 4 + 2]; nonneg += partial[b * 4 + 3];
+    }
+    l = wave_sum_d(l); v = wave_sum_d(v); h = wave_sum_d(h); nonneg = wave_sum_d(nonneg);
     if (lane == 0) {
         out[0] = (float)(l / v);                                   // mean over non-ignored (0/0 -> NaN as torch)
         out[1] = (float)h / ((float)nonneg + 1e-10f);              // models.py:17
@@ -157,11 +159,11 @@ extern "C" int semseg_nll_acc_fwd(const float* logp, const int64_t* label, int i
                                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!logp || !label || !out || P <= 0 || C <= 0) return SEMSEG_EINVAL;
     const int blocks = min(NLL_BLOCKS, ceil_div(P, 4));
-    if (!workspace || workspace_bytes < (size_t)blocks * 3 * sizeof(double)) return SEMSEG_EWORKSPACE;
+    if (!workspace || workspace_bytes < (size_t)blocks * 4 * sizeof(double)) return SEMSEG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nll_acc_partial_kernel, dim3(blocks), dim3(256), 0, st, logp, label, ignore_index, P, C, (double*)workspace);
     SEMSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nll_acc_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, blocks, label, P, out);
+    hipLaunchKernelGGL(nll_acc_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, blocks, out);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }

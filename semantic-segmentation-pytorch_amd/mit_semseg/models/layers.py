@@ -49,16 +49,19 @@ class Conv2d(nn.Module):
                'dilation={dilation}'.format(**self.__dict__) + (', bias=False' if self.bias is None else '')
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False):
+def conv_bn(conv, bn, x, residual=None, relu=False, passthrough=False):
     """bn(conv(x), residual=..., relu=...) -- the conv -> BN [-> +residual] [-> ReLU] unit every block of the reference
     is made of (resnet.py:72-92, models.py:160-167, hrnet.py:45-61) -- dispatched as ONE fused autograd node when the
-    h2 path can run it (ops.conv_bn_act), else as the two modules."""
+    h2 path can run it (ops.conv_bn_act), else as the two modules.  passthrough=True returns (y, x'), x' being x routed
+    through the node (see ops.conv_bn_act): the blocks hand x' to their shortcut so that its gradient is accumulated in
+    this conv's data-gradient kernel."""
     if conv.bias is None and x.dim() == 4 and type(conv) is Conv2d and isinstance(bn, SynchronizedBatchNorm2d):
         return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                bn.num_batches_tracked, residual=residual, stride=conv.stride[0],
                                padding=conv.padding[0], dilation=conv.dilation[0], training=bn.training,
-                               momentum=bn.momentum, eps=bn.eps, relu=relu)
-    return bn(conv(x), residual=residual, relu=relu)
+                               momentum=bn.momentum, eps=bn.eps, relu=relu, passthrough=passthrough)
+    y = bn(conv(x), residual=residual, relu=relu)
+    return (y, x) if passthrough else y
 
 
 class ReLU(nn.Module):

@@ -40,8 +40,8 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        out, x = conv_bn(self.conv1, self.bn1, x, relu=True, passthrough=True)    # the shortcut hangs off conv1's node
         residual = x if self.downsample is None else self.downsample(x)
-        out = conv_bn(self.conv1, self.bn1, x, relu=True)
         return conv_bn(self.conv2, self.bn2, out, residual=residual, relu=True)
 
 
@@ -62,8 +62,8 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        out, x = conv_bn(self.conv1, self.bn1, x, relu=True, passthrough=True)    # the shortcut hangs off conv1's node
         residual = x if self.downsample is None else self.downsample(x)
-        out = conv_bn(self.conv1, self.bn1, x, relu=True)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)
         return conv_bn(self.conv3, self.bn3, out, residual=residual, relu=True)
 

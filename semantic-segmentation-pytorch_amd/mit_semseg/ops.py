@@ -392,8 +392,9 @@ def side_wgrad_join():
     _SIDE['on'] = False
 
 
-def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
-    """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys)."""
+def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, addend=None):
+    """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys).
+    `addend` (h2): a gradient w.r.t. the same input that is already known; it is accumulated in the dgrad epilogue."""
     n, h, wd, c, k, r, s, stride, pad, dil = geom
     dev = w.device
     dx = dw = None
@@ -422,10 +423,16 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
         wts = wtp if wtp is not None else _weight_crsk_planes(L, sch, w, dev)
         dx = empty_nhwc(n, c, h, wd, dev)
 
+        add, add_ld = as_nhwc(addend) if addend is not None else (None, 0)
+
         def launch_d():
             ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
-            _native.check(sch.fn(L, 'dgrad')(_p(dys), _p(wts), _p(dx), c, *geom, _p(ws), ws.numel(), _st()),
-                          'conv2d_dgrad_' + scheme)
+            if add is None:
+                _native.check(sch.fn(L, 'dgrad')(_p(dys), _p(wts), _p(dx), c, *geom, _p(ws), ws.numel(), _st()),
+                              'conv2d_dgrad_' + scheme)
+            else:
+                _native.check(L.semseg_conv2d_dgrad_acc_h2(_p(dys), _p(wts), _p(add), add_ld, _p(dx), c, *geom, _p(ws),
+                                                           ws.numel(), _st()), 'conv2d_dgrad_acc_h2')
         tuner.ensure(scheme, 1, geom, launch_d)
         launch_d()
     return dx, dw
@@ -560,7 +567,7 @@ class ConvBNActFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg, box):
-        stride, pad, dil, momentum, eps, relu, emit = cfg
+        stride, pad, dil, momentum, eps, relu, emit, passthrough = cfg
         L = _native.lib()
         sch = SCHEMES['h2']
         w = krsc(weight.detach())
@@ -626,11 +633,15 @@ class ConvBNActFn(Function):
         ctx.geom = geom
         ctx.cfg = (bool(relu), residual is not None)
         box['planes'], box['absmax'] = yp, absmax
+        if passthrough:
+            # the input travels on as a second output: its other consumers (residual add, downsample conv) hang off THIS
+            # node, their gradient arrives here as `dx_other` and is accumulated in the dgrad epilogue (no add pass)
+            return y, x
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_other=None):
         L = _native.lib()
         sch = SCHEMES['h2']
         xp, w, wtp, z, y, coef, gamma, stats, zmm = ctx.saved_tensors
@@ -673,32 +684,46 @@ class ConvBNActFn(Function):
         _native.check(L.semseg_bn_bwd_apply_h2(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gamma),
                                                _p(sums), _p(count), 1, int(relu), _p(dzp), _p(dres), P, k, _p(gsc), _p(gsh),
                                                _p(bb), _st()), 'bn_bwd_apply_h2')
-        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                   addend=dx_other)
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
                 None, None, None, None, None, None, None, None, None)
 
 
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, residual=None, stride=1,
-                padding=0, dilation=1, training=False, momentum=0.1, eps=1e-5, relu=False):
+                padding=0, dilation=1, training=False, momentum=0.1, eps=1e-5, relu=False, passthrough=False):
     """act(BN(conv(x)) + residual) for a bias-free conv.  Training on the h2 path with K % 8 == 0 runs the fused node
-    (ConvBNActFn); everything else composes conv2d + batch_norm_act."""
+    (ConvBNActFn); everything else composes conv2d + batch_norm_act.
+    passthrough=True returns (y, x'): x' is x routed through the node -- a block that feeds x' (instead of x) to its
+    other consumers (residual add / downsample conv, resnet.py:72-92) gets their gradient accumulated inside this conv's
+    data-gradient kernel instead of a separate add pass."""
     if not (FUSE and CONV_MODE == 'h2' and training and weight.shape[0] % 8 == 0):
         z = conv2d(x, weight, None, stride, padding, dilation)
-        return batch_norm_act(z, gamma, beta, running_mean, running_var, residual=residual, training=training,
-                              momentum=momentum, eps=eps, relu=relu, num_batches_tracked=num_batches_tracked)
+        y = batch_norm_act(z, gamma, beta, running_mean, running_var, residual=residual, training=training,
+                           momentum=momentum, eps=eps, relu=relu, num_batches_tracked=num_batches_tracked)
+        return (y, x) if passthrough else y
     _require_cuda(x)
     xp = input_planes(x, 'h2')
     wp, wtp = weight_planes(weight, 'h2')
-    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu))
+    want_pair = bool(passthrough)
+    passthrough = want_pair and x.requires_grad and torch.is_grad_enabled()
+    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu), passthrough)
     box = {}
-    y = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean, running_var,
-                          num_batches_tracked, cfg, box)
+    out = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean, running_var,
+                            num_batches_tracked, cfg, box)
+    y, xr = out if passthrough else (out, x)
     yp, absmax = box['planes'], box['absmax']
     if yp is not None:
         attach_planes(y, yp, 'h2', y.shape[0] * y.shape[2] * y.shape[3], y.shape[1])
     if absmax is not None:
         attach_absmax(y, absmax)
-    return y
+    if xr is not x:                        # same storage, new tensor object: carry the plane / bound records over
+        n, c, h, w = x.shape
+        attach_planes(xr, xp, 'h2', n * h * w, c)
+        bound = absmax_of(x)
+        if bound is not None:
+            attach_absmax(xr, bound)
+    return (y, xr) if want_pair else y
 
 
 # ------------------------------------------------------------------------------------------------
@@ -976,7 +1001,7 @@ class NLLAccFn(Function):
             raise ValueError('Expected target size %s, got %s' % ([logp.shape[0], logp.shape[2], logp.shape[3]],
                                                                  list(label.shape)))
         out = torch.empty((3,), device=logp.device, dtype=torch.float32)
-        ws = workspace(256 * 3 * 8, logp.device)
+        ws = workspace(256 * 4 * 8, logp.device)
         _native.check(_native.lib().semseg_nll_acc_fwd(_p(logp), _p(label), int(ignore_index), P, c, _p(out), _p(ws),
                                                        ws.numel(), _st()), 'nll_acc_fwd')
         ctx.save_for_backward(out, label)

@@ -621,3 +621,39 @@ def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
         L.semseg_conv2d_h2_set_plan(pass_id, *geom, -1, 0)
     got, ref = ((y, yr), (xg.grad, xr.grad), (wg.grad, wr.grad))[pass_id]
     assert rel_err(got, ref) < (REL * 4 if pass_id == 2 else REL), (pass_id, tile, split, rel_err(got, ref))
+
+
+@pytest.mark.parametrize('case', [(2, 64, 24, 24, 128, 3, 1, 1, 1), (2, 256, 17, 19, 64, 1, 2, 0, 1), (2, 512, 16, 16, 256, 3, 1, 2, 2)], ids=str)
+def test_conv_bn_passthrough_accumulates_shortcut_gradient(case, monkeypatch):
+    """ops.conv_bn_act(passthrough=True): the gradient of the block shortcut (x' = x routed through the node) is added
+    inside the data-gradient kernel -- same x.grad as letting autograd add the two branches"""
+    from mit_semseg import ops
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    n, c, h, w, k, ks, stride, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, ks, ks, generator=g) / (c * ks * ks) ** 0.5
+    gam, bet = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g) * 0.1
+    oh = (h + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+    ow = (w + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+    gy, gx = torch.randn(n, k, oh, ow, generator=g), torch.randn(n, c, h, w, generator=g)
+
+    def run(passthrough):
+        xg = cl(x).requires_grad_(True)
+        wg = torch.nn.Parameter(cl(wt))
+        gg, bg = torch.nn.Parameter(gam.to(dev())), torch.nn.Parameter(bet.to(dev()))
+        bufs = (torch.zeros(k, device=dev()), torch.ones(k, device=dev()), torch.zeros((), dtype=torch.long, device=dev()))
+        out = ops.conv_bn_act(xg, wg, gg, bg, *bufs, stride=stride, padding=pad, dilation=dil, training=True, relu=True,
+                              passthrough=passthrough)
+        y, xr = out if passthrough else (out, xg)
+        if passthrough:
+            assert xr is not xg and xr.data_ptr() == xg.data_ptr()
+            assert ops.planes_of(xr, 'h2', n * h * w, c) is not None          # the planes travel with x'
+        ((y * cl(gy)).sum() + (xr * cl(gx)).sum()).backward()
+        torch.cuda.synchronize()
+        return y.detach(), xg.grad, wg.grad
+
+    y0, dx0, dw0 = run(False)
+    y1, dx1, dw1 = run(True)
+    assert torch.equal(y0, y1) and torch.equal(dw0, dw1)
+    torch.testing.assert_close(dx1, dx0, rtol=1e-6, atol=1e-6)
