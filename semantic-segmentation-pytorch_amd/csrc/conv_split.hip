@@ -97,9 +97,10 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 
 // fwd/dgrad tiles: 0 = 128x128, 1 = 128x64, 2 = 64x64 (register staged); 3 = 256x128 LDS-DMA 2-slot;
 // h2 only: 4 = 256x128 LDS-DMA 3-slot ring, 5 = 256x256 LDS-DMA 2-slot, 6 = 128x128 LDS-DMA 2-slot (8 waves, 64 KiB of LDS:
-// two blocks per CU overlap each other's prologue / epilogue on the short-K layers).  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
+// two blocks per CU overlap each other's prologue / epilogue on the short-K layers); 7 / 8 / 9 = the 2-slot tiles 3 / 5 / 6 with
+// software-pipelined fragment reads (one barrier per k-tile).  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 4 : 1) : (sch == SchH2::ID ? 6 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 4 : 1) : (sch == SchH2::ID ? 9 : 3); }
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
     constexpr int LPT = NP * (AG + BG);                // DMA instructions per wave per tile
     constexpr int A_BYTES = NP * BM * 64, B_BYTES = NP * BN * 64, BUF_BYTES = A_BYTES + B_BYTES;
     static_assert(AG >= 1 && BG >= 1 && FM >= 1 && FN >= 1, "tile");
-    static_assert(NSLOT == 2 || NSLOT == 3, "slots");
+    static_assert(NSLOT == 2 || NSLOT == 3 || NSLOT == 12, "slots");     // 12: two slots, software-pipelined fragment reads
     static_assert(2 * LPT < 64, "vmcnt range");
 
     extern __shared__ __align__(16) uint4 smem4[];
@@ -823,29 +824,36 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
     const int frow = lane & 31;
     const int kb = lane >> 5;
 
-    auto compute_tile = [&](int slot) {
+    // fragments of k-step `ks` (16 of the 32 channels of the k-tile) of the tile in `slot`
+    auto read_frags = [&](int slot, int ks, frag (&av)[FM][NP], frag (&bv)[FN][NP]) {
         const uint4* As = reinterpret_cast<const uint4*>(smem + slot * BUF_BYTES);
         const uint4* Bs = reinterpret_cast<const uint4*>(smem + slot * BUF_BYTES + A_BYTES);
+        const int ch = 2 * ks + kb;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int r = wn * WN + j * 32 + frow;
+#pragma unroll
+            for (int s = 0; s < NP; ++s) bv[j][s] = *reinterpret_cast<const frag*>(&Bs[s * BN * 4 + s_slot(r, ch)]);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int r = wm * WM + i * 32 + frow;
+#pragma unroll
+            for (int s = 0; s < NP; ++s) av[i][s] = *reinterpret_cast<const frag*>(&As[s * BM * 4 + s_slot(r, ch)]);
+        }
+    };
+    auto mma = [&](const frag (&av)[FM][NP], const frag (&bv)[FN][NP]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) SCH::mac(av[i], bv[j], acc[i][j]);
+    };
+    auto compute_tile = [&](int slot) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int ch = 2 * ks + kb;
             frag av[FM][NP], bv[FN][NP];
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int r = wn * WN + j * 32 + frow;
-#pragma unroll
-                for (int s = 0; s < NP; ++s) bv[j][s] = *reinterpret_cast<const frag*>(&Bs[s * BN * 4 + s_slot(r, ch)]);
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int r = wm * WM + i * 32 + frow;
-#pragma unroll
-                for (int s = 0; s < NP; ++s) av[i][s] = *reinterpret_cast<const frag*>(&As[s * BM * 4 + s_slot(r, ch)]);
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) SCH::mac(av[i], bv[j], acc[i][j]);
+            read_frags(slot, ks, av, bv);
+            mma(av, bv);
         }
     };
 
@@ -853,7 +861,25 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
     // the newest LPT have landed" == "tile `it` has landed" at the top of every iteration.
     issue(kt_begin, 0);
     issue(kt_begin + 1, 1);
-    if constexpr (NSLOT == 2) {
+    if constexpr (NSLOT == 12) {
+        // Software-pipelined 2-slot loop, ONE barrier per k-tile: the first half of the next tile's fragments is read
+        // from LDS behind the MFMAs of the second half of the current tile, so no wave ever sits in front of the MFMA pipe
+        // waiting for its first ds_read after a barrier (with the plain loop all 8 waves hit the LDS at once there).
+        //   it: read ks=1 of tile it | MMA ks=0 | wait: my reads done, tile it+1 landed | barrier |
+        //       DMA tile it+2 -> the slot just read | read ks=0 of tile it+1 | MMA ks=1
+        frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+        wait_vm_barrier<LPT>();                               // tile 0 has landed for every wave
+        read_frags(0, 0, a0, b0);
+        for (int it = 0; it < nk; ++it) {
+            const int slot = it & 1;
+            read_frags(slot, 1, a1, b1);
+            mma(a0, b0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue(kt_begin + it + 2, slot);
+            read_frags(slot ^ 1, 0, a0, b0);                  // past the last tile: zero-tail / stale data, never multiplied
+            mma(a1, b1);
+        }
+    } else if constexpr (NSLOT == 2) {
         for (int it = 0; it < nk; ++it) {
             const int slot = it & 1;
             wait_vm_barrier<LPT>();
@@ -902,7 +928,8 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[7][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128}};
+static const int kTiles[10][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
+                                   {256, 128}, {256, 256}, {128, 128}};
 
 // Launch plan: same wave-quantisation model as plan_igemm (conv_igemm.hip) -- tile x split-K candidates, cost =
 // waves * (k-tiles per block * tile cost + fixed) + split-K slab traffic.  The LDS-DMA tiles (3..5) are chosen by the
@@ -965,7 +992,7 @@ static int launch_rs(const SParams& p, hipStream_t st) {
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 static int launch_dma(const SParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)NSLOT * SCH::NP * (BM + BN) * 64;
+    constexpr size_t smem = (size_t)(NSLOT == 12 ? 2 : NSLOT) * SCH::NP * (BM + BN) * 64;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (!attr_done) {
@@ -1018,6 +1045,15 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
         case 6:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 4, 2, 2>(p, st);
+            break;
+        case 7:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 128, 4, 2, 12>(p, st);
+            break;
+        case 8:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 256, 2, 4, 12>(p, st);
+            break;
+        case 9:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 4, 2, 12>(p, st);
             break;
     }
     if (rc) return rc;

@@ -212,6 +212,12 @@ class Conv2dFn(Function):
 FUSE = os.environ.get('SEMSEG_FUSE', '1') != '0'
 
 
+# SEMSEG_PASSTHROUGH=1: block shortcuts hang off conv1's fused node and their gradient is accumulated in its dgrad epilogue.
+# Measured (one box, interleaved A/B, gpurun r1x): 17.15 ms with vs 17.04 ms without -- the strided 4-byte addend reads in
+# the MFMA epilogue cost more than the 16 vectorised add launches they replace, so the default is off.
+PASSTHROUGH = os.environ.get('SEMSEG_PASSTHROUGH', '0') == '1'
+
+
 def attach_planes(t, buf, scheme, rows, ch):
     """Remember the split planes of activation `t` on the tensor object: the next conv that consumes this very object
     (unchanged: same version counter, same storage) reads them instead of splitting again."""
@@ -706,7 +712,7 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
     xp = input_planes(x, 'h2')
     wp, wtp = weight_planes(weight, 'h2')
     want_pair = bool(passthrough)
-    passthrough = want_pair and x.requires_grad and torch.is_grad_enabled()
+    passthrough = want_pair and PASSTHROUGH and x.requires_grad and torch.is_grad_enabled()
     cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu), passthrough)
     box = {}
     out = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean, running_var,
