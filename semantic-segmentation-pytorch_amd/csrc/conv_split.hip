@@ -98,9 +98,10 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // fwd/dgrad tiles: 0 = 128x128, 1 = 128x64, 2 = 64x64 (register staged); 3 = 256x128 LDS-DMA 2-slot;
 // h2 only: 4 = 256x128 LDS-DMA 3-slot ring, 5 = 256x256 LDS-DMA 2-slot, 6 = 128x128 LDS-DMA 2-slot (8 waves, 64 KiB of LDS:
 // two blocks per CU overlap each other's prologue / epilogue on the short-K layers); 7 / 8 / 9 = the 2-slot tiles 3 / 5 / 6 with
-// software-pipelined fragment reads (one barrier per k-tile).  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
-// staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 4 : 1) : (sch == SchH2::ID ? 9 : 3); }
+// software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
+// staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
+// software-pipelined fragment reads.
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 6 : 1) : (sch == SchH2::ID ? 10 : 3); }
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
@@ -656,8 +657,8 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
     constexpr int LPT = NP * (AG + BG);                // DMA instructions per wave per tile
     constexpr int A_BYTES = NP * BM * 64, B_BYTES = NP * BN * 64, BUF_BYTES = A_BYTES + B_BYTES;
     static_assert(AG >= 1 && BG >= 1 && FM >= 1 && FN >= 1, "tile");
-    static_assert(NSLOT == 2 || NSLOT == 3 || NSLOT == 12, "slots");     // 12: two slots, software-pipelined fragment reads
-    static_assert(2 * LPT < 64, "vmcnt range");
+    static_assert(NSLOT == 2 || NSLOT == 3 || NSLOT == 12 || NSLOT == 13, "slots");     // 12 / 13: 2 / 3 slots, software-pipelined fragment reads
+    static_assert(3 * LPT < 64, "vmcnt range");
 
     extern __shared__ __align__(16) uint4 smem4[];
     unsigned char* smem = reinterpret_cast<unsigned char*>(smem4);
@@ -861,7 +862,25 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
     // the newest LPT have landed" == "tile `it` has landed" at the top of every iteration.
     issue(kt_begin, 0);
     issue(kt_begin + 1, 1);
-    if constexpr (NSLOT == 12) {
+    if constexpr (NSLOT == 13) {
+        // 3-slot ring with the same software pipeline: tile it+3 is issued into the slot of tile it right after the
+        // barrier, two k-tiles before it is needed (the 2-slot form leaves one)
+        issue(kt_begin + 2, 2);
+        frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+        wait_vm_barrier<2 * LPT>();                           // tile 0 has landed for every wave
+        read_frags(0, 0, a0, b0);
+        int slot = 0;
+        for (int it = 0; it < nk; ++it) {
+            const int next = (slot == 2) ? 0 : slot + 1;
+            read_frags(slot, 1, a1, b1);
+            mma(a0, b0);
+            wait_vm_barrier<LPT>();                           // my reads of `slot` are done, tile it+1 has landed
+            issue(kt_begin + it + 3, slot);
+            read_frags(next, 0, a0, b0);
+            mma(a1, b1);
+            slot = next;
+        }
+    } else if constexpr (NSLOT == 12) {
         // Software-pipelined 2-slot loop, ONE barrier per k-tile: the first half of the next tile's fragments is read
         // from LDS behind the MFMAs of the second half of the current tile, so no wave ever sits in front of the MFMA pipe
         // waiting for its first ds_read after a barrier (with the plain loop all 8 waves hit the LDS at once there).
@@ -928,8 +947,8 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[10][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
-                                   {256, 128}, {256, 256}, {128, 128}};
+static const int kTiles[11][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
+                                   {256, 128}, {256, 256}, {128, 128}, {256, 128}};
 
 // Launch plan: same wave-quantisation model as plan_igemm (conv_igemm.hip) -- tile x split-K candidates, cost =
 // waves * (k-tiles per block * tile cost + fixed) + split-K slab traffic.  The LDS-DMA tiles (3..5) are chosen by the
@@ -992,7 +1011,7 @@ static int launch_rs(const SParams& p, hipStream_t st) {
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 static int launch_dma(const SParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)(NSLOT == 12 ? 2 : NSLOT) * SCH::NP * (BM + BN) * 64;
+    constexpr size_t smem = (size_t)(NSLOT == 12 ? 2 : NSLOT == 13 ? 3 : NSLOT) * SCH::NP * (BM + BN) * 64;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (!attr_done) {
@@ -1054,6 +1073,9 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
         case 9:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 4, 2, 12>(p, st);
+            break;
+        case 10:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 128, 4, 2, 13>(p, st);
             break;
     }
     if (rc) return rc;
@@ -1439,7 +1461,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
     constexpr int LPT = GPW * NP * (CBA + CBB);            // DMA pieces per wave per k-tile
     constexpr int A_BYTES = NP * CBA * 32 * 256, B_BYTES = NP * CBB * 32 * 256, BUF_BYTES = A_BYTES + B_BYTES;
     static_assert(BM % 128 == 0 && BN % 128 == 0 && (NW == 4 || NW == 8) && FM >= 1 && FN >= 1, "tile");
-    static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3) && 2 * LPT < 64, "tile");
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3 || NSLOT == 12) && 2 * LPT < 64, "tile");
 
     extern __shared__ __align__(16) unsigned char smem_w[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1547,42 +1569,62 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
         b_foff[j] = ((cbase >> 7) * 32 + tr_row) * 256 + (((within >> 3) ^ swz) << 4) + ((within & 7) << 1);
     }
 
-    auto compute_tile = [&](int slot) {
+    auto read_frags = [&](int slot, int ks, frag (&av)[FM][NP], frag (&bv)[FN][NP]) {
         const unsigned char* As = smem_w + slot * BUF_BYTES;
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                const unsigned char* q0 = As + a_foff[i] + (h * CBA * 32 + 16 * ks) * 256;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 256));
+                const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                av[i][h] = __builtin_bit_cast(frag, v);
+            }
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                const unsigned char* q0 = Bs + b_foff[j] + (h * CBB * 32 + 16 * ks) * 256;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 256));
+                const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                bv[j][h] = __builtin_bit_cast(frag, v);
+            }
+    };
+    auto mma = [&](const frag (&av)[FM][NP], const frag (&bv)[FN][NP]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) SCH::mac(av[i], bv[j], acc[i][j]);
+    };
+    auto compute_tile = [&](int slot) {
+#pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             frag av[FM][NP], bv[FN][NP];
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int h = 0; h < NP; ++h) {
-                    const unsigned char* q0 = As + a_foff[i] + (h * CBA * 32 + 16 * ks) * 256;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 256));
-                    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    av[i][h] = __builtin_bit_cast(frag, v);
-                }
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int h = 0; h < NP; ++h) {
-                    const unsigned char* q0 = Bs + b_foff[j] + (h * CBB * 32 + 16 * ks) * 256;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 256));
-                    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    bv[j][h] = __builtin_bit_cast(frag, v);
-                }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) SCH::mac(av[i], bv[j], acc[i][j]);
+            read_frags(slot, ks, av, bv);
+            mma(av, bv);
         }
     };
 
     issue(m_begin, 0);
     issue(m_begin + 32, 1);
-    if constexpr (NSLOT == 2) {
+    if constexpr (NSLOT == 12) {
+        // software-pipelined 2-slot loop, one barrier per k-tile (see igemm_dma_kernel)
+        frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+        wait_vm_barrier<LPT>();
+        read_frags(0, 0, a0, b0);
+        for (int it = 0; it < nk; ++it) {
+            const int slot = it & 1;
+            read_frags(slot, 1, a1, b1);
+            mma(a0, b0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue(m_begin + (it + 2) * 32, slot);
+            read_frags(slot ^ 1, 0, a0, b0);
+            mma(a1, b1);
+        }
+    } else if constexpr (NSLOT == 2) {
         for (int it = 0; it < nk; ++it) {
             const int slot = it & 1;
             wait_vm_barrier<LPT>();
@@ -1637,20 +1679,21 @@ struct WPlan {
 };
 
 // wgrad tiles (k x c): 0 = 128x128, 1 = 64x64 (register staged); h2 only: 2 = 128x128 LDS-DMA 2-slot (4 waves),
-// 3 = 256x128 LDS-DMA 3-slot ring (8 waves), 4 = 256x256 LDS-DMA 2-slot (8 waves) -- chosen by the tuner / overrides only
-static const int kWTiles[5][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}};
+// 3 = 256x128 LDS-DMA 3-slot ring (8 waves), 4 = 256x256 LDS-DMA 2-slot (8 waves), 5 / 6 = 2 / 4 software pipelined -- chosen by
+// the tuner / overrides only
+static const int kWTiles[7][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}};
 
 // tuning overrides: SEMSEG_W3_TILE=0..3, SEMSEG_W3_SPLIT=n
 static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_split = 0) {
     WPlan pl;
     const int mtiles = ceil_div(M, 32);
-    const double tile_cost[5] = {1.0, 0.32, 1.0, 2.0, 4.0};
-    const int slots[5] = {512, 1024, 512, 256, 256};
+    const double tile_cost[7] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0};
+    const int slots[7] = {512, 1024, 512, 256, 256, 512, 256};
     const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_W3_TILE", -1);
     const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_W3_SPLIT", 0);
     double best = 1e30;
     int best_t = 1, best_s = 1;
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < 7; ++t) {
         if (force_tile >= 0 && t != force_tile) continue;
         if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
@@ -1703,7 +1746,7 @@ static int launch_wgrad(const WParams& p, hipStream_t st) {
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)NSLOT * SCH::NP * (BM / 128 + BN / 128) * 32 * 256;
+    constexpr size_t smem = (size_t)(NSLOT == 12 ? 2 : NSLOT) * SCH::NP * (BM / 128 + BN / 128) * 32 * 256;
     static_assert(smem <= 160 * 1024, "LDS");
     // 32-bit byte offsets in the buffer descriptors
     if ((size_t)2 * SCH::NP * p.x_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
@@ -1767,6 +1810,12 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
             break;
         case 4:
             if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 256, 256, 2, 4, 2>(p, st);
+            break;
+        case 5:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 2, 2, 12>(p, st);
+            break;
+        case 6:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 256, 256, 2, 4, 12>(p, st);
             break;
     }
     if (rc) return rc;

@@ -48,9 +48,9 @@ def _save_cache():
 _SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
 # fwd/dgrad tile ids per scheme (csrc/conv_split.hip): 0..2 register staged, 3 = 256x128 LDS-DMA, h2 only: 4 = 256x128
 # 3-slot ring, 5 = 256x256.  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).
-_TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)}
+_TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)}
 # weight-gradient tile ids: 0 = 128x128, 1 = 64x64 register staged; h2 only: 2 = 128x128 LDS-DMA, 3 = 256x128 LDS-DMA ring
-_WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4)}
+_WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4, 5, 6)}
 _ALLOW = os.environ.get('SEMSEG_TUNE_TILES', '')
 if _ALLOW:
     _allow = tuple(int(t) for t in _ALLOW.split(','))
