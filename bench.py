@@ -33,11 +33,12 @@ F32_CONV_LAST_HBM_BYTES = 1.78e9      # profiles/r1b_pmc_conv_last_fwd_wgrad.txt
 S3_CONV_LAST_HBM_BYTES = None
 
 
-# profiles/r1n_pmc_conv_last_fwd_h2.txt: FETCH_SIZE 170295 KiB x 2 + WRITE_SIZE 65536 KiB (4 split-K slabs of 16 MiB);
+# profiles/r2c_pmc_conv_last_fwd_h2.txt: FETCH_SIZE 169436 KiB x 2 + WRITE_SIZE 65536 KiB (4 split-K slabs of 16 MiB);
 # the algorithmic bytes of this launch are 227 MB (x planes 134 MB + w planes 75.5 MB + 16.8 MB fp32 output)
-H2_CONV_LAST_HBM_BYTES = (2 * 170295 + 65536) * 1024
-H2_CONV_LAST_CLOCK_GHZ = 1.69     # SQ_WAVE_CYCLES x 4 / waves / duration of the same PMC pass: the MFMA-dense kernel runs
-                                  # power-limited well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at
+H2_CONV_LAST_HBM_BYTES = (2 * 169436 + 65536) * 1024
+H2_CONV_LAST_CLOCK_GHZ = 1.59     # SQ_WAVE_CYCLES x 4 / waves / duration of the same PMC pass: the MFMA-dense kernel runs
+                                  # power-limited well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at (the faster
+                                  # software-pipelined loop lowered it further: 1.69 -> 1.59 GHz)
 DTYPE = {'h2': 'f32 (fp32 in/out/accumulate; products on the fp16 MFMA via a scaled 2-way fp16 split, 3 terms, 2^-22 per product)',
          's3': 'f32 (fp32 in/out/accumulate; products on the bf16 MFMA via an exact 3-way bf16 split, 6 terms)', 'f32': 'f32'}
 # MFMA products per fp32-accurate MAC block and the issued instruction, per split scheme
@@ -72,7 +73,7 @@ def synth_feed(dev, rank, n=2, h=512, w=512, seg_rate=8):
 def time_dominant_kernel(dev, iters=10):
     """HIP-event timing of the dominant kernel of the step -- the implicit-GEMM convolution of decoder.conv_last.0
     (3x3, 4096->512 @64x64, N=2: 38 % of the step's FLOPs) -- through the C ABI on pre-split operands, i.e. ONLY the
-    conv entry point (igemm_s3_kernel + its split-K reduction; the exact-fp32 igemm_conv_kernel under SEMSEG_CONV=f32)
+    conv entry point (igemm_dma_kernel<SchH2,256,256> + its split-K reduction on the default h2 path)
     on the stream it is launched on (torch's current stream).  The launch plan is the tuned one."""
     import ctypes
     from mit_semseg import ops, _native, tuner

@@ -9,6 +9,7 @@
 // can all-reduce them between `stats` and `finalize` -- this is what replaces the reference's
 // SyncMaster/SlavePipe rendezvous (batchnorm.py:63-117, comm.py).
 #include "common.h"
+#include <stdlib.h>
 
 // block = 256 threads arranged as cx channel-quads x py row lanes; grid = (quad groups, row chunks)
 struct ColGeom {
@@ -20,8 +21,9 @@ static ColGeom col_geom(int P, int C) {
     g.cx = quads < 64 ? quads : 64;
     g.py = 256 / g.cx;
     g.gx = ceil_div(quads, g.cx);
-    // ~512 blocks in total (2 per CU); every thread walks >= 8 rows
-    int gy = ceil_div(512, g.gx);
+    // ~SEMSEG_BN_BLOCKS blocks in total (default 512 = 2 per CU); every thread walks >= 8 rows
+    static const int target = [] { const char* v = getenv("SEMSEG_BN_BLOCKS"); return (v && *v) ? atoi(v) : 512; }();
+    int gy = ceil_div(target, g.gx);
     const int min_rows = g.py * 8;
     if (gy > ceil_div(P, min_rows)) gy = ceil_div(P, min_rows);
     if (gy < 1) gy = 1;

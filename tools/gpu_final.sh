@@ -22,6 +22,6 @@ python tools/rocprof_summary.py $src $OUT/kernel_stats.csv
 python tools/rocprof_summary.py $src $OUT/kernel_stats_by_grid.csv --by-grid
 python tools/trace_gaps.py $src 0.6 > $OUT/trace_gaps.txt; head -3 $OUT/trace_gaps.txt
 rm -rf $OUT/prof
-echo "== PMC on conv_last fwd (h2, tuned plan: tile 5 split 4)"
-MODE=h2 TILE=5 SPLIT=4 bash tools/gpu_pmc.sh $TAG/pmc conv_last fwd > $OUT/pmc.log 2>&1; grep -A 22 "igemm_dma" $OUT/pmc.log
+echo "== PMC on conv_last fwd (h2, tuned plan: tile 8 = 256x256 software-pipelined, split 4)"
+MODE=h2 TILE=8 SPLIT=4 bash tools/gpu_pmc.sh $TAG/pmc conv_last fwd > $OUT/pmc.log 2>&1; grep -A 22 "igemm_dma" $OUT/pmc.log
 du -sh $OUT
