@@ -629,6 +629,7 @@ def test_conv_bn_passthrough_accumulates_shortcut_gradient(case, monkeypatch):
     inside the data-gradient kernel -- same x.grad as letting autograd add the two branches"""
     from mit_semseg import ops
     monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    monkeypatch.setattr(ops, 'PASSTHROUGH', True)          # opt-in feature (SEMSEG_PASSTHROUGH=1)
     n, c, h, w, k, ks, stride, pad, dil = case
     g = torch.Generator().manual_seed(hash(case) & 0xffff)
     x = torch.randn(n, c, h, w, generator=g)
