@@ -191,7 +191,7 @@ def main():
         NativeDataParallel(sm)          # enables SyncBN statistics all-reduce over RCCL
     feed = synth_feed(dev, rank)
     step = TrainStep(sm, lr_encoder=0.02, lr_decoder=0.02, max_iters=5000 * 20,
-                     graph=(not args.no_graph) and world == 1)
+                     graph=not args.no_graph)      # world > 1: eager unless SEMSEG_DDP_GRAPH=1 (TrainStep)
 
     for _ in range(args.warmup):
         loss, acc = step.step(feed)
@@ -226,7 +226,7 @@ def main():
             'config': {'workload': 'ade20k-resnet50dilated-ppm_deepsup (BASELINE configs[1]): full train step '
                                    '(fwd+NLL loss+bwd+2xSGD), bs 2/GPU 512x512x3, 150 classes, labels 64x64',
                        'global_batch': 2 * world, 'parallelism': 'dp%d' % world,
-                       'launch': 'eager' if (args.no_graph or world > 1) else 'hipGraph replay',
+                       'launch': 'hipGraph replay' if (step._graph is not None) else 'eager',
                        'conv_path': ops_mode(),
                        'images_per_sec_per_gpu': round(per_gpu, 3),
                        'step_conv_tflops_per_gpu': round(per_gpu * TRAIN_GFLOP_PER_IMG['resnet50dilated+ppm_deepsup'] * 1e-3, 2),

@@ -148,7 +148,11 @@ class TrainStep:
         return loss.detach(), acc.detach()
 
     def step(self, feed):
-        if not self.use_graph or self.world > 1:
+        # world > 1: the RCCL all-reduces (SyncBN statistics on the compute stream, gradient buckets on the side stream)
+        # can be captured too -- a world-1 RCCL all-reduce survives capture + replay on this stack
+        # (tools/probes/rccl_graph_probe.py) -- but the N > 1 capture has not run on a multi-GPU box yet, so it is
+        # opt-in (SEMSEG_DDP_GRAPH=1) and the default data-parallel step launches eagerly.
+        if not self.use_graph or (self.world > 1 and os.environ.get('SEMSEG_DDP_GRAPH', '0') != '1'):
             self.adjust_learning_rate()
             self.iter += 1
             return self._eager(feed)

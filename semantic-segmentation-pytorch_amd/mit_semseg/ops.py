@@ -26,7 +26,14 @@ def _p(t):
     return vp(t.data_ptr()) if t is not None else vp(0)
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _st():
+    """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object
+    (8 us, 222 calls per eager step = 1.9 ms of host time, tools/probes/eager_cpu_profile.py); the raw getter is ~0.3 us."""
+    if _raw_stream is not None:
+        return vp(_raw_stream(torch.cuda.current_device()))
     return vp(torch.cuda.current_stream().cuda_stream)
 
 
