@@ -45,7 +45,7 @@ def _save_cache():
     with open(tmp, 'w') as f:
         json.dump({','.join(map(str, k)): list(v) for k, v in _done.items()}, f)
     os.replace(tmp, CACHE)
-_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32)
+_SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64)
 # fwd/dgrad tile ids per scheme (csrc/conv_split.hip): 0..2 register staged, 3 = 256x128 LDS-DMA, h2 only: 4 = 256x128
 # 3-slot ring, 5 = 256x256.  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).
 _TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)}
