@@ -99,8 +99,12 @@ int semseg_conv2d_s3_set_plan(int pass, int N, int H, int W, int C, int K, int R
  * The conv entry points accumulate X0 W0 + X0 W1 + X1 W0 in fp32 and descale by 2^-(ex+ew) in their epilogue
  * (per-product error ~2^-21: below the fp32 accumulation noise of any reduction >= 27 terms; csrc/conv_split.hip).
  * Split layout: fp16 [2][rows][pitch] (pitch as for s3) + 256 B of zeros + a 4352-byte header (int32 e, partial maxima);
- * size = semseg_split_h2_bytes; 16-byte aligned.  fwd/dgrad tiles for set_plan: 0..3 as s3, 4 = 256x128 LDS-DMA 3-slot
- * ring, 5 = 256x256 LDS-DMA. */
+ * size = semseg_split_h2_bytes; 16-byte aligned.
+ * Tile ids for semseg_conv2d_h2_set_plan -- fwd/dgrad (pass 0/1): 0..3 as s3, 4 = 256x128 LDS-DMA 3-slot ring, 5 = 256x256
+ * LDS-DMA, 6 = 128x128 LDS-DMA (two blocks per CU), 7/8/9 = 3/5/6 with software-pipelined fragment reads (one barrier
+ * per k-tile), 10 = the ring 4 with the same pipeline; wgrad (pass 2): 0 = 128x128, 1 = 64x64 register staged, 2 = 128x128,
+ * 3 = 256x128 ring, 4 = 256x256 LDS-DMA, 5/6 = 2/4 software pipelined.  Every variant computes the same sums (only the
+ * fp32 summation order differs); tests/test_gpu_ops.py::test_h2_conv_every_tile_pinned runs each one. */
 size_t semseg_split_h2_bytes(int rows, int C);
 int semseg_split_h2(const float* x, int x_ld, void* xs, int rows, int C, void* stream);
 size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);

@@ -9,6 +9,7 @@
 // can all-reduce them between `stats` and `finalize` -- this is what replaces the reference's
 // SyncMaster/SlavePipe rendezvous (batchnorm.py:63-117, comm.py).
 #include "common.h"
+#include "split_layout.h"
 #include <stdlib.h>
 
 // block = 256 threads arranged as cx channel-quads x py row lanes; grid = (quad groups, row chunks)
@@ -396,7 +397,6 @@ extern "C" int semseg_bn_bwd_apply(const float* dy, int dy_ld, const float* y, i
 //             gradients, which read planes)
 // which removes the absmax + split passes (2 launches, 12 B/element) on both sides of every conv -> BN pair.
 // ================================================================================================
-#include "split_layout.h"
 
 // ReLU gate of a BN WITHOUT residual recomputed from z: y = max(fmaf(z, scale, shift), 0), so y > 0 <=> the very same fmaf
 // > 0 -- bit-identical to the forward decision; saves the 4 B/element read of y in both backward passes.
