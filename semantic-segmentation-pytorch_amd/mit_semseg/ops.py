@@ -301,8 +301,17 @@ def prepare_conv_weights(weights):
 
 def weight_planes(w, scheme):
     """(KRSC planes, CRSK planes) prepared by prepare_conv_weights for this exact parameter state, else (None, None)."""
-    rec = _WPLANES.get(id(w)) if (FUSE and scheme == 'h2') else None
+    if not (FUSE and scheme == 'h2'):
+        return None, None
+    rec = _WPLANES.get(id(w))
     if rec is not None and rec[0]() is w and rec[1] == w._version and rec[2] == w.data_ptr():
+        return rec[3], rec[4]
+    if not torch.is_grad_enabled() and w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous():
+        # inference (eval.py / test.py run under no_grad): the weights do not change between calls, so their planes are
+        # built on first use and kept (2 launches per conv and per forward otherwise); any torch-side update bumps the
+        # version counter and the fused SGD kernel invalidates the record (sgd_step)
+        prepare_conv_weights([w])
+        rec = _WPLANES[id(w)]
         return rec[3], rec[4]
     return None, None
 
@@ -1059,3 +1068,9 @@ def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum
         arr[i].first_step = 1 if first_step else 0
     _native.check(_native.lib().semseg_sgd_step(arr, n, _p(lr_tensor), float(momentum), float(grad_scale), _st()),
                   'sgd_step')
+    # the kernel updates the parameters behind torch's back (no version bump): prepared weight planes are stale until
+    # prepare_conv_weights runs again (TrainStep does, right after this call)
+    for p in params:
+        rec = _WPLANES.get(id(p))
+        if rec is not None:
+            _WPLANES[id(p)] = (rec[0], -1, rec[2], rec[3], rec[4])

@@ -658,3 +658,28 @@ def test_conv_bn_passthrough_accumulates_shortcut_gradient(case, monkeypatch):
     y1, dx1, dw1 = run(True)
     assert torch.equal(y0, y1) and torch.equal(dw0, dw1)
     torch.testing.assert_close(dx1, dx0, rtol=1e-6, atol=1e-6)
+
+
+def test_inference_weight_planes_follow_sgd_updates(monkeypatch):
+    """no_grad forwards build the weight planes once and keep them; the fused SGD kernel (which updates parameters behind
+    torch's version counter) must invalidate them"""
+    from mit_semseg import ops
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    g = torch.Generator().manual_seed(5)
+    x = cl(torch.randn(2, 64, 12, 12, generator=g))
+    w = torch.nn.Parameter(cl(torch.randn(96, 64, 3, 3, generator=g) * 0.05))
+    with torch.no_grad():
+        y0 = ops.conv2d(x, w, None, 1, 1, 1)
+        assert ops.weight_planes(w, 'h2')[0] is not None              # cached by the first inference call
+        ref0 = F.conv2d(x.cpu().double(), w.detach().cpu().double(), None, 1, 1, 1)
+        assert rel_err(y0, ref0) < REL
+    grad = cl(torch.randn(96, 64, 3, 3, generator=g))
+    buf = torch.empty_like(grad)
+    lr = torch.tensor([0.5], device=dev())
+    ops.sgd_step([w], [grad], [buf], True, [0.0], lr)                 # raw-pointer update, no version bump
+    with torch.no_grad():
+        y1 = ops.conv2d(x, w, None, 1, 1, 1)
+    torch.cuda.synchronize()
+    ref1 = F.conv2d(x.cpu().double(), w.detach().cpu().double(), None, 1, 1, 1)
+    assert rel_err(y1, ref1) < REL, rel_err(y1, ref1)
+    assert rel_err(y1, ref0) > 1e-2                                    # the weights really moved
