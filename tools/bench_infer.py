@@ -1,0 +1,61 @@
+"""Inference throughput of the segSize branch (models.py:480-484 / eval.py:58-75): one 512x512 image -> class
+probabilities at full resolution -> argmax + metric tallies on the device, R50dilated+PPM_deepsup, eval mode, no_grad.
+Informational (the reference README quotes inference fps per model).
+
+    python tools/bench_infer.py [--steps 50]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd'))
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    args = ap.parse_args()
+    import __graft_entry__ as ge
+    ge.build()
+    from mit_semseg.models import ModelBuilder, SegmentationModule, resnet
+    from mit_semseg.models.models import ResnetDilated
+    from mit_semseg import utils as U
+    dev = torch.device('cuda:0')
+    torch.manual_seed(304)
+    enc = ResnetDilated(resnet.resnet50(pretrained=False), 8)
+    dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=2048, num_class=150, use_softmax=True)
+    sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1)).to(dev).eval()
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(1, 3, 512, 512, generator=g).to(dev)
+    lab = torch.randint(-1, 150, (512, 512), generator=g).to(dev)
+    tally = None
+
+    def once():
+        nonlocal tally
+        with torch.no_grad():
+            prob = sm({'img_data': img}, segSize=(512, 512))
+            pred, tally = U.segmentation_metrics(prob, lab, tally)
+        return pred
+    for _ in range(args.warmup):
+        once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    acc, iou, miou = tally.summary()
+    print(json.dumps({'workload': 'R50dilated+PPM_deepsup inference, 1x512x512 -> 150-class probabilities @512x512 + argmax + '
+                                  'metric tallies', 'ms_per_image': round(dt * 1e3, 3), 'images_per_sec': round(1 / dt, 1),
+                      'launch': 'eager', 'pixel_acc_random_weights': round(float(acc), 4)}), flush=True)
+
+
+if __name__ == '__main__':
+    main()
