@@ -189,3 +189,21 @@ def test_config1_full_size_vs_oracle():
         got = mod.state_dict()
         for k in keys:
             torch.testing.assert_close(got[k].cpu().contiguous(), sd[k].detach(), atol=2e-5, rtol=1e-3, msg=lambda s, k=k: k + ': ' + s)
+
+
+def test_inference_graph_replay_equals_eager():
+    """engine.InferenceGraph: the captured inference branch returns exactly what the eager call returns, for new inputs too"""
+    from mit_semseg.engine import InferenceGraph
+    g = load_golden('r18d_ppm_infer_64x80')
+    m = g['meta']
+    dev = torch.device('cuda:0')
+    sm, _, _ = build_native(g, dev, use_softmax=True)
+    run = InferenceGraph(sm)
+    for seed in (1, 2, 3):
+        img, _ = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=seed)
+        img = img.to(dev)
+        with torch.no_grad():
+            want = sm({'img_data': img}, segSize=tuple(m['seg_size'])).clone()
+        got = run(img, tuple(m['seg_size']))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), seed
