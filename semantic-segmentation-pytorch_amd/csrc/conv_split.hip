@@ -922,10 +922,35 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
 }
 
 // out[m*out_ld + n] = bias[n] + sum_z partial[z][m*Cout + n]   (fixed order => deterministic)
+template <bool VEC>
 __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                          const float* __restrict__ addend, int addend_ld, float* __restrict__ out, int out_ld,
                                          int M, int Cout, int splits) {
     const size_t total = (size_t)M * Cout;
+    if (VEC) {          // Cout, out_ld, addend_ld multiples of 4 and 16-byte aligned bases (checked by the launcher)
+        const int qpr = Cout >> 2;
+        const size_t quads = total >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(partial);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+            const int m = (int)(i / qpr);
+            const int n = (int)(i - (size_t)m * qpr) << 2;
+            float4 s = p4[i];
+            for (int zz = 1; zz < splits; ++zz) {
+                const float4 v = p4[(size_t)zz * quads + i];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + n);
+                s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+            }
+            if (addend) {
+                const float4 a = *reinterpret_cast<const float4*>(addend + (size_t)m * addend_ld + n);
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+            *reinterpret_cast<float4*>(out + (size_t)m * out_ld + n) = s;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / Cout);
         const int n = (int)(i - (size_t)m * Cout);
@@ -1081,9 +1106,15 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
     if (rc) return rc;
     if (pl.splits > 1) {
         const size_t total = (size_t)p.M * p.Cout;
-        const int blocks = (int)min((size_t)2048, ceil_div_sz(total, 256));
-        hipLaunchKernelGGL(split_gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.addend, p.addend_ld, p.out, p.out_ld, p.M,
-                           p.Cout, pl.splits);
+        const bool vec = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && aligned16(p.out) && aligned16(p.partial) &&
+                         (!p.bias || aligned16(p.bias)) && (!p.addend || ((p.addend_ld % 4 == 0) && aligned16(p.addend)));
+        const int blocks = (int)min((size_t)2048, ceil_div_sz(vec ? total / 4 : total, 256));
+        if (vec)
+            hipLaunchKernelGGL(split_gemm_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.addend,
+                               p.addend_ld, p.out, p.out_ld, p.M, p.Cout, pl.splits);
+        else
+            hipLaunchKernelGGL(split_gemm_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.addend,
+                               p.addend_ld, p.out, p.out_ld, p.M, p.Cout, pl.splits);
         SEMSEG_LAUNCH_CHECK();
     }
     return 0;
@@ -1667,6 +1698,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
 }
 
 __global__ void split_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t total, int splits) {
+    // float4 lanes (the slabs are 16-byte aligned and total % 4 == 0 is checked by the launcher; scalar tail otherwise)
+    const size_t quads = total >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(partial);
+    float4* o4 = reinterpret_cast<float4*>(dw);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = p4[i];
+        for (int z = 1; z < splits; ++z) {
+            const float4 v = p4[(size_t)z * quads + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        o4[i] = s;
+    }
+}
+
+__global__ void split_wgrad_reduce_scalar_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t total,
+                                                 int splits) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         float s = partial[i];
         for (int z = 1; z < splits; ++z) s += partial[(size_t)z * total + i];
@@ -1821,8 +1868,13 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
     if (rc) return rc;
     if (pl.splits > 1) {
         const size_t total = (size_t)K * p.T * C;
-        const int blocks = (int)min((size_t)2048, ceil_div_sz(total, 256));
-        hipLaunchKernelGGL(split_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, total, pl.splits);
+        if (total % 4 == 0 && aligned16(p.partial) && aligned16(dw)) {
+            const int blocks = (int)min((size_t)2048, ceil_div_sz(total / 4, 256));
+            hipLaunchKernelGGL(split_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, total, pl.splits);
+        } else {
+            const int blocks = (int)min((size_t)2048, ceil_div_sz(total, 256));
+            hipLaunchKernelGGL(split_wgrad_reduce_scalar_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, total, pl.splits);
+        }
         SEMSEG_LAUNCH_CHECK();
     }
     return 0;
