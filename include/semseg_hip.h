@@ -267,6 +267,17 @@ int semseg_bilinear_fwd(const float* x, int x_ld, float* y, int y_ld, int accumu
 int semseg_bilinear_bwd(const float* dy, int dy_ld, float* dx, int dx_ld, int accumulate,
                         int N, int IH, int IW, int OH, int OW, int C, void* stream);
 
+/* Pyramid pooling: nn.AdaptiveAvgPool2d of the SAME map to several square grids at once (models.py:447-450,511-514;
+ * scales 1, 2, 3, 6): the map is read once (forward) / the gradient written once (backward) instead of once per scale plus
+ * three accumulation passes.  sizes_host / ys_host / dys_host: host arrays of nscale (<= 4, sum of sizes <= 16) entries;
+ * ys[i] / dys[i]: device [N][s_i][s_i][C] dense. */
+size_t semseg_adaptive_avgpool_multi_workspace_bytes(int N, int H, int C, const int* sizes_host, int nscale);
+int semseg_adaptive_avgpool_multi_fwd(const float* x, int x_ld, int N, int H, int W, int C, int nscale,
+                                      const int* sizes_host, void* const* ys_host, void* workspace, size_t workspace_bytes,
+                                      void* stream);
+int semseg_adaptive_avgpool_multi_bwd(void* const* dys_host, const int* sizes_host, int nscale, float* dx, int dx_ld,
+                                      int N, int H, int W, int C, void* stream);
+
 /* ---------------- head: softmax / NLL / pixel accuracy -------------------------------------- */
 /* F.log_softmax(dim=1) models.py:383,492-493,584 on [P,C] rows (C <= 1024) */
 int semseg_log_softmax_fwd(const float* z, float* logp, int P, int C, void* stream);

@@ -328,6 +328,164 @@ extern "C" int semseg_adaptive_avgpool_bwd(const float* dy, float* dx, int dx_ld
     return 0;
 }
 
+// ------------------------------------------------------------------ pyramid pooling: all scales in one pass
+// PPM / UPerNet pool the SAME map to several square grids (models.py:447-450,511-514: scales 1, 2, 3, 6).  Per-scale
+// kernels read the map once per scale and the four backward results are summed by three more passes; here
+//   forward : pass 1 -- one thread per (n, row, channel quad) walks the row once and keeps the column-bin sums of every scale
+//             in registers (<= MP_MAXCOLS bins in total: 12 for 1+2+3+6) -> rowsum[n][h][col][c];
+//             pass 2 -- per output bin, sum its rows of rowsum in row order and scale by 1/count.  Fixed summation order.
+//   backward: one pass writes dx = sum over scales and bins containing the pixel of g/count.
+constexpr int MP_MAXSCALES = 4;
+constexpr int MP_MAXCOLS = 16;
+struct MultiPool {
+    float* y[MP_MAXSCALES];          // forward outputs / backward incoming gradients, [N][s][s][C] dense
+    int s[MP_MAXSCALES];
+    int col0[MP_MAXSCALES];          // first column-bin slot of the scale
+    int nscale, ncols;
+};
+
+__global__ __launch_bounds__(256) void multipool_rowsum_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ rowsum,
+                                                               MultiPool mp, int N, int H, int W, int C) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)N * H * qpr;
+    GRID_STRIDE(i, total) {
+        const size_t row = i / qpr;                 // n * H + h
+        const int c = (int)(i - row * qpr) * 4;
+        float4 acc[MP_MAXCOLS];
+#pragma unroll
+        for (int k = 0; k < MP_MAXCOLS; ++k) acc[k] = f4zero();
+        const float* src = x + row * W * (size_t)x_ld + c;
+        for (int w = 0; w < W; ++w) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)w * x_ld);
+#pragma unroll
+            for (int k = 0; k < MP_MAXCOLS; ++k) {
+                // slot k belongs to scale sc, column bin j: static unrolled slots, dynamic membership test
+                int sc = 0;
+#pragma unroll
+                for (int t = 1; t < MP_MAXSCALES; ++t) sc += (t < mp.nscale && k >= mp.col0[t]) ? 1 : 0;
+                const int j = k - mp.col0[sc];
+                const bool in = (k < mp.ncols) && (w >= bin_start(j, W, mp.s[sc])) && (w < bin_end(j, W, mp.s[sc]));
+                if (in) { acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w; }
+            }
+        }
+        float* dst = rowsum + row * (size_t)mp.ncols * C + c;
+#pragma unroll
+        for (int k = 0; k < MP_MAXCOLS; ++k)
+            if (k < mp.ncols) *reinterpret_cast<float4*>(dst + (size_t)k * C) = acc[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void multipool_finish_kernel(const float* __restrict__ rowsum, MultiPool mp, int N, int H, int W,
+                                                               int C, int bins_total) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)N * bins_total * qpr;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % qpr) * 4;
+        size_t b = i / qpr;
+        const int n = (int)(b / bins_total);
+        int bin = (int)(b - (size_t)n * bins_total);
+        int sc = 0;
+        while (sc + 1 < mp.nscale && bin >= mp.s[sc] * mp.s[sc]) { bin -= mp.s[sc] * mp.s[sc]; ++sc; }
+        const int S = mp.s[sc], oh = bin / S, ow = bin % S;
+        const int h0 = bin_start(oh, H, S), h1 = bin_end(oh, H, S);
+        const int cnt = (h1 - h0) * (bin_end(ow, W, S) - bin_start(ow, W, S));
+        float4 a = f4zero();
+        for (int h = h0; h < h1; ++h) {
+            const float4 v = *reinterpret_cast<const float4*>(rowsum + (((size_t)n * H + h) * mp.ncols + mp.col0[sc] + ow) * C + c);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        const float inv = 1.0f / (float)cnt;
+        *reinterpret_cast<float4*>(mp.y[sc] + (((size_t)n * S + oh) * S + ow) * C + c) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    }
+}
+
+__global__ __launch_bounds__(256) void multipool_bwd_kernel(MultiPool mp, float* __restrict__ dx, int dx_ld, int N, int H, int W,
+                                                            int C) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)N * H * W * qpr;
+    GRID_STRIDE(i, total) {
+        const size_t ip = i / qpr;
+        const int c = (int)(i - ip * qpr) * 4;
+        const int iw = (int)(ip % W);
+        const int ih = (int)((ip / W) % H);
+        const int n = (int)(ip / ((size_t)W * H));
+        float4 acc = f4zero();
+        for (int sc = 0; sc < mp.nscale; ++sc) {
+            const int S = mp.s[sc];
+            const float* dy = mp.y[sc];
+            int oh_lo = (ih * S) / H; if (oh_lo > 0) --oh_lo;
+            int ow_lo = (iw * S) / W; if (ow_lo > 0) --ow_lo;
+            for (int oh = oh_lo; oh < S && bin_start(oh, H, S) <= ih; ++oh) {
+                const int h0 = bin_start(oh, H, S), h1 = bin_end(oh, H, S);
+                if (ih < h0 || ih >= h1) continue;
+                for (int ow = ow_lo; ow < S && bin_start(ow, W, S) <= iw; ++ow) {
+                    const int w0 = bin_start(ow, W, S), w1 = bin_end(ow, W, S);
+                    if (iw < w0 || iw >= w1) continue;
+                    const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+                    const float4 g = *reinterpret_cast<const float4*>(dy + ((size_t)(n * S + oh) * S + ow) * C + c);
+                    acc.x += g.x * inv; acc.y += g.y * inv; acc.z += g.z * inv; acc.w += g.w * inv;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(dx + ip * dx_ld + c) = acc;
+    }
+}
+
+static int multipool_setup(MultiPool& mp, void* const* ys_host, const int* sizes_host, int nscale) {
+    if (!ys_host || !sizes_host || nscale <= 0 || nscale > MP_MAXSCALES) return SEMSEG_EINVAL;
+    mp.nscale = nscale;
+    mp.ncols = 0;
+    for (int i = 0; i < MP_MAXSCALES; ++i) { mp.y[i] = nullptr; mp.s[i] = 1; mp.col0[i] = 0; }
+    for (int i = 0; i < nscale; ++i) {
+        if (!ys_host[i] || sizes_host[i] <= 0) return SEMSEG_EINVAL;
+        mp.y[i] = (float*)ys_host[i];
+        mp.s[i] = sizes_host[i];
+        mp.col0[i] = mp.ncols;
+        mp.ncols += sizes_host[i];
+    }
+    return mp.ncols <= MP_MAXCOLS ? 0 : SEMSEG_EINVAL;
+}
+
+extern "C" size_t semseg_adaptive_avgpool_multi_workspace_bytes(int N, int H, int C, const int* sizes_host, int nscale) {
+    size_t cols = 0;
+    for (int i = 0; i < nscale; ++i) cols += (size_t)sizes_host[i];
+    return (size_t)N * H * cols * C * sizeof(float);
+}
+
+extern "C" int semseg_adaptive_avgpool_multi_fwd(const float* x, int x_ld, int N, int H, int W, int C, int nscale,
+                                                 const int* sizes_host, void* const* ys_host, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+    if (!x || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) || (x_ld % 4) || x_ld < C) return SEMSEG_EINVAL;
+    MultiPool mp;
+    const int rc = multipool_setup(mp, ys_host, sizes_host, nscale);
+    if (rc) return rc;
+    const size_t need = (size_t)N * H * mp.ncols * C * sizeof(float);
+    if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* rowsum = (float*)workspace;
+    hipLaunchKernelGGL(multipool_rowsum_kernel, dim3(stream_blocks((size_t)N * H * (C / 4))), dim3(256), 0, st, x, x_ld, rowsum, mp,
+                       N, H, W, C);
+    SEMSEG_LAUNCH_CHECK();
+    int bins = 0;
+    for (int i = 0; i < nscale; ++i) bins += sizes_host[i] * sizes_host[i];
+    hipLaunchKernelGGL(multipool_finish_kernel, dim3(stream_blocks((size_t)N * bins * (C / 4))), dim3(256), 0, st,
+                       (const float*)rowsum, mp, N, H, W, C, bins);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int semseg_adaptive_avgpool_multi_bwd(void* const* dys_host, const int* sizes_host, int nscale, float* dx, int dx_ld,
+                                                 int N, int H, int W, int C, void* stream) {
+    if (!dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 4) || (dx_ld % 4) || dx_ld < C) return SEMSEG_EINVAL;
+    MultiPool mp;
+    const int rc = multipool_setup(mp, dys_host, sizes_host, nscale);
+    if (rc) return rc;
+    hipLaunchKernelGGL(multipool_bwd_kernel, dim3(stream_blocks((size_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, mp,
+                       dx, dx_ld, N, H, W, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------ bilinear, align_corners=False
 // torch area_pixel_compute_source_index: src = max(0, scale*(dst+0.5)-0.5), scale = in/out (float);
 // i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.
@@ -404,15 +562,18 @@ extern "C" int semseg_bilinear_fwd(const float* x, int x_ld, float* y, int y_ld,
     return 0;
 }
 
-// gather-form backward: block.x = one input pixel, block.y = 64-channel chunk; 16 pixel lanes sweep the
-// window of output pixels that can touch this input pixel, fixed-order LDS combine.
+// gather-form backward: block.x = one input pixel, block.y = a chunk of 4*ql channels; the 256/ql pixel lanes sweep the
+// window of output pixels that can touch this input pixel, fixed-order LDS combine.  ql = 16 (64 channels, 16 pixel
+// lanes) for ordinary maps; ql = 4 (16 channels, 64 pixel lanes) when the input map is tiny and every input pixel
+// gathers from thousands of output pixels (PPM: 1x1 .. 6x6 -> 64x64 took 85 us per scale with 16 lanes).
 template <bool ACC>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int dy_ld, float* __restrict__ dx,
                                                            int dx_ld, int N, int IH, int IW, int OH, int OW, int C, float sh,
-                                                           float sw) {
-    __shared__ float4 red[16][16];
-    const int tq = threadIdx.x & 15, tp = threadIdx.x >> 4;
-    const int c = (blockIdx.y * 16 + tq) * 4;
+                                                           float sw, int ql) {
+    __shared__ float4 red[256];
+    const int pl = 256 / ql;
+    const int tq = threadIdx.x % ql, tp = threadIdx.x / ql;
+    const int c = (blockIdx.y * ql + tq) * 4;
     const int ip = blockIdx.x;
     const int iw = ip % IW, ih = (ip / IW) % IH, n = ip / (IW * IH);
     // candidate output rows: src in (ih-1, ih+1)  =>  d in ((ih-0.5)/s - 0.5, (ih+1.5)/s - 0.5); widen by 1, clamp
@@ -427,7 +588,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     const int nh = oh_hi - oh_lo + 1, nw = ow_hi - ow_lo + 1;
     float4 s = f4zero();
     if (c < C) {
-        for (int k = tp; k < nh * nw; k += 16) {
+        for (int k = tp; k < nh * nw; k += pl) {
             const int oh = oh_lo + k / nw, ow = ow_lo + k % nw;
             int h0, h1, w0, w1;
             float lh0, lh1, lw0, lw1;
@@ -445,11 +606,11 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
             }
         }
     }
-    red[tp][tq] = s;
+    red[tp * ql + tq] = s;
     __syncthreads();
     if (tp == 0 && c < C) {
         float4 a = f4zero();
-        for (int k = 0; k < 16; ++k) { const float4 v = red[k][tq]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        for (int k = 0; k < pl; ++k) { const float4 v = red[k * ql + tq]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
         float4* d = reinterpret_cast<float4*>(dx + (size_t)ip * dx_ld + c);
         if (ACC) { const float4 o = *d; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
         *d = a;
@@ -461,9 +622,11 @@ extern "C" int semseg_bilinear_bwd(const float* dy, int dy_ld, float* dx, int dx
     if (!dy || !dx || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) || (dx_ld % 4))
         return SEMSEG_EINVAL;
     const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
-    dim3 grid(N * IH * IW, ceil_div(C, 64));
-    if (accumulate) hipLaunchKernelGGL(bilinear_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw);
-    else            hipLaunchKernelGGL(bilinear_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw);
+    // tiny input maps: few blocks, huge gather windows -> more pixel lanes per block and more (narrower) blocks
+    const int ql = ((long)N * IH * IW * ceil_div(C, 64) < 512 && (long)OH * OW >= 16L * IH * IW) ? 4 : 16;
+    dim3 grid(N * IH * IW, ceil_div(C, 4 * ql));
+    if (accumulate) hipLaunchKernelGGL(bilinear_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw, ql);
+    else            hipLaunchKernelGGL(bilinear_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw, ql);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -80,6 +80,11 @@ SIGNATURES = {
     'semseg_maxpool3x3s2_bwd': (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
     'semseg_adaptive_avgpool_fwd': (c_int, [vp, c_int, vp] + [c_int] * 6 + [vp]),
     'semseg_adaptive_avgpool_bwd': (c_int, [vp, vp, c_int, c_int] + [c_int] * 6 + [vp]),
+    'semseg_adaptive_avgpool_multi_workspace_bytes': (c_sz, [c_int, c_int, c_int, ctypes.POINTER(c_int), c_int]),
+    'semseg_adaptive_avgpool_multi_fwd': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int),
+                                                  ctypes.POINTER(vp), vp, c_sz, vp]),
+    'semseg_adaptive_avgpool_multi_bwd': (c_int, [ctypes.POINTER(vp), ctypes.POINTER(c_int), c_int, vp, c_int, c_int, c_int,
+                                                  c_int, c_int, vp]),
     'semseg_bilinear_fwd': (c_int, [vp, c_int, vp, c_int, c_int, c_int] + [c_int] * 6 + [vp]),
     'semseg_bilinear_bwd': (c_int, [vp, c_int, vp, c_int, c_int] + [c_int] * 6 + [vp]),
     'semseg_log_softmax_fwd': (c_int, [vp, vp, c_int, c_int, vp]),

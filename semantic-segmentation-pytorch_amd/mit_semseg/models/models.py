@@ -200,8 +200,11 @@ class _PoolBranch(nn.Sequential):
         self.add_module('3', ReLU(inplace=True))      # fused into the BN kernel; kept so indices match the reference
 
     def forward(self, x):
+        return self.after_pool(self._modules['0'](x))
+
+    def after_pool(self, pooled):
         m = self._modules
-        return conv_bn(m['1'], m['2'], m['0'](x), relu=True)
+        return conv_bn(m['1'], m['2'], pooled, relu=True)
 
 
 class _ClassifierHead(nn.Sequential):
@@ -265,7 +268,9 @@ class PPM(nn.Module):
 
     def _pyramid(self, conv5):
         size = conv5.shape[2:]
-        return ops.concat([conv5] + [ops.interpolate_bilinear(b(conv5), size) for b in self.ppm])
+        # all pyramid scales pooled in one pass over conv5 (ops.adaptive_avg_pool_multi)
+        pooled = ops.adaptive_avg_pool_multi(conv5, [b._modules['0'].output_size for b in self.ppm])
+        return ops.concat([conv5] + [ops.interpolate_bilinear(b.after_pool(p), size) for b, p in zip(self.ppm, pooled)])
 
     def forward(self, conv_out, segSize=None):
         x = self.conv_last(self._pyramid(conv_out[-1]))
@@ -312,8 +317,8 @@ class UPerNet(nn.Module):
     def forward(self, conv_out, segSize=None):
         conv5 = conv_out[-1]
         size = conv5.shape[2:]
-        ppm_out = [conv5] + [conv(ops.interpolate_bilinear(pool(conv5), size))
-                             for pool, conv in zip(self.ppm_pooling, self.ppm_conv)]
+        pooled = ops.adaptive_avg_pool_multi(conv5, [pool.output_size for pool in self.ppm_pooling])    # one pass over conv5
+        ppm_out = [conv5] + [conv(ops.interpolate_bilinear(p, size)) for p, conv in zip(pooled, self.ppm_conv)]
         f = self.ppm_last_conv(ops.concat(ppm_out))
         fpn_feature_list = [f]
         for i in reversed(range(len(conv_out) - 1)):

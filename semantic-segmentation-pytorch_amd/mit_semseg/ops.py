@@ -916,6 +916,60 @@ def adaptive_avg_pool(x, size):
     return AdaptiveAvgPoolFn.apply(x, int(oh), int(ow))
 
 
+class MultiAdaptiveAvgPoolFn(Function):
+    """nn.AdaptiveAvgPool2d of one map to several square grids (the pyramid of PPM / UPerNet): the map is read once,
+    the gradient written once (csrc/pool_resize.hip, multipool_*)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        L = _native.lib()
+        x, ld = as_nhwc(x.detach())
+        n, c, h, w = x.shape
+        ns = len(sizes)
+        ys = [empty_nhwc(n, c, s, s, x.device) for s in sizes]
+        sz = (ctypes.c_int * ns)(*sizes)
+        ptrs = (vp * ns)(*[y.data_ptr() for y in ys])
+        ws = workspace(L.semseg_adaptive_avgpool_multi_workspace_bytes(n, h, c, sz, ns), x.device)
+        _native.check(L.semseg_adaptive_avgpool_multi_fwd(_p(x), ld, n, h, w, c, ns, sz, ptrs, _p(ws), ws.numel(), _st()),
+                      'adaptive_avgpool_multi_fwd')
+        ctx.shape = (n, c, h, w)
+        ctx.sizes = tuple(sizes)
+        return tuple(ys)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        L = _native.lib()
+        n, c, h, w = ctx.shape
+        sizes = ctx.sizes
+        dev = next(d for d in dys if d is not None).device
+        gs = []
+        for d, s in zip(dys, sizes):
+            if d is None:
+                d = torch.zeros((n, s, s, c), device=dev).permute(0, 3, 1, 2)
+            d, ld = as_nhwc(d)
+            if ld != c:
+                d = d.contiguous(memory_format=torch.channels_last)
+            gs.append(d)
+        ns = len(sizes)
+        sz = (ctypes.c_int * ns)(*sizes)
+        ptrs = (vp * ns)(*[g.data_ptr() for g in gs])
+        dx = empty_nhwc(n, c, h, w, dev)
+        _native.check(L.semseg_adaptive_avgpool_multi_bwd(ptrs, sz, ns, _p(dx), c, n, h, w, c, _st()),
+                      'adaptive_avgpool_multi_bwd')
+        return dx, None
+
+
+def adaptive_avg_pool_multi(x, sizes):
+    """[adaptive_avg_pool(x, s) for s in sizes] -- fused when the sizes are square ints, at most 4 scales and 16 column
+    bins in total (PPM: 1 + 2 + 3 + 6); anything else pools scale by scale."""
+    sizes = list(sizes)
+    if (os.environ.get('SEMSEG_MULTIPOOL', '1') != '0' and len(sizes) <= 4 and all(isinstance(s, int) and s > 0 for s in sizes) and sum(sizes) <= 16 and x.shape[1] % 4 == 0
+            and len(sizes) > 1):
+        return list(MultiAdaptiveAvgPoolFn.apply(x, tuple(sizes)))
+    return [adaptive_avg_pool(x, s) for s in sizes]
+
+
 class BilinearFn(Function):
     """F.interpolate(mode='bilinear', align_corners=False); optional fused `+ base` (FPN / HRNet sums)
     and trailing ReLU (hrnet.py:248)."""

@@ -683,3 +683,24 @@ def test_inference_weight_planes_follow_sgd_updates(monkeypatch):
     ref1 = F.conv2d(x.cpu().double(), w.detach().cpu().double(), None, 1, 1, 1)
     assert rel_err(y1, ref1) < REL, rel_err(y1, ref1)
     assert rel_err(y1, ref0) > 1e-2                                    # the weights really moved
+
+
+@pytest.mark.parametrize('n,c,h,w,sizes', [(2, 64, 64, 64, (1, 2, 3, 6)), (2, 8, 9, 13, (1, 2, 3, 6)), (1, 128, 16, 16, (1, 2, 3, 6)),
+                                            (2, 32, 7, 5, (2, 5))], ids=str)
+def test_adaptive_avg_pool_multi(n, c, h, w, sizes):
+    """all pyramid scales in one pass == nn.AdaptiveAvgPool2d per scale (forward and the summed backward)"""
+    from mit_semseg import ops
+    g = torch.Generator().manual_seed(n * 100 + c)
+    x = torch.randn(n, c, h, w, generator=g)
+    gys = [torch.randn(n, c, s, s, generator=g) for s in sizes]
+    xr = x.double().requires_grad_(True)
+    yr = [F.adaptive_avg_pool2d(xr, s) for s in sizes]
+    sum((y * gy.double()).sum() for y, gy in zip(yr, gys)).backward()
+    xg = cl(x).requires_grad_(True)
+    ys = ops.adaptive_avg_pool_multi(xg, sizes)
+    assert len(ys) == len(sizes)
+    sum((y * cl(gy)).sum() for y, gy in zip(ys, gys)).backward()
+    torch.cuda.synchronize()
+    for y, r in zip(ys, yr):
+        assert y.shape == r.shape and rel_err(y, r) < 1e-5, rel_err(y, r)
+    assert rel_err(xg.grad, xr.grad) < 1e-5, rel_err(xg.grad, xr.grad)
