@@ -33,7 +33,7 @@ F32_CONV_LAST_HBM_BYTES = 1.78e9      # profiles/r1b_pmc_conv_last_fwd_wgrad.txt
 S3_CONV_LAST_HBM_BYTES = None
 
 
-# profiles/r2e_pmc_conv_last_fwd_h2.txt: FETCH_SIZE 169436 KiB x 2 + WRITE_SIZE 65536 KiB (4 split-K slabs of 16 MiB);
+# profiles/r2l_pmc_conv_last_fwd_h2.txt: FETCH_SIZE 169436 KiB x 2 + WRITE_SIZE 65536 KiB (4 split-K slabs of 16 MiB);
 # the algorithmic bytes of this launch are 227 MB (x planes 134 MB + w planes 75.5 MB + 16.8 MB fp32 output)
 H2_CONV_LAST_HBM_BYTES = (2 * 169436 + 65536) * 1024
 H2_CONV_LAST_CLOCK_GHZ = 1.59     # SQ_WAVE_CYCLES x 4 / waves / duration of the same PMC pass: the MFMA-dense kernel runs
