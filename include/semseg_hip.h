@@ -301,6 +301,8 @@ int semseg_nll_bwd(const float* gloss, const float* nll_out, const int64_t* labe
  * krsc / crsk: buffers of semseg_split_h2_bytes(K*T, C) / semseg_split_h2_bytes(C*T, K) bytes. */
 typedef struct {
     const float* w; void* krsc; void* crsk; int K, T, C;
+    void* wino;   /* optional, T == 9 only: Winograd-transformed weights U = G g G^T as h2 planes, rows 16*K (f, k), channels C:
+                     semseg_split_h2_bytes(16*K, C) bytes; NULL = not wanted */
 } semseg_wprep_tensor;
 int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host, int n, void* stream);
 
@@ -314,6 +316,20 @@ int semseg_argmax_metrics(const float* scores, int ld, const int64_t* label, int
 
 /* the same tallies from an existing prediction map (pred, label: int64 [P]); counts as above, accumulated */
 int semseg_label_metrics(const int64_t* pred, const int64_t* label, int P, int C, int64_t* counts, void* stream);
+
+/* ---------------- Winograd F(2x2, 3x3) forward convolution on h2 planes (csrc/winograd.hip) -------------
+ * For 3x3, stride 1, pad == dil convolutions (resnet.py:61-66 as dilated by models.py:209-251; models.py:163,456-457):
+ *   semseg_winograd_input_h2 : x (fp32 NHWC) -> V = B^T d B as h2 planes, rows 16*tiles (f, tile), channels C;
+ *                              bounds_host: nbounds (<= 8) DEVICE scalars, max|x| <= max of them (exponent = f(4*max))
+ *   semseg_winograd_gemm_h2  : M[f] = V[f] U[f]^T for the 16 frequencies in one batched launch; M fp32 [16*tiles][K]
+ *   semseg_winograd_output   : z = A^T M A (fp32 NHWC, ld z_ld)
+ * tiles = semseg_winograd_tiles(N, H, W, dil); U comes from semseg_weights_prepare_h2 (field `wino`).  2.25x fewer MFMA
+ * products than semseg_conv2d_fwd_h2, same error class. */
+int semseg_winograd_tiles(int N, int H, int W, int dil);
+int semseg_winograd_input_h2(const float* x, int x_ld, const float* const* bounds_host, int nbounds, void* v_planes,
+                             int N, int H, int W, int C, int dil, void* stream);
+int semseg_winograd_gemm_h2(const void* v_planes, const void* u_planes, float* M, int tiles, int C, int K, void* stream);
+int semseg_winograd_output(const float* M, float* z, int z_ld, int N, int H, int W, int K, int dil, void* stream);
 
 /* ---------------- optimiser (torch.optim.SGD, train.py:117-126) ----------------------------- */
 typedef struct {

@@ -323,6 +323,9 @@ struct SParams {
     int a, off, step, div;
     int chunks, ktiles, kt_per_split;
     int tiles_m, tiles_n, splits;
+    int batches;                                       // 0 / 1: plain; > 1: gridDim.z batches (splits must be 1)
+    int batch_in_rows, batch_w_rows, batch_out_rows;   // batched GEMM (blockIdx.z = batch): row offsets per batch of the
+                                                       // activation planes, of the weight planes (in units of T rows) and of `out`
     int tap_major;           // k-tile order: 0 = channel chunk major, taps inner (default); 1 = tap major (SEMSEG_TAP_MAJOR=1)
 };
 
@@ -382,7 +385,7 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
     int dst_ld;
     const bool direct = p.splits == 1;
     if (direct) {
-        dst = p.out;
+        dst = p.out + (size_t)blockIdx.z * p.batch_out_rows * p.out_ld;
         dst_ld = p.out_ld;
     } else {
         dst = p.partial + (size_t)z * p.M * p.Cout;
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
             const int ow = rem - oh * p.Wout;
             a_ih0[i] = oh * p.a + p.off;
             a_iw0[i] = ow * p.a + p.off;
-            a_base[i] = n * p.Hin * p.Win;
+            a_base[i] = n * p.Hin * p.Win + (int)blockIdx.z * p.batch_in_rows;
         } else {
             a_ih0[i] = -(1 << 28);
             a_iw0[i] = -(1 << 28);
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
     for (int i = 0; i < BPASS; ++i) {
         const int n = n0 + lrow + i * RPP;
         const bool ok = n < p.Cout;
-        b_off[i] = ok ? (uint32_t)n * w_row + 8u * q : 0u;
+        b_off[i] = ok ? (uint32_t)(n + (int)blockIdx.z * p.batch_w_rows) * w_row + 8u * q : 0u;
         b_ok |= (ok ? 1u : 0u) << i;
     }
     KWalk kw;
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
             const int ow = rem - oh * p.Wout;
             a_ih0[i] = oh * p.a + p.off;
             a_iw0[i] = ow * p.a + p.off;
-            a_base[i] = n * p.Hin * p.Win;
+            a_base[i] = n * p.Hin * p.Win + (int)blockIdx.z * p.batch_in_rows;
         } else {
             a_ih0[i] = -(1 << 28);
             a_iw0[i] = -(1 << 28);
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
     for (int i = 0; i < BG; ++i) {
         const int n = n0 + (wave + NW * i) * 16 + lrow;
         const bool ok = n < p.Cout;
-        b_src[i] = ok ? (uint32_t)n * w_row_b + 16u * q : b_zero;
+        b_src[i] = ok ? (uint32_t)(n + (int)blockIdx.z * p.batch_w_rows) * w_row_b + 16u * q : b_zero;
         b_msk[i] = ok ? 0xffffffffu : 0u;
     }
     uint32_t a_src[AG], a_msk[AG];
@@ -1028,7 +1031,7 @@ static int launch_rs(const SParams& p, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    dim3 grid(p.tiles_m * p.tiles_n, p.splits);
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
     hipLaunchKernelGGL((igemm_rs_kernel<SCH, BM, BN>), grid, dim3(256), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -1045,7 +1048,7 @@ static int launch_dma(const SParams& p, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    dim3 grid(p.tiles_m * p.tiles_n, p.splits);
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
     hipLaunchKernelGGL((igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(512), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -1200,6 +1203,50 @@ extern "C" int semseg_conv2d_dgrad_h2(const void* dys, const void* wts, float* d
                                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                       void* workspace, size_t workspace_bytes, void* stream) {
     return conv_dgrad<SchH2>(dys, wts, dx, dx_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
+}
+
+// the 16 GEMMs of a Winograd convolution (winograd.hip) as one batched launch of the LDS-DMA kernels: per frequency f
+// M[f] ([tiles][K]) = V[f] ([tiles][C] planes) x U[f]^T ([K][C] planes); no split-K (16 batches fill the chip)
+extern "C" int semseg_winograd_gemm_h2(const void* v_planes, const void* u_planes, float* Mout, int tiles, int C, int K,
+                                       void* stream) {
+    if (!v_planes || !u_planes || !Mout || tiles <= 0 || C <= 0 || K <= 0 || !aligned16(v_planes) || !aligned16(u_planes))
+        return SEMSEG_EINVAL;
+    SParams p = {};
+    p.in = (const uint16_t*)v_planes; p.wgt = (const uint16_t*)u_planes; p.bias = nullptr; p.addend = nullptr; p.out = Mout;
+    p.Cp = round_up32(C); p.pitch = split_pitch(C); p.out_ld = K;
+    p.Hin = 1; p.Win = tiles; p.Hout = 1; p.Wout = tiles; p.Cout = K;
+    p.M = tiles;
+    p.S = 1; p.T = 1;
+    p.a = 1; p.off = 0; p.step = 1; p.div = 1;
+    p.in_exp = h2_exp_ptr(v_planes, (size_t)16 * tiles, C);
+    p.w_exp = h2_exp_ptr(u_planes, (size_t)16 * K, C);
+    const size_t in_plane = (size_t)16 * tiles * p.pitch, w_plane = (size_t)16 * K * p.pitch;
+    if (2 * H2_NP * in_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) || 2 * H2_NP * w_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31))
+        return SEMSEG_EINVAL;
+    p.in_plane = (uint32_t)in_plane;
+    p.w_plane = (uint32_t)w_plane;
+    p.tap_major = 0;
+    p.chunks = p.Cp / 32;
+    p.ktiles = p.chunks;
+    p.kt_per_split = p.ktiles;
+    p.splits = 1;
+    p.partial = nullptr;
+    p.batches = 16; p.batch_in_rows = tiles; p.batch_w_rows = K; p.batch_out_rows = tiles;
+    static const int force = env_int("SEMSEG_WINO_TILE", -1);
+    const int tile = force >= 0 ? force : ((tiles >= 1024 && K >= 256) ? 8 : 9);
+    const int BM = kTiles[tile][0], BN = kTiles[tile][1];
+    p.tiles_m = ceil_div(tiles, BM);
+    p.tiles_n = ceil_div(K, BN);
+    hipStream_t st = (hipStream_t)stream;
+    switch (tile) {
+        case 0: return launch_rs<SchH2, 128, 128>(p, st);
+        case 6: return launch_dma<SchH2, 128, 128, 4, 2, 2>(p, st);
+        case 7: return launch_dma<SchH2, 256, 128, 4, 2, 12>(p, st);
+        case 8: return launch_dma<SchH2, 256, 256, 2, 4, 12>(p, st);
+        case 9: return launch_dma<SchH2, 128, 128, 4, 2, 12>(p, st);
+        case 10: return launch_dma<SchH2, 256, 128, 4, 2, 13>(p, st);
+        default: return SEMSEG_EINVAL;
+    }
 }
 
 // dx = addend + dgrad(dys, wts): the gradient another consumer of the same input has already produced is accumulated in the

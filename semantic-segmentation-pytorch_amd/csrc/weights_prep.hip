@@ -9,7 +9,7 @@
 #include "common.h"
 #include "split_layout.h"
 
-constexpr int WPREP_MAX_TENSORS = 64;
+constexpr int WPREP_MAX_TENSORS = 48;      // 48 x 56 B of descriptors stay below the 4 KiB kernel-argument limit
 constexpr int WPREP_CHUNKS = 256;          // absmax partial blocks per tensor (<= H2_MAX_PARTIALS)
 
 struct WPrepTensor {
@@ -18,6 +18,8 @@ struct WPrepTensor {
     uint16_t* crsk;        // h2 split buffer, rows C*T, channels K
     int K, T, C;
     int tile_base;         // first flat tile id of this tensor
+    uint16_t* wino;        // optional (T == 9): h2 split buffer of the Winograd-transformed weights, rows 16*K, channels C
+    int wino_base;         // first flat block id of this tensor in wprep_wino_kernel
 };
 struct WPrepBatch {
     WPrepTensor t[WPREP_MAX_TENSORS];
@@ -134,6 +136,82 @@ __global__ __launch_bounds__(256) void wprep_split_kernel(const WPrepBatch b, in
     }
 }
 
+// U = G g G^T of every 3x3 weight that asked for it (winograd.hip): one thread = 4 channels of one k; |U| <= 2.25 max|g|
+// (G has rows of absolute sum <= 1.5), so the exponent comes from the absmax partials that are already there.
+__global__ __launch_bounds__(256) void wprep_wino_kernel(const WPrepBatch b, int pitch_pad) {
+    int ti = -1;
+    for (int i = 0; i < b.n; ++i)
+        if (b.t[i].wino && (int)blockIdx.x >= b.t[i].wino_base) ti = i;         // block-uniform; bases ascend
+    if (ti < 0) return;
+    const WPrepTensor t = b.t[ti];
+    const int K = t.K, C = t.C;
+    const int Cp = (C + 31) & ~31;
+    const int pitch = ((Cp * 2) % 2048 == 0) ? Cp + pitch_pad : Cp;
+    const size_t plane_krsc = (size_t)K * t.T * pitch;
+    const size_t plane = (size_t)16 * K * pitch;
+    const uint32_t* partial = wprep_partials(t, plane_krsc);
+    uint32_t m = threadIdx.x < WPREP_CHUNKS ? partial[threadIdx.x] : 0u;
+    m = block_max_u32(m);
+    const float bound = 2.25f * __uint_as_float(m);
+    const int ex = h2_exponent((m >> 23) == 255 ? m : __float_as_uint(bound));
+    const float sc = pow2i(ex);
+    if ((int)blockIdx.x == t.wino_base) {
+        unsigned char* tail = reinterpret_cast<unsigned char*>(t.wino) + (size_t)H2_NP * plane * 2;
+        if (threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16) reinterpret_cast<uint4*>(tail)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) *reinterpret_cast<int*>(tail + SPLIT_ZERO_TAIL_BYTES) = ex;
+    }
+    const int G4 = Cp >> 2;
+    const size_t item = (size_t)((int)blockIdx.x - t.wino_base) * 256 + threadIdx.x;
+    if (item >= (size_t)K * G4) return;
+    const int k = (int)(item / G4);
+    const int c = (int)(item - (size_t)k * G4) << 2;
+    float g[3][3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[r][q][e] = (c + e < C) ? t.w[((size_t)k * 9 + r * 3 + q) * C + c + e] : 0.f;
+    // G g (rows), then (.) G^T (columns):  u0 = g0, u1 = (g0 + g1 + g2)/2, u2 = (g0 - g1 + g2)/2, u3 = g2
+    float a[4][3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g0 = g[0][q][e], g1 = g[1][q][e], g2 = g[2][q][e];
+            a[0][q][e] = g0;
+            a[1][q][e] = 0.5f * (g0 + g1 + g2);
+            a[2][q][e] = 0.5f * (g0 - g1 + g2);
+            a[3][q][e] = g2;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float u[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = a[i][0][e], a1 = a[i][1][e], a2 = a[i][2][e];
+            u[0][e] = a0;
+            u[1][e] = 0.5f * (a0 + a1 + a2);
+            u[2][e] = 0.5f * (a0 - a1 + a2);
+            u[3][e] = a2;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f16x4 p0, p1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 hi, lo;
+                h2_split_of(u[j][e] * sc, hi, lo);
+                p0[e] = hi;
+                p1[e] = lo;
+            }
+            const size_t off = ((size_t)(i * 4 + j) * K + k) * pitch + c;
+            *reinterpret_cast<f16x4*>(t.wino + off) = p0;
+            *reinterpret_cast<f16x4*>(t.wino + plane + off) = p1;
+        }
+    }
+}
+
 extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host, int n, void* stream) {
     if (!tensors_host || n < 0) return SEMSEG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -141,7 +219,7 @@ extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host
     for (int base = 0; base < n; base += WPREP_MAX_TENSORS) {
         WPrepBatch b;
         b.n = min(WPREP_MAX_TENSORS, n - base);
-        int tiles = 0;
+        int tiles = 0, wino_blocks = 0;
         for (int i = 0; i < b.n; ++i) {
             const semseg_wprep_tensor& s = tensors_host[base + i];
             if (!s.w || !s.krsc || !s.crsk || s.K <= 0 || s.T <= 0 || s.C <= 0) return SEMSEG_EINVAL;
@@ -154,12 +232,23 @@ extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host
             b.t[i].C = s.C;
             b.t[i].tile_base = tiles;
             tiles += ((s.K + 63) / 64) * ((round_up32(s.C) + 63) / 64) * s.T;
+            b.t[i].wino = nullptr;
+            b.t[i].wino_base = wino_blocks;
+            if (s.wino) {
+                if (s.T != 9 || !aligned16(s.wino)) return SEMSEG_EINVAL;
+                b.t[i].wino = (uint16_t*)s.wino;
+                wino_blocks += (int)ceil_div_sz((size_t)s.K * (round_up32(s.C) / 4), 256);
+            }
         }
         if (b.n == 0) break;
         hipLaunchKernelGGL(wprep_absmax_kernel, dim3(WPREP_CHUNKS, b.n), dim3(256), 0, st, b, pitch_pad);
         SEMSEG_LAUNCH_CHECK();
         hipLaunchKernelGGL(wprep_split_kernel, dim3(tiles), dim3(256), 0, st, b, pitch_pad);
         SEMSEG_LAUNCH_CHECK();
+        if (wino_blocks > 0) {
+            hipLaunchKernelGGL(wprep_wino_kernel, dim3(wino_blocks), dim3(256), 0, st, b, pitch_pad);
+            SEMSEG_LAUNCH_CHECK();
+        }
     }
     return 0;
 }

@@ -1,0 +1,198 @@
+// Winograd F(2x2, 3x3) forward convolution on h2 split planes (stride 1, pad == dilation; the taps of a dilated 3x3 form a
+// plain 3x3 on each of the dil x dil phase images).  2.25x fewer MFMA products than the direct implicit GEMM:
+//   V = B^T d B   (input transform, fp32, one 4x4 input tile -> 16 "frequencies")        -> h2 planes, rows (f, tile)
+//   U = G g G^T   (weight transform, fp32, once per optimiser step: weights_prep.hip)      -> h2 planes, rows (f, k)
+//   M[f] = V[f] U[f]^T   16 independent [tiles x C] x [C x K] GEMMs = ONE batched launch of the LDS-DMA igemm kernels
+//   z = A^T M A   (output transform, fp32, 2x2 outputs per tile)
+// The exponent of the V planes needs no pass over V: |V| <= 4 max|x| (B^T has rows of at most two +-1), and x comes
+// with a bound (BN outputs of the fused chain; max over the inputs of a concat).  Accuracy: same error class as the direct
+// h2 path and torch's CPU fp32 convolution (tools/studies/winograd_h2_accuracy.py, tests/test_gpu_ops.py).
+// Replaces nn.Conv2d forward at the 3x3 stride-1 call sites (resnet.py:61-66 dilated by models.py:209-251; models.py:163,
+// 456-457) when ops enables it.
+#include "common.h"
+#include "split_layout.h"
+
+struct WinoGeom {
+    int N, H, W, C, K, dil;
+    int TH, TW;          // 2x2-output tiles per phase image (same grid for every phase; surplus tiles are empty)
+    int tiles;           // N * dil * dil * TH * TW
+};
+
+static WinoGeom wino_geom(int N, int H, int W, int C, int K, int dil) {
+    WinoGeom g;
+    g.N = N; g.H = H; g.W = W; g.C = C; g.K = K; g.dil = dil;
+    g.TH = (ceil_div(H, dil) + 1) / 2;
+    g.TW = (ceil_div(W, dil) + 1) / 2;
+    g.tiles = N * dil * dil * g.TH * g.TW;
+    return g;
+}
+
+extern "C" int semseg_winograd_tiles(int N, int H, int W, int dil) {
+    if (N <= 0 || H <= 0 || W <= 0 || dil <= 0) return 0;
+    return wino_geom(N, H, W, 1, 1, dil).tiles;
+}
+
+// tile id -> (n, phase, tile coordinates)
+__device__ __forceinline__ void wino_tile(const WinoGeom& g, int t, int& n, int& ph, int& pw, int& ty, int& tx) {
+    tx = t % g.TW; t /= g.TW;
+    ty = t % g.TH; t /= g.TH;
+    pw = t % g.dil; t /= g.dil;
+    ph = t % g.dil;
+    n = t / g.dil;
+}
+
+constexpr int WINO_MAX_BOUNDS = 8;
+struct WinoBounds {
+    const float* p[WINO_MAX_BOUNDS];
+    int n;
+};
+
+// one thread = 4 channels of one tile: 16 float4 loads, 32 + 32 adds per channel, 16 rows x 8 B per plane
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_ld, uint16_t* __restrict__ planes,
+                                                         size_t plane, int pitch, int* __restrict__ hdr, WinoGeom g, int Cp,
+                                                         WinoBounds bounds) {
+    // exponent from the bound 4 * max(bounds of x)
+    float b = 0.f;
+    bool bad = false;
+    for (int i = 0; i < bounds.n; ++i) {
+        const float v = bounds.p[i][0];
+        bad = bad || !(v == v);
+        b = fmaxf(b, v);
+    }
+    const uint32_t bits = bad ? 0x7fc00000u : __float_as_uint(4.0f * b);
+    const int ex = h2_exponent(bits);
+    const float sc = pow2i(ex);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16) reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) hdr[0] = ex;
+    }
+    const int G4 = Cp >> 2;
+    const size_t total = (size_t)g.tiles * G4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx / G4);
+        const int c = (int)(idx - (size_t)t * G4) << 2;
+        int n, ph, pw, ty, tx;
+        wino_tile(g, t, n, ph, pw, ty, tx);
+        float4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int qh = 2 * ty - 1 + a;                    // row in the phase image
+            const int h = qh * g.dil + ph;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int qw = 2 * tx - 1 + bb;
+                const int w = qw * g.dil + pw;
+                const bool ok = (c < g.C) && (qh >= 0) && (qw >= 0) && (h < g.H) && (w < g.W);
+                d[a][bb] = ok ? *reinterpret_cast<const float4*>(x + ((size_t)(n * g.H + h) * g.W + w) * x_ld + c) : f4zero();
+            }
+        }
+        // B^T d (columns), then (.) B (rows)
+        float4 v[4][4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float4 d0 = d[0][bb], d1 = d[1][bb], d2 = d[2][bb], d3 = d[3][bb];
+            v[0][bb] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+            v[1][bb] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+            v[2][bb] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+            v[3][bb] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 t0 = v[a][0], t1 = v[a][1], t2 = v[a][2], t3 = v[a][3];
+            const float4 o[4] = {make_float4(t0.x - t2.x, t0.y - t2.y, t0.z - t2.z, t0.w - t2.w),
+                                 make_float4(t1.x + t2.x, t1.y + t2.y, t1.z + t2.z, t1.w + t2.w),
+                                 make_float4(t2.x - t1.x, t2.y - t1.y, t2.z - t1.z, t2.w - t1.w),
+                                 make_float4(t1.x - t3.x, t1.y - t3.y, t1.z - t3.z, t1.w - t3.w)};
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int f = a * 4 + bb;
+                const float e[4] = {o[bb].x * sc, o[bb].y * sc, o[bb].z * sc, o[bb].w * sc};
+                f16x4 p0, p1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    _Float16 hi, lo;
+                    h2_split_of(e[q], hi, lo);
+                    p0[q] = hi;
+                    p1[q] = lo;
+                }
+                const size_t off = ((size_t)f * g.tiles + t) * pitch + c;
+                *reinterpret_cast<f16x4*>(planes + off) = p0;
+                *reinterpret_cast<f16x4*>(planes + plane + off) = p1;
+            }
+        }
+    }
+}
+
+extern "C" int semseg_winograd_input_h2(const float* x, int x_ld, const float* const* bounds_host, int nbounds, void* v_planes,
+                                        int N, int H, int W, int C, int dil, void* stream) {
+    if (!x || !v_planes || !bounds_host || nbounds <= 0 || nbounds > WINO_MAX_BOUNDS || N <= 0 || H <= 0 || W <= 0 || C <= 0 ||
+        (C % 4) || (x_ld % 4) || x_ld < C || dil <= 0 || !aligned16(x) || !aligned16(v_planes))
+        return SEMSEG_EINVAL;
+    const WinoGeom g = wino_geom(N, H, W, C, 1, dil);
+    const size_t rows = (size_t)16 * g.tiles;
+    const int Cp = round_up32(C), pitch = split_pitch(C);
+    const size_t plane = h2_plane_elems(rows, C);
+    if ((size_t)2 * H2_NP * plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31)) return SEMSEG_EINVAL;     // 32-bit DMA offsets
+    WinoBounds b;
+    b.n = nbounds;
+    for (int i = 0; i < WINO_MAX_BOUNDS; ++i) b.p[i] = i < nbounds ? bounds_host[i] : nullptr;
+    for (int i = 0; i < nbounds; ++i)
+        if (!b.p[i]) return SEMSEG_EINVAL;
+    int* hdr = const_cast<int*>(h2_exp_ptr(v_planes, rows, C));
+    size_t blocks = ceil_div_sz((size_t)g.tiles * (Cp / 4), 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)v_planes,
+                       plane, pitch, hdr, g, Cp, b);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// one thread = 4 output channels of one tile: 16 float4 loads of M, 2x2 outputs
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, float* __restrict__ z, int z_ld, WinoGeom g) {
+    const int K4 = g.K >> 2;
+    const size_t total = (size_t)g.tiles * K4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx / K4);
+        const int k = (int)(idx - (size_t)t * K4) << 2;
+        int n, ph, pw, ty, tx;
+        wino_tile(g, t, n, ph, pw, ty, tx);
+        float4 m[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+                m[a][bb] = *reinterpret_cast<const float4*>(M + ((size_t)(a * 4 + bb) * g.tiles + t) * g.K + k);
+        // A^T m (columns): s0 = m0 + m1 + m2, s1 = m1 - m2 - m3; then (.) A (rows)
+        float4 s[2][4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float4 m0 = m[0][bb], m1 = m[1][bb], m2 = m[2][bb], m3 = m[3][bb];
+            s[0][bb] = make_float4(m0.x + m1.x + m2.x, m0.y + m1.y + m2.y, m0.z + m1.z + m2.z, m0.w + m1.w + m2.w);
+            s[1][bb] = make_float4(m1.x - m2.x - m3.x, m1.y - m2.y - m3.y, m1.z - m2.z - m3.z, m1.w - m2.w - m3.w);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 s0 = s[i][0], s1 = s[i][1], s2 = s[i][2], s3 = s[i][3];
+            const float4 y0 = make_float4(s0.x + s1.x + s2.x, s0.y + s1.y + s2.y, s0.z + s1.z + s2.z, s0.w + s1.w + s2.w);
+            const float4 y1 = make_float4(s1.x - s2.x - s3.x, s1.y - s2.y - s3.y, s1.z - s2.z - s3.z, s1.w - s2.w - s3.w);
+            const int h = (2 * ty + i) * g.dil + ph;
+            const int w0 = (2 * tx) * g.dil + pw, w1 = (2 * tx + 1) * g.dil + pw;
+            if (h < g.H) {
+                if (w0 < g.W) *reinterpret_cast<float4*>(z + ((size_t)(n * g.H + h) * g.W + w0) * z_ld + k) = y0;
+                if (w1 < g.W) *reinterpret_cast<float4*>(z + ((size_t)(n * g.H + h) * g.W + w1) * z_ld + k) = y1;
+            }
+        }
+    }
+}
+
+extern "C" int semseg_winograd_output(const float* M, float* z, int z_ld, int N, int H, int W, int K, int dil, void* stream) {
+    if (!M || !z || N <= 0 || H <= 0 || W <= 0 || K <= 0 || (K % 4) || (z_ld % 4) || z_ld < K || dil <= 0 || !aligned16(M) ||
+        !aligned16(z))
+        return SEMSEG_EINVAL;
+    const WinoGeom g = wino_geom(N, H, W, 1, K, dil);
+    size_t blocks = ceil_div_sz((size_t)g.tiles * (K / 4), 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, z, z_ld, g);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}

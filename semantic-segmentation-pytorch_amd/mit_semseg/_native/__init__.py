@@ -21,7 +21,7 @@ class SgdTensor(ctypes.Structure):
 
 
 class WPrepTensor(ctypes.Structure):
-    _fields_ = [('w', vp), ('krsc', vp), ('crsk', vp), ('K', c_int), ('T', c_int), ('C', c_int)]
+    _fields_ = [('w', vp), ('krsc', vp), ('crsk', vp), ('K', c_int), ('T', c_int), ('C', c_int), ('wino', vp)]
 
 
 # name -> (restype, argtypes); mirrors include/semseg_hip.h one to one
@@ -94,6 +94,10 @@ SIGNATURES = {
     'semseg_nll_bwd': (c_int, [vp, vp, vp, c_int, vp, c_int, c_int, vp]),
     'semseg_argmax_metrics': (c_int, [vp, c_int, vp, c_int, c_int, vp, vp, vp]),
     'semseg_label_metrics': (c_int, [vp, vp, c_int, c_int, vp, vp]),
+    'semseg_winograd_tiles': (c_int, [c_int, c_int, c_int, c_int]),
+    'semseg_winograd_input_h2': (c_int, [vp, c_int, ctypes.POINTER(vp), c_int, vp, c_int, c_int, c_int, c_int, c_int, vp]),
+    'semseg_winograd_gemm_h2': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
+    'semseg_winograd_output': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'semseg_sgd_step': (c_int, [ctypes.POINTER(SgdTensor), c_int, vp, c_f, c_f, vp]),
 }
 

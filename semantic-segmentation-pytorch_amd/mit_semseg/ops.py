@@ -251,16 +251,36 @@ def input_planes(x, scheme):
     return xp
 
 
-def attach_absmax(t, absmax):
-    """`absmax`: 1-element device tensor holding an upper bound of max|t| (BN kernels of the fused path)."""
-    t._semseg_absmax = (absmax, t._version, t.data_ptr())
+def attach_absmax(t, bounds):
+    """`bounds`: one 1-element device tensor, or a tuple of them: max|t| <= max(bounds) (BN kernels of the fused path;
+    a concat carries the bounds of its inputs)."""
+    if torch.is_tensor(bounds):
+        bounds = (bounds,)
+    t._semseg_absmax = (tuple(bounds), t._version, t.data_ptr())
 
 
-def absmax_of(t):
+def bounds_of(t):
+    """tuple of device scalars bounding max|t|, or None"""
     rec = getattr(t, '_semseg_absmax', None) if (FUSE and t is not None) else None
     if rec is not None and rec[1] == t._version and rec[2] == t.data_ptr():
         return rec[0]
     return None
+
+
+def absmax_of(t):
+    """the single device scalar bounding max|t| (None if unknown or if the bound is a set of several scalars)"""
+    b = bounds_of(t)
+    return b[0] if (b is not None and len(b) == 1) else None
+
+
+# Winograd F(2x2, 3x3) for the forward pass of 3x3 stride-1 convs with at least this many input channels (csrc/winograd.hip).
+# SEMSEG_WINOGRAD=0 disables.
+WINOGRAD = os.environ.get('SEMSEG_WINOGRAD', '1') != '0'
+WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '256'))
+
+
+def _wino_eligible(k, c, r, s):
+    return WINOGRAD and FUSE and CONV_MODE == 'h2' and r == 3 and s == 3 and c % 4 == 0 and k % 4 == 0 and c >= WINOGRAD_MIN_C
 
 
 # ---- conv weights: split planes prepared for ALL convs in one multi-tensor launch (engine calls it after the SGD step)
@@ -283,9 +303,11 @@ def prepare_conv_weights(weights):
         if rec is None or rec[0]() is not w or rec[2] != w.data_ptr():
             kb = torch.empty(L.semseg_split_h2_bytes(k * r * s, c), dtype=torch.uint8, device=w.device)
             cb = torch.empty(L.semseg_split_h2_bytes(c * r * s, k), dtype=torch.uint8, device=w.device)
-            rec = (weakref.ref(w), w._version, w.data_ptr(), kb, cb)
+            ub = torch.empty(L.semseg_split_h2_bytes(16 * k, c), dtype=torch.uint8, device=w.device) \
+                if _wino_eligible(k, c, r, s) else None
+            rec = (weakref.ref(w), w._version, w.data_ptr(), kb, cb, ub)
         else:
-            rec = (rec[0], w._version, rec[2], rec[3], rec[4])
+            rec = (rec[0], w._version, rec[2], rec[3], rec[4], rec[5])
         _WPLANES[id(w)] = rec
         todo.append((w, rec))
     if not todo:
@@ -295,8 +317,17 @@ def prepare_conv_weights(weights):
         k, c, r, s = w.shape
         arr[i].w, arr[i].krsc, arr[i].crsk = w.data_ptr(), rec[3].data_ptr(), rec[4].data_ptr()
         arr[i].K, arr[i].T, arr[i].C = k, r * s, c
+        arr[i].wino = rec[5].data_ptr() if rec[5] is not None else None
     _native.check(L.semseg_weights_prepare_h2(arr, len(todo), _st()), 'weights_prepare_h2')
     return len(todo)
+
+
+def weight_wino(w):
+    """Winograd-transformed planes of `w` prepared for this exact parameter state, else None"""
+    rec = _WPLANES.get(id(w)) if FUSE else None
+    if rec is not None and rec[0]() is w and rec[1] == w._version and rec[2] == w.data_ptr():
+        return rec[5]
+    return None
 
 
 def weight_planes(w, scheme):
@@ -576,6 +607,22 @@ def batch_norm_act(z, gamma, beta, running_mean, running_var, residual=None, tra
                                 float(momentum), float(eps), bool(relu), num_batches_tracked)
 
 
+def _winograd_fwd(L, x, bounds, u_planes, z, geom):
+    """z = conv3x3(x) (stride 1, pad == dil) by Winograd F(2x2, 3x3) on h2 planes: input transform -> one batched GEMM
+    launch over the 16 frequencies -> output transform (csrc/winograd.hip)."""
+    n, h, wd, c, k, r, s, stride, pad, dil = geom
+    x, x_ld = as_nhwc(x)
+    dev = x.device
+    tiles = L.semseg_winograd_tiles(n, h, wd, dil)
+    v = torch.empty(L.semseg_split_h2_bytes(16 * tiles, c), dtype=torch.uint8, device=dev)
+    m = torch.empty((16 * tiles, k), dtype=torch.float32, device=dev)
+    nb = len(bounds)
+    bp = (vp * nb)(*[b.data_ptr() for b in bounds])
+    _native.check(L.semseg_winograd_input_h2(_p(x), x_ld, bp, nb, _p(v), n, h, wd, c, dil, _st()), 'winograd_input_h2')
+    _native.check(L.semseg_winograd_gemm_h2(_p(v), _p(u_planes), _p(m), tiles, c, k, _st()), 'winograd_gemm_h2')
+    _native.check(L.semseg_winograd_output(_p(m), _p(z), k, n, h, wd, k, dil, _st()), 'winograd_output')
+
+
 class ConvBNActFn(Function):
     """y = act(BN_train(conv(x)) [+ residual]) as ONE autograd node on the h2 path (resnet.py:72-92 blocks,
     models.py:160-167 conv3x3_bn_relu, hrnet.py).  Versus Conv2dSplitFn + BatchNormActFn:
@@ -606,15 +653,19 @@ class ConvBNActFn(Function):
                              % str([n, k, oh, ow]))
         geom = (n, h, wd, c, k, r, s, stride, pad, dil)
         dev = x.device
-        wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
         z = empty_nhwc(n, k, oh, ow, dev)
+        wino = box.get('wino')
+        if wino is not None:
+            _winograd_fwd(L, x.detach(), box['x_bounds'], wino, z, geom)
+        else:
+            wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
 
-        def launch():
-            ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
-            _native.check(sch.fn(L, 'fwd')(_p(xp), _p(wsp), _p(None), _p(z), k, *geom, _p(ws), ws.numel(), _st()),
-                          'conv2d_fwd_h2')
-        tuner.ensure('h2', 0, geom, launch)
-        launch()
+            def launch():
+                ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
+                _native.check(sch.fn(L, 'fwd')(_p(xp), _p(wsp), _p(None), _p(z), k, *geom, _p(ws), ws.numel(), _st()),
+                              'conv2d_fwd_h2')
+            tuner.ensure('h2', 0, geom, launch)
+            launch()
         stats = torch.empty((2 * k + 1,), device=dev, dtype=torch.float64)
         zmm = torch.empty((2 * k,), device=dev, dtype=torch.float32)
         ws = workspace(L.semseg_bn_mm_workspace_bytes(P, k), dev)
@@ -731,6 +782,12 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
     passthrough = want_pair and PASSTHROUGH and x.requires_grad and torch.is_grad_enabled()
     cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu), passthrough)
     box = {}
+    kk, cc, rr, ss = weight.shape
+    if int(stride) == 1 and int(padding) == int(dilation) and _wino_eligible(kk, cc, rr, ss):
+        xb = bounds_of(x)
+        if xb is not None and len(xb) <= 8:
+            box['wino'] = weight_wino(weight)            # None until prepare_conv_weights has run for this weight state
+            box['x_bounds'] = xb
     out = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean, running_var,
                             num_batches_tracked, cfg, box)
     y, xr = out if passthrough else (out, x)
@@ -742,7 +799,7 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
     if xr is not x:                        # same storage, new tensor object: carry the plane / bound records over
         n, c, h, w = x.shape
         attach_planes(xr, xp, 'h2', n * h * w, c)
-        bound = absmax_of(x)
+        bound = bounds_of(x)
         if bound is not None:
             attach_absmax(xr, bound)
     return (y, xr) if want_pair else y
@@ -813,7 +870,11 @@ class ConcatFn(Function):
 
 
 def concat(xs):
-    return ConcatFn.apply(*xs)
+    y = ConcatFn.apply(*xs)
+    bs = [bounds_of(x) for x in xs]
+    if all(b is not None for b in bs):                   # max|cat| <= max over the inputs' bounds
+        attach_absmax(y, tuple(t for b in bs for t in b))
+    return y
 
 
 class ScaleNCFn(Function):
@@ -881,7 +942,7 @@ class MaxPool3x3s2Fn(Function):
 
 def max_pool_3x3_s2(x):
     y = MaxPool3x3s2Fn.apply(x)
-    bound = absmax_of(x)
+    bound = bounds_of(x)
     if bound is not None:
         attach_absmax(y, bound)          # max over windows of x: the bound of |x| holds for |y|
     return y
@@ -1016,7 +1077,12 @@ def interpolate_bilinear(x, size, base=None, relu=False):
     oh, ow = int(size[0]), int(size[1])
     if base is None and not relu and x.shape[2] == oh and x.shape[3] == ow:
         return x                                            # identity resize (scale 1): exact copy in torch too
-    return BilinearFn.apply(x, oh, ow, base, bool(relu))
+    y = BilinearFn.apply(x, oh, ow, base, bool(relu))
+    if base is None:
+        b = bounds_of(x)                                    # convex combination of source pixels (and ReLU): same bound
+        if b is not None:
+            attach_absmax(y, b)
+    return y
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1127,4 +1193,4 @@ def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum
     for p in params:
         rec = _WPLANES.get(id(p))
         if rec is not None:
-            _WPLANES[id(p)] = (rec[0], -1, rec[2], rec[3], rec[4])
+            _WPLANES[id(p)] = (rec[0], -1, rec[2], rec[3], rec[4], rec[5])

@@ -704,3 +704,31 @@ def test_adaptive_avg_pool_multi(n, c, h, w, sizes):
     for y, r in zip(ys, yr):
         assert y.shape == r.shape and rel_err(y, r) < 1e-5, rel_err(y, r)
     assert rel_err(xg.grad, xr.grad) < 1e-5, rel_err(xg.grad, xr.grad)
+
+
+@pytest.mark.parametrize('n,c,h,w,k,dil', [(2, 256, 16, 16, 256, 1), (1, 512, 24, 24, 128, 4), (2, 256, 17, 19, 64, 2),
+                                           (1, 320, 7, 9, 36, 1), (2, 1024, 8, 8, 512, 1), (1, 256, 5, 6, 32, 4)], ids=str)
+def test_winograd_forward(n, c, h, w, k, dil, monkeypatch):
+    """Winograd F(2x2, 3x3) on h2 planes (input transform, batched GEMM over the 16 frequencies, output transform; weights
+    transformed by the multi-tensor preparation) against a float64 convolution -- same tolerance as the direct kernels"""
+    from mit_semseg import ops, _native
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    monkeypatch.setattr(ops, 'WINOGRAD', True)
+    monkeypatch.setattr(ops, 'WINOGRAD_MIN_C', 64)
+    L = _native.lib()
+    g = torch.Generator().manual_seed(n * 1000 + c + dil)
+    x = torch.randn(n, c, h, w, generator=g).relu() * 1.5
+    x.view(-1)[::997] *= 30.0
+    wt = torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), None, 1, dil, dil)
+    xg = cl(x)
+    wp = torch.nn.Parameter(cl(wt))
+    ops.prepare_conv_weights([wp])
+    u = ops.weight_wino(wp)
+    assert u is not None
+    z = ops.empty_nhwc(n, k, h, w, xg.device)
+    z.fill_(float('nan'))
+    bound = xg.abs().max().reshape(1)
+    ops._winograd_fwd(L, xg, (bound * 0.5, bound), u, z, (n, h, w, c, k, 3, 3, 1, dil, dil))       # two bounds: max is taken
+    torch.cuda.synchronize()
+    assert rel_err(z, ref) < REL, rel_err(z, ref)
