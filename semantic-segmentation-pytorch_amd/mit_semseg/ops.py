@@ -274,9 +274,11 @@ def absmax_of(t):
 
 
 # Winograd F(2x2, 3x3) for the forward pass of 3x3 stride-1 convs with at least this many input channels (csrc/winograd.hip).
+# Measured per layer (gpurun r2n, R50dilated+PPM, 2x64x64 maps): 4096 ch 0.55 vs 0.79 ms direct, 1024 ch ~0.14 vs 0.23 ms,
+# 512 ch break-even, 256 ch 63 vs 50 us (the transforms are HBM-bound passes: V is 4x the input) -> threshold 1024.
 # SEMSEG_WINOGRAD=0 disables.
 WINOGRAD = os.environ.get('SEMSEG_WINOGRAD', '1') != '0'
-WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '256'))
+WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '1024'))
 
 
 def _wino_eligible(k, c, r, s):
