@@ -24,7 +24,7 @@ import torch.nn as nn   # noqa: E402
 
 # SURVEY 8d (hooks on the reference modules): 2*MACs of every Conv2d; train = 3*fwd - fwd(first conv)
 TRAIN_GFLOP_PER_IMG = {'resnet50dilated+ppm_deepsup': 1224.2}
-FWD_GFLOP_CONV_LAST = 309.24          # decoder.conv_last.0: 3x3 4096->512 @64x64, N=2 (per launch, fwd)
+FWD_GFLOP_CONV_LAST = 309.24          # decoder.conv_last.0: 3x3 4096->512 @64x64, N=2 (per launch; fwd and dgrad alike)
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 # HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the guide's gfx950
@@ -33,12 +33,11 @@ F32_CONV_LAST_HBM_BYTES = 1.78e9      # profiles/r1b_pmc_conv_last_fwd_wgrad.txt
 S3_CONV_LAST_HBM_BYTES = None
 
 
-# profiles/r2l_pmc_conv_last_fwd_h2.txt: FETCH_SIZE 169436 KiB x 2 + WRITE_SIZE 65536 KiB (4 split-K slabs of 16 MiB);
-# the algorithmic bytes of this launch are 227 MB (x planes 134 MB + w planes 75.5 MB + 16.8 MB fp32 output)
-H2_CONV_LAST_HBM_BYTES = (2 * 169436 + 65536) * 1024
-H2_CONV_LAST_CLOCK_GHZ = 1.59     # SQ_WAVE_CYCLES x 4 / waves / duration of the same PMC pass: the MFMA-dense kernel runs
-                                  # power-limited well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at (the faster
-                                  # software-pipelined loop lowered it further: 1.69 -> 1.59 GHz)
+# profiles/r2s_pmc_conv_last_dgrad_h2.txt: FETCH_SIZE 168153 KiB x 2 + WRITE_SIZE 131072 KiB (the fp32 dx, no split-K);
+# the algorithmic bytes of this launch are 226.5 MB (dy planes 16.8 MB + w planes 75.5 MB + 134.2 MB fp32 output)
+H2_CONV_LAST_HBM_BYTES = (2 * 168153 + 131072) * 1024
+H2_CONV_LAST_CLOCK_GHZ = 1.55     # SQ_WAVE_CYCLES x 4 / waves / duration of the same PMC pass: the MFMA-dense kernel runs
+                                  # power-limited well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at
 DTYPE = {'h2': 'f32 (fp32 in/out/accumulate; products on the fp16 MFMA via a scaled 2-way fp16 split, 3 terms, 2^-22 per product)',
          's3': 'f32 (fp32 in/out/accumulate; products on the bf16 MFMA via an exact 3-way bf16 split, 6 terms)', 'f32': 'f32'}
 # MFMA products per fp32-accurate MAC block and the issued instruction, per split scheme
@@ -71,33 +70,34 @@ def synth_feed(dev, rank, n=2, h=512, w=512, seg_rate=8):
 
 
 def time_dominant_kernel(dev, iters=10):
-    """HIP-event timing of the dominant kernel of the step -- the implicit-GEMM convolution of decoder.conv_last.0
-    (3x3, 4096->512 @64x64, N=2: 38 % of the step's FLOPs) -- through the C ABI on pre-split operands, i.e. ONLY the
-    conv entry point (igemm_dma_kernel<SchH2,256,256> + its split-K reduction on the default h2 path)
-    on the stream it is launched on (torch's current stream).  The launch plan is the tuned one."""
+    """HIP-event timing of the dominant kernel of the step -- the implicit-GEMM DATA GRADIENT of decoder.conv_last.0 (3x3,
+    4096->512 @64x64, N=2: 309.24 GFLOP, 12.6 % of the step's FLOPs; its forward runs through the Winograd path since r2m,
+    so the largest single launch of the step is this one) -- through the C ABI on pre-split operands, i.e. ONLY the conv
+    entry point (igemm_dma_kernel<SchH2,256,256> on the default h2 path, tuned plan: no split-K) on the stream it is
+    launched on (torch's current stream)."""
     import ctypes
     from mit_semseg import ops, _native, tuner
     L = _native.lib()
     vp = ctypes.c_void_p
     n, h, w, c, k = 2, 64, 64, 4096, 512
     geom = (n, h, w, c, k, 3, 3, 1, 1, 1)
-    x = torch.randn(n, h, w, c, device=dev)
-    wt = torch.randn(k, 3, 3, c, device=dev) * 0.01
-    y = torch.empty(n, h, w, k, device=dev)
+    dy = torch.randn(n, h, w, k, device=dev) * 1e-3
+    wtt = torch.randn(c, 3, 3, k, device=dev) * 0.01               # CRSK
+    dx = torch.empty(n, h, w, c, device=dev)
     st = lambda: vp(torch.cuda.current_stream().cuda_stream)   # noqa: E731
     P = lambda t: vp(t.data_ptr())                              # noqa: E731
     if ops.CONV_MODE in ops.SCHEMES:
         sch = ops.SCHEMES[ops.CONV_MODE]
-        xs, wsp = sch.split(x, n * h * w, c, c), sch.split(wt, k * 9, c, c)
+        dys, wts = sch.split(dy, n * h * w, k, k), sch.split(wtt, c * 9, k, k)
 
         def launch():
             ws = ops.workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
-            _native.check(sch.fn(L, 'fwd')(P(xs), P(wsp), vp(0), P(y), k, *geom, P(ws), ws.numel(), st()), 'fwd_split')
-        tuner.ensure(ops.CONV_MODE, 0, geom, launch)
+            _native.check(sch.fn(L, 'dgrad')(P(dys), P(wts), P(dx), c, *geom, P(ws), ws.numel(), st()), 'dgrad_split')
+        tuner.ensure(ops.CONV_MODE, 1, geom, launch)
     else:
         def launch():
             ws = ops.workspace(L.semseg_conv2d_workspace_bytes(*geom), dev)
-            _native.check(L.semseg_conv2d_fwd(P(x), c, P(wt), vp(0), P(y), k, *geom, P(ws), ws.numel(), st()), 'fwd')
+            _native.check(L.semseg_conv2d_dgrad(P(dy), k, P(wtt), P(dx), c, *geom, P(ws), ws.numel(), st()), 'dgrad')
     for _ in range(2):
         launch()
     torch.cuda.synchronize()
@@ -125,17 +125,17 @@ def roofline_entry(kt):
                 'mfma_pipe_utilisation': round(terms * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
                 'path_ceiling_tflops': round(PEAK_BF16_MFMA_TFLOPS / terms, 1),
                 'frac_of_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                'algorithmic_bytes': 227.0e6 if ops.CONV_MODE == 'h2' else None,
+                'algorithmic_bytes': 226.5e6 if ops.CONV_MODE == 'h2' else None,
                 'clock_ghz_under_load': H2_CONV_LAST_CLOCK_GHZ if ops.CONV_MODE == 'h2' else None,
                 'mfma_pipe_utilisation_at_measured_clock': round(terms * achieved / (PEAK_BF16_MFMA_TFLOPS * H2_CONV_LAST_CLOCK_GHZ / 2.4), 4)
                 if ops.CONV_MODE == 'h2' else None,
-                'kernel': 'igemm_dma/rs_kernel<%s> fwd (%s per fp32-accurate MAC block, %s), '
+                'kernel': 'igemm_dma_kernel<%s,256,256> data gradient (%s per fp32-accurate MAC block, %s), '
                           'decoder.conv_last.0 3x3 4096->512 @64x64 N=2 (309.24 GFLOP/launch algorithmic, %.3f ms/launch, '
                           'HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE from profiles/, bytes/launch)'
                           % (ops.CONV_MODE, what, inst, kt * 1e3)}
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': F32_CONV_LAST_HBM_BYTES,
-            'kernel': 'igemm_conv_kernel fwd (exact fp32 MFMA), decoder.conv_last.0 3x3 4096->512 @64x64 N=2 '
+            'kernel': 'igemm_conv_kernel data gradient (exact fp32 MFMA), decoder.conv_last.0 3x3 4096->512 @64x64 N=2 '
                       '(309.24 GFLOP/launch, %.3f ms/launch, HIP events)' % (kt * 1e3)}
 
 
