@@ -330,6 +330,16 @@ int semseg_winograd_input_h2(const float* x, int x_ld, const float* const* bound
                              int N, int H, int W, int C, int dil, void* stream);
 int semseg_winograd_gemm_h2(const void* v_planes, const void* u_planes, float* M, int tiles, int C, int K, void* stream);
 int semseg_winograd_output(const float* M, float* z, int z_ld, int N, int H, int W, int K, int dil, void* stream);
+/* Weight gradient of the same layers in the Winograd domain (the autograd of nn.Conv2d.weight at those call sites):
+ *   semseg_winograd_dm_h2         : h2 planes of dz [N*H*W][K] -> dM = A dz A^T as h2 planes, rows 16*tiles (f, tile)
+ *   semseg_winograd_wgrad_gemm_h2 : dU[f] = dM[f]^T V[f] (V = the forward's input transform), fp32 [16][K][C], one batched
+ *                                   launch; workspace of semseg_winograd_wgrad_workspace_bytes for its split partials
+ *   semseg_winograd_dg            : dw = G^T dU G, fp32 KRSC [K][3][3][C] */
+int semseg_winograd_dm_h2(const void* dz_planes, void* dm_planes, int N, int H, int W, int K, int dil, void* stream);
+size_t semseg_winograd_wgrad_workspace_bytes(int tiles, int C, int K);
+int semseg_winograd_wgrad_gemm_h2(const void* v_planes, const void* dm_planes, float* dU, int tiles, int C, int K,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+int semseg_winograd_dg(const float* dU, float* dw, int K, int C, void* stream);
 
 /* ---------------- optimiser (torch.optim.SGD, train.py:117-126) ----------------------------- */
 typedef struct {

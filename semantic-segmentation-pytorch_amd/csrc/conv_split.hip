@@ -1336,6 +1336,8 @@ struct WParams {
     int stride, pad, dil;
     int tiles_k, tiles_c;
     int m_per_split, splits;
+    int batches, batch_rows;   // batched weight gradient (wgrad_dma_kernel only, blockIdx.z = batch): both operands advance by
+                               // batch_rows rows per batch, the output by K*T*C; slabs are [split][batch][K*T*C]
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -1598,8 +1600,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
             const int iw = ow * p.stride - p.pad + s * p.dil;
             const bool pixok = rowok & (ih >= 0) & (iw >= 0) & (ih < p.H) & (iw < p.W);
             const uint32_t a_msk = rowok ? 0xffffffffu : 0u, b_msk = pixok ? 0xffffffffu : 0u;
-            const uint32_t a_off = (uint32_t)m * a_row_b + a_col_b;
-            const uint32_t b_off = (uint32_t)((n * p.H + ih) * p.W + iw) * b_row_b + b_col_b;
+            const uint32_t brow = (uint32_t)blockIdx.z * (uint32_t)p.batch_rows;
+            const uint32_t a_off = ((uint32_t)m + brow) * a_row_b + a_col_b;
+            const uint32_t b_off = ((uint32_t)((n * p.H + ih) * p.W + iw) + brow) * b_row_b + b_col_b;
 #pragma unroll
             for (int cb = 0; cb < CBA; ++cb)
 #pragma unroll
@@ -1725,7 +1728,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
 
     float f1 = 1.f, f2 = 1.f;
     descale_factors<SCH>(p.x_exp, p.dy_exp, f1, f2);
-    float* dst = (p.splits == 1) ? p.dw : p.partial + (size_t)z * p.K * p.T * p.C;
+    const size_t slab = (size_t)p.K * p.T * p.C;
+    const int nb = p.batches > 0 ? p.batches : 1;
+    float* dst = (p.splits == 1) ? p.dw + (size_t)blockIdx.z * slab : p.partial + ((size_t)z * nb + blockIdx.z) * slab;
     const int col_l = lane & 31, row_l = 4 * (lane >> 5);
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -1853,7 +1858,7 @@ static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits);
+    dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits, p.batches > 0 ? p.batches : 1);
     hipLaunchKernelGGL((wgrad_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(WGM * WGN * 64), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -1925,6 +1930,55 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
         SEMSEG_LAUNCH_CHECK();
     }
     return 0;
+}
+
+// the 16 weight-gradient GEMMs of a Winograd convolution (winograd.hip) as one batched launch of the LDS-DMA wgrad kernel:
+// dU[f] ([K][C]) = dM[f]^T ([tiles][K] planes) x V[f] ([tiles][C] planes), reduction over the tiles
+extern "C" int semseg_winograd_wgrad_gemm_h2(const void* v_planes, const void* dm_planes, float* dU, int tiles, int C, int K,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!v_planes || !dm_planes || !dU || tiles <= 0 || C <= 0 || K <= 0 || !aligned16(v_planes) || !aligned16(dm_planes))
+        return SEMSEG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    WParams p = {};
+    p.xs = (const uint16_t*)v_planes; p.dys = (const uint16_t*)dm_planes; p.dw = dU;
+    p.Cp = round_up32(C); p.Kp = round_up32(K); p.xpitch = split_pitch(C); p.dypitch = split_pitch(K);
+    p.H = 1; p.W = tiles; p.C = C; p.OH = 1; p.OW = tiles; p.K = K;
+    p.M = tiles;
+    p.S = 1; p.T = 1;
+    p.stride = 1; p.pad = 0; p.dil = 1;
+    const size_t x_plane = (size_t)16 * tiles * p.xpitch, dy_plane = (size_t)16 * tiles * p.dypitch;
+    if (x_plane >= ((size_t)1 << 31) || dy_plane >= ((size_t)1 << 31)) return SEMSEG_EINVAL;
+    p.x_plane = (uint32_t)x_plane; p.dy_plane = (uint32_t)dy_plane;
+    p.x_exp = h2_exp_ptr(v_planes, (size_t)16 * tiles, C);
+    p.dy_exp = h2_exp_ptr(dm_planes, (size_t)16 * tiles, K);
+    p.batches = 16; p.batch_rows = tiles;
+    static const int force_split = env_int("SEMSEG_WINO_WSPLIT", 0);
+    const bool big = K >= 256 && C >= 256;
+    const int BM = big ? 256 : 128, BN = big ? 256 : 128;
+    p.tiles_k = ceil_div(K, BM); p.tiles_c = ceil_div(C, BN);
+    const int mtiles = ceil_div(tiles, 32);
+    // enough blocks for two waves of the chip; splits over the tiles only when the 16 batches do not provide them
+    int splits = force_split > 0 ? force_split : 1;
+    if (force_split <= 0)
+        while (splits < 8 && (long)p.tiles_k * p.tiles_c * 16 * splits < 384 && mtiles / (splits * 2) >= 8) splits *= 2;
+    p.m_per_split = ceil_div(mtiles, splits) * 32;
+    p.splits = ceil_div(tiles, p.m_per_split);
+    const size_t slab = (size_t)16 * K * C;
+    if (p.splits > 1) {
+        if (!workspace || workspace_bytes < (size_t)p.splits * slab * sizeof(float)) return SEMSEG_EWORKSPACE;
+        p.partial = (float*)workspace;
+    }
+    const int rc = big ? launch_wgrad_dma<SchH2, 256, 256, 2, 4, 2>(p, st) : launch_wgrad_dma<SchH2, 128, 128, 2, 2, 2>(p, st);
+    if (rc) return rc;
+    if (p.splits > 1) {
+        const int blocks = (int)min((size_t)2048, ceil_div_sz(slab / 4, 256));
+        hipLaunchKernelGGL(split_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dU, slab, p.splits);
+        SEMSEG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+extern "C" size_t semseg_winograd_wgrad_workspace_bytes(int tiles, int C, int K) {
+    return (size_t)8 * 16 * K * C * sizeof(float);      // at most 8 splits
 }
 
 extern "C" int semseg_conv2d_wgrad_s3(const void* xs, const void* dys, float* dw,

@@ -196,3 +196,138 @@ extern "C" int semseg_winograd_output(const float* M, float* z, int z_ld, int N,
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Winograd weight gradient (same layers):  dU[f] = dM[f]^T V[f]  with  dM = A dY A^T  (the adjoint of the output
+// transform; 2x2 output-gradient tile -> 16 frequencies) and V the input transform kept from the forward; then
+// dg = G^T dU G (the adjoint of the weight transform).  dY is read from the h2 planes the BN backward kernel wrote
+// (dz has no fp32 copy); |dM| <= 4 max|dz|, so the planes of dM use the exponent of dz minus 2 and the values are formed in
+// the scaled domain: 0.25 * (+-p +- p ...) of the fp16 parts (exact in fp32) -- no bound pass, no rescaling.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_dm_kernel(const uint16_t* __restrict__ dzp, size_t dz_plane, int dz_pitch,
+                                                      const int* __restrict__ dz_hdr, uint16_t* __restrict__ planes, size_t plane,
+                                                      int pitch, int* __restrict__ hdr, WinoGeom g, int Kp) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16) reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) hdr[0] = dz_hdr[0] - 2;
+    }
+    const int G4 = Kp >> 2;
+    const size_t total = (size_t)g.tiles * G4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx / G4);
+        const int k = (int)(idx - (size_t)t * G4) << 2;
+        int n, ph, pw, ty, tx;
+        wino_tile(g, t, n, ph, pw, ty, tx);
+        float y[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int h = (2 * ty + i) * g.dil + ph, w = (2 * tx + j) * g.dil + pw;
+                const bool ok = (k < g.K) && (h < g.H) && (w < g.W);
+                f16x4 p0, p1;
+                if (ok) {
+                    const size_t off = ((size_t)(n * g.H + h) * g.W + w) * dz_pitch + k;
+                    p0 = *reinterpret_cast<const f16x4*>(dzp + off);
+                    p1 = *reinterpret_cast<const f16x4*>(dzp + dz_plane + off);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[i][j][e] = ok ? ((float)p0[e] + (float)p1[e]) * 0.25f : 0.f;
+            }
+        // A y (rows): m0 = y0, m1 = y0 + y1, m2 = y0 - y1, m3 = -y1; then (.) A^T (columns)
+        float a[4][2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y0 = y[0][j][e], y1 = y[1][j][e];
+                a[0][j][e] = y0; a[1][j][e] = y0 + y1; a[2][j][e] = y0 - y1; a[3][j][e] = -y1;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float m[4][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = a[i][0][e], a1 = a[i][1][e];
+                m[0][e] = a0; m[1][e] = a0 + a1; m[2][e] = a0 - a1; m[3][e] = -a1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f16x4 q0, q1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 hi, lo;
+                    h2_split_of(m[j][e], hi, lo);
+                    q0[e] = hi;
+                    q1[e] = lo;
+                }
+                const size_t off = ((size_t)(i * 4 + j) * g.tiles + t) * pitch + k;
+                *reinterpret_cast<f16x4*>(planes + off) = q0;
+                *reinterpret_cast<f16x4*>(planes + plane + off) = q1;
+            }
+        }
+    }
+}
+
+extern "C" int semseg_winograd_dm_h2(const void* dz_planes, void* dm_planes, int N, int H, int W, int K, int dil, void* stream) {
+    if (!dz_planes || !dm_planes || N <= 0 || H <= 0 || W <= 0 || K <= 0 || dil <= 0 || !aligned16(dz_planes) ||
+        !aligned16(dm_planes))
+        return SEMSEG_EINVAL;
+    const WinoGeom g = wino_geom(N, H, W, 1, K, dil);
+    const size_t P = (size_t)N * H * W, rows = (size_t)16 * g.tiles;
+    const int Kp = round_up32(K), pitch = split_pitch(K);
+    const size_t dz_plane = h2_plane_elems(P, K), plane = h2_plane_elems(rows, K);
+    if ((size_t)2 * H2_NP * plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31)) return SEMSEG_EINVAL;
+    const int* dz_hdr = h2_exp_ptr(dz_planes, P, K);
+    int* hdr = const_cast<int*>(h2_exp_ptr(dm_planes, rows, K));
+    size_t blocks = ceil_div_sz((size_t)g.tiles * (Kp / 4), 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(wino_dm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dz_planes,
+                       dz_plane, pitch, dz_hdr, (uint16_t*)dm_planes, plane, pitch, hdr, g, Kp);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dw[k][r][s][c] = (G^T dU G)[r][s]:  one thread = 4 channels of one k
+__global__ __launch_bounds__(256) void wino_dg_kernel(const float* __restrict__ dU, float* __restrict__ dw, int K, int C) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)K * C4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx / C4);
+        const int c = (int)(idx - (size_t)k * C4) << 2;
+        float4 u[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[i][j] = *reinterpret_cast<const float4*>(dU + ((size_t)(i * 4 + j) * K + k) * C + c);
+        // G^T u (rows): r0 = u0 + (u1 + u2)/2, r1 = (u1 - u2)/2, r2 = (u1 + u2)/2 + u3; then (.) G (columns)
+        float4 r[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 u0 = u[0][j], u1 = u[1][j], u2 = u[2][j], u3 = u[3][j];
+            r[0][j] = make_float4(u0.x + 0.5f * (u1.x + u2.x), u0.y + 0.5f * (u1.y + u2.y), u0.z + 0.5f * (u1.z + u2.z), u0.w + 0.5f * (u1.w + u2.w));
+            r[1][j] = make_float4(0.5f * (u1.x - u2.x), 0.5f * (u1.y - u2.y), 0.5f * (u1.z - u2.z), 0.5f * (u1.w - u2.w));
+            r[2][j] = make_float4(0.5f * (u1.x + u2.x) + u3.x, 0.5f * (u1.y + u2.y) + u3.y, 0.5f * (u1.z + u2.z) + u3.z, 0.5f * (u1.w + u2.w) + u3.w);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float4 a0 = r[i][0], a1 = r[i][1], a2 = r[i][2], a3 = r[i][3];
+            const float4 o0 = make_float4(a0.x + 0.5f * (a1.x + a2.x), a0.y + 0.5f * (a1.y + a2.y), a0.z + 0.5f * (a1.z + a2.z), a0.w + 0.5f * (a1.w + a2.w));
+            const float4 o1 = make_float4(0.5f * (a1.x - a2.x), 0.5f * (a1.y - a2.y), 0.5f * (a1.z - a2.z), 0.5f * (a1.w - a2.w));
+            const float4 o2 = make_float4(0.5f * (a1.x + a2.x) + a3.x, 0.5f * (a1.y + a2.y) + a3.y, 0.5f * (a1.z + a2.z) + a3.z, 0.5f * (a1.w + a2.w) + a3.w);
+            float* d = dw + ((size_t)k * 9 + i * 3) * C + c;
+            *reinterpret_cast<float4*>(d) = o0;
+            *reinterpret_cast<float4*>(d + C) = o1;
+            *reinterpret_cast<float4*>(d + 2 * (size_t)C) = o2;
+        }
+    }
+}
+
+extern "C" int semseg_winograd_dg(const float* dU, float* dw, int K, int C, void* stream) {
+    if (!dU || !dw || K <= 0 || C <= 0 || (C % 4) || !aligned16(dU) || !aligned16(dw)) return SEMSEG_EINVAL;
+    size_t blocks = ceil_div_sz((size_t)K * (C / 4), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wino_dg_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dU, dw, K, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}

@@ -98,6 +98,10 @@ SIGNATURES = {
     'semseg_winograd_input_h2': (c_int, [vp, c_int, ctypes.POINTER(vp), c_int, vp, c_int, c_int, c_int, c_int, c_int, vp]),
     'semseg_winograd_gemm_h2': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
     'semseg_winograd_output': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'semseg_winograd_dm_h2': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
+    'semseg_winograd_wgrad_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
+    'semseg_winograd_wgrad_gemm_h2': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, c_sz, vp]),
+    'semseg_winograd_dg': (c_int, [vp, vp, c_int, c_int, vp]),
     'semseg_sgd_step': (c_int, [ctypes.POINTER(SgdTensor), c_int, vp, c_f, c_f, vp]),
 }
 

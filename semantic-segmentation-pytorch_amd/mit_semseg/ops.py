@@ -279,6 +279,8 @@ def absmax_of(t):
 # SEMSEG_WINOGRAD=0 disables.
 WINOGRAD = os.environ.get('SEMSEG_WINOGRAD', '1') != '0'
 WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '1024'))
+# the weight gradient of the same layers in the Winograd domain (dU[f] = dM[f]^T V[f], V kept from the forward pass)
+WINOGRAD_WGRAD = os.environ.get('SEMSEG_WINOGRAD_WGRAD', '0') == '1'
 
 
 def _wino_eligible(k, c, r, s):
@@ -623,6 +625,24 @@ def _winograd_fwd(L, x, bounds, u_planes, z, geom):
     _native.check(L.semseg_winograd_input_h2(_p(x), x_ld, bp, nb, _p(v), n, h, wd, c, dil, _st()), 'winograd_input_h2')
     _native.check(L.semseg_winograd_gemm_h2(_p(v), _p(u_planes), _p(m), tiles, c, k, _st()), 'winograd_gemm_h2')
     _native.check(L.semseg_winograd_output(_p(m), _p(z), k, n, h, wd, k, dil, _st()), 'winograd_output')
+    return v
+
+
+def _winograd_wgrad(L, v, dzp, geom):
+    """dw of the same convolution from the forward's V planes and the h2 planes of dz: dM = A dz A^T (planes), one batched
+    launch dU[f] = dM[f]^T V[f], dw = G^T dU G.  Returns dw as [K, C, 3, 3] (a view of the KRSC buffer)."""
+    n, h, wd, c, k, r, s, stride, pad, dil = geom
+    dev = v.device
+    tiles = L.semseg_winograd_tiles(n, h, wd, dil)
+    dm = torch.empty(L.semseg_split_h2_bytes(16 * tiles, k), dtype=torch.uint8, device=dev)
+    du = torch.empty((16, k, c), dtype=torch.float32, device=dev)
+    dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
+    ws = workspace(L.semseg_winograd_wgrad_workspace_bytes(tiles, c, k), dev)
+    _native.check(L.semseg_winograd_dm_h2(_p(dzp), _p(dm), n, h, wd, k, dil, _st()), 'winograd_dm_h2')
+    _native.check(L.semseg_winograd_wgrad_gemm_h2(_p(v), _p(dm), _p(du), tiles, c, k, _p(ws), ws.numel(), _st()),
+                  'winograd_wgrad_gemm_h2')
+    _native.check(L.semseg_winograd_dg(_p(du), _p(dwb), k, c, _st()), 'winograd_dg')
+    return dwb.permute(0, 3, 1, 2)
 
 
 class ConvBNActFn(Function):
@@ -657,8 +677,11 @@ class ConvBNActFn(Function):
         dev = x.device
         z = empty_nhwc(n, k, oh, ow, dev)
         wino = box.get('wino')
+        wino_v = None
         if wino is not None:
-            _winograd_fwd(L, x.detach(), box['x_bounds'], wino, z, geom)
+            wino_v = _winograd_fwd(L, x.detach(), box['x_bounds'], wino, z, geom)
+            if not (WINOGRAD_WGRAD and ctx.needs_input_grad[1]):
+                wino_v = None
         else:
             wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
 
@@ -704,7 +727,7 @@ class ConvBNActFn(Function):
                                                 _st()), 'bn_apply')
         # the ReLU gate of a BN without residual is recomputed from z in backward: y need not be kept for it
         keep_y = relu and residual is not None
-        ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm)
+        ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v)
         ctx.geom = geom
         ctx.cfg = (bool(relu), residual is not None)
         box['planes'], box['absmax'] = yp, absmax
@@ -719,7 +742,7 @@ class ConvBNActFn(Function):
     def backward(ctx, dy, dx_other=None):
         L = _native.lib()
         sch = SCHEMES['h2']
-        xp, w, wtp, z, y, coef, gamma, stats, zmm = ctx.saved_tensors
+        xp, w, wtp, z, y, coef, gamma, stats, zmm, wino_v = ctx.saved_tensors
         relu, has_res = ctx.cfg
         geom = ctx.geom
         n, h, wd, c, k, r, s, stride, pad, dil = geom
@@ -759,8 +782,14 @@ class ConvBNActFn(Function):
         _native.check(L.semseg_bn_bwd_apply_h2(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gamma),
                                                _p(sums), _p(count), 1, int(relu), _p(dzp), _p(dres), P, k, _p(gsc), _p(gsh),
                                                _p(bb), _st()), 'bn_bwd_apply_h2')
-        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                   addend=dx_other)
+        need_dw = ctx.needs_input_grad[1]
+        dw_wino = None
+        if wino_v is not None and need_dw:
+            dw_wino = _winograd_wgrad(L, wino_v, dzp, geom)
+            need_dw = False
+        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, ctx.needs_input_grad[0], need_dw, addend=dx_other)
+        if dw_wino is not None:
+            dw = dw_wino
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
                 None, None, None, None, None, None, None, None, None)
 

@@ -732,3 +732,71 @@ def test_winograd_forward(n, c, h, w, k, dil, monkeypatch):
     ops._winograd_fwd(L, xg, (bound * 0.5, bound), u, z, (n, h, w, c, k, 3, 3, 1, dil, dil))       # two bounds: max is taken
     torch.cuda.synchronize()
     assert rel_err(z, ref) < REL, rel_err(z, ref)
+
+
+@pytest.mark.parametrize('n,c,h,w,k,dil', [(2, 256, 16, 16, 256, 1), (1, 512, 24, 24, 128, 4), (2, 256, 17, 19, 64, 2),
+                                           (1, 320, 7, 9, 36, 1), (2, 1024, 8, 8, 512, 1), (4, 256, 40, 40, 256, 1)], ids=str)
+def test_winograd_wgrad(n, c, h, w, k, dil, monkeypatch):
+    """weight gradient in the Winograd domain (dM = A dz A^T from the h2 planes of dz, batched dU[f] = dM[f]^T V[f] on the
+    forward's V planes -- with split partials for the last case --, dw = G^T dU G) against a float64 weight gradient"""
+    from mit_semseg import ops, _native
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    L = _native.lib()
+    g = torch.Generator().manual_seed(n * 1000 + c + dil + 7)
+    x = torch.randn(n, c, h, w, generator=g).relu() * 1.5
+    x.view(-1)[::997] *= 30.0
+    dz = torch.randn(n, k, h, w, generator=g) * 1e-3
+    dz.view(-1)[::1013] *= 20.0
+    ref = torch.nn.grad.conv2d_weight(x.double(), (k, c, 3, 3), dz.double(), stride=1, padding=dil, dilation=dil)
+    geom = (n, h, w, c, k, 3, 3, 1, dil, dil)
+    xg, dzg = cl(x), cl(dz)
+    wp = torch.nn.Parameter(cl(torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5))
+    monkeypatch.setattr(ops, 'WINOGRAD', True)
+    monkeypatch.setattr(ops, 'WINOGRAD_MIN_C', 32)
+    ops.prepare_conv_weights([wp])
+    z = ops.empty_nhwc(n, k, h, w, xg.device)
+    v = ops._winograd_fwd(L, xg, (xg.abs().max().reshape(1),), ops.weight_wino(wp), z, geom)
+    dzp = ops.SCHEMES['h2'].split(dzg.permute(0, 2, 3, 1), n * h * w, k, k)
+    dw = ops._winograd_wgrad(L, v, dzp, geom)
+    torch.cuda.synchronize()
+    assert dw.shape == ref.shape
+    assert rel_err(dw, ref) < REL * 4, rel_err(dw, ref)
+
+
+def test_conv_bn_act_winograd_wgrad_matches_direct(monkeypatch):
+    """the fused node with SEMSEG_WINOGRAD_WGRAD: same weight gradient as the direct wgrad kernels and as float64"""
+    from mit_semseg import ops
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    monkeypatch.setattr(ops, 'WINOGRAD', True)
+    monkeypatch.setattr(ops, 'WINOGRAD_MIN_C', 64)
+    n, c, h, w, k, dil = 2, 192, 20, 24, 128, 2
+    g = torch.Generator().manual_seed(4242)
+    x = torch.randn(n, c, h, w, generator=g).relu()
+    wt = torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    ga, be = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g) * 0.1
+    gy = torch.randn(n, k, h, w, generator=g)
+
+    def run(wino_wgrad):
+        monkeypatch.setattr(ops, 'WINOGRAD_WGRAD', wino_wgrad)
+        xg = cl(x).requires_grad_(True)
+        ops.attach_absmax(xg, xg.detach().abs().max().reshape(1))
+        wg, gg, bg = torch.nn.Parameter(cl(wt)), torch.nn.Parameter(ga.to(dev())), torch.nn.Parameter(be.to(dev()))
+        ops.prepare_conv_weights([wg])
+        y = ops.conv_bn_act(xg, wg, gg, bg, torch.zeros(k, device=dev()), torch.ones(k, device=dev()),
+                            torch.zeros((), dtype=torch.long, device=dev()), stride=1, padding=dil, dilation=dil,
+                            training=True, relu=True)
+        y.backward(cl(gy))
+        torch.cuda.synchronize()
+        return y.detach(), xg.grad, wg.grad
+
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yr = torch.relu(F.batch_norm(F.conv2d(xd, wd, None, 1, dil, dil), None, None, ga.double(), be.double(), True, 0.1, 1e-5))
+    yr.backward(gy.double())
+    y1, dx1, dw1 = run(True)
+    y0, dx0, dw0 = run(False)
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    assert dw1.shape == dw0.shape
+    e = ((dw1.double() - dw0.double()).norm() / dw0.double().norm()).item()
+    assert e < 1e-5, e
+    e = ((dw1.double().cpu() - wd.grad).norm() / wd.grad.norm()).item()
+    assert e < 3e-3, e
