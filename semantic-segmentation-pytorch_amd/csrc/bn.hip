@@ -87,8 +87,17 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 __device__ __forceinline__ double colsum_block(const double* __restrict__ partial, int nparts, int C2, int j, int lane,
                                                double (*red)[17]) {
     double s = 0.0;
-    if (j < C2)
-        for (int b = lane; b < nparts; b += 16) s += partial[(size_t)b * C2 + j];
+    if (j < C2) {
+        int b = lane;
+        for (; b + 7 * 16 < nparts; b += 8 * 16) {       // 8 loads in flight, additions in the order of the plain loop
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + 16 * u) * C2 + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nparts; b += 16) s += partial[(size_t)b * C2 + j];
+    }
     red[lane][threadIdx.x & 15] = s;
     __syncthreads();
     double t = 0.0;
@@ -414,6 +423,7 @@ extern "C" size_t semseg_bn_mm_workspace_bytes(int P, int C) {
 }
 
 // as bn_stats_partial_kernel + per-channel min / max of z:  mm[by][0][c] = min, mm[by][1][c] = max
+constexpr int ROWS_IN_FLIGHT = 8;
 __global__ __launch_bounds__(256) void bn_stats_mm_partial_kernel(const float* __restrict__ z, int P, int C, int cx, int py,
                                                                   int rows_per_block, double* __restrict__ partial,
                                                                   float* __restrict__ mm) {
@@ -429,14 +439,24 @@ __global__ __launch_bounds__(256) void bn_stats_mm_partial_kernel(const float* _
     float4 hi = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     const bool active = (ty < py) && (c < C);
     if (active) {
-        for (int p = row0 + ty; p < row1; p += py) {
-            const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + c);
+        auto acc = [&](const float4 v) {
             const double x = v.x, y = v.y, zz = v.z, w = v.w;
             a0 += x; a1 += y; a2 += zz; a3 += w;
             q0 = fma(x, x, q0); q1 = fma(y, y, q1); q2 = fma(zz, zz, q2); q3 = fma(w, w, q3);
             lo.x = fminf(lo.x, v.x); lo.y = fminf(lo.y, v.y); lo.z = fminf(lo.z, v.z); lo.w = fminf(lo.w, v.w);
             hi.x = fmaxf(hi.x, v.x); hi.y = fmaxf(hi.y, v.y); hi.z = fmaxf(hi.z, v.z); hi.w = fmaxf(hi.w, v.w);
+        };
+        // ROWS_IN_FLIGHT loads are issued before the first is consumed (a thread walks only ~8 rows: one load per
+        // iteration makes the pass latency-bound); the accumulation order is that of the plain loop
+        int p = row0 + ty;
+        for (; p + (ROWS_IN_FLIGHT - 1) * py < row1; p += ROWS_IN_FLIGHT * py) {
+            float4 v[ROWS_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) v[u] = *reinterpret_cast<const float4*>(z + (size_t)(p + u * py) * C + c);
+#pragma unroll
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) acc(v[u]);
         }
+        for (; p < row1; p += py) acc(*reinterpret_cast<const float4*>(z + (size_t)p * C + c));
     }
     if (ty < py) {
         double* r = red + ((size_t)ty * cx + tx) * 8;
@@ -485,11 +505,13 @@ __global__ __launch_bounds__(256) void bn_stats_mm_finish_kernel(const double* _
     const int lane = threadIdx.x >> 4;
     const bool is_min = j < C;
     float m = is_min ? INFINITY : -INFINITY;
-    if (j < C2)
-        for (int b = lane; b < nparts; b += 16) {
+    if (j < C2) {
+#pragma unroll 8
+        for (int b = lane; b < nparts; b += 16) {        // min / max: order-free, the compiler may batch the loads
             const float v = mm[(size_t)b * C2 + j];
             m = is_min ? fminf(m, v) : fmaxf(m, v);
         }
+    }
     redf[lane][threadIdx.x & 15] = m;
     const double t = colsum_block(partial, nparts, C2, j, lane, red);     // contains the __syncthreads
     if (lane == 0 && j < C2) {
@@ -700,13 +722,10 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
     if (ty < py && c < C) {
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        for (int p = row0 + ty; p < row1; p += py) {
-            float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c);
-            const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + c);
+        const bool gate_z = relu && gscale, gate_y = relu && !gscale;
+        auto acc = [&](float4 g, const float4 v, const float4 yin) {
             if (relu) {
-                float4 yy;
-                if (gscale) yy = relu_gate_from_z(v, gscale + c, gshift + c);
-                else yy = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c);
+                const float4 yy = gate_z ? relu_gate_from_z(v, gscale + c, gshift + c) : yin;
                 g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                 g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
             }
@@ -718,7 +737,24 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
             gx.y = (fabsf(g.y) > gx.y || g.y != g.y) ? fabsf(g.y) : gx.y;
             gx.z = (fabsf(g.z) > gx.z || g.z != g.z) ? fabsf(g.z) : gx.z;
             gx.w = (fabsf(g.w) > gx.w || g.w != g.w) ? fabsf(g.w) : gx.w;
+        };
+        // 4 rows (8-12 loads) in flight, accumulation order of the plain loop (see bn_stats_mm_partial_kernel)
+        constexpr int U = 4;
+        int p = row0 + ty;
+        for (; p + (U - 1) * py < row1; p += U * py) {
+            float4 g[U], v[U], yy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                g[u] = *reinterpret_cast<const float4*>(dy + (size_t)(p + u * py) * dy_ld + c);
+                v[u] = *reinterpret_cast<const float4*>(z + (size_t)(p + u * py) * C + c);
+                yy[u] = gate_y ? *reinterpret_cast<const float4*>(y + (size_t)(p + u * py) * y_ld + c) : f4zero();
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc(g[u], v[u], yy[u]);
         }
+        for (; p < row1; p += py)
+            acc(*reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c), *reinterpret_cast<const float4*>(z + (size_t)p * C + c),
+                gate_y ? *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c) : f4zero());
     }
     if (ty < py) {
         double* r = red + ((size_t)ty * cx + tx) * 8;
@@ -759,8 +795,10 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_finish_kernel(const double* __r
     const int j = blockIdx.x * 16 + (threadIdx.x & 15);
     const int lane = threadIdx.x >> 4;
     uint32_t m = 0;
-    if (j < C)
+    if (j < C) {
+#pragma unroll 8
         for (int b = lane; b < nparts; b += 16) m = max(m, absbits(gm[(size_t)b * C + j]));
+    }
     redu[lane][threadIdx.x & 15] = m;
     const double s = colsum_block(partial, nparts, 2 * C, j, lane, red);   // contains the __syncthreads
     if (lane != 0 || j >= 2 * C) return;
@@ -967,13 +1005,32 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     const int C2 = 2 * C;
     double su = 0.0, sq = 0.0;
     float lo = INFINITY, hi = -INFINITY;
-    if (c < C)
-        for (int b = lane; b < nparts; b += 16) {
+    if (c < C) {
+        // 8 partial rows (32 loads) in flight; additions in the order of the plain loop (bit-identical sums)
+        constexpr int U = 8;
+        int b = lane;
+        for (; b + (U - 1) * 16 < nparts; b += U * 16) {
+            double ps[U], pq[U];
+            float pl[U], ph[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t o = (size_t)(b + 16 * u) * C2;
+                ps[u] = partial[o + c]; pq[u] = partial[o + C + c];
+                pl[u] = mm[o + c]; ph[u] = mm[o + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                su += ps[u]; sq += pq[u];
+                lo = fminf(lo, pl[u]); hi = fmaxf(hi, ph[u]);
+            }
+        }
+        for (; b < nparts; b += 16) {
             su += partial[(size_t)b * C2 + c];
             sq += partial[(size_t)b * C2 + C + c];
             lo = fminf(lo, mm[(size_t)b * C2 + c]);
             hi = fmaxf(hi, mm[(size_t)b * C2 + C + c]);
         }
+    }
     rs[lane][cl] = su; rq[lane][cl] = sq; rlo[lane][cl] = lo; rhi[lane][cl] = hi;
     __syncthreads();
     uint32_t bits = 0;
@@ -1056,12 +1113,29 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
     const int C2 = 2 * C;
     double su = 0.0, sq = 0.0;
     uint32_t gmx = 0;
-    if (c < C)
-        for (int b = lane; b < nparts; b += 16) {
+    if (c < C) {
+        constexpr int U = 8;                   // as bn_fwd_finish_fused_kernel
+        int b = lane;
+        for (; b + (U - 1) * 16 < nparts; b += U * 16) {
+            double ps[U], pq[U];
+            float pg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ps[u] = partial[(size_t)(b + 16 * u) * C2 + c]; pq[u] = partial[(size_t)(b + 16 * u) * C2 + C + c];
+                pg[u] = gm[(size_t)(b + 16 * u) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                su += ps[u]; sq += pq[u];
+                gmx = max(gmx, absbits(pg[u]));
+            }
+        }
+        for (; b < nparts; b += 16) {
             su += partial[(size_t)b * C2 + c];
             sq += partial[(size_t)b * C2 + C + c];
             gmx = max(gmx, absbits(gm[(size_t)b * C + c]));
         }
+    }
     rs[lane][cl] = su; rq[lane][cl] = sq; rg[lane][cl] = gmx;
     __syncthreads();
     uint32_t bits = 0;

@@ -937,19 +937,22 @@ __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, cons
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
             const int m = (int)(i / qpr);
             const int n = (int)(i - (size_t)m * qpr) << 2;
+            // all loads of a group of 4 slabs are issued before the first add (the plain loop has ONE load in flight per
+            // thread and is latency-bound); the additions keep the order z = 0, 1, 2, ...
             float4 s = p4[i];
-            for (int zz = 1; zz < splits; ++zz) {
-                const float4 v = p4[(size_t)zz * quads + i];
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            const float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : f4zero();
+            const float4 a = addend ? *reinterpret_cast<const float4*>(addend + (size_t)m * addend_ld + n) : f4zero();
+            for (int zz = 1; zz < splits; zz += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (zz + u < splits) v[u] = p4[(size_t)(zz + u) * quads + i];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (zz + u < splits) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
             }
-            if (bias) {
-                const float4 b = *reinterpret_cast<const float4*>(bias + n);
-                s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-            }
-            if (addend) {
-                const float4 a = *reinterpret_cast<const float4*>(addend + (size_t)m * addend_ld + n);
-                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-            }
+            if (bias) { s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
+            if (addend) { s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
             *reinterpret_cast<float4*>(out + (size_t)m * out_ld + n) = s;
         }
         return;
@@ -1756,9 +1759,14 @@ __global__ void split_wgrad_reduce_kernel(const float* __restrict__ partial, flo
     float4* o4 = reinterpret_cast<float4*>(dw);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = p4[i];
-        for (int z = 1; z < splits; ++z) {
-            const float4 v = p4[(size_t)z * quads + i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int z = 1; z < splits; z += 4) {     // 4 loads in flight, additions in slab order (see split_gemm_reduce_kernel)
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (z + u < splits) v[u] = p4[(size_t)(z + u) * quads + i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (z + u < splits) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
         o4[i] = s;
     }

@@ -204,12 +204,38 @@ __global__ __launch_bounds__(256) void sgd_kernel(const SgdBatch b, const float*
     const float lr = lr_ptr[0];
     const int64_t n = t.numel;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float w = t.param[i];
-        const float g = fmaf(t.weight_decay, w, t.grad[i] * grad_scale);
-        const float m = t.first_step ? g : fmaf(momentum, t.momentum_buf[i], g);
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto upd = [&](float w, float gr, float mb, float& m_out, float& w_out) {
+        const float g = fmaf(t.weight_decay, w, gr * grad_scale);
+        const float m = t.first_step ? g : fmaf(momentum, mb, g);
+        m_out = m;
+        w_out = w - lr * m;
+    };
+    // 16-byte lanes when the three arrays allow it (gradients that live inside a bucket may start at any element)
+    const bool vec = ((reinterpret_cast<uintptr_t>(t.param) | reinterpret_cast<uintptr_t>(t.grad) |
+                       reinterpret_cast<uintptr_t>(t.momentum_buf)) & 15) == 0;
+    int64_t done = 0;
+    if (vec) {
+        const int64_t quads = n >> 2;
+        float4* p4 = reinterpret_cast<float4*>(t.param);
+        float4* m4 = reinterpret_cast<float4*>(t.momentum_buf);
+        const float4* g4 = reinterpret_cast<const float4*>(t.grad);
+        for (int64_t i = tid; i < quads; i += stride) {
+            const float4 w = p4[i], gr = g4[i];
+            const float4 mb = t.first_step ? f4zero() : m4[i];
+            float4 m, wn;
+            upd(w.x, gr.x, mb.x, m.x, wn.x); upd(w.y, gr.y, mb.y, m.y, wn.y);
+            upd(w.z, gr.z, mb.z, m.z, wn.z); upd(w.w, gr.w, mb.w, m.w, wn.w);
+            m4[i] = m;
+            p4[i] = wn;
+        }
+        done = quads << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += stride) {
+        float m, wn;
+        upd(t.param[i], t.grad[i], t.first_step ? 0.f : t.momentum_buf[i], m, wn);
         t.momentum_buf[i] = m;
-        t.param[i] = w - lr * m;
+        t.param[i] = wn;
     }
 }
 

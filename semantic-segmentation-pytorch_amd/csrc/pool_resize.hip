@@ -4,6 +4,7 @@
 // backward is written in GATHER form (each output element owned by exactly one thread, fixed
 // summation order) so results are deterministic without atomics.
 #include "common.h"
+#include <stdlib.h>
 
 static inline int stream_blocks(size_t items) {
     size_t b = ceil_div_sz(items, 256);
@@ -431,6 +432,123 @@ __global__ __launch_bounds__(256) void multipool_bwd_kernel(MultiPool mp, float*
     }
 }
 
+// ---- second generation of the two streaming passes.  The kernels above are ALU-bound, not HBM-bound: the bin bounds are
+// integer divisions by run-time values, evaluated per (pixel, slot) in the forward row walk and per (pixel, channel quad)
+// in the backward pass (rocprof r2s: 123 us / 111 us for a 2x64x64x2048 map whose 67 MB stream in ~15 us).  Here the bounds
+// are computed once per thread (forward: 16 slots before the row walk; backward: per pixel, reused for every channel quad
+// of the thread) and the forward walk keeps 8 row loads in flight.  Same summation order, bit-identical results.
+__global__ __launch_bounds__(256) void multipool_rowsum2_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ rowsum,
+                                                                MultiPool mp, int N, int H, int W, int C) {
+    int lo[MP_MAXCOLS], hi[MP_MAXCOLS];
+#pragma unroll
+    for (int k = 0; k < MP_MAXCOLS; ++k) {
+        int sc = 0;
+#pragma unroll
+        for (int t = 1; t < MP_MAXSCALES; ++t) sc += (t < mp.nscale && k >= mp.col0[t]) ? 1 : 0;
+        const int j = k - mp.col0[sc];
+        const bool live = k < mp.ncols;
+        lo[k] = live ? bin_start(j, W, mp.s[sc]) : 0;
+        hi[k] = live ? bin_end(j, W, mp.s[sc]) : 0;
+    }
+    const int qpr = C / 4;
+    const size_t total = (size_t)N * H * qpr;
+    GRID_STRIDE(i, total) {
+        const size_t row = i / qpr;                 // n * H + h
+        const int c = (int)(i - row * qpr) * 4;
+        float4 acc[MP_MAXCOLS];
+#pragma unroll
+        for (int k = 0; k < MP_MAXCOLS; ++k) acc[k] = f4zero();
+        const float* src = x + row * W * (size_t)x_ld + c;
+        for (int w0 = 0; w0 < W; w0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = (w0 + u < W) ? *reinterpret_cast<const float4*>(src + (size_t)(w0 + u) * x_ld) : f4zero();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int w = w0 + u;
+                if (w < W) {
+#pragma unroll
+                    for (int k = 0; k < MP_MAXCOLS; ++k) {
+                        const bool in = (w >= lo[k]) && (w < hi[k]);
+                        acc[k].x += in ? v[u].x : 0.f; acc[k].y += in ? v[u].y : 0.f;
+                        acc[k].z += in ? v[u].z : 0.f; acc[k].w += in ? v[u].w : 0.f;
+                    }
+                }
+            }
+        }
+        float* dst = rowsum + row * (size_t)mp.ncols * C + c;
+#pragma unroll
+        for (int k = 0; k < MP_MAXCOLS; ++k)
+            if (k < mp.ncols) *reinterpret_cast<float4*>(dst + (size_t)k * C) = acc[k];
+    }
+}
+
+// block = 4 pixels x 64 channel-quad lanes.  Requires H >= 2 S and W >= 2 S for every scale (checked by the launcher):
+// then a pixel lies in at most two bins per axis.
+__global__ __launch_bounds__(256) void multipool_bwd2_kernel(MultiPool mp, float* __restrict__ dx, int dx_ld, int N, int H, int W,
+                                                             int C) {
+    const int lane = threadIdx.x & 63;
+    const unsigned P = (unsigned)N * H * W;
+    const int qpr = C / 4;
+    for (unsigned ip = blockIdx.x * 4 + (threadIdx.x >> 6); ip < P; ip += gridDim.x * 4) {
+        const int iw = (int)(ip % (unsigned)W);
+        const unsigned t = ip / (unsigned)W;
+        const int ih = (int)(t % (unsigned)H);
+        const int n = (int)(t / (unsigned)H);
+        // per scale: first bin and number of bins (1 or 2) containing the pixel on each axis, 1/count of the 2x2 candidates
+        int base[MP_MAXSCALES], nh[MP_MAXSCALES], nw[MP_MAXSCALES];
+        float inv[MP_MAXSCALES][2][2];
+#pragma unroll
+        for (int sc = 0; sc < MP_MAXSCALES; ++sc) {
+            base[sc] = 0; nh[sc] = 0; nw[sc] = 0;
+            if (sc < mp.nscale) {
+                const int S = mp.s[sc];
+                int oh = (ih * S) / H; if (oh > 0) --oh;
+                if (!(ih >= bin_start(oh, H, S) && ih < bin_end(oh, H, S))) ++oh;        // the first bin containing ih
+                int ow = (iw * S) / W; if (ow > 0) --ow;
+                if (!(iw >= bin_start(ow, W, S) && iw < bin_end(ow, W, S))) ++ow;
+                const int hl0 = bin_end(oh, H, S) - bin_start(oh, H, S), wl0 = bin_end(ow, W, S) - bin_start(ow, W, S);
+                int hl1 = 0, wl1 = 0;
+                nh[sc] = 1; nw[sc] = 1;
+                if (oh + 1 < S && bin_start(oh + 1, H, S) <= ih) { nh[sc] = 2; hl1 = bin_end(oh + 1, H, S) - bin_start(oh + 1, H, S); }
+                if (ow + 1 < S && bin_start(ow + 1, W, S) <= iw) { nw[sc] = 2; wl1 = bin_end(ow + 1, W, S) - bin_start(ow + 1, W, S); }
+                base[sc] = (n * S + oh) * S + ow;
+                inv[sc][0][0] = 1.0f / (float)(hl0 * wl0);
+                inv[sc][0][1] = 1.0f / (float)(hl0 * (wl1 > 0 ? wl1 : 1));
+                inv[sc][1][0] = 1.0f / (float)((hl1 > 0 ? hl1 : 1) * wl0);
+                inv[sc][1][1] = 1.0f / (float)((hl1 > 0 ? hl1 : 1) * (wl1 > 0 ? wl1 : 1));
+            }
+        }
+        for (int q = lane; q < qpr; q += 64) {
+            const int c = q * 4;
+            float4 acc = f4zero();
+#pragma unroll
+            for (int sc = 0; sc < MP_MAXSCALES; ++sc) {
+                if (sc < mp.nscale) {
+                    const int S = mp.s[sc];
+                    const float* dy = mp.y[sc];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            if (a < nh[sc] && b < nw[sc]) {
+                                const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)(base[sc] + a * S + b) * C + c);
+                                const float f = inv[sc][a][b];
+                                acc.x += g.x * f; acc.y += g.y * f; acc.z += g.z * f; acc.w += g.w * f;
+                            }
+                }
+            }
+            *reinterpret_cast<float4*>(dx + (size_t)ip * dx_ld + c) = acc;
+        }
+    }
+}
+
+static bool multipool_v2() {
+    static const bool on = [] { const char* v = getenv("SEMSEG_MULTIPOOL_V1"); return !(v && *v == '1'); }();
+    return on;
+}
+
 static int multipool_setup(MultiPool& mp, void* const* ys_host, const int* sizes_host, int nscale) {
     if (!ys_host || !sizes_host || nscale <= 0 || nscale > MP_MAXSCALES) return SEMSEG_EINVAL;
     mp.nscale = nscale;
@@ -463,8 +581,12 @@ extern "C" int semseg_adaptive_avgpool_multi_fwd(const float* x, int x_ld, int N
     if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* rowsum = (float*)workspace;
-    hipLaunchKernelGGL(multipool_rowsum_kernel, dim3(stream_blocks((size_t)N * H * (C / 4))), dim3(256), 0, st, x, x_ld, rowsum, mp,
-                       N, H, W, C);
+    if (multipool_v2())
+        hipLaunchKernelGGL(multipool_rowsum2_kernel, dim3(stream_blocks((size_t)N * H * (C / 4))), dim3(256), 0, st, x, x_ld, rowsum,
+                           mp, N, H, W, C);
+    else
+        hipLaunchKernelGGL(multipool_rowsum_kernel, dim3(stream_blocks((size_t)N * H * (C / 4))), dim3(256), 0, st, x, x_ld, rowsum,
+                           mp, N, H, W, C);
     SEMSEG_LAUNCH_CHECK();
     int bins = 0;
     for (int i = 0; i < nscale; ++i) bins += sizes_host[i] * sizes_host[i];
@@ -480,8 +602,16 @@ extern "C" int semseg_adaptive_avgpool_multi_bwd(void* const* dys_host, const in
     MultiPool mp;
     const int rc = multipool_setup(mp, dys_host, sizes_host, nscale);
     if (rc) return rc;
-    hipLaunchKernelGGL(multipool_bwd_kernel, dim3(stream_blocks((size_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, mp,
-                       dx, dx_ld, N, H, W, C);
+    bool two_bins = (size_t)N * H * W < ((size_t)1 << 31);
+    for (int i = 0; i < nscale; ++i) two_bins = two_bins && H >= 2 * sizes_host[i] && W >= 2 * sizes_host[i];
+    if (multipool_v2() && two_bins) {
+        size_t blocks = ceil_div_sz((size_t)N * H * W, 4);
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(multipool_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mp, dx, dx_ld, N, H, W, C);
+    } else {
+        hipLaunchKernelGGL(multipool_bwd_kernel, dim3(stream_blocks((size_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                           mp, dx, dx_ld, N, H, W, C);
+    }
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }

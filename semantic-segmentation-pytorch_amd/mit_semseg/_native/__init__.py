@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  (loads libamdhip64 first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsemseg_hip.so')
+# SEMSEG_NATIVE_LIB: another build of the same library (in-box A/B of kernel changes, tools/gpu_ab_lib.sh)
+LIB_PATH = os.environ.get('SEMSEG_NATIVE_LIB') or os.path.join(_HERE, 'libsemseg_hip.so')
 _lib = None
 
 c_int, c_f, c_sz, vp = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p

@@ -279,8 +279,9 @@ def absmax_of(t):
 # SEMSEG_WINOGRAD=0 disables.
 WINOGRAD = os.environ.get('SEMSEG_WINOGRAD', '1') != '0'
 WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '1024'))
-# the weight gradient of the same layers in the Winograd domain (dU[f] = dM[f]^T V[f], V kept from the forward pass)
-WINOGRAD_WGRAD = os.environ.get('SEMSEG_WINOGRAD_WGRAD', '0') == '1'
+# the weight gradient of the same layers in the Winograd domain (dU[f] = dM[f]^T V[f], V kept from the forward pass):
+# in-box A/B (gpurun wg1) 16.50 -> 16.02 ms per step.  SEMSEG_WINOGRAD_WGRAD=0 disables.
+WINOGRAD_WGRAD = os.environ.get('SEMSEG_WINOGRAD_WGRAD', '1') != '0'
 
 
 def _wino_eligible(k, c, r, s):
@@ -807,7 +808,6 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
                            momentum=momentum, eps=eps, relu=relu, num_batches_tracked=num_batches_tracked)
         return (y, x) if passthrough else y
     _require_cuda(x)
-    xp = input_planes(x, 'h2')
     wp, wtp = weight_planes(weight, 'h2')
     want_pair = bool(passthrough)
     passthrough = want_pair and PASSTHROUGH and x.requires_grad and torch.is_grad_enabled()
@@ -819,6 +819,11 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
         if xb is not None and len(xb) <= 8:
             box['wino'] = weight_wino(weight)            # None until prepare_conv_weights has run for this weight state
             box['x_bounds'] = xb
+    n, c, h, w = x.shape
+    if box.get('wino') is not None and (WINOGRAD_WGRAD or not weight.requires_grad):
+        xp = planes_of(x, 'h2', n * h * w, c)        # Winograd forward and weight gradient work on V: x needs no planes
+    else:
+        xp = input_planes(x, 'h2')
     out = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean, running_var,
                             num_batches_tracked, cfg, box)
     y, xr = out if passthrough else (out, x)
@@ -828,8 +833,8 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
     if absmax is not None:
         attach_absmax(y, absmax)
     if xr is not x:                        # same storage, new tensor object: carry the plane / bound records over
-        n, c, h, w = x.shape
-        attach_planes(xr, xp, 'h2', n * h * w, c)
+        if xp is not None:
+            attach_planes(xr, xp, 'h2', n * h * w, c)
         bound = bounds_of(x)
         if bound is not None:
             attach_absmax(xr, bound)
