@@ -718,22 +718,35 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     const int nh = oh_hi - oh_lo + 1, nw = ow_hi - ow_lo + 1;
     float4 s = f4zero();
     if (c < C) {
-        for (int k = tp; k < nh * nw; k += pl) {
-            const int oh = oh_lo + k / nw, ow = ow_lo + k % nw;
-            int h0, h1, w0, w1;
-            float lh0, lh1, lw0, lw1;
-            bl_coord(oh, sh, IH, h0, h1, lh0, lh1);
-            bl_coord(ow, sw, IW, w0, w1, lw0, lw1);
-            float wh = 0.f, ww = 0.f;
-            if (h0 == ih) wh += lh0;
-            if (h1 == ih) wh += lh1;
-            if (w0 == iw) ww += lw0;
-            if (w1 == iw) ww += lw1;
-            const float wgt = wh * ww;
-            if (wgt != 0.f) {
-                const float4 g = *reinterpret_cast<const float4*>(dy + ((size_t)(n * OH + oh) * OW + ow) * dy_ld + c);
-                s.x += wgt * g.x; s.y += wgt * g.y; s.z += wgt * g.z; s.w += wgt * g.w;
+        // 4 window positions per round: their loads are issued together (a tiny input map makes this a long serial walk:
+        // 1x1 -> 64x64 is 64 rounds per lane), the accumulation keeps the order of the window walk
+        const int nwin = nh * nw;
+        for (int k0 = tp; k0 < nwin; k0 += 4 * pl) {
+            float wgt[4];
+            float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * pl;
+                wgt[u] = 0.f;
+                g[u] = f4zero();
+                if (k < nwin) {
+                    const int oh = oh_lo + k / nw, ow = ow_lo + k % nw;
+                    int h0, h1, w0, w1;
+                    float lh0, lh1, lw0, lw1;
+                    bl_coord(oh, sh, IH, h0, h1, lh0, lh1);
+                    bl_coord(ow, sw, IW, w0, w1, lw0, lw1);
+                    float wh = 0.f, ww = 0.f;
+                    if (h0 == ih) wh += lh0;
+                    if (h1 == ih) wh += lh1;
+                    if (w0 == iw) ww += lw0;
+                    if (w1 == iw) ww += lw1;
+                    wgt[u] = wh * ww;
+                    if (wgt[u] != 0.f) g[u] = *reinterpret_cast<const float4*>(dy + ((size_t)(n * OH + oh) * OW + ow) * dy_ld + c);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (wgt[u] != 0.f) { s.x += wgt[u] * g[u].x; s.y += wgt[u] * g[u].y; s.z += wgt[u] * g[u].z; s.w += wgt[u] * g[u].w; }
         }
     }
     red[tp * ql + tq] = s;
