@@ -88,15 +88,16 @@ __device__ __forceinline__ double colsum_block(const double* __restrict__ partia
                                                double (*red)[17]) {
     double s = 0.0;
     if (j < C2) {
-        int b = lane;
-        for (; b + 7 * 16 < nparts; b += 8 * 16) {       // 8 loads in flight, additions in the order of the plain loop
+        // 8 loads in flight per round (rows past the end: clamped loads, values unused); additions in the order of the
+        // plain loop
+        for (int b = lane; b < nparts; b += 8 * 16) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + 16 * u) * C2 + j];
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(b + 16 * u, nparts - 1) * C2 + j];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 8; ++u) s = (b + 16 * u < nparts) ? s + v[u] : s;
         }
-        for (; b < nparts; b += 16) s += partial[(size_t)b * C2 + j];
     }
     red[lane][threadIdx.x & 15] = s;
     __syncthreads();
@@ -704,6 +705,8 @@ extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const floa
 
 // ---- backward ----------------------------------------------------------------------------------
 // as bn_bwd_partial_kernel + per-channel max |g|:  gm[by][c]
+// GATE: 0 = no ReLU, 1 = ReLU gate recomputed from z (gscale/gshift), 2 = ReLU gate read from y
+template <int GATE>
 __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __restrict__ dy, int dy_ld,
                                                                 const float* __restrict__ y, int y_ld,
                                                                 const float* __restrict__ z, const float* __restrict__ mean,
@@ -722,9 +725,9 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
     if (ty < py && c < C) {
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        const bool gate_z = relu && gscale, gate_y = relu && !gscale;
+        constexpr bool gate_z = GATE == 1, gate_y = GATE == 2;
         auto acc = [&](float4 g, const float4 v, const float4 yin) {
-            if (relu) {
+            if (GATE != 0) {
                 const float4 yy = gate_z ? relu_gate_from_z(v, gscale + c, gshift + c) : yin;
                 g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                 g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
@@ -749,6 +752,7 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
                 v[u] = *reinterpret_cast<const float4*>(z + (size_t)(p + u * py) * C + c);
                 yy[u] = gate_y ? *reinterpret_cast<const float4*>(y + (size_t)(p + u * py) * y_ld + c) : f4zero();
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < U; ++u) acc(g[u], v[u], yy[u]);
         }
@@ -827,8 +831,12 @@ extern "C" int semseg_bn_bwd_reduce_mm(const float* dy, int dy_ld, const float* 
     double* partial = (double*)workspace;
     float* gm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
-    hipLaunchKernelGGL(bn_bwd_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
-                       relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr);
+    if (relu)
+        hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<2>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
+                           relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<0>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
+                           relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr);
     SEMSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_mm_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)partial,
                        (const float*)gm, g.gy, C, sums, gmax, dgamma, dbeta);
@@ -1006,29 +1014,25 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     double su = 0.0, sq = 0.0;
     float lo = INFINITY, hi = -INFINITY;
     if (c < C) {
-        // 8 partial rows (32 loads) in flight; additions in the order of the plain loop (bit-identical sums)
+        // 8 partial rows (32 loads) in flight per round; rows past the end are clamped loads whose values are not used.
+        // Additions in the order of the plain loop (bit-identical sums).
         constexpr int U = 8;
-        int b = lane;
-        for (; b + (U - 1) * 16 < nparts; b += U * 16) {
+        for (int b = lane; b < nparts; b += U * 16) {
             double ps[U], pq[U];
             float pl[U], ph[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const size_t o = (size_t)(b + 16 * u) * C2;
+                const size_t o = (size_t)min(b + 16 * u, nparts - 1) * C2;
                 ps[u] = partial[o + c]; pq[u] = partial[o + C + c];
                 pl[u] = mm[o + c]; ph[u] = mm[o + C + c];
             }
+            __builtin_amdgcn_sched_barrier(0);      // keep the loads together (the scheduler otherwise sinks each to its use)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                su += ps[u]; sq += pq[u];
-                lo = fminf(lo, pl[u]); hi = fmaxf(hi, ph[u]);
+                const bool live = b + 16 * u < nparts;
+                su = live ? su + ps[u] : su; sq = live ? sq + pq[u] : sq;
+                lo = live ? fminf(lo, pl[u]) : lo; hi = live ? fmaxf(hi, ph[u]) : hi;
             }
-        }
-        for (; b < nparts; b += 16) {
-            su += partial[(size_t)b * C2 + c];
-            sq += partial[(size_t)b * C2 + C + c];
-            lo = fminf(lo, mm[(size_t)b * C2 + c]);
-            hi = fmaxf(hi, mm[(size_t)b * C2 + C + c]);
         }
     }
     rs[lane][cl] = su; rq[lane][cl] = sq; rlo[lane][cl] = lo; rhi[lane][cl] = hi;
@@ -1115,25 +1119,22 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
     uint32_t gmx = 0;
     if (c < C) {
         constexpr int U = 8;                   // as bn_fwd_finish_fused_kernel
-        int b = lane;
-        for (; b + (U - 1) * 16 < nparts; b += U * 16) {
+        for (int b = lane; b < nparts; b += U * 16) {
             double ps[U], pq[U];
             float pg[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                ps[u] = partial[(size_t)(b + 16 * u) * C2 + c]; pq[u] = partial[(size_t)(b + 16 * u) * C2 + C + c];
-                pg[u] = gm[(size_t)(b + 16 * u) * C + c];
+                const size_t r = (size_t)min(b + 16 * u, nparts - 1);
+                ps[u] = partial[r * C2 + c]; pq[u] = partial[r * C2 + C + c];
+                pg[u] = gm[r * C + c];
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                su += ps[u]; sq += pq[u];
-                gmx = max(gmx, absbits(pg[u]));
+                const bool live = b + 16 * u < nparts;
+                su = live ? su + ps[u] : su; sq = live ? sq + pq[u] : sq;
+                gmx = live ? max(gmx, absbits(pg[u])) : gmx;
             }
-        }
-        for (; b < nparts; b += 16) {
-            su += partial[(size_t)b * C2 + c];
-            sq += partial[(size_t)b * C2 + C + c];
-            gmx = max(gmx, absbits(gm[(size_t)b * C + c]));
         }
     }
     rs[lane][cl] = su; rq[lane][cl] = sq; rg[lane][cl] = gmx;
@@ -1182,8 +1183,13 @@ extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const floa
     double* partial = (double*)workspace;
     float* gm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
-    hipLaunchKernelGGL(bn_bwd_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
-                       relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, gate_scale, gate_shift);
+#define LAUNCH_PARTIAL(GATE)                                                                                              \
+    hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<GATE>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, \
+                       invstd, relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, gate_scale, gate_shift)
+    if (!relu) LAUNCH_PARTIAL(0);
+    else if (gate_scale) LAUNCH_PARTIAL(1);
+    else LAUNCH_PARTIAL(2);
+#undef LAUNCH_PARTIAL
     SEMSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
                        (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,

@@ -391,9 +391,21 @@ __global__ __launch_bounds__(256) void multipool_finish_kernel(const float* __re
         const int h0 = bin_start(oh, H, S), h1 = bin_end(oh, H, S);
         const int cnt = (h1 - h0) * (bin_end(ow, W, S) - bin_start(ow, W, S));
         float4 a = f4zero();
-        for (int h = h0; h < h1; ++h) {
-            const float4 v = *reinterpret_cast<const float4*>(rowsum + (((size_t)n * H + h) * mp.ncols + mp.col0[sc] + ow) * C + c);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        // 8 rows in flight per round (rows past the bin: clamped loads, values unused); additions in row order
+        for (int hb = h0; hb < h1; hb += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int h = min(hb + u, h1 - 1);
+                v[u] = *reinterpret_cast<const float4*>(rowsum + (((size_t)n * H + h) * mp.ncols + mp.col0[sc] + ow) * C + c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool live = hb + u < h1;
+                a.x = live ? a.x + v[u].x : a.x; a.y = live ? a.y + v[u].y : a.y;
+                a.z = live ? a.z + v[u].z : a.z; a.w = live ? a.w + v[u].w : a.w;
+            }
         }
         const float inv = 1.0f / (float)cnt;
         *reinterpret_cast<float4*>(mp.y[sc] + (((size_t)n * S + oh) * S + ow) * C + c) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
