@@ -20,28 +20,47 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+def _run(cmd, verbose):
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
 def build(force=False, verbose=True):
+    """Compile what is out of date and link.  Safe under concurrent callers (one process per GPU all call
+    __graft_entry__.build()): an exclusive file lock serialises them, the freshness check runs under the lock (later callers
+    find everything built), and every output is written to a temporary name and renamed into place, so a process that has
+    already mapped the library never sees it truncated."""
+    import fcntl
     os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'split_layout.h'), os.path.join(ROOT, 'include', 'semseg_hip.h')]
     objs, jobs = [], []
+    tag = '.tmp%d' % os.getpid()
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OUT_DIR, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
-            jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
+            jobs.append((obj, [HIPCC] + FLAGS + ['-c', src, '-o', obj + tag]))
     if jobs:
-        def run(cmd):
-            if verbose:
-                print(' '.join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+        def run(job):
+            obj, cmd = job
+            _run(cmd, verbose)
+            os.replace(obj + tag, obj)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        _run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB + tag] + objs, verbose)
+        os.replace(LIB + tag, LIB)
     return LIB
 
 
