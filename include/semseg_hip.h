@@ -341,6 +341,33 @@ int semseg_winograd_wgrad_gemm_h2(const void* v_planes, const void* dm_planes, f
                                   void* workspace, size_t workspace_bytes, void* stream);
 int semseg_winograd_dg(const float* dU, float* dw, int K, int C, void* stream);
 
+/* ---------------- input pipeline: training-batch assembly on the device (csrc/input_pipeline.hip) -------------------
+ * Contract of mit_semseg/dataset.py:110-199 (TrainDataset.__getitem__) from DECODED uint8 arrays (the JPEG/PNG decode stays
+ * on the host): `imresize(img, (w, h), 'bilinear')` = Pillow BILINEAR (dataset.py:9-19,167; antialiased triangle filter,
+ * 22-bit fixed-point taps, horizontal then vertical pass), `imresize(segm, ..., 'nearest')` twice (dataset.py:168-179),
+ * random flip (dataset.py:162-164), img_transform (dataset.py:53-58: /255, Normalize) and segm_transform (dataset.py:60-63:
+ * long - 1), placement into the zero-initialised batch tensors (dataset.py:143-151,188-189).  Bit-exact against Pillow.
+ *   host-side table builders (no GPU needed):
+ *     semseg_input_resample_ksize / _coeffs : Pillow precompute_coeffs + normalize_coeffs_8bpc; bounds [out][2] =
+ *                                             (first source index, tap count), kk [out][ksize] int32
+ *     semseg_input_nearest_table            : Pillow ImagingScaleAffine source index per output index (-1 = outside)
+ *   device kernels (uint8 HWC RGB in, pointers are device pointers, tables int32 on the device):
+ *     semseg_input_resample_h_u8            : src [H][W][3] (mirrored when flip) -> tmp [H][ow][3]
+ *     semseg_input_resample_v_normalize     : tmp -> fp32 NHWC slice of the batch (pixel pitch 3, row pitch BW*3):
+ *                                             ((u8 / 255) - mean[c]) / std[c]; mean_std_host = {mean[3], std[3]} (host)
+ *     semseg_input_label_gather             : dst[y][x] = (ytab[y] >= 0 && xtab[x] >= 0 ? src[ytab[y]][xtab[x]] : 0) - 1,
+ *                                             int64, row pitch LW (both resizes, the canvas and the flip folded into the
+ *                                             tables by the caller) */
+int semseg_input_resample_ksize(int in_size, int out_size);
+int semseg_input_resample_coeffs(int in_size, int out_size, int32_t* bounds_host, int32_t* kk_host);
+int semseg_input_nearest_table(int in_size, int out_size, int32_t* tab_host);
+int semseg_input_resample_h_u8(const uint8_t* src, int H, int W, int flip, const int32_t* bounds, const int32_t* kk, int ksize,
+                               uint8_t* tmp, int ow, void* stream);
+int semseg_input_resample_v_normalize(const uint8_t* tmp, int H, int ow, const int32_t* bounds, const int32_t* kk, int ksize,
+                                      int oh, const float* mean_std_host, float* dst, int BW, void* stream);
+int semseg_input_label_gather(const uint8_t* src, int W, const int32_t* ytab, const int32_t* xtab, int lh, int lw, int64_t* dst,
+                              int LW, void* stream);
+
 /* ---------------- optimiser (torch.optim.SGD, train.py:117-126) ----------------------------- */
 typedef struct {
     float* param; const float* grad; float* momentum_buf; int64_t numel; float weight_decay; int first_step;

@@ -103,6 +103,12 @@ SIGNATURES = {
     'semseg_winograd_wgrad_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
     'semseg_winograd_wgrad_gemm_h2': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, c_sz, vp]),
     'semseg_winograd_dg': (c_int, [vp, vp, c_int, c_int, vp]),
+    'semseg_input_resample_ksize': (c_int, [c_int, c_int]),
+    'semseg_input_resample_coeffs': (c_int, [c_int, c_int, vp, vp]),
+    'semseg_input_nearest_table': (c_int, [c_int, c_int, vp]),
+    'semseg_input_resample_h_u8': (c_int, [vp, c_int, c_int, c_int, vp, vp, c_int, vp, c_int, vp]),
+    'semseg_input_resample_v_normalize': (c_int, [vp, c_int, c_int, vp, vp, c_int, c_int, vp, vp, c_int, vp]),
+    'semseg_input_label_gather': (c_int, [vp, c_int, vp, vp, c_int, c_int, vp, c_int, vp]),
     'semseg_sgd_step': (c_int, [ctypes.POINTER(SgdTensor), c_int, vp, c_f, c_f, vp]),
 }
 

@@ -1,0 +1,191 @@
+"""Training-batch assembly on the device -- the input-pipeline contract of the reference (mit_semseg/dataset.py:110-199,
+`TrainDataset.__getitem__`): per-sample resize to the drawn short-side size (Pillow BILINEAR for the image, NEAREST for the
+label map), random horizontal flip, label down-sampling by `segm_downsampling_rate` through a zero canvas, ToTensor +
+Normalize, label - 1, zero-padded placement into the batch.  The reference does all of it on 16 CPU workers
+(train.py:163-177); here only the file decode stays on the host, everything from the decoded uint8 array on runs as HIP
+kernels (csrc/input_pipeline.hip), bit-exact against Pillow.
+
+    asm = TrainBatchAssembler(imgSizes, imgMaxSize, padding_constant, segm_downsampling_rate, device)
+    feed = asm.assemble(images_u8, segms_u8, flips, this_short_size)      # {'img_data', 'seg_label'} on the device
+
+`TrainDataset` mirrors the reference class (same record grouping, same numpy random draws) on top of the assembler.
+There is no CPU fallback: without the HIP library / a HIP device the assembler raises."""
+import functools
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import _native
+from .ops import _p, _st, _require_cuda
+
+MEAN = (0.485, 0.456, 0.406)         # dataset.py:34-36
+STD = (0.229, 0.224, 0.225)
+
+
+def round2nearest_multiple(x, p):
+    """dataset.py:66-67: the smallest multiple of p that is >= x"""
+    return ((x - 1) // p + 1) * p
+
+
+@functools.lru_cache(maxsize=512)
+def _resample_tables(in_size, out_size):
+    """Pillow tap tables (host): int32 [out*2] bounds followed by [out*ksize] taps, and ksize"""
+    L = _native.lib()
+    ks = L.semseg_input_resample_ksize(in_size, out_size)
+    buf = np.zeros(out_size * 2 + out_size * ks, dtype=np.int32)
+    _native.check(L.semseg_input_resample_coeffs(in_size, out_size, buf.ctypes.data, buf[out_size * 2:].ctypes.data),
+                  'input_resample_coeffs')
+    return buf, ks
+
+
+@functools.lru_cache(maxsize=512)
+def _nearest_table(in_size, out_size):
+    L = _native.lib()
+    tab = np.zeros(out_size, dtype=np.int32)
+    _native.check(L.semseg_input_nearest_table(in_size, out_size, tab.ctypes.data), 'input_nearest_table')
+    return tab
+
+
+def _label_axis_table(src_size, mid_size, rate, flip):
+    """index table of one axis of the label path: NEAREST src_size -> mid_size, paste into a zero canvas of
+    round2nearest_multiple(mid_size, rate), NEAREST canvas -> canvas / rate (dataset.py:168-179); -1 = canvas / outside"""
+    t1 = _nearest_table(src_size, mid_size)
+    canvas = round2nearest_multiple(mid_size, rate)
+    t2 = _nearest_table(canvas, canvas // rate)
+    inside = (t2 >= 0) & (t2 < mid_size)
+    out = np.full(t2.shape, -1, dtype=np.int32)
+    src = t1[np.clip(t2, 0, mid_size - 1)]
+    if flip:
+        src = np.where(src >= 0, src_size - 1 - src, -1)
+    out[inside] = src[inside]
+    return out
+
+
+class TrainBatchAssembler:
+    def __init__(self, imgSizes, imgMaxSize, padding_constant, segm_downsampling_rate, device='cuda'):
+        assert padding_constant >= segm_downsampling_rate, \
+            'padding constant must be equal or large than segm downsamping rate'            # dataset.py:141-142
+        self.imgSizes, self.imgMaxSize = imgSizes, imgMaxSize
+        self.padding_constant, self.segm_downsampling_rate = padding_constant, segm_downsampling_rate
+        self.device = torch.device(device)
+        self._mean_std = (_native.c_f * 6)(*MEAN, *STD)
+
+    def geometry(self, sizes_hw, this_short_size):
+        """dataset.py:127-142: per-sample resized widths / heights (int32 truncation) and the padded batch (H, W)"""
+        n = len(sizes_hw)
+        bw, bh = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        for i, (h, w) in enumerate(sizes_hw):
+            this_scale = min(this_short_size / min(h, w), self.imgMaxSize / max(h, w))
+            bw[i] = w * this_scale
+            bh[i] = h * this_scale
+        batch_w = int(round2nearest_multiple(np.max(bw), self.padding_constant))
+        batch_h = int(round2nearest_multiple(np.max(bh), self.padding_constant))
+        return bw, bh, batch_h, batch_w
+
+    def assemble(self, images, segms, flips, this_short_size):
+        """images: uint8 [H][W][3] tensors (decoded RGB), segms: uint8 [H][W] tensors, host or device; flips: bools.
+        Returns {'img_data': fp32 logical [B,3,BH,BW] in NHWC memory, 'seg_label': int64 [B,BH/s,BW/s]} on the device."""
+        L = _native.lib()
+        dev = self.device
+        s = self.segm_downsampling_rate
+        bw, bh, BH, BW = self.geometry([tuple(im.shape[:2]) for im in images], this_short_size)
+        B = len(images)
+        img_data = torch.zeros((B, BH, BW, 3), dtype=torch.float32, device=dev)
+        seg_label = torch.zeros((B, BH // s, BW // s), dtype=torch.int64, device=dev)
+        _require_cuda(img_data)
+        for i in range(B):
+            img = images[i].to(dev, non_blocking=True).contiguous()
+            seg = segms[i].to(dev, non_blocking=True).contiguous()
+            if img.dtype != torch.uint8 or seg.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or \
+                    tuple(seg.shape) != tuple(img.shape[:2]):
+                raise ValueError('expected uint8 [H,W,3] image and uint8 [H,W] label map of the same size')
+            H, W = int(img.shape[0]), int(img.shape[1])
+            ow, oh = int(bw[i]), int(bh[i])
+            flip = bool(flips[i])
+            th, ksh = _resample_tables(W, ow)
+            tv, ksv = _resample_tables(H, oh)
+            ytab = _label_axis_table(H, oh, s, False)
+            xtab = _label_axis_table(W, ow, s, flip)
+            lh, lw = ytab.shape[0], xtab.shape[0]
+            host = torch.from_numpy(np.concatenate([th, tv, ytab, xtab]))
+            tabs = host.to(dev, non_blocking=True)
+            o_tv = th.shape[0]
+            o_y = o_tv + tv.shape[0]
+            o_x = o_y + lh
+            tmp = torch.empty((H, ow, 3), dtype=torch.uint8, device=dev)
+            _native.check(L.semseg_input_resample_h_u8(_p(img), H, W, int(flip), _p(tabs), _p(tabs[ow * 2:]), ksh, _p(tmp), ow,
+                                                       _st()), 'input_resample_h_u8')
+            _native.check(L.semseg_input_resample_v_normalize(_p(tmp), H, ow, _p(tabs[o_tv:]), _p(tabs[o_tv + oh * 2:]), ksv, oh,
+                                                              self._mean_std, _p(img_data[i]), BW, _st()),
+                          'input_resample_v_normalize')
+            _native.check(L.semseg_input_label_gather(_p(seg), W, _p(tabs[o_y:]), _p(tabs[o_x:]), lh, lw, _p(seg_label[i]),
+                                                      BW // s, _st()), 'input_label_gather')
+        return {'img_data': img_data.permute(0, 3, 1, 2), 'seg_label': seg_label}
+
+
+class TrainDataset:
+    """Mirror of the reference `TrainDataset` (dataset.py:70-203): one item = one per-GPU batch.  Same record grouping
+    (portrait / landscape lists, dataset.py:85-108), the same numpy random draws in the same order (shuffle seeded by the
+    first index, short-side size, one flip per sample), PIL decode on the host -- and the assembly on the device."""
+
+    def __init__(self, root_dataset, odgt, opt, batch_per_gpu=1, device='cuda', max_sample=-1, start_idx=-1, end_idx=-1):
+        if isinstance(odgt, list):
+            self.list_sample = odgt
+        else:
+            self.list_sample = [json.loads(x.rstrip()) for x in open(odgt, 'r')]
+        if max_sample > 0:
+            self.list_sample = self.list_sample[0:max_sample]
+        if start_idx >= 0 and end_idx >= 0:
+            self.list_sample = self.list_sample[start_idx:end_idx]
+        self.num_sample = len(self.list_sample)
+        assert self.num_sample > 0
+        self.root_dataset = root_dataset
+        self.imgSizes, self.imgMaxSize = opt.imgSizes, opt.imgMaxSize
+        self.padding_constant, self.segm_downsampling_rate = opt.padding_constant, opt.segm_downsampling_rate
+        self.batch_per_gpu = batch_per_gpu
+        self.batch_record_list = [[], []]
+        self.cur_idx = 0
+        self.if_shuffled = False
+        self.assembler = TrainBatchAssembler(self.imgSizes, self.imgMaxSize, self.padding_constant,
+                                             self.segm_downsampling_rate, device)
+
+    def _get_sub_batch(self):
+        while True:
+            this_sample = self.list_sample[self.cur_idx]
+            self.batch_record_list[0 if this_sample['height'] > this_sample['width'] else 1].append(this_sample)
+            self.cur_idx += 1
+            if self.cur_idx >= self.num_sample:
+                self.cur_idx = 0
+                np.random.shuffle(self.list_sample)
+            for k in (0, 1):
+                if len(self.batch_record_list[k]) == self.batch_per_gpu:
+                    batch_records = self.batch_record_list[k]
+                    self.batch_record_list[k] = []
+                    return batch_records
+
+    def __getitem__(self, index):
+        from PIL import Image
+        if not self.if_shuffled:
+            np.random.seed(index)
+            np.random.shuffle(self.list_sample)
+            self.if_shuffled = True
+        batch_records = self._get_sub_batch()
+        if isinstance(self.imgSizes, (list, tuple)):
+            this_short_size = np.random.choice(self.imgSizes)
+        else:
+            this_short_size = self.imgSizes
+        images, segms, flips = [], [], []
+        for rec in batch_records:
+            img = Image.open(os.path.join(self.root_dataset, rec['fpath_img'])).convert('RGB')
+            segm = Image.open(os.path.join(self.root_dataset, rec['fpath_segm']))
+            assert segm.mode == 'L'
+            assert img.size == segm.size
+            flips.append(bool(np.random.choice([0, 1])))
+            images.append(torch.from_numpy(np.array(img)))
+            segms.append(torch.from_numpy(np.array(segm)))
+        return self.assembler.assemble(images, segms, flips, this_short_size)
+
+    def __len__(self):
+        return int(1e10)          # dataset.py:201-203: every loader keeps its own list
