@@ -167,3 +167,20 @@ def assemble_train_batch(images, segms, flips, this_short_size, img_max_size, pa
         batch_images[i, :, :t.shape[1], :t.shape[2]] = t
         batch_segms[i, :segm.shape[0], :segm.shape[1]] = segm.astype(np.int64) - 1
     return {'img_data': batch_images, 'seg_label': batch_segms}
+
+
+def eval_image_inputs(img, img_sizes, img_max_size, padding_constant, segm=None):
+    """dataset.py:210-255 (ValDataset) / 263-296 (TestDataset): per short-side size the whole image resized to the target
+    rounded up to a multiple of padding_constant, normalised -> [1][3][th][tw] fp32; label map: int64 - 1, [1][H][W]"""
+    h, w = img.shape[:2]
+    outs = []
+    for this_short_size in img_sizes:
+        scale = min(this_short_size / float(min(h, w)), img_max_size / float(max(h, w)))
+        th, tw = int(h * scale), int(w * scale)
+        tw = round2nearest_multiple(tw, padding_constant)
+        th = round2nearest_multiple(th, padding_constant)
+        outs.append(image_to_tensor(pil_resize_bilinear(img, (tw, th)))[None])
+    out = {'img_data': outs}
+    if segm is not None:
+        out['seg_label'] = (segm.astype(np.int64) - 1)[None]
+    return out

@@ -125,6 +125,117 @@ class TrainBatchAssembler:
         return {'img_data': img_data.permute(0, 3, 1, 2), 'seg_label': seg_label}
 
 
+class EvalImageAssembler:
+    """Inputs of the evaluation / test loops (dataset.py:210-255, 263-296): ONE image resized (stretched, not padded) to every
+    short-side size of `imgSizes`, each target rounded up to a multiple of `padding_constant`, normalised; the label map is
+    only shifted by -1.  Same kernels as the training assembler."""
+
+    def __init__(self, imgSizes, imgMaxSize, padding_constant, device='cuda'):
+        self.imgSizes = tuple(imgSizes) if isinstance(imgSizes, (list, tuple)) else (imgSizes,)
+        self.imgMaxSize, self.padding_constant = imgMaxSize, padding_constant
+        self.device = torch.device(device)
+        self._mean_std = (_native.c_f * 6)(*MEAN, *STD)
+
+    def target_sizes(self, ori_height, ori_width):
+        """dataset.py:225-232: [(target_height, target_width)] per short-side size"""
+        out = []
+        for this_short_size in self.imgSizes:
+            scale = min(this_short_size / float(min(ori_height, ori_width)), self.imgMaxSize / float(max(ori_height, ori_width)))
+            th, tw = int(ori_height * scale), int(ori_width * scale)
+            out.append((round2nearest_multiple(th, self.padding_constant), round2nearest_multiple(tw, self.padding_constant)))
+        return out
+
+    def assemble(self, image, segm=None):
+        """image: uint8 [H][W][3]; segm: uint8 [H][W] or None.  Returns {'img_data': [fp32 logical [1,3,th,tw] (NHWC
+        memory) per scale], 'seg_label': int64 [1,H,W] (if segm)} on the device."""
+        L = _native.lib()
+        dev = self.device
+        img = image.to(dev, non_blocking=True).contiguous()
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+            raise ValueError('expected a uint8 [H,W,3] image')
+        _require_cuda(img)
+        H, W = int(img.shape[0]), int(img.shape[1])
+        outs = []
+        for th_, tw_ in self.target_sizes(H, W):
+            tabh, ksh = _resample_tables(W, tw_)
+            tabv, ksv = _resample_tables(H, th_)
+            tabs = torch.from_numpy(np.concatenate([tabh, tabv])).to(dev, non_blocking=True)
+            o_v = tabh.shape[0]
+            tmp = torch.empty((H, tw_, 3), dtype=torch.uint8, device=dev)
+            out = torch.empty((1, th_, tw_, 3), dtype=torch.float32, device=dev)
+            _native.check(L.semseg_input_resample_h_u8(_p(img), H, W, 0, _p(tabs), _p(tabs[tw_ * 2:]), ksh, _p(tmp), tw_, _st()),
+                          'input_resample_h_u8')
+            _native.check(L.semseg_input_resample_v_normalize(_p(tmp), H, tw_, _p(tabs[o_v:]), _p(tabs[o_v + th_ * 2:]), ksv, th_,
+                                                              self._mean_std, _p(out), tw_, _st()), 'input_resample_v_normalize')
+            outs.append(out.permute(0, 3, 1, 2))
+        feed = {'img_data': outs}
+        if segm is not None:
+            seg = segm.to(dev, non_blocking=True).contiguous()
+            if seg.dtype != torch.uint8 or tuple(seg.shape) != (H, W):
+                raise ValueError('expected a uint8 [H,W] label map of the image size')
+            ident = torch.arange(max(H, W), dtype=torch.int32, device=dev)
+            lab = torch.empty((1, H, W), dtype=torch.int64, device=dev)
+            _native.check(L.semseg_input_label_gather(_p(seg), W, _p(ident), _p(ident), H, W, _p(lab), W, _st()),
+                          'input_label_gather')
+            feed['seg_label'] = lab
+        return feed
+
+
+class _EvalBase:
+    def __init__(self, odgt, opt, device, max_sample=-1, start_idx=-1, end_idx=-1):
+        if isinstance(odgt, list):
+            self.list_sample = odgt
+        else:
+            self.list_sample = [json.loads(x.rstrip()) for x in open(odgt, 'r')]
+        if max_sample > 0:
+            self.list_sample = self.list_sample[0:max_sample]
+        if start_idx >= 0 and end_idx >= 0:
+            self.list_sample = self.list_sample[start_idx:end_idx]
+        self.num_sample = len(self.list_sample)
+        assert self.num_sample > 0
+        self.assembler = EvalImageAssembler(opt.imgSizes, opt.imgMaxSize, opt.padding_constant, device)
+
+    def __len__(self):
+        return self.num_sample
+
+
+class ValDataset(_EvalBase):
+    """Mirror of the reference `ValDataset` (dataset.py:206-255): img_ori (host uint8), img_data per scale, seg_label, info."""
+
+    def __init__(self, root_dataset, odgt, opt, device='cuda', **kwargs):
+        super().__init__(odgt, opt, device, **kwargs)
+        self.root_dataset = root_dataset
+
+    def __getitem__(self, index):
+        from PIL import Image
+        rec = self.list_sample[index]
+        img = Image.open(os.path.join(self.root_dataset, rec['fpath_img'])).convert('RGB')
+        segm = Image.open(os.path.join(self.root_dataset, rec['fpath_segm']))
+        assert segm.mode == 'L'
+        assert img.size == segm.size
+        arr = np.array(img)
+        out = self.assembler.assemble(torch.from_numpy(arr), torch.from_numpy(np.array(segm)))
+        out['img_ori'] = arr
+        out['info'] = rec['fpath_img']
+        return out
+
+
+class TestDataset(_EvalBase):
+    """Mirror of the reference `TestDataset` (dataset.py:258-296)."""
+
+    def __init__(self, odgt, opt, device='cuda', **kwargs):
+        super().__init__(odgt, opt, device, **kwargs)
+
+    def __getitem__(self, index):
+        from PIL import Image
+        rec = self.list_sample[index]
+        arr = np.array(Image.open(rec['fpath_img']).convert('RGB'))
+        out = self.assembler.assemble(torch.from_numpy(arr))
+        out['img_ori'] = arr
+        out['info'] = rec['fpath_img']
+        return out
+
+
 class TrainDataset:
     """Mirror of the reference `TrainDataset` (dataset.py:70-203): one item = one per-GPU batch.  Same record grouping
     (portrait / landscape lists, dataset.py:85-108), the same numpy random draws in the same order (shuffle seeded by the

@@ -91,6 +91,26 @@ def main():
             out[pre + 'seg_label'] = batch['seg_label'].numpy()
             print('case %d: short %d flips %s -> img_data %s seg_label %s' % (ci, short, flips, tuple(batch['img_data'].shape),
                                                                           tuple(batch['seg_label'].shape)))
+    # ValDataset (dataset.py:206-255): multi-scale inputs of one image + its label map
+    rng = np.random.default_rng(77)
+    with tempfile.TemporaryDirectory() as d:
+        h, w = 46, 67
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.clip(np.stack([np.sin(xx / 4.0), np.cos(yy / 6.0), np.sin((xx - yy) / 8.0)], -1) * 100 + 128 +
+                      rng.normal(0, 20, (h, w, 3)), 0, 255).astype(np.uint8)
+        seg = ((yy // 5 + xx // 7) % 151).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(d, 'v.png'))
+        Image.fromarray(seg, mode='L').save(os.path.join(d, 'vs.png'))
+        opt = types.SimpleNamespace(imgSizes=(30, 45, 60, 75), imgMaxSize=100, padding_constant=8)
+        ds = ref.ValDataset(d, [{'fpath_img': 'v.png', 'fpath_segm': 'vs.png', 'width': w, 'height': h}], opt)
+        item = ds[0]
+        out['val_params'] = np.array(list(opt.imgSizes) + [opt.imgMaxSize, opt.padding_constant], dtype=np.int64)
+        out['val_img'], out['val_seg'] = img, seg
+        assert np.array_equal(item['img_ori'], img)
+        for k, t in enumerate(item['img_data']):
+            out['val_img_data%d' % k] = t.numpy()
+        out['val_seg_label'] = item['seg_label'].numpy()
+        print('val: scales', [tuple(t.shape) for t in item['img_data']], 'label', tuple(item['seg_label'].shape))
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'input_golden.npz')
     np.savez_compressed(dst, **out)
     print('wrote', dst, os.path.getsize(dst), 'bytes')

@@ -26,7 +26,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden', 'input_golden.npz')
 
 def golden_cases():
     g = np.load(GOLDEN)
-    n = len([k for k in g.files if k.endswith('_params')])
+    n = len([k for k in g.files if k.endswith('_params') and k.startswith('c')])
     for ci in range(n):
         pre = 'c%d_' % ci
         short, mx, pad, rate, bpg = [int(v) for v in g[pre + 'params']]
@@ -165,3 +165,37 @@ def test_product_dataset_mirror_draws_like_the_reference(emulated_kernels, monke
                                   short, 100, 8, 8)
     assert np.array_equal(feed['img_data'].numpy(), want['img_data'])
     assert np.array_equal(feed['seg_label'].numpy(), want['seg_label'])
+
+
+def val_golden():
+    g = np.load(GOLDEN)
+    p = [int(v) for v in g['val_params']]
+    sizes, mx, pad = tuple(p[:-2]), p[-2], p[-1]
+    return dict(sizes=sizes, max_size=mx, pad=pad, img=g['val_img'], seg=g['val_seg'],
+                img_data=[g['val_img_data%d' % k] for k in range(len(sizes))], seg_label=g['val_seg_label'])
+
+
+def test_oracle_eval_inputs_match_reference_golden():
+    v = val_golden()
+    out = O.eval_image_inputs(v['img'], v['sizes'], v['max_size'], v['pad'], v['seg'])
+    assert len(out['img_data']) == len(v['img_data'])
+    for a, b in zip(out['img_data'], v['img_data']):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert np.array_equal(out['seg_label'], v['seg_label'])
+
+
+def test_product_eval_assembly_on_emulated_kernels_matches_reference(emulated_kernels, monkeypatch):
+    from mit_semseg import _native
+    from mit_semseg import dataset as D
+    lib = _HostKernels(_native.lib(), emulated_kernels, _native.SIGNATURES)
+    monkeypatch.setattr(_native, 'lib', lambda: lib)
+    monkeypatch.setattr(D, '_require_cuda', lambda *a: None)
+    monkeypatch.setattr(D, '_st', lambda: ctypes.c_void_p(0))
+    v = val_golden()
+    asm = D.EvalImageAssembler(v['sizes'], v['max_size'], v['pad'], device='cpu')
+    feed = asm.assemble(torch.from_numpy(v['img']), torch.from_numpy(v['seg']))
+    assert len(feed['img_data']) == len(v['img_data'])
+    for a, b in zip(feed['img_data'], v['img_data']):
+        assert tuple(a.shape) == b.shape and np.array_equal(a.numpy(), b)
+    assert np.array_equal(feed['seg_label'].numpy(), v['seg_label'])
+    assert 'seg_label' not in asm.assemble(torch.from_numpy(v['img']))           # TestDataset: no label map
