@@ -231,3 +231,41 @@ class InferenceGraph:
         static.copy_(img)
         graph.replay()
         return out
+
+
+def evaluate(segmentation_module, loader, num_class, device=None, tally=None, use_graph=True, on_item=None):
+    """The evaluation loop of the reference (eval.py:40-105) with the arithmetic on the device: per item of a
+    `ValDataset`-like iterable ({'img_data': [one tensor per scale], 'seg_label': [1,H,W]}) the softmax scores of every
+    scale are produced at the label map's size and averaged in the reference's order (`scores = scores + scores_tmp / n`,
+    eval.py:59-71), `pred = argmax` (first maximum, eval.py:73) and the tallies of `accuracy()` / `intersectionAndUnion()`
+    (eval.py:81-86, utils.py:128-156) accumulate in a `MetricTally`.
+    Returns (pixel accuracy, per-class IoU, mean IoU, tally) -- what eval.py:98-105 prints.
+    `on_item(item, pred)` (optional) sees every prediction (visualisation hook, eval.py:88-94)."""
+    from . import utils
+    segmentation_module.eval()
+    run = InferenceGraph(segmentation_module) if use_graph else None
+    if device is None:
+        device = next(segmentation_module.parameters()).device
+    for item in loader:
+        if isinstance(item, (list, tuple)):
+            item = item[0]                                    # user_scattered_collate batches of one (eval.py:51)
+        label = item['seg_label'][0].to(device)
+        seg_size = (int(label.shape[0]), int(label.shape[1]))
+        imgs = item['img_data']
+        scores = None
+        for img in imgs:
+            img = img.to(device)
+            if run is not None:
+                s = run(img, seg_size)
+            else:
+                with torch.no_grad():
+                    s = segmentation_module({'img_data': img}, segSize=seg_size)
+            s = s / len(imgs)                                 # a new tensor: the graph's output buffer is reused next call
+            scores = s if scores is None else scores + s      # 0 + s == s exactly: same sums as the reference's zeros start
+        pred, tally = utils.segmentation_metrics(scores, label, tally)
+        if on_item is not None:
+            on_item(item, pred)
+    if tally is None:
+        tally = utils.MetricTally(num_class, device)
+    acc, iou, miou = tally.summary()
+    return acc, iou, miou, tally
