@@ -1805,7 +1805,10 @@ static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_spl
         if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
         const long tiles = (long)ceil_div(K, kWTiles[t][0]) * ceil_div(C, kWTiles[t][1]) * T;
-        for (int sp = 1; sp <= 64; ++sp) {
+        // SEMSEG_WGRAD_MAX_SPLIT (default 64): the M = 131 072 stem layers still walk 73 serial k-tiles per block at 56
+        // splits; raising the cap is the queued experiment of DESIGN section 8 (the tuner then tries 96 ... 256)
+        static const int max_split = max(1, env_int("SEMSEG_WGRAD_MAX_SPLIT", 64));
+        for (int sp = 1; sp <= max_split; ++sp) {
             if (force_split > 0 && sp != min(force_split, mtiles)) continue;
             if (force_split <= 0 && sp > 1 && mtiles / sp < 8) break;
             const int mps = ceil_div(mtiles, sp);

@@ -46,6 +46,10 @@ def _save_cache():
         json.dump({','.join(map(str, k)): list(v) for k, v in _done.items()}, f)
     os.replace(tmp, CACHE)
 _SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64)
+# weight gradient only: more split candidates when the library's cap is raised (SEMSEG_WGRAD_MAX_SPLIT, csrc/conv_split.hip
+# plan_wgrad) -- off by default
+_WGRAD_MAX_SPLIT = int(os.environ.get('SEMSEG_WGRAD_MAX_SPLIT', '64'))
+_WSPLITS = _SPLITS + tuple(s for s in (96, 128, 192, 256) if s <= _WGRAD_MAX_SPLIT)
 # fwd/dgrad tile ids per scheme (csrc/conv_split.hip): 0..2 register staged, 3 = 256x128 LDS-DMA, h2 only: 4 = 256x128
 # 3-slot ring, 5 = 256x256.  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).
 _TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)}
@@ -111,7 +115,7 @@ def ensure(scheme, pass_id, geom, launch):
         base = _time(launch, 2)
         best = (-1, 0, base)
         for tile in tiles:
-            for split in _SPLITS:
+            for split in (_WSPLITS if pass_id == 2 else _SPLITS):
                 if split > 1 and kt // split < 4:
                     break
                 _native.check(set_plan(pass_id, *geom, tile, split), 'set_plan')
