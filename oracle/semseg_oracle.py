@@ -207,6 +207,84 @@ def resnet_encoder(sd, arch, x, ctx):
 
 
 # ----------------------------------------------------------------------------
+# ResNeXt-101 (32 groups) through models.Resnet (models/resnext.py, models.py:96-98)
+# ----------------------------------------------------------------------------
+RESNEXT_LAYERS = {'resnext101': (3, 4, 23, 3)}           # resnext.py:143-152
+RESNEXT_GROUPS = 32                                      # resnext.py:67
+
+
+def _group_bottleneck(sd, p, x, stride, downsample, ctx, mom):
+    """models/resnext.py:41-62"""
+    out = F.relu(_bn(sd, p + 'bn1', _conv(sd, p + 'conv1', x), ctx, mom))
+    out = F.conv2d(out, sd[p + 'conv2.weight'], None, stride, 1, 1, RESNEXT_GROUPS)
+    out = F.relu(_bn(sd, p + 'bn2', out, ctx, mom))
+    out = _bn(sd, p + 'bn3', _conv(sd, p + 'conv3', out), ctx, mom)
+    res = x
+    if downsample:
+        res = _bn(sd, p + 'downsample.1', _conv(sd, p + 'downsample.0', x, stride), ctx, mom)
+    return F.relu(out + res)
+
+
+def resnext_encoder(sd, arch, x, ctx):
+    mom = RESNET_BN_MOMENTUM
+    x = F.relu(_bn(sd, 'bn1', _conv(sd, 'conv1', x, 2, 1), ctx, mom))     # resnext.py:69-78, same deep stem
+    x = F.relu(_bn(sd, 'bn2', _conv(sd, 'conv2', x, 1, 1), ctx, mom))
+    x = F.relu(_bn(sd, 'bn3', _conv(sd, 'conv3', x, 1, 1), ctx, mom))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs, inplanes = [], 128
+    for li, (planes, n) in enumerate(zip((128, 256, 512, 1024), RESNEXT_LAYERS[arch])):
+        for bi in range(n):
+            stride = (1 if li == 0 else 2) if bi == 0 else 1
+            ds = bi == 0 and (stride != 1 or inplanes != planes * 2)      # resnext.py:98-105
+            x = _group_bottleneck(sd, 'layer%d.%d.' % (li + 1, bi), x, stride, ds, ctx, mom)
+            inplanes = planes * 2
+        outs.append(x)
+    return outs
+
+
+# ----------------------------------------------------------------------------
+# MobileNetV2Dilated (models/mobilenet.py, models.py:271-323, dilate_scale 8)
+# ----------------------------------------------------------------------------
+MOBILENET_SETTING = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+
+
+def _relu6(x):
+    return F.hardtanh(x, 0.0, 6.0)                       # nn.ReLU6
+
+
+def mobilenetv2_dilated_encoder(sd, x, ctx):
+    """features[0 .. 17] of mobilenet.py:95-108 after MobileNetV2Dilated._nostride_dilate (models.py:297-311): blocks 7..13
+    dilate 2, blocks 14.. dilate 4; a stride-2 depthwise conv becomes stride 1 with dilation dilate // 2."""
+    mom = RESNET_BN_MOMENTUM
+    x = _relu6(_bn(sd, 'features.0.1', _conv(sd, 'features.0.0', x, 2, 1), ctx, mom))
+    outs, idx, inp = [], 1, 32
+    for t, c, n, s in MOBILENET_SETTING:
+        for i in range(n):
+            stride = s if i == 0 else 1
+            dilate = 2 if 7 <= idx < 14 else (4 if idx >= 14 else 1)
+            if dilate > 1:
+                stride, d = (1, dilate // 2) if stride == 2 else (stride, dilate)
+            else:
+                d = 1
+            p = 'features.%d.conv.' % idx
+            hidden = inp * t
+            y, j = x, 0
+            if t != 1:
+                y = _relu6(_bn(sd, p + '1', _conv(sd, p + '0', y), ctx, mom))
+                j = 3
+            y = F.conv2d(y, sd[p + '%d.weight' % j], None, stride, d, d, hidden)           # depthwise 3x3
+            y = _relu6(_bn(sd, p + '%d' % (j + 1), y, ctx, mom))
+            y = _bn(sd, p + '%d' % (j + 4), _conv(sd, p + '%d' % (j + 3), y), ctx, mom)     # linear projection
+            x = x + y if (s if i == 0 else 1) == 1 and inp == c else y                      # mobilenet.py:44 (original stride)
+            inp = c
+            if idx in (2, 4, 7, 14):
+                outs.append(x)
+            idx += 1
+    outs.append(x)
+    return outs
+
+
+# ----------------------------------------------------------------------------
 # HRNetV2-W48 encoder (models/hrnet.py)
 # ----------------------------------------------------------------------------
 HRNET_STAGES = (('stage2', 1, (48, 96)), ('stage3', 4, (48, 96, 192)), ('stage4', 3, (48, 96, 192, 384)))
@@ -390,6 +468,10 @@ def encode(enc_sd, arch_encoder, img, ctx):
     arch_encoder = arch_encoder.lower()
     if arch_encoder == 'hrnetv2':
         return hrnet_encoder(enc_sd, img, ctx)
+    if arch_encoder == 'mobilenetv2dilated':
+        return mobilenetv2_dilated_encoder(enc_sd, img, ctx)
+    if arch_encoder in RESNEXT_LAYERS:
+        return resnext_encoder(enc_sd, arch_encoder, img, ctx)
     return resnet_encoder(enc_sd, arch_encoder, img, ctx)
 
 

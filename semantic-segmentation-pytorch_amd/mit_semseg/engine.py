@@ -102,7 +102,7 @@ class TrainStep:
             self.buckets = GradientBuckets(list(enc.parameters()) + list(dec.parameters()), bucket_bytes, group, side)
         # h2 path: the split planes of every conv weight are rebuilt by ONE multi-tensor launch after each optimiser
         # step (csrc/weights_prep.hip) instead of 5 small launches per conv inside forward/backward
-        self._conv_weights = [m.weight for m in segmentation_module.modules() if isinstance(m, Conv2d)]
+        self._conv_weights = [m.weight for m in segmentation_module.modules() if type(m) is Conv2d]      # not the grouped ones
         self._weights_ready = False
         self.use_graph = graph
         # hipGraph replay.  `graph_steps` consecutive training steps are captured into ONE graph: every hipGraphLaunch

@@ -49,6 +49,72 @@ class Conv2d(nn.Module):
                'dilation={dilation}'.format(**self.__dict__) + (', bias=False' if self.bias is None else '')
 
 
+class GroupedConv2d(Conv2d):
+    """nn.Conv2d(..., groups=g) of the reference's MobileNetV2 (depthwise 3x3, mobilenet.py:48,60) and ResNeXt (g = 32,
+    resnext.py:30-31).  FUNCTIONAL coverage on the validated dense kernels: the grouped weight ([K, C/g, R, S], the shape the
+    reference checkpoints carry) is expanded to its block-diagonal dense form (zeros outside the group blocks contribute exact
+    zeros) and runs through the same h2 convolution path; autograd carries the dense gradient back to the group blocks.
+    g-fold redundant MFMA work -- these backbones are outside the BASELINE configs; a dedicated grouped kernel is the
+    follow-up."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=False):
+        if bias:
+            raise NotImplementedError('grouped convolutions of the reference are bias-free')
+        if in_channels % groups or out_channels % groups:
+            raise ValueError('in_channels and out_channels must be divisible by groups')
+        nn.Module.__init__(self)
+        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        k = self.kernel_size[0]
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, k, k))
+        self.bias = None
+        self._dense = None          # (parameter version, data_ptr, dense weight): reused under no_grad (evaluation)
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def dense_weight(self):
+        """block-diagonal [K, C, R, S] weight in KRSC memory"""
+        w = self.weight
+        if not torch.is_grad_enabled() and self._dense is not None and self._dense[0] == w._version and \
+                self._dense[1] == w.data_ptr():
+            return self._dense[2]
+        g, r = self.groups, self.kernel_size[0]
+        kg, cg = self.out_channels // g, self.in_channels // g
+        dense = w.new_zeros(g, kg, r, r, g, cg)
+        idx = torch.arange(g, device=w.device)
+        dense[idx, :, :, :, idx] = w.view(g, kg, cg, r, r).permute(0, 1, 3, 4, 2)
+        dense = dense.view(self.out_channels, r, r, self.in_channels).permute(0, 3, 1, 2)
+        if not torch.is_grad_enabled():
+            self._dense = (w._version, w.data_ptr(), dense)
+        return dense
+
+    def train(self, mode=True):
+        self._dense = None          # the fused SGD kernel updates parameters without bumping torch's version counter
+        return super().train(mode)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.dense_weight(), None, self.stride[0], self.padding[0], self.dilation[0])
+
+    def extra_repr(self):
+        return Conv2d.extra_repr(self) + ', groups=%d' % self.groups
+
+
+class ReLU6(nn.Module):
+    """nn.ReLU6 (mobilenet.py:26,34): min(max(x, 0), 6).  Inside conv -> BN -> ReLU6 units the lower clamp runs fused in the
+    BN kernel and only the upper clamp is applied here (`conv_bn_relu6`)."""
+
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x):
+        return torch.clamp(x, min=0.0, max=6.0)
+
+
+def conv_bn_relu6(conv, bn, x):
+    """conv -> BN -> ReLU6: the fused conv/BN/ReLU unit followed by the upper clamp (elementwise glue)"""
+    return torch.clamp(conv_bn(conv, bn, x, relu=True), max=6.0)
+
+
 def conv_bn(conv, bn, x, residual=None, relu=False, passthrough=False):
     """bn(conv(x), residual=..., relu=...) -- the conv -> BN [-> +residual] [-> ReLU] unit every block of the reference
     is made of (resnet.py:72-92, models.py:160-167, hrnet.py:45-61) -- dispatched as ONE fused autograd node when the

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from . import resnet, hrnet
+from . import resnet, hrnet, mobilenet, resnext
 from .layers import (Conv2d, BatchNorm2d, AdaptiveAvgPool2d, Dropout2d, ConvBNReLU, ReLU, conv3x3_bn_relu, conv_bn)
 
 
@@ -81,10 +81,11 @@ class ModelBuilder:
         arch = arch.lower()
         if arch in ('resnet34', 'resnet34dilated'):
             raise NotImplementedError
-        if arch in ('mobilenetv2dilated', 'resnext101'):
-            raise NotImplementedError(
-                '%s (depthwise / grouped convolutions) is outside the MI355X hot-path scope of this build' % arch)
-        if arch in ('resnet18', 'resnet50', 'resnet101'):
+        if arch == 'mobilenetv2dilated':
+            net_encoder = MobileNetV2Dilated(mobilenet.__dict__['mobilenetv2'](pretrained=pretrained), dilate_scale=8)
+        elif arch == 'resnext101':
+            net_encoder = Resnet(resnext.__dict__['resnext101'](pretrained=pretrained))      # models.py:96-98
+        elif arch in ('resnet18', 'resnet50', 'resnet101'):
             net_encoder = Resnet(resnet.__dict__[arch](pretrained=pretrained))
         elif arch in ('resnet18dilated', 'resnet50dilated', 'resnet101dilated'):
             net_encoder = ResnetDilated(resnet.__dict__[arch[:-7]](pretrained=pretrained), dilate_scale=8)
@@ -176,6 +177,37 @@ class ResnetDilated(Resnet):
         elif three:                         # other convolutions
             m.dilation = (dilate, dilate)
             m.padding = (dilate, dilate)
+
+
+class MobileNetV2Dilated(nn.Module):
+    """models.py:271-323: the MobileNetV2 feature stack without its last 1x1 unit; with dilate_scale 8 the blocks from
+    index 7 on lose their stride (dilation 2, from index 14: dilation 4).  Returns the maps after blocks 2, 4, 7, 14 and the
+    last one."""
+
+    def __init__(self, orig_net, dilate_scale=8):
+        super(MobileNetV2Dilated, self).__init__()
+        self.features = orig_net.features[:-1]
+        self.total_idx = len(self.features)
+        self.down_idx = [2, 4, 7, 14]
+        if dilate_scale == 8:
+            for i in range(self.down_idx[-2], self.down_idx[-1]):
+                ResnetDilated._dilate_stage(self.features[i], 2)
+            for i in range(self.down_idx[-1], self.total_idx):
+                ResnetDilated._dilate_stage(self.features[i], 4)
+        elif dilate_scale == 16:
+            for i in range(self.down_idx[-1], self.total_idx):
+                ResnetDilated._dilate_stage(self.features[i], 2)
+
+    def forward(self, x, return_feature_maps=False):
+        if not return_feature_maps:
+            return [self.features(x)]
+        conv_out = []
+        for i in range(self.total_idx):
+            x = self.features[i](x)
+            if i in self.down_idx:
+                conv_out.append(x)
+        conv_out.append(x)
+        return conv_out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ REF = os.environ.get('SEMSEG_REFERENCE', '/root/reference')
 sys.path.insert(0, REF)
 
 from mit_semseg.models import ModelBuilder, SegmentationModule   # noqa: E402  (the reference)
-from mit_semseg.models import resnet, hrnet, models as ref_models  # noqa: E402
+from mit_semseg.models import resnet, hrnet, mobilenet, resnext, models as ref_models  # noqa: E402
 from oracle import semseg_oracle as O                              # noqa: E402
 
 assert os.path.realpath(ref_models.__file__).startswith(os.path.realpath(REF)), ref_models.__file__
@@ -49,6 +49,10 @@ def build_reference(arch_enc, arch_dec, fc_dim, use_softmax=False):
     base = arch_enc.replace('dilated', '')
     if arch_enc == 'hrnetv2':
         enc0 = hrnet.hrnetv2(pretrained=False)
+    elif arch_enc == 'mobilenetv2dilated':
+        enc0 = ref_models.MobileNetV2Dilated(mobilenet.mobilenetv2(pretrained=False), dilate_scale=8)
+    elif arch_enc == 'resnext101':
+        enc0 = ref_models.Resnet(resnext.resnext101(pretrained=False))
     else:
         r = resnet.__dict__[base](pretrained=False)
         enc0 = ref_models.ResnetDilated(r, 8) if arch_enc.endswith('dilated') else ref_models.Resnet(r)
@@ -168,13 +172,22 @@ CASES = [
          n=1, h=64, w=80, seg_rate=8, training=False, deep_sup_scale=None, seg_size=[35, 45]),
     dict(name='r50_upernet_infer_64', arch_enc='resnet50', arch_dec='upernet', fc_dim=2048,
          n=1, h=64, w=64, seg_rate=4, training=False, deep_sup_scale=None, seg_size=[40, 40]),
+    # the remaining arch strings of ModelBuilder (depthwise / grouped convolutions)
+    dict(name='mnv2d_c1ds_64_train', arch_enc='mobilenetv2dilated', arch_dec='c1_deepsup', fc_dim=320,
+         n=2, h=64, w=64, seg_rate=8, training=True, deep_sup_scale=0.4, step=True),
+    dict(name='resnext101_upernet_64_train', arch_enc='resnext101', arch_dec='upernet', fc_dim=2048,
+         n=2, h=64, w=64, seg_rate=4, training=True, deep_sup_scale=None, step=True),
 ]
 
 
 def main():
     torch.set_num_threads(os.cpu_count())
-    manifests = {}
+    only = set(sys.argv[1:])                 # `make_golden.py name ...`: regenerate just these cases (manifests are merged)
+    mpath = os.path.join(HERE, 'manifests.json')
+    manifests = json.load(open(mpath)) if (only and os.path.exists(mpath)) else {}
     for c in CASES:
+        if only and c['name'] not in only:
+            continue
         r = run_case(**c)
         path = os.path.join(HERE, c['name'] + '.pt')
         manifests[c['arch_enc']] = r['manifest_enc']

@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.util import golden_cases, load_golden, check_summary
+from tests.util import golden_cases, golden_params, load_golden, check_summary, first_gpu_run_pending
 from oracle import semseg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -50,7 +50,7 @@ def argmax_check(got_logp, ref_logp, what):
     assert hard.sum().item() == 0
 
 
-@pytest.mark.parametrize('name', golden_cases())
+@pytest.mark.parametrize('name', golden_params())
 def test_native_matches_reference_golden(name):
     g = load_golden(name)
     m = g['meta']
@@ -209,6 +209,7 @@ def test_inference_graph_replay_equals_eager():
         assert torch.equal(got, want), seed
 
 
+@first_gpu_run_pending
 def test_evaluate_multiscale_loop_vs_oracle():
     """engine.evaluate (eval.py:40-105): multi-scale average of the softmax scores at the label size, argmax, tallies over
     two items -- scores against the oracle's, tallies exact for the predictions made, predictions equal to the oracle's

@@ -42,7 +42,8 @@ def stub(monkeypatch):
 
 CONFIGS = [('resnet18dilated', 'ppm_deepsup', 512, 0.4, 8, 64), ('resnet50dilated', 'ppm_deepsup', 2048, 0.4, 8, 64),
            ('resnet50', 'upernet', 2048, None, 4, 128), ('hrnetv2', 'c1', 720, None, 4, 64),
-           ('resnet18dilated', 'c1_deepsup', 512, 0.4, 8, 64), ('resnet18dilated', 'ppm', 512, None, 8, 64)]
+           ('resnet18dilated', 'c1_deepsup', 512, 0.4, 8, 64), ('resnet18dilated', 'ppm', 512, None, 8, 64),
+           ('mobilenetv2dilated', 'c1_deepsup', 320, 0.4, 8, 64), ('resnext101', 'upernet', 2048, None, 4, 64)]
 
 
 @pytest.mark.parametrize('mode', ['h2', 's3', 'f32'])
@@ -51,12 +52,16 @@ def test_train_step_host_logic(stub, cfg, mode, monkeypatch):
     from mit_semseg import ops
     monkeypatch.setattr(ops, 'CONV_MODE', mode)
     from mit_semseg.models import ModelBuilder, SegmentationModule
-    from mit_semseg.models import resnet, hrnet
-    from mit_semseg.models.models import Resnet, ResnetDilated
+    from mit_semseg.models import resnet, hrnet, mobilenet, resnext
+    from mit_semseg.models.models import Resnet, ResnetDilated, MobileNetV2Dilated
     from mit_semseg.engine import TrainStep
     arch_enc, arch_dec, fc_dim, dss, rate, size = cfg
     if arch_enc == 'hrnetv2':
         enc = hrnet.hrnetv2(pretrained=False)
+    elif arch_enc == 'mobilenetv2dilated':
+        enc = MobileNetV2Dilated(mobilenet.mobilenetv2(pretrained=False), dilate_scale=8)
+    elif arch_enc == 'resnext101':
+        enc = Resnet(resnext.resnext101(pretrained=False))
     else:
         base = resnet.__dict__[arch_enc.replace('dilated', '')](pretrained=False)
         enc = ResnetDilated(base, 8) if arch_enc.endswith('dilated') else Resnet(base)
