@@ -341,6 +341,20 @@ int semseg_winograd_wgrad_gemm_h2(const void* v_planes, const void* dm_planes, f
                                   void* workspace, size_t workspace_bytes, void* stream);
 int semseg_winograd_dg(const float* dU, float* dw, int K, int C, void* stream);
 
+/* ---------------- depthwise 3x3 convolution (csrc/depthwise.hip) -----------------------------------------------------
+ * nn.Conv2d(C, C, 3, stride, padding, dilation, groups=C, bias=False) of MobileNetV2 (models/mobilenet.py:48,60, geometry
+ * rewritten by models.py:297-311) and its autograd: fp32 NHWC, C % 4 == 0, weights TAP-MAJOR w_taps[9][C]
+ * (w_taps[r*3+s][c] = weight[c][0][r][s]).  dgrad is a gather (deterministic); wgrad reduces per-chunk partial sums in a
+ * fixed order (workspace of semseg_depthwise3x3_workspace_bytes).  Opt-in behind layers.GroupedConv2d
+ * (SEMSEG_DEPTHWISE_DIRECT=1) until it has run on a GPU; the default is the block-diagonal dense path. */
+size_t semseg_depthwise3x3_workspace_bytes(int N, int H, int W, int C, int stride, int pad, int dil);
+int semseg_depthwise3x3_fwd(const float* x, int x_ld, const float* w_taps, float* y, int y_ld, int N, int H, int W, int C,
+                            int stride, int pad, int dil, void* stream);
+int semseg_depthwise3x3_dgrad(const float* dy, int dy_ld, const float* w_taps, float* dx, int dx_ld, int N, int H, int W, int C,
+                              int stride, int pad, int dil, void* stream);
+int semseg_depthwise3x3_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, float* dw_taps, int N, int H, int W, int C,
+                              int stride, int pad, int dil, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------- input pipeline: training-batch assembly on the device (csrc/input_pipeline.hip) -------------------
  * Contract of mit_semseg/dataset.py:110-199 (TrainDataset.__getitem__) from DECODED uint8 arrays (the JPEG/PNG decode stays
  * on the host): `imresize(img, (w, h), 'bilinear')` = Pillow BILINEAR (dataset.py:9-19,167; antialiased triangle filter,

@@ -103,6 +103,11 @@ SIGNATURES = {
     'semseg_winograd_wgrad_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
     'semseg_winograd_wgrad_gemm_h2': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, c_sz, vp]),
     'semseg_winograd_dg': (c_int, [vp, vp, c_int, c_int, vp]),
+    'semseg_depthwise3x3_workspace_bytes': (c_sz, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'semseg_depthwise3x3_fwd': (c_int, [vp, c_int, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'semseg_depthwise3x3_dgrad': (c_int, [vp, c_int, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'semseg_depthwise3x3_wgrad': (c_int, [vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, c_sz,
+                                          vp]),
     'semseg_input_resample_ksize': (c_int, [c_int, c_int]),
     'semseg_input_resample_coeffs': (c_int, [c_int, c_int, vp, vp]),
     'semseg_input_nearest_table': (c_int, [c_int, c_int, vp]),

@@ -496,6 +496,60 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, a
     return dx, dw
 
 
+# dedicated depthwise 3x3 kernels (csrc/depthwise.hip) instead of the block-diagonal dense expansion of
+# models.layers.GroupedConv2d.  Opt-in until they have executed on a GPU (written after the round's GPU budget was spent;
+# their per-element code is checked on the host, tests/test_depthwise_cpu.py).
+DEPTHWISE_DIRECT = os.environ.get('SEMSEG_DEPTHWISE_DIRECT', '0') == '1'
+
+
+class DepthwiseConv3x3Fn(Function):
+    """nn.Conv2d(C, C, 3, stride, padding, dilation, groups=C, bias=False) (mobilenet.py:48,60): weight [C, 1, 3, 3]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, dil):
+        L = _native.lib()
+        x, x_ld = as_nhwc(x.detach())
+        n, c, h, w = x.shape
+        if tuple(weight.shape) != (c, 1, 3, 3) or c % 4:
+            raise RuntimeError('depthwise3x3: expected a [C, 1, 3, 3] weight with C %% 4 == 0, got %s for C = %d'
+                               % (tuple(weight.shape), c))
+        _require_cuda(weight)
+        wt = weight.detach().reshape(c, 9).t().contiguous()                  # tap-major [9][C]
+        oh, ow = conv_out_size(h, 3, stride, pad, dil), conv_out_size(w, 3, stride, pad, dil)
+        y = empty_nhwc(n, c, oh, ow, x.device)
+        _native.check(L.semseg_depthwise3x3_fwd(_p(x), x_ld, _p(wt), _p(y), c, n, h, w, c, stride, pad, dil, _st()),
+                      'depthwise3x3_fwd')
+        ctx.save_for_backward(x, wt)
+        ctx.geom = (n, h, w, c, stride, pad, dil)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        L = _native.lib()
+        x, wt = ctx.saved_tensors
+        n, h, w, c, stride, pad, dil = ctx.geom
+        _, x_ld = as_nhwc(x)
+        dy, dy_ld = as_nhwc(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_nhwc(n, c, h, w, x.device)
+            _native.check(L.semseg_depthwise3x3_dgrad(_p(dy), dy_ld, _p(wt), _p(dx), c, n, h, w, c, stride, pad, dil, _st()),
+                          'depthwise3x3_dgrad')
+        if ctx.needs_input_grad[1]:
+            dwt = torch.empty((9, c), device=x.device, dtype=torch.float32)
+            ws = workspace(L.semseg_depthwise3x3_workspace_bytes(n, h, w, c, stride, pad, dil), x.device)
+            _native.check(L.semseg_depthwise3x3_wgrad(_p(x), x_ld, _p(dy), dy_ld, _p(dwt), n, h, w, c, stride, pad, dil, _p(ws),
+                                                      ws.numel(), _st()), 'depthwise3x3_wgrad')
+            dw = dwt.t().reshape(c, 1, 3, 3)
+        return dx, dw, None, None, None
+
+
+def depthwise_conv3x3(x, weight, stride=1, padding=1, dilation=1):
+    _require_cuda(x)
+    return DepthwiseConv3x3Fn.apply(x, weight, int(stride), int(padding), int(dilation))
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     if CONV_MODE == 'f32':
         return Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
