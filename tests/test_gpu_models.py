@@ -51,7 +51,13 @@ def argmax_check(got_logp, ref_logp, what):
 
 
 @pytest.mark.parametrize('name', golden_params())
-def test_native_matches_reference_golden(name):
+def test_native_matches_reference_golden(name, monkeypatch):
+    from tests.util import PENDING_GOLDEN
+    if name in PENDING_GOLDEN:
+        # ~150 convolution geometries that no other test uses (dense forms of the grouped convs): run them on the library's
+        # heuristic plans instead of timing every tile x split candidate
+        from mit_semseg import tuner
+        monkeypatch.setattr(tuner, 'ENABLED', False)
     g = load_golden(name)
     m = g['meta']
     dev = torch.device('cuda:0')
