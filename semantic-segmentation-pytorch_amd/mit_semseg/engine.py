@@ -233,14 +233,18 @@ class InferenceGraph:
         return out
 
 
-def evaluate(segmentation_module, loader, num_class, device=None, tally=None, use_graph=True, on_item=None):
+def evaluate(segmentation_module, loader, num_class, device=None, tally=None, use_graph=True, on_item=None, group=None,
+             reduce=True):
     """The evaluation loop of the reference (eval.py:40-105) with the arithmetic on the device: per item of a
     `ValDataset`-like iterable ({'img_data': [one tensor per scale], 'seg_label': [1,H,W]}) the softmax scores of every
     scale are produced at the label map's size and averaged in the reference's order (`scores = scores + scores_tmp / n`,
     eval.py:59-71), `pred = argmax` (first maximum, eval.py:73) and the tallies of `accuracy()` / `intersectionAndUnion()`
     (eval.py:81-86, utils.py:128-156) accumulate in a `MetricTally`.
     Returns (pixel accuracy, per-class IoU, mean IoU, tally) -- what eval.py:98-105 prints.
-    `on_item(item, pred)` (optional) sees every prediction (visualisation hook, eval.py:88-94)."""
+    `on_item(item, pred)` (optional) sees every prediction (visualisation hook, eval.py:88-94).
+    Several processes (one per GPU, eval_multipro.py:122-169 shards the file list with start_idx / end_idx): every rank runs
+    this loop over ITS shard and the integer tallies are summed over `group` at the end (`reduce`), so each rank returns the
+    metrics of the whole set -- order-independent integer sums, identical to a single-process run."""
     from . import utils
     segmentation_module.eval()
     run = InferenceGraph(segmentation_module) if use_graph else None
@@ -267,5 +271,8 @@ def evaluate(segmentation_module, loader, num_class, device=None, tally=None, us
             on_item(item, pred)
     if tally is None:
         tally = utils.MetricTally(num_class, device)
+    if reduce and world_size(group) > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tally.counts, op=dist.ReduceOp.SUM, group=group)
     acc, iou, miou = tally.summary()
     return acc, iou, miou, tally

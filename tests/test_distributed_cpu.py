@@ -218,3 +218,49 @@ def _w_trainstep_world2(rank, world):
 
 def test_trainstep_host_logic_world2():
     _run('_w_trainstep_world2')
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _w_sharded_evaluate(rank, world):
+    """engine.evaluate over per-rank shards (eval_multipro.py:148-160 start_idx / end_idx) == one process over the whole list"""
+    import numpy as np
+    from mit_semseg import engine, utils
+    from oracle import metrics_oracle as M
+    C = 5
+
+    def cpu_metrics(scores, label=None, tally=None):
+        pred = M.argmax_first(scores.numpy()[0])[None]
+        if tally is None:
+            tally = utils.MetricTally(C, 'cpu')
+        lab = label.numpy()
+        valid = lab >= 0
+        tally.counts[0] += int(((pred[0] == lab) & valid).sum())
+        tally.counts[1] += int(valid.sum())
+        for c in range(C):
+            tally.counts[2 + c] += int(((pred[0] == c) & (lab == c)).sum())
+            tally.counts[2 + C + c] += int(((pred[0] == c) & valid).sum())
+            tally.counts[2 + 2 * C + c] += int((lab == c).sum())
+        return torch.from_numpy(pred), tally
+    utils.segmentation_metrics = cpu_metrics
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, feed, segSize=None):
+            g = torch.Generator().manual_seed(int(feed['img_data'].abs().sum().item() * 1000) % 100003)
+            return torch.softmax(torch.randn(1, C, segSize[0], segSize[1], generator=g) * 2, dim=1)
+    rng = np.random.default_rng(0)
+    items = [{'img_data': [torch.from_numpy(rng.standard_normal((1, 3, 8, 8)).astype(np.float32)) for _ in range(2)],
+              'seg_label': torch.from_numpy(rng.integers(-1, C, (1, 6 + k, 7)))} for k in range(5)]
+    whole = engine.evaluate(Fake(), items, C, device='cpu', use_graph=False, reduce=False)
+    n = len(items)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    mine = engine.evaluate(Fake(), items[lo:hi], C, device='cpu', use_graph=False)
+    assert torch.equal(mine[3].counts, whole[3].counts)
+    assert mine[0] == whole[0] and mine[2] == whole[2]
+
+
+def test_sharded_evaluate_equals_single_process():
+    _run('_w_sharded_evaluate')
