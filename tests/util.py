@@ -18,11 +18,6 @@ first_gpu_run_pending = pytest.mark.xfail(reason='first execution on a GPU pendi
 PENDING_GOLDEN = ('mnv2d_c1ds_64_train', 'resnext101_upernet_128_train')
 
 
-def golden_params():
-    """golden case names as pytest params (cases whose first GPU run is pending carry the marker)"""
-    return [pytest.param(n, marks=first_gpu_run_pending) if n in PENDING_GOLDEN else n for n in golden_cases()]
-
-
 def golden_cases():
     return sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*.pt')))
 
