@@ -199,3 +199,43 @@ def test_product_eval_assembly_on_emulated_kernels_matches_reference(emulated_ke
         assert tuple(a.shape) == b.shape and np.array_equal(a.numpy(), b)
     assert np.array_equal(feed['seg_label'].numpy(), v['seg_label'])
     assert 'seg_label' not in asm.assemble(torch.from_numpy(v['img']))           # TestDataset: no label map
+
+
+def test_val_and_test_dataset_mirrors(emulated_kernels, monkeypatch, tmp_path):
+    """ValDataset / TestDataset (dataset.py:206-296): keys, img_ori, info, shard selection, and the tensors the oracle
+    computes from the decoded files"""
+    Image = pytest.importorskip('PIL.Image')
+    import types
+    from mit_semseg import _native
+    from mit_semseg import dataset as D
+    lib = _HostKernels(_native.lib(), emulated_kernels, _native.SIGNATURES)
+    monkeypatch.setattr(_native, 'lib', lambda: lib)
+    monkeypatch.setattr(D, '_require_cuda', lambda *a: None)
+    monkeypatch.setattr(D, '_st', lambda: ctypes.c_void_p(0))
+    rng = np.random.default_rng(11)
+    recs, store = [], []
+    for k, (h, w) in enumerate([(33, 47), (52, 40), (41, 41)]):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        seg = rng.integers(0, 151, (h, w), dtype=np.uint8)
+        Image.fromarray(img).save(str(tmp_path / ('i%d.png' % k)))
+        Image.fromarray(seg, mode='L').save(str(tmp_path / ('s%d.png' % k)))
+        recs.append({'fpath_img': 'i%d.png' % k, 'fpath_segm': 's%d.png' % k, 'width': w, 'height': h})
+        store.append((img, seg))
+    opt = types.SimpleNamespace(imgSizes=(24, 40), imgMaxSize=64, padding_constant=8)
+    ds = D.ValDataset(str(tmp_path), recs, opt, device='cpu', start_idx=1, end_idx=3)       # eval_multipro.py shard
+    assert len(ds) == 2
+    item = ds[0]
+    img, seg = store[1]
+    assert set(item) == {'img_ori', 'img_data', 'seg_label', 'info'} and item['info'] == 'i1.png'
+    assert np.array_equal(item['img_ori'], img)
+    want = O.eval_image_inputs(img, opt.imgSizes, opt.imgMaxSize, opt.padding_constant, seg)
+    assert len(item['img_data']) == 2
+    for a, b in zip(item['img_data'], want['img_data']):
+        assert np.array_equal(a.numpy(), b)
+    assert np.array_equal(item['seg_label'].numpy(), want['seg_label'])
+    ts = D.TestDataset([{'fpath_img': str(tmp_path / 'i0.png')}], opt, device='cpu')
+    t = ts[0]
+    assert set(t) == {'img_ori', 'img_data', 'info'}
+    want = O.eval_image_inputs(store[0][0], opt.imgSizes, opt.imgMaxSize, opt.padding_constant)
+    for a, b in zip(t['img_data'], want['img_data']):
+        assert np.array_equal(a.numpy(), b)
