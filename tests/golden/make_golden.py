@@ -175,8 +175,11 @@ CASES = [
     # the remaining arch strings of ModelBuilder (depthwise / grouped convolutions)
     dict(name='mnv2d_c1ds_64_train', arch_enc='mobilenetv2dilated', arch_dec='c1_deepsup', fc_dim=320,
          n=2, h=64, w=64, seg_rate=8, training=True, deep_sup_scale=0.4, step=True),
-    dict(name='resnext101_upernet_128_train', arch_enc='resnext101', arch_dec='upernet', fc_dim=2048,
-         n=2, h=128, w=128, seg_rate=4, training=True, deep_sup_scale=None, step=True),
+    # eval mode: a train step through 101 layers with 2-sample BN statistics in the pyramid branches is chaotic (a 1e-6
+    # relative input perturbation moves the stem gradient by 1.7 %), i.e. not a parity case; the grouped-conv TRAINING path is
+    # pinned by the MobileNetV2 case above
+    dict(name='resnext101_upernet_128_eval', arch_enc='resnext101', arch_dec='upernet', fc_dim=2048,
+         n=2, h=128, w=128, seg_rate=4, training=False, deep_sup_scale=None),
 ]
 
 

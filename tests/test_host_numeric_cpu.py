@@ -1,0 +1,75 @@
+"""The product's Python stack, numerically, on the CPU (tests/cpu_twin.py stands in for the HIP launches): for EVERY golden
+case of the unmodified reference -- all model families, train / eval / inference -- ModelBuilder + SegmentationModule +
+TrainStep reproduce log-probs, loss, accuracy and, for the training cases, every parameter and BN buffer after the SGD step.
+Pins module wiring, state-dict naming, parameter grouping (weight decay on conv weights only), the LR plumbing and the
+dropout replay independently of any kernel."""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.nn as nn
+
+from tests import cpu_twin
+from tests.util import golden_cases, load_golden, check_summary
+from oracle import semseg_oracle as O
+
+
+def _build(g, use_softmax):
+    from mit_semseg.models import ModelBuilder, SegmentationModule
+    m = g['meta']
+    enc_sd = O.synth_state_dict(g['manifest_enc'], m['seed'])
+    dec_sd = O.synth_state_dict(g['manifest_dec'], m['seed'] + 1)
+    with tempfile.TemporaryDirectory() as d:
+        pe, pd = os.path.join(d, 'e.pth'), os.path.join(d, 'd.pth')
+        torch.save(enc_sd, pe)
+        torch.save(dec_sd, pd)
+        enc = ModelBuilder.build_encoder(m['arch_encoder'], fc_dim=m['fc_dim'], weights=pe)
+        dec = ModelBuilder.build_decoder(m['arch_decoder'], fc_dim=m['fc_dim'], num_class=150, weights=pd, use_softmax=use_softmax)
+    if 'main' in g['dropout']:
+        dec.conv_last[3].mask_override = g['dropout']['main']
+    if 'deepsup' in g['dropout']:
+        dec.dropout_deepsup.mask_override = g['dropout']['deepsup']
+    sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), m['deep_sup_scale'])
+    sm.train(m['training'])
+    return sm
+
+
+@pytest.mark.parametrize('name', [n for n in golden_cases() if n != 'cfg0_r18d_ppmds_384_eval'])      # 384x384: slow on CPU
+def test_python_stack_matches_reference_golden(name, monkeypatch):
+    cpu_twin.install(monkeypatch)
+    g = load_golden(name)
+    m = g['meta']
+    sm = _build(g, use_softmax=m['seg_size'] is not None)
+    img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=304 + m['seed'])
+    feed = {'img_data': img, 'seg_label': lab}
+    if m['seg_size'] is not None:
+        with torch.no_grad():
+            prob = sm(feed, segSize=tuple(m['seg_size']))
+        torch.testing.assert_close(prob, g['prob'], atol=1e-5, rtol=1e-4)
+        return
+    cap = {}
+    hk = sm.decoder.register_forward_hook(lambda mod, i, o: cap.__setitem__('out', o))
+    if m['step']:
+        from mit_semseg.engine import TrainStep
+        ts = TrainStep(sm, lr_encoder=m['lr'], lr_decoder=m['lr'], max_iters=10 ** 9)
+        loss, acc = ts.step(feed)
+    else:
+        with torch.no_grad():
+            loss, acc = sm(feed)
+    hk.remove()
+    out = cap['out']
+    pred, pred_ds = out if isinstance(out, tuple) else (out, None)
+    torch.testing.assert_close(pred.detach(), g['pred'], atol=2e-4, rtol=1e-3)
+    if pred_ds is not None:
+        torch.testing.assert_close(pred_ds.detach(), g['pred_deepsup'], atol=2e-4, rtol=1e-3)
+    assert abs(loss.item() - g['loss'].item()) < 1e-4 * max(1.0, abs(g['loss'].item()))
+    assert abs(acc.item() - g['acc'].item()) < 1e-6
+    if not m['step']:
+        return
+    for mod, want in ((sm.encoder, g['after_enc']), (sm.decoder, g['after_dec'])):
+        sd = mod.state_dict()
+        for k in want:
+            if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
+                continue
+            check_summary(sd[k].detach().contiguous(), want[k], 1e-4, 1e-3, 'after-step ' + k)
