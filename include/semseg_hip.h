@@ -355,6 +355,20 @@ int semseg_depthwise3x3_dgrad(const float* dy, int dy_ld, const float* w_taps, f
 int semseg_depthwise3x3_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, float* dw_taps, int N, int H, int W, int C,
                               int stride, int pad, int dil, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------- grouped 3x3 convolution (csrc/grouped.hip) ------------------------------------------------------------
+ * nn.Conv2d(C, K, 3, stride, padding, dilation, groups=g, bias=False) of the ResNeXt bottleneck (models/resnext.py:30-31,
+ * g = 32) and its autograd: fp32 NHWC, (C/g) % 4 == 0 and (K/g) % 4 == 0, weights w_taps[K][9][C/g]
+ * (w_taps[k][r*3+s][ci] = weight[k][ci][r][s]).  Same structure and determinism as the depthwise family; opt-in behind
+ * layers.GroupedConv2d (SEMSEG_GROUPED_DIRECT=1) until it has run on a GPU. */
+size_t semseg_grouped3x3_workspace_bytes(int N, int H, int W, int C, int K, int groups, int stride, int pad, int dil);
+int semseg_grouped3x3_fwd(const float* x, int x_ld, const float* w_taps, float* y, int y_ld, int N, int H, int W, int C, int K,
+                          int groups, int stride, int pad, int dil, void* stream);
+int semseg_grouped3x3_dgrad(const float* dy, int dy_ld, const float* w_taps, float* dx, int dx_ld, int N, int H, int W, int C,
+                            int K, int groups, int stride, int pad, int dil, void* stream);
+int semseg_grouped3x3_wgrad(const float* x, int x_ld, const float* dy, int dy_ld, float* dw_taps, int N, int H, int W, int C,
+                            int K, int groups, int stride, int pad, int dil, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* ---------------- input pipeline: training-batch assembly on the device (csrc/input_pipeline.hip) -------------------
  * Contract of mit_semseg/dataset.py:110-199 (TrainDataset.__getitem__) from DECODED uint8 arrays (the JPEG/PNG decode stays
  * on the host): `imresize(img, (w, h), 'bilinear')` = Pillow BILINEAR (dataset.py:9-19,167; antialiased triangle filter,

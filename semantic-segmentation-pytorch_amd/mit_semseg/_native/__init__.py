@@ -108,6 +108,10 @@ SIGNATURES = {
     'semseg_depthwise3x3_dgrad': (c_int, [vp, c_int, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'semseg_depthwise3x3_wgrad': (c_int, [vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, c_sz,
                                           vp]),
+    'semseg_grouped3x3_workspace_bytes': (c_sz, [c_int] * 9),
+    'semseg_grouped3x3_fwd': (c_int, [vp, c_int, vp, vp, c_int] + [c_int] * 9 + [vp]),
+    'semseg_grouped3x3_dgrad': (c_int, [vp, c_int, vp, vp, c_int] + [c_int] * 9 + [vp]),
+    'semseg_grouped3x3_wgrad': (c_int, [vp, c_int, vp, c_int, vp] + [c_int] * 9 + [vp, c_sz, vp]),
     'semseg_input_resample_ksize': (c_int, [c_int, c_int]),
     'semseg_input_resample_coeffs': (c_int, [c_int, c_int, vp, vp]),
     'semseg_input_nearest_table': (c_int, [c_int, c_int, vp]),

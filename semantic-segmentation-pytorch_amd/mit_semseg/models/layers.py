@@ -96,6 +96,9 @@ class GroupedConv2d(Conv2d):
         if ops.DEPTHWISE_DIRECT and self.groups == self.in_channels == self.out_channels and self.kernel_size == (3, 3) \
                 and self.in_channels % 4 == 0:
             return ops.depthwise_conv3x3(x, self.weight, self.stride[0], self.padding[0], self.dilation[0])
+        cg, kg = self.in_channels // self.groups, self.out_channels // self.groups
+        if ops.GROUPED_DIRECT and self.kernel_size == (3, 3) and cg % 4 == 0 and kg % 4 == 0:
+            return ops.grouped_conv3x3(x, self.weight, self.groups, self.stride[0], self.padding[0], self.dilation[0])
         return ops.conv2d(x, self.dense_weight(), None, self.stride[0], self.padding[0], self.dilation[0])
 
     def extra_repr(self):

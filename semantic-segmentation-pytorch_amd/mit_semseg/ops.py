@@ -550,6 +550,59 @@ def depthwise_conv3x3(x, weight, stride=1, padding=1, dilation=1):
     return DepthwiseConv3x3Fn.apply(x, weight, int(stride), int(padding), int(dilation))
 
 
+GROUPED_DIRECT = os.environ.get('SEMSEG_GROUPED_DIRECT', '0') == '1'       # csrc/grouped.hip, same status as DEPTHWISE_DIRECT
+
+
+class GroupedConv3x3Fn(Function):
+    """nn.Conv2d(C, K, 3, stride, padding, dilation, groups=g, bias=False) (resnext.py:30-31): weight [K, C/g, 3, 3]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, groups, stride, pad, dil):
+        L = _native.lib()
+        x, x_ld = as_nhwc(x.detach())
+        n, c, h, w = x.shape
+        k, cg = int(weight.shape[0]), int(weight.shape[1])
+        if tuple(weight.shape[2:]) != (3, 3) or cg * groups != c or k % groups or cg % 4 or (k // groups) % 4:
+            raise RuntimeError('grouped3x3: weight %s does not fit C = %d, groups = %d (channels per group must be multiples of 4)'
+                               % (tuple(weight.shape), c, groups))
+        _require_cuda(weight)
+        wt = weight.detach().permute(0, 2, 3, 1).reshape(k, 9, cg).contiguous()
+        oh, ow = conv_out_size(h, 3, stride, pad, dil), conv_out_size(w, 3, stride, pad, dil)
+        y = empty_nhwc(n, k, oh, ow, x.device)
+        _native.check(L.semseg_grouped3x3_fwd(_p(x), x_ld, _p(wt), _p(y), k, n, h, w, c, k, groups, stride, pad, dil, _st()),
+                      'grouped3x3_fwd')
+        ctx.save_for_backward(x, wt)
+        ctx.geom = (n, h, w, c, k, groups, stride, pad, dil)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        L = _native.lib()
+        x, wt = ctx.saved_tensors
+        n, h, w, c, k, groups, stride, pad, dil = ctx.geom
+        _, x_ld = as_nhwc(x)
+        dy, dy_ld = as_nhwc(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_nhwc(n, c, h, w, x.device)
+            _native.check(L.semseg_grouped3x3_dgrad(_p(dy), dy_ld, _p(wt), _p(dx), c, n, h, w, c, k, groups, stride, pad, dil,
+                                                    _st()), 'grouped3x3_dgrad')
+        if ctx.needs_input_grad[1]:
+            cg = c // groups
+            dwt = torch.empty((k, 9, cg), device=x.device, dtype=torch.float32)
+            ws = workspace(L.semseg_grouped3x3_workspace_bytes(n, h, w, c, k, groups, stride, pad, dil), x.device)
+            _native.check(L.semseg_grouped3x3_wgrad(_p(x), x_ld, _p(dy), dy_ld, _p(dwt), n, h, w, c, k, groups, stride, pad, dil,
+                                                    _p(ws), ws.numel(), _st()), 'grouped3x3_wgrad')
+            dw = dwt.reshape(k, 3, 3, cg).permute(0, 3, 1, 2)
+        return dx, dw, None, None, None, None
+
+
+def grouped_conv3x3(x, weight, groups, stride=1, padding=1, dilation=1):
+    _require_cuda(x)
+    return GroupedConv3x3Fn.apply(x, weight, int(groups), int(stride), int(padding), int(dilation))
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     if CONV_MODE == 'f32':
         return Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))

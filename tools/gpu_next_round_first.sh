@@ -13,6 +13,9 @@ timeout 300 python -m pytest tests/test_gpu_zz_depthwise.py tests/test_gpu_zz_in
 echo "== MobileNetV2 golden on the depthwise kernels"
 SEMSEG_DEPTHWISE_DIRECT=1 timeout 200 python -m pytest "tests/test_gpu_zz_models.py::test_new_backbones_match_reference_golden[mnv2d_c1ds_64_train]" \
     -m gpu -q --runxfail > $OUT/pytest_mnv2_direct.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest_mnv2_direct.log | cut -c1-300
+echo "== ResNeXt golden on the grouped kernels"
+SEMSEG_GROUPED_DIRECT=1 timeout 200 python -m pytest "tests/test_gpu_zz_models.py::test_new_backbones_match_reference_golden[resnext101_upernet_128_eval]" \
+    -m gpu -q --runxfail > $OUT/pytest_resnext_direct.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest_resnext_direct.log | cut -c1-300
 echo "== queued A/B (bench, interleaved, 2 rounds)"
 bash tools/gpu_ab.sh $TAG/ab base:X=1 wino512:SEMSEG_WINOGRAD_MIN_C=512 \
     wsplit:SEMSEG_WGRAD_MAX_SPLIT=256,SEMSEG_TUNE_CACHE=/tmp/plans_wsplit.json
