@@ -165,6 +165,39 @@ def cpu_baseline():
                       'torch %s CPU, no warm-up, %.1f s' % (torch.__version__, dt)}
 
 
+def ddp_graph_selftest(timeout_s=150):
+    """world > 1: decide whether the real run may capture its RCCL all-reduces into the step's hipGraph.  Every rank runs
+    tools/probes/ddp_graph_selftest.py (a small model through exactly that code path) in a CHILD process, on its own
+    rendezvous port, BEFORE this process touches the GPU or RCCL; a child that fails or does not finish in time is killed and
+    counts as a failure.  Returns True if this rank's child passed (the ranks agree on the outcome afterwards)."""
+    import subprocess
+    import tempfile
+    env = dict(os.environ)
+    env['MASTER_PORT'] = str(int(env.get('MASTER_PORT', '29500')) + 17)
+    env.pop('TORCHELASTIC_USE_AGENT_STORE', None)       # rank 0 of the children opens its own store on the new port
+    env.pop('SEMSEG_TUNE_CACHE', None)
+    script = os.path.join(ROOT, 'tools', 'probes', 'ddp_graph_selftest.py')
+    ok, why = False, 'not started'
+    with tempfile.TemporaryFile() as log:
+        try:
+            p = subprocess.Popen([sys.executable, script], env=env, stdout=log, stderr=subprocess.STDOUT)
+            try:
+                rc = p.wait(timeout=timeout_s)
+                ok, why = rc == 0, 'exit code %d' % rc
+            except subprocess.TimeoutExpired:
+                p.kill()                                 # the exact child started above
+                p.wait()
+                why = 'no result within %d s (killed)' % timeout_s
+        except OSError as e:
+            why = str(e)
+        if not ok and env.get('RANK', '0') == '0':
+            log.seek(0)
+            tail = log.read()[-1500:].decode('utf-8', 'replace')
+            print('[bench] data-parallel hipGraph self-test did not pass (%s); launching eagerly.\n%s' % (why, tail),
+                  file=sys.stderr, flush=True)
+    return ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -180,12 +213,24 @@ def main():
     from mit_semseg.engine import TrainStep
     import torch.distributed as dist
 
+    # Data-parallel runs launch eagerly unless SEMSEG_DDP_GRAPH says otherwise.  With nothing said, let a self-test decide:
+    # if the captured RCCL all-reduces work for a small model on THIS node (every rank, inside a time limit), the real run
+    # replays a hipGraph as the single-GPU run does; if not, nothing changes.
+    selftest_ok = None
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'SEMSEG_DDP_GRAPH' not in os.environ and not args.no_graph and \
+            not os.environ.get('SEMSEG_DIST_BACKEND') and not os.environ.get('SEMSEG_BENCH_DEVICE'):
+        selftest_ok = ddp_graph_selftest()
     rank, world, local = init_distributed()
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     if os.environ.get('SEMSEG_BENCH_DEVICE'):          # several ranks on one GPU (gloo): functional check of the N>1 path
         local = int(os.environ['SEMSEG_BENCH_DEVICE'])
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    if selftest_ok is not None:
+        flag = torch.tensor([1 if selftest_ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # every rank's child must have passed
+        if int(flag.item()) == 1:
+            os.environ['SEMSEG_DDP_GRAPH'] = '1'
     sm = build_model(dev)
     if world > 1:
         NativeDataParallel(sm)          # enables SyncBN statistics all-reduce over RCCL
@@ -227,6 +272,7 @@ def main():
                                    '(fwd+NLL loss+bwd+2xSGD), bs 2/GPU 512x512x3, 150 classes, labels 64x64',
                        'global_batch': 2 * world, 'parallelism': 'dp%d' % world,
                        'launch': 'hipGraph replay' if (step._graph is not None) else 'eager',
+                       'ddp_graph_selftest': selftest_ok,
                        'conv_path': ops_mode(),
                        'images_per_sec_per_gpu': round(per_gpu, 3),
                        'step_conv_tflops_per_gpu': round(per_gpu * TRAIN_GFLOP_PER_IMG['resnet50dilated+ppm_deepsup'] * 1e-3, 2),

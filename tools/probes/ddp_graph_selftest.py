@@ -1,0 +1,73 @@
+"""Self-test of the hipGraph data-parallel step, one process per GPU (launched by bench.py on every rank before the real run,
+or by hand under torchrun): a small model (ResNet18dilated + PPM_deepsup, 2 x 64 x 64 per rank) trains a few steps with
+SEMSEG_DDP_GRAPH=1 -- SyncBN statistics all-reduces on the compute stream and the gradient buckets on the side stream are
+CAPTURED with the rest of the step and replayed.  Passes (exit 0) only if the graph was really used, the loss is finite and
+the replicas stay bit-identical (their parameters could not agree if any captured all-reduce were dropped or stale: every
+rank trains on different data).  bench.py enables the graph path for the real run only when every rank's self-test passed
+inside its time limit; anything else -- an exception, a hang that the parent kills -- leaves the eager path in place."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd'))
+os.environ['SEMSEG_DDP_GRAPH'] = '1'
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+
+def main():
+    from mit_semseg.models import ModelBuilder, SegmentationModule, resnet
+    from mit_semseg.models.models import ResnetDilated
+    from mit_semseg.parallel import init_distributed, NativeDataParallel
+    from mit_semseg.engine import TrainStep
+    rank, world, local = init_distributed()
+    assert world > 1, 'run with one process per GPU (WORLD_SIZE > 1)'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(304)
+    enc = ResnetDilated(resnet.resnet18(pretrained=False), dilate_scale=8)
+    dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=512, num_class=150)
+    sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), 0.4).to(dev).train()
+    NativeDataParallel(sm)
+    g = torch.Generator().manual_seed(1000 + rank)
+    feed = {'img_data': torch.randn(2, 3, 64, 64, generator=g).to(dev),
+            'seg_label': torch.randint(-1, 150, (2, 8, 8), generator=g).to(dev)}
+    ts = TrainStep(sm, max_iters=1000, graph=True, bucket_bytes=8 << 20)
+    assert ts.buckets is not None and len(ts.buckets.buckets) > 1
+    loss = None
+    for _ in range(6):
+        loss, acc = ts.step(feed)
+    torch.cuda.synchronize()
+    assert ts._graph is not None, 'the step did not run as a graph'
+    assert torch.isfinite(loss).item(), 'loss is not finite'
+    sums = torch.stack([p.detach().double().abs().sum() for p in sm.parameters()] +
+                       [b.detach().double().abs().sum() for n, b in sm.named_buffers() if n.endswith('running_var')])
+    hi, lo = sums.clone(), sums.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    assert torch.equal(hi, lo), 'replicas diverged: max |hi - lo| = %g' % (hi - lo).abs().max().item()
+    # bucket-sized message through a graph as well (the real run reduces 64 MiB gradient buckets)
+    big = torch.ones(16 << 20, device=dev, dtype=torch.float32)
+    dist.all_reduce(big)
+    torch.cuda.synchronize()
+    gg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gg):
+        dist.all_reduce(big)
+    for _ in range(2):
+        gg.replay()
+    torch.cuda.synchronize()
+    want = float(world) ** 3                     # 1 -> eager reduce -> two replays (the capture itself executes nothing)
+    assert float(big[0]) == want and float(big[-1]) == want, (float(big[0]), want)
+    ref = torch.tensor([loss.item()], device=dev, dtype=torch.float64)
+    dist.all_reduce(ref)                          # also proves an eager collective still works after the replays
+    dist.barrier()
+    if rank == 0:
+        print('ddp graph selftest ok: world %d, loss %.5f' % (world, loss.item()), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
