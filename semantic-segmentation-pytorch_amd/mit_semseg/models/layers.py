@@ -205,3 +205,26 @@ def conv3x3_bn_relu(in_planes, out_planes, stride=1):
     """3x3 convolution + BN + relu (models.py:160-167)."""
     return ConvBNReLU(Conv2d(in_planes, out_planes, 3, stride=stride, padding=1, bias=False),
                       BatchNorm2d(out_planes))
+
+
+# ------------------------------------------------------------------------------------------------
+# the deep stem shared by the ResNet and ResNeXt backbones (resnet.py:100-109, resnext.py:69-78)
+# ------------------------------------------------------------------------------------------------
+_DEEP_STEM = ((3, 64, 2), (64, 64, 1), (64, 128, 1))      # (in, out, stride) of conv1..3, all 3x3 / pad 1 / no bias
+
+
+def add_deep_stem(module):
+    """registers conv{i} / bn{i} / relu{i} (i = 1..3) and `maxpool` on `module`, in the reference's order and names"""
+    for i, (cin, cout, stride) in enumerate(_DEEP_STEM, 1):
+        module.add_module('conv%d' % i, Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False))
+        module.add_module('bn%d' % i, BatchNorm2d(cout))
+        module.add_module('relu%d' % i, ReLU(inplace=True))
+    module.add_module('maxpool', MaxPool3x3s2())
+    return _DEEP_STEM[-1][1]
+
+
+def run_deep_stem(module, x):
+    """three fused conv -> BN -> ReLU units, then the 3x3 / stride-2 max-pool"""
+    for i in (1, 2, 3):
+        x = conv_bn(getattr(module, 'conv%d' % i), getattr(module, 'bn%d' % i), x, relu=True)
+    return module.maxpool(x)

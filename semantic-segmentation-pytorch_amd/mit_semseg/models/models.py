@@ -9,7 +9,8 @@ import torch.nn as nn
 
 from .. import ops
 from . import resnet, hrnet, mobilenet, resnext
-from .layers import (Conv2d, BatchNorm2d, AdaptiveAvgPool2d, Dropout2d, ConvBNReLU, ReLU, conv3x3_bn_relu, conv_bn)
+from .layers import (Conv2d, BatchNorm2d, AdaptiveAvgPool2d, Dropout2d, ConvBNReLU, ReLU, conv3x3_bn_relu, conv_bn,
+                     run_deep_stem)
 
 
 class SegmentationModuleBase(nn.Module):
@@ -136,10 +137,7 @@ class Resnet(nn.Module):
             setattr(self, name, getattr(orig_resnet, name))
 
     def forward(self, x, return_feature_maps=False):
-        x = conv_bn(self.conv1, self.bn1, x, relu=True)
-        x = conv_bn(self.conv2, self.bn2, x, relu=True)
-        x = conv_bn(self.conv3, self.bn3, x, relu=True)
-        x = self.maxpool(x)
+        x = run_deep_stem(self, x)
         conv_out = []
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             x = stage(x)

@@ -6,7 +6,7 @@ import math
 
 import torch.nn as nn
 
-from .layers import Conv2d, BatchNorm2d, ReLU, MaxPool3x3s2, ConvBNReLU, conv_bn
+from .layers import Conv2d, BatchNorm2d, ReLU, ConvBNReLU, conv_bn, add_deep_stem, run_deep_stem
 from .utils import load_url
 
 __all__ = ['ResNet', 'resnet18', 'resnet50', 'resnet101']
@@ -75,17 +75,7 @@ class ResNet(nn.Module):
 
     def __init__(self, block, layers, num_classes=1000):
         super().__init__()
-        self.inplanes = 128
-        self.conv1 = Conv2d(3, 64, 3, stride=2, padding=1, bias=False)
-        self.bn1 = BatchNorm2d(64)
-        self.relu1 = ReLU(inplace=True)
-        self.conv2 = Conv2d(64, 64, 3, padding=1, bias=False)
-        self.bn2 = BatchNorm2d(64)
-        self.relu2 = ReLU(inplace=True)
-        self.conv3 = Conv2d(64, 128, 3, padding=1, bias=False)
-        self.bn3 = BatchNorm2d(128)
-        self.relu3 = ReLU(inplace=True)
-        self.maxpool = MaxPool3x3s2()
+        self.inplanes = add_deep_stem(self)            # conv1..3 / bn1..3 / relu1..3 / maxpool (resnet.py:100-109); 128 wide
         self.layer1 = self._stage(block, 64, layers[0], 1)
         self.layer2 = self._stage(block, 128, layers[1], 2)
         self.layer3 = self._stage(block, 256, layers[2], 2)
@@ -107,10 +97,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*blocks)
 
     def stem(self, x):
-        x = conv_bn(self.conv1, self.bn1, x, relu=True)
-        x = conv_bn(self.conv2, self.bn2, x, relu=True)
-        x = conv_bn(self.conv3, self.bn3, x, relu=True)
-        return self.maxpool(x)
+        return run_deep_stem(self, x)
 
     def forward(self, x):
         x = self.stem(x)
