@@ -38,6 +38,15 @@ def _build(g, use_softmax):
 @pytest.mark.parametrize('name', [n for n in golden_cases() if n != 'cfg0_r18d_ppmds_384_eval'])      # 384x384: slow on CPU
 def test_python_stack_matches_reference_golden(name, monkeypatch):
     cpu_twin.install(monkeypatch)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(8, prev))            # small tensors: torch's CPU kernels thrash on hundreds of threads
+    try:
+        _run_case(name)
+    finally:
+        torch.set_num_threads(prev)
+
+
+def _run_case(name):
     g = load_golden(name)
     m = g['meta']
     sm = _build(g, use_softmax=m['seg_size'] is not None)
