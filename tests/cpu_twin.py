@@ -94,12 +94,14 @@ def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum
             p.sub_(lr * b)
 
 
-def install(monkeypatch):
+def install(monkeypatch, keep=()):
+    """`keep`: names of ops functions to leave in place (they then need a native library, e.g. a host-emulated one)"""
     from mit_semseg import ops
     g = globals()
     for name in ('conv2d', 'depthwise_conv3x3', 'batch_norm_act', 'conv_bn_act', 'add_act', 'concat', 'scale_nc',
                  'max_pool_3x3_s2', 'adaptive_avg_pool', 'adaptive_avg_pool_multi', 'interpolate_bilinear', 'log_softmax',
                  'softmax', 'nll_loss_acc', 'sgd_step'):
-        monkeypatch.setattr(ops, name, g[name])
+        if name not in keep:
+            monkeypatch.setattr(ops, name, g[name])
     monkeypatch.setattr(ops, 'prepare_conv_weights', lambda ws: 0)
     monkeypatch.setattr(ops, '_require_cuda', lambda *a: None)

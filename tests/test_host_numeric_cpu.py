@@ -46,7 +46,7 @@ def test_python_stack_matches_reference_golden(name, monkeypatch):
         torch.set_num_threads(prev)
 
 
-def _run_case(name):
+def _run_case(name, step_tol=(1e-4, 1e-3)):
     g = load_golden(name)
     m = g['meta']
     sm = _build(g, use_softmax=m['seg_size'] is not None)
@@ -81,4 +81,47 @@ def _run_case(name):
         for k in want:
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue
-            check_summary(sd[k].detach().contiguous(), want[k], 1e-4, 1e-3, 'after-step ' + k)
+            check_summary(sd[k].detach().contiguous(), want[k], step_tol[0], step_tol[1], 'after-step ' + k)
+
+
+def test_mobilenet_golden_with_direct_depthwise_kernels_emulated(monkeypatch, tmp_path):
+    """the opt-in depthwise path (SEMSEG_DEPTHWISE_DIRECT=1: layers.GroupedConv2d -> ops.DepthwiseConv3x3Fn -> csrc/depthwise.hip)
+    inside the full MobileNetV2 training step: everything else on the torch twin, the depthwise launches on the host build of
+    the kernels' per-element code -- against the golden of the unmodified reference"""
+    import ctypes
+    import subprocess
+    from mit_semseg import _native, ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'libdepthwise_emulate.so')
+    subprocess.run(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-I' + os.path.join(root, 'semantic-segmentation-pytorch_amd', 'csrc'),
+                    os.path.join(root, 'tests', 'native', 'depthwise_emulate.cpp'), '-o', out], check=True)
+    emu = ctypes.CDLL(out)
+    real = _native.lib()
+
+    class Lib:
+        def __getattr__(self, name):
+            return getattr(real, name)
+    lib = Lib()
+    for name in ('semseg_depthwise3x3_workspace_bytes', 'semseg_depthwise3x3_fwd', 'semseg_depthwise3x3_dgrad',
+                 'semseg_depthwise3x3_wgrad'):
+        fn = getattr(emu, name)
+        fn.restype, fn.argtypes = _native.SIGNATURES[name]
+        setattr(lib, name, fn)
+    cpu_twin.install(monkeypatch)
+    monkeypatch.undo()                                   # keep the REAL ops.depthwise_conv3x3 ...
+    cpu_twin.install(monkeypatch, keep=('depthwise_conv3x3',))
+    monkeypatch.setattr(_native, 'lib', lambda: lib)
+    monkeypatch.setattr(ops, '_st', lambda: ctypes.c_void_p(0))
+    monkeypatch.setattr(ops, '_WS', {})
+    monkeypatch.setattr(ops, 'DEPTHWISE_DIRECT', True)
+    calls = []
+    orig = ops.DepthwiseConv3x3Fn.apply
+    monkeypatch.setattr(ops.DepthwiseConv3x3Fn, 'apply', staticmethod(lambda *a: (calls.append(1), orig(*a))[1]))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(8, prev))
+    try:
+        # other fp32 summation order in the depthwise kernels; the stem gradient moves by 0.5 % per 1e-6 of input noise
+        _run_case('mnv2d_c1ds_64_train', step_tol=(5e-4, 5e-3))
+    finally:
+        torch.set_num_threads(prev)
+    assert len(calls) == 17                              # one depthwise conv per inverted-residual block
