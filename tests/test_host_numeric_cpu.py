@@ -107,9 +107,7 @@ def test_mobilenet_golden_with_direct_depthwise_kernels_emulated(monkeypatch, tm
         fn = getattr(emu, name)
         fn.restype, fn.argtypes = _native.SIGNATURES[name]
         setattr(lib, name, fn)
-    cpu_twin.install(monkeypatch)
-    monkeypatch.undo()                                   # keep the REAL ops.depthwise_conv3x3 ...
-    cpu_twin.install(monkeypatch, keep=('depthwise_conv3x3',))
+    cpu_twin.install(monkeypatch, keep=('depthwise_conv3x3',))      # the REAL Function, on the emulated kernels
     monkeypatch.setattr(_native, 'lib', lambda: lib)
     monkeypatch.setattr(ops, '_st', lambda: ctypes.c_void_p(0))
     monkeypatch.setattr(ops, '_WS', {})
@@ -125,3 +123,41 @@ def test_mobilenet_golden_with_direct_depthwise_kernels_emulated(monkeypatch, tm
     finally:
         torch.set_num_threads(prev)
     assert len(calls) == 17                              # one depthwise conv per inverted-residual block
+
+
+def test_resnext_golden_with_direct_grouped_kernels_emulated(monkeypatch, tmp_path):
+    """the opt-in grouped path (SEMSEG_GROUPED_DIRECT=1 -> ops.GroupedConv3x3Fn -> csrc/grouped.hip) inside ResNeXt-101 + UPerNet:
+    33 grouped convolutions on the host build of the kernels' per-element code, the rest on the torch twin"""
+    import ctypes
+    import subprocess
+    from mit_semseg import _native, ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'libgrouped_emulate.so')
+    subprocess.run(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-I' + os.path.join(root, 'semantic-segmentation-pytorch_amd', 'csrc'),
+                    os.path.join(root, 'tests', 'native', 'grouped_emulate.cpp'), '-o', out], check=True)
+    emu = ctypes.CDLL(out)
+    real = _native.lib()
+
+    class Lib:
+        def __getattr__(self, name):
+            return getattr(real, name)
+    lib = Lib()
+    for name in ('semseg_grouped3x3_workspace_bytes', 'semseg_grouped3x3_fwd', 'semseg_grouped3x3_dgrad', 'semseg_grouped3x3_wgrad'):
+        fn = getattr(emu, name)
+        fn.restype, fn.argtypes = _native.SIGNATURES[name]
+        setattr(lib, name, fn)
+    cpu_twin.install(monkeypatch)
+    monkeypatch.setattr(_native, 'lib', lambda: lib)
+    monkeypatch.setattr(ops, '_st', lambda: ctypes.c_void_p(0))
+    monkeypatch.setattr(ops, '_WS', {})
+    monkeypatch.setattr(ops, 'GROUPED_DIRECT', True)
+    calls = []
+    orig = ops.GroupedConv3x3Fn.apply
+    monkeypatch.setattr(ops.GroupedConv3x3Fn, 'apply', staticmethod(lambda *a: (calls.append(1), orig(*a))[1]))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(8, prev))
+    try:
+        _run_case('resnext101_upernet_128_eval')
+    finally:
+        torch.set_num_threads(prev)
+    assert len(calls) == 33
