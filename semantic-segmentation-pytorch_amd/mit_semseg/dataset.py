@@ -9,6 +9,9 @@ kernels (csrc/input_pipeline.hip), bit-exact against Pillow.
     feed = asm.assemble(images_u8, segms_u8, flips, this_short_size)      # {'img_data', 'seg_label'} on the device
 
 `TrainDataset` mirrors the reference class (same record grouping, same numpy random draws) on top of the assembler.
+Its items are device tensors: iterate it directly or through a `DataLoader(..., batch_size=1, num_workers=0,
+collate_fn=user_scattered_collate)` -- the 16 CPU workers of train.py:163-177 existed to do on the host what the kernels do here;
+only the file decode is left, and that can be prefetched by any host-side loader that yields uint8 arrays.
 There is no CPU fallback: without the HIP library / a HIP device the assembler raises."""
 import functools
 import json
