@@ -12,3 +12,15 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests need an MI355X and the built native library: skip them (instead of erroring) on a CPU-only box, so
+    a plain `pytest tests` is green there too."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no HIP device visible (gpu-marked tests run on the MI355X box)')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)

@@ -13,9 +13,7 @@ for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from tests.util import first_gpu_run_pending  # noqa: E402
-
-pytestmark = [pytest.mark.gpu, first_gpu_run_pending]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('case', [(2, 32, 64, 64, 1, 1, 1), (2, 96, 33, 29, 2, 1, 1), (2, 384, 16, 16, 1, 2, 2),

@@ -1,20 +1,12 @@
-"""GPU tests whose FIRST execution on an MI355X is still pending (written after the round's GPU budget was spent; see
-tests/util.py first_gpu_run_pending).  The file sorts last on purpose: whatever happens here cannot disturb the validated
-suite that runs before it.  Contents: the parity cases of the MobileNetV2 / ResNeXt backbones against the goldens of the
-unmodified reference, and the multi-scale evaluation loop against the oracle."""
+"""The multi-scale evaluation loop (engine.evaluate, eval.py:40-105) on the device against the oracle."""
 import pytest
 import torch
 
-from tests.util import load_golden, first_gpu_run_pending, PENDING_GOLDEN
-from tests.test_gpu_models import build_native, argmax_check, test_native_matches_reference_golden as _golden_case
+from tests.util import load_golden
+from tests.test_gpu_models import build_native, argmax_check
 from oracle import semseg_oracle as O
 
-pytestmark = [pytest.mark.gpu, first_gpu_run_pending]
-
-
-@pytest.mark.parametrize('name', PENDING_GOLDEN)
-def test_new_backbones_match_reference_golden(name, monkeypatch):
-    _golden_case(name, monkeypatch)
+pytestmark = pytest.mark.gpu
 
 
 def test_evaluate_multiscale_loop_vs_oracle():

@@ -8,9 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import first_gpu_run_pending  # noqa: E402
-
-pytestmark = [pytest.mark.gpu, first_gpu_run_pending]
+pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
     if p not in sys.path:

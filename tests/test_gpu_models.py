@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.util import golden_cases, load_golden, check_summary, PENDING_GOLDEN
+from tests.util import golden_cases, load_golden, check_summary, HEURISTIC_PLAN_GOLDEN
 from oracle import semseg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -50,11 +50,9 @@ def argmax_check(got_logp, ref_logp, what):
     assert hard.sum().item() == 0
 
 
-@pytest.mark.parametrize('name', [n for n in golden_cases() if n not in PENDING_GOLDEN])
+@pytest.mark.parametrize('name', golden_cases())
 def test_native_matches_reference_golden(name, monkeypatch):
-    if name in PENDING_GOLDEN:
-        # ~150 convolution geometries that no other test uses (dense forms of the grouped convs): run them on the library's
-        # heuristic plans instead of timing every tile x split candidate
+    if name in HEURISTIC_PLAN_GOLDEN:
         from mit_semseg import tuner
         monkeypatch.setattr(tuner, 'ENABLED', False)
     g = load_golden(name)

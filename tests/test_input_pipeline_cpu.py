@@ -4,7 +4,7 @@
   * the product's host-side table builders (C, inside libsemseg_hip.so) are pinned against the oracle's;
   * the product's Python assembly (mit_semseg/dataset.py) runs end to end with the three kernel entry points replaced by a
     host build of the SAME per-element code (tests/native/input_emulate.cpp includes csrc/input_pipeline_math.h) and must
-    reproduce the reference's batches bit for bit.  The GPU tests (tests/test_gpu_zz_input.py) then only add the launch."""
+    reproduce the reference's batches bit for bit.  The GPU tests (tests/test_gpu_input.py) then only add the launch."""
 import ctypes
 import os
 import subprocess
