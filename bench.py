@@ -4,6 +4,8 @@ ade20k-resnet50dilated-ppm_deepsup (configs[1]), synthetic ADE20K-shaped batches
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --config 2|3|4      # the other BASELINE.json configs, same JSON line (default 1 = the metric's config):
+                                        # 2 R50+UPerNet, 3 R101dilated+PPM_deepsup on variable-size batches, 4 HRNetV2+C1
 
 One "step" = train.py:34-48: zero_grad, SegmentationModule.forward (loss+acc), backward, 2x SGD (poly LR), fp32.
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
@@ -23,8 +25,24 @@ import torch            # noqa: E402
 import torch.nn as nn   # noqa: E402
 
 # SURVEY 8d (hooks on the reference modules): 2*MACs of every Conv2d; train = 3*fwd - fwd(first conv)
-TRAIN_GFLOP_PER_IMG = {'resnet50dilated+ppm_deepsup': 1224.2}
-FWD_GFLOP_CONV_LAST = 309.24          # decoder.conv_last.0: 3x3 4096->512 @64x64, N=2 (per launch; fwd and dgrad alike)
+# BASELINE.json configs[i] -> workload.  train GFLOP/img at 512x512 (variable-size batches scale it by H*W / 512^2);
+# `dominant`: the largest single conv launch of the step -- (pass 0 fwd / 1 dgrad, (N,H,W,C,K,R,S,stride,pad,dil), layer) --
+# timed live for the roofline entry.  conv_last of the PPM / UPerNet heads runs its FORWARD through the Winograd path, so the
+# largest single launch of those steps is its data gradient.
+CONFIGS = {
+    1: dict(name='resnet50dilated+ppm_deepsup', yaml='ade20k-resnet50dilated-ppm_deepsup', enc='resnet50', dilated=True,
+            dec='ppm_deepsup', fc_dim=2048, dss=0.4, rate=8, pad=8, gflop=1224.2,
+            dominant=(1, (2, 64, 64, 4096, 512, 3, 3, 1, 1, 1), 'decoder.conv_last.0 3x3 4096->512 @64x64 N=2')),
+    2: dict(name='resnet50+upernet', yaml='ade20k-resnet50-upernet', enc='resnet50', dilated=False, dec='upernet', fc_dim=2048,
+            dss=None, rate=4, pad=32, gflop=1468.0,
+            dominant=(1, (2, 128, 128, 2048, 512, 3, 3, 1, 1, 1), 'decoder.conv_last.0.0 3x3 2048->512 @128x128 N=2')),
+    3: dict(name='resnet101dilated+ppm_deepsup', yaml='ade20k-resnet101dilated-ppm_deepsup', enc='resnet101', dilated=True,
+            dec='ppm_deepsup', fc_dim=2048, dss=0.4, rate=8, pad=8, gflop=1689.6, variable=True,
+            dominant=(1, (2, 64, 64, 4096, 512, 3, 3, 1, 1, 1),
+                      'decoder.conv_last.0 3x3 4096->512 N=2, timed at the 64x64 map of a 512x512 batch')),
+    4: dict(name='hrnetv2+c1', yaml='ade20k-hrnetv2', enc='hrnetv2', dilated=False, dec='c1', fc_dim=720, dss=None, rate=4, pad=32,
+            gflop=625.4, dominant=(0, (2, 128, 128, 720, 180, 3, 3, 1, 1, 1), 'decoder.cbr.0 3x3 720->180 @128x128 N=2')),
+}
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 # HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the guide's gfx950
@@ -36,6 +54,7 @@ S3_CONV_LAST_HBM_BYTES = None
 # profiles/r2s_pmc_conv_last_dgrad_h2.txt: FETCH_SIZE 168153 KiB x 2 + WRITE_SIZE 131072 KiB (the fp32 dx, no split-K);
 # the algorithmic bytes of this launch are 226.5 MB (dy planes 16.8 MB + w planes 75.5 MB + 134.2 MB fp32 output)
 H2_CONV_LAST_HBM_BYTES = (2 * 168153 + 131072) * 1024
+H2_HBM_BYTES = {1: H2_CONV_LAST_HBM_BYTES, 3: H2_CONV_LAST_HBM_BYTES}      # config -> measured traffic of its dominant launch
 H2_CONV_LAST_CLOCK_GHZ = 1.55     # SQ_WAVE_CYCLES x 4 / waves / duration of the same PMC pass: the MFMA-dense kernel runs
                                   # power-limited well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at
 DTYPE = {'h2': 'f32 (fp32 in/out/accumulate; products on the fp16 MFMA via a scaled 2-way fp16 split, 3 terms, 2^-22 per product)',
@@ -50,54 +69,90 @@ def ops_mode():
     return ops.CONV_MODE
 
 
-def build_model(dev, seed=304):
+def build_model(dev, cfg, seed=304):
     from mit_semseg.models import ModelBuilder, SegmentationModule
-    from mit_semseg.models import resnet
-    from mit_semseg.models.models import ResnetDilated
+    from mit_semseg.models import resnet, hrnet
+    from mit_semseg.models.models import ResnetDilated, Resnet
     torch.manual_seed(seed)
-    # random init exactly as the reference builds it without a checkpoint (resnet.py:118-124, models.py:52-61)
-    enc = ResnetDilated(resnet.resnet50(pretrained=False), dilate_scale=8)
-    dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=2048, num_class=150)
+    # random init exactly as the reference builds it without a checkpoint (resnet.py:118-124, hrnet.py, models.py:52-61)
+    if cfg['enc'] == 'hrnetv2':
+        enc = hrnet.hrnetv2(pretrained=False)
+    else:
+        base = resnet.__dict__[cfg['enc']](pretrained=False)
+        enc = ResnetDilated(base, dilate_scale=8) if cfg['dilated'] else Resnet(base)
+    dec = ModelBuilder.build_decoder(cfg['dec'], fc_dim=cfg['fc_dim'], num_class=150)
     crit = nn.NLLLoss(ignore_index=-1)
-    return SegmentationModule(enc, dec, crit, deep_sup_scale=0.4).to(dev).train()
+    return SegmentationModule(enc, dec, crit, deep_sup_scale=cfg['dss']).to(dev).train()
 
 
-def synth_feed(dev, rank, n=2, h=512, w=512, seg_rate=8):
-    g = torch.Generator().manual_seed(304 + rank)
+def synth_feed(dev, rank, cfg, n=2, h=512, w=512, gen=None):
+    g = gen or torch.Generator().manual_seed(304 + rank)
     img = torch.randn(n, 3, h, w, generator=g)
-    lab = torch.randint(-1, 150, (n, h // seg_rate, w // seg_rate), generator=g)
+    lab = torch.randint(-1, 150, (n, h // cfg['rate'], w // cfg['rate']), generator=g)
     return {'img_data': img.to(dev), 'seg_label': lab.to(dev)}
 
 
-def time_dominant_kernel(dev, iters=10):
-    """HIP-event timing of the dominant kernel of the step -- the implicit-GEMM DATA GRADIENT of decoder.conv_last.0 (3x3,
-    4096->512 @64x64, N=2: 309.24 GFLOP, 12.6 % of the step's FLOPs; its forward runs through the Winograd path since r2m,
-    so the largest single launch of the step is this one) -- through the C ABI on pre-split operands, i.e. ONLY the conv
-    entry point (igemm_dma_kernel<SchH2,256,256> on the default h2 path, tuned plan: no split-K) on the stream it is
-    launched on (torch's current stream)."""
+def variable_feeds(dev, rank, cfg, count):
+    """BASELINE configs[3]: `count` per-GPU batches whose (H, W) follow the multi-scale rule of dataset.py:110-142 (short side
+    in {300,...,600}, long side <= 1000, padded to multiples of 8) over the ADE20K size histogram
+    (tests/golden/ade20k_train_sizes.npz); one resident synthetic batch per distinct shape."""
+    import itertools
+    import numpy as np
+    from mit_semseg.dataset import batch_shape_stream
+    d = np.load(os.path.join(ROOT, 'tests', 'golden', 'ade20k_train_sizes.npz'))
+    stream = batch_shape_stream(list(zip(d['width'].tolist(), d['height'].tolist())), d['count'], padding_constant=cfg['pad'],
+                                seed=304 + rank)
+    shapes = list(itertools.islice(stream, count))
+    g = torch.Generator().manual_seed(304 + rank)
+    pool = {}
+    for hw in shapes:
+        if hw not in pool:
+            pool[hw] = synth_feed(dev, rank, cfg, h=hw[0], w=hw[1], gen=g)
+    return shapes, pool
+
+
+def time_dominant_kernel(dev, cfg, iters=10):
+    """HIP-event timing of the dominant kernel of the step (CONFIGS[..]['dominant']; for configs[1] the implicit-GEMM DATA
+    GRADIENT of decoder.conv_last.0, 3x3 4096->512 @64x64, N=2: 309.24 GFLOP, 12.6 % of the step's FLOPs) through the C ABI on
+    pre-split operands, i.e. ONLY the conv entry point (igemm_dma_kernel<SchH2,...> on the default h2 path, tuned plan) on the
+    stream it is launched on (torch's current stream).  Returns (seconds per launch, GFLOP per launch)."""
     import ctypes
     from mit_semseg import ops, _native, tuner
     L = _native.lib()
     vp = ctypes.c_void_p
-    n, h, w, c, k = 2, 64, 64, 4096, 512
-    geom = (n, h, w, c, k, 3, 3, 1, 1, 1)
-    dy = torch.randn(n, h, w, k, device=dev) * 1e-3
-    wtt = torch.randn(c, 3, 3, k, device=dev) * 0.01               # CRSK
-    dx = torch.empty(n, h, w, c, device=dev)
+    pass_id, geom, _ = cfg['dominant']
+    n, h, w, c, k, r, s, stride, pad, dil = geom
+    gflop = 2.0 * n * h * w * c * k * r * s * 1e-9
     st = lambda: vp(torch.cuda.current_stream().cuda_stream)   # noqa: E731
     P = lambda t: vp(t.data_ptr())                              # noqa: E731
+    if pass_id == 1:
+        a = torch.randn(n, h, w, k, device=dev) * 1e-3                 # dy
+        wt = torch.randn(c, r, s, k, device=dev) * 0.01                # CRSK
+        out = torch.empty(n, h, w, c, device=dev)
+        a_ch, w_rows, w_ch, out_ld = k, c * r * s, k, c
+    else:
+        a = torch.randn(n, h, w, c, device=dev)
+        wt = torch.randn(k, r, s, c, device=dev) * 0.01                # KRSC
+        out = torch.empty(n, h, w, k, device=dev)
+        a_ch, w_rows, w_ch, out_ld = c, k * r * s, c, k
     if ops.CONV_MODE in ops.SCHEMES:
         sch = ops.SCHEMES[ops.CONV_MODE]
-        dys, wts = sch.split(dy, n * h * w, k, k), sch.split(wtt, c * 9, k, k)
+        ap, wp = sch.split(a, n * h * w, a_ch, a_ch), sch.split(wt, w_rows, w_ch, w_ch)
 
         def launch():
             ws = ops.workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
-            _native.check(sch.fn(L, 'dgrad')(P(dys), P(wts), P(dx), c, *geom, P(ws), ws.numel(), st()), 'dgrad_split')
-        tuner.ensure(ops.CONV_MODE, 1, geom, launch)
+            if pass_id == 1:
+                _native.check(sch.fn(L, 'dgrad')(P(ap), P(wp), P(out), out_ld, *geom, P(ws), ws.numel(), st()), 'dgrad_split')
+            else:
+                _native.check(sch.fn(L, 'fwd')(P(ap), P(wp), vp(0), P(out), out_ld, *geom, P(ws), ws.numel(), st()), 'fwd_split')
+        tuner.ensure(ops.CONV_MODE, pass_id, geom, launch)
     else:
         def launch():
             ws = ops.workspace(L.semseg_conv2d_workspace_bytes(*geom), dev)
-            _native.check(L.semseg_conv2d_dgrad(P(dy), k, P(wtt), P(dx), c, *geom, P(ws), ws.numel(), st()), 'dgrad')
+            if pass_id == 1:
+                _native.check(L.semseg_conv2d_dgrad(P(a), k, P(wt), P(out), c, *geom, P(ws), ws.numel(), st()), 'dgrad')
+            else:
+                _native.check(L.semseg_conv2d_fwd(P(a), c, P(wt), vp(0), P(out), k, *geom, P(ws), ws.numel(), st()), 'fwd')
     for _ in range(2):
         launch()
     torch.cuda.synchronize()
@@ -107,62 +162,59 @@ def time_dominant_kernel(dev, iters=10):
         launch()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    return e0.elapsed_time(e1) / iters * 1e-3, gflop
 
 
-def roofline_entry(kt):
+def roofline_entry(kt, gflop, cfg, cfg_id):
     """bound = MFMA.  `achieved` is ALGORITHMIC conv TFLOP/s (2*MACs of the layer / kernel time)."""
-    from mit_semseg import ops
-    achieved = FWD_GFLOP_CONV_LAST / kt * 1e-3
+    from mit_semseg import ops, tuner
+    achieved = gflop / kt * 1e-3
+    pass_id, geom, layer = cfg['dominant']
+    what_pass = 'data gradient' if pass_id == 1 else 'forward'
+    plan = tuner.tuned_plans().get((ops.CONV_MODE, pass_id) + tuple(geom))
     if ops.CONV_MODE in SPLIT_TERMS:
         # the kernel issues 16-bit MFMAs (dense peak 2.5 PF); each fp32-accurate MAC costs `terms` 16-bit MACs, so the
         # path's own ceiling is 2500/terms algorithmic TFLOP/s and its MFMA-pipe utilisation is terms*achieved/2500
         terms, inst, what = SPLIT_TERMS[ops.CONV_MODE]
-        traffic = H2_CONV_LAST_HBM_BYTES if ops.CONV_MODE == 'h2' else S3_CONV_LAST_HBM_BYTES
+        traffic = H2_HBM_BYTES.get(cfg_id) if ops.CONV_MODE == 'h2' else S3_CONV_LAST_HBM_BYTES
+        has_pmc = ops.CONV_MODE == 'h2' and cfg_id in H2_HBM_BYTES
         return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic,
                 'executed_16bit_mfma_tflops': round(terms * achieved, 1),
                 'mfma_pipe_utilisation': round(terms * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
                 'path_ceiling_tflops': round(PEAK_BF16_MFMA_TFLOPS / terms, 1),
                 'frac_of_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                'algorithmic_bytes': 226.5e6 if ops.CONV_MODE == 'h2' else None,
-                'clock_ghz_under_load': H2_CONV_LAST_CLOCK_GHZ if ops.CONV_MODE == 'h2' else None,
+                'algorithmic_bytes': 226.5e6 if has_pmc else None,
+                'clock_ghz_under_load': H2_CONV_LAST_CLOCK_GHZ if has_pmc else None,
                 'mfma_pipe_utilisation_at_measured_clock': round(terms * achieved / (PEAK_BF16_MFMA_TFLOPS * H2_CONV_LAST_CLOCK_GHZ / 2.4), 4)
-                if ops.CONV_MODE == 'h2' else None,
-                'kernel': 'igemm_dma_kernel<%s,256,256> data gradient (%s per fp32-accurate MAC block, %s), '
-                          'decoder.conv_last.0 3x3 4096->512 @64x64 N=2 (309.24 GFLOP/launch algorithmic, %.3f ms/launch, '
-                          'HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE from profiles/, bytes/launch)'
-                          % (ops.CONV_MODE, what, inst, kt * 1e3)}
+                if has_pmc else None,
+                'plan_tile_split': list(plan[:2]) if plan else None,
+                'kernel': 'split-%s implicit-GEMM %s (%s per fp32-accurate MAC block, %s), %s (%.2f GFLOP/launch algorithmic, '
+                          '%.3f ms/launch, HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE from profiles/, bytes/launch)'
+                          % (ops.CONV_MODE, what_pass, what, inst, layer, gflop, kt * 1e3)}
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': F32_CONV_LAST_HBM_BYTES,
-            'kernel': 'igemm_conv_kernel data gradient (exact fp32 MFMA), decoder.conv_last.0 3x3 4096->512 @64x64 N=2 '
-                      '(309.24 GFLOP/launch, %.3f ms/launch, HIP events)' % (kt * 1e3)}
+            'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': F32_CONV_LAST_HBM_BYTES if cfg_id in (1, 3) else None,
+            'kernel': 'exact-fp32 MFMA implicit-GEMM %s, %s (%.2f GFLOP/launch, %.3f ms/launch, HIP events)'
+                      % (what_pass, layer, gflop, kt * 1e3)}
 
 
-def cpu_baseline():
-    """The CPU oracle (port of the reference path over torch CPU operators) timed on this host: ONE full
-    training step (fwd + loss + bwd + SGD) of the same 2x512x512 workload, all cores."""
-    from oracle import semseg_oracle as O
-    man = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'manifests.json')))
-    # torch's CPU conv/BN kernels stop scaling (and thrash) far below the 256 hardware threads of the GPU box:
-    # 256 threads took 203 s for this step, so the port is timed on at most 32 threads and `cores` reports that.
-    cores = min(os.cpu_count() or 1, int(os.environ.get('SEMSEG_CPU_BASELINE_THREADS', '32')))
-    torch.set_num_threads(cores)
-    enc = O.clone_sd(O.synth_state_dict(man['resnet50dilated'], 0), True)
-    dec = O.clone_sd(O.synth_state_dict(man['ppm_deepsup@2048'], 1), True)
-    img, lab = O.synth_batch(2, 512, 512, 8)
-    masks = {'main': O.synth_dropout_mask(2, 512), 'deepsup': O.synth_dropout_mask(2, 512, seed=1)}
-    t0 = time.perf_counter()
-    res = O.segmentation_forward(enc, dec, 'resnet50dilated', 'ppm_deepsup', img, lab, training=True,
-                                 dropout=masks, deep_sup_scale=0.4)
-    res['loss'].backward()
-    for sd in (enc, dec):
-        params = {k: v for k, v in sd.items() if v.requires_grad}
-        O.sgd_step(params, {k: v.grad for k, v in params.items()}, {}, 0.02)
-    dt = time.perf_counter() - t0
-    return {'value': round(2.0 / dt, 4), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '1 training step (fwd+loss+bwd+SGD) of the same 2x512x512 R50dilated+PPM_deepsup batch, '
-                      'torch %s CPU, no warm-up, %.1f s' % (torch.__version__, dt)}
+def cpu_baseline(cfg, steps=3):
+    """the reference's CPU path timed on this host in the same run -- oracle/cpu_baseline.py in a subprocess (the
+    UNMODIFIED reference where /root/reference is importable, else the oracle port over the same torch CPU kernels): 1 warm-up
+    + `steps` timed training steps of the same 2x512x512 synthetic batch.  torch's CPU conv/BN kernels stop scaling (and
+    thrash) far below the 256 hardware threads of the GPU box (203 s per step at 256 threads), so at most 32 threads are used;
+    `cores` = threads used, `host_cores` = what the host has."""
+    import subprocess
+    host = os.cpu_count() or 1
+    threads = min(host, int(os.environ.get('SEMSEG_CPU_BASELINE_THREADS', '32')))
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_baseline.py'), '--config', cfg['name'], '--n', '2', '--h', '512',
+           '--w', '512', '--threads', str(threads), '--steps', str(steps)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+        return json.loads(line)
+    except Exception as e:                                    # never lose the GPU line to the CPU leg
+        return {'value': None, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
 
 
 def ddp_graph_selftest(timeout_s=150):
@@ -205,7 +257,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS),
+                    help='index into BASELINE.json configs (default 1: the configuration the metric is quoted on)')
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import __graft_entry__ as ge
     ge.build()
@@ -231,23 +286,27 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # every rank's child must have passed
         if int(flag.item()) == 1:
             os.environ['SEMSEG_DDP_GRAPH'] = '1'
-    sm = build_model(dev)
+    sm = build_model(dev, cfg)
     if world > 1:
         NativeDataParallel(sm)          # enables SyncBN statistics all-reduce over RCCL
-    feed = synth_feed(dev, rank)
+    if cfg.get('variable'):
+        shapes, pool = variable_feeds(dev, rank, cfg, args.warmup + args.steps)
+        feeds = [pool[hw] for hw in shapes]
+    else:
+        shapes = [(512, 512)] * (args.warmup + args.steps)
+        feeds = [synth_feed(dev, rank, cfg)] * (args.warmup + args.steps)
     step = TrainStep(sm, lr_encoder=0.02, lr_decoder=0.02, max_iters=5000 * 20,
                      graph=not args.no_graph)      # world > 1: eager unless SEMSEG_DDP_GRAPH=1 (TrainStep)
 
-    for _ in range(args.warmup):
-        loss, acc = step.step(feed)
-    step.flush()                     # multi-step graphs: no staged step crosses into the timed region
+    for i in range(args.warmup):
+        loss, acc = step.step(feeds[i])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    before = dict(step.stats)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, acc = step.step(feed)
-    step.flush()                     # ... and every one of the K timed steps has run before the clock stops
+    for i in range(args.warmup, args.warmup + args.steps):
+        loss, acc = step.step(feeds[i])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -261,26 +320,38 @@ def main():
     value = imgs / dt
     lossv = loss.item()
 
+    timed = {k: step.stats[k] - before[k] for k in step.stats}
+    px = [h * w for h, w in shapes[args.warmup:]]
+    gflop_img = cfg['gflop'] * (sum(px) / len(px)) / (512.0 * 512.0)
     if rank == 0:
-        kt = time_dominant_kernel(dev)
+        kt, kgflop = time_dominant_kernel(dev, cfg)
         per_gpu = value / world
         out = {
-            'metric': 'train images/sec (whole job) @512x512 bs2/GPU', 'value': round(value, 3), 'unit': 'images/sec',
+            'metric': 'train images/sec (whole job) @%s bs2/GPU' % ('multi-scale variable-size' if cfg.get('variable') else '512x512'), 'value': round(value, 3), 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[ops_mode()], 'data': 'synthetic',
-            'config': {'workload': 'ade20k-resnet50dilated-ppm_deepsup (BASELINE configs[1]): full train step '
-                                   '(fwd+NLL loss+bwd+2xSGD), bs 2/GPU 512x512x3, 150 classes, labels 64x64',
+            'config': {'workload': '%s (BASELINE configs[%d]): full train step (fwd+NLL loss+bwd+2xSGD), bs 2/GPU, %s, 150 '
+                                   'classes, labels at 1/%d' % (
+                                       cfg['yaml'], args.config,
+                                       ('variable-size batches (dataset.py:110-142 rule over the ADE20K size histogram): mean %.0f '
+                                        'px/img = %.0f^2, %d distinct shapes in the timed steps'
+                                        % (sum(px) / len(px), (sum(px) / len(px)) ** 0.5, len(set(shapes[args.warmup:]))))
+                                       if cfg.get('variable') else '512x512x3', cfg['rate']),
                        'global_batch': 2 * world, 'parallelism': 'dp%d' % world,
-                       'launch': 'hipGraph replay' if (step._graph is not None) else 'eager',
+                       'launch': ('hipGraph replay' if timed['replayed'] == args.steps else
+                                  'eager' if timed['replayed'] == 0 else
+                                  'per-shape hipGraphs: %(replayed)d of the timed steps replayed (%(captured)d captured in the '
+                                  'timed region), %(eager)d eager (first sight of a shape)' % timed),
                        'ddp_graph_selftest': selftest_ok,
                        'conv_path': ops_mode(),
                        'images_per_sec_per_gpu': round(per_gpu, 3),
-                       'step_conv_tflops_per_gpu': round(per_gpu * TRAIN_GFLOP_PER_IMG['resnet50dilated+ppm_deepsup'] * 1e-3, 2),
+                       'step_conv_tflops_per_gpu': round(per_gpu * gflop_img * 1e-3, 2),
+                       'train_gflop_per_image': round(gflop_img, 1),
                        'final_loss': round(lossv, 5)},
-            'roofline': roofline_entry(kt),
+            'roofline': roofline_entry(kt, kgflop, cfg, args.config),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -239,6 +239,15 @@ int semseg_add_act(const float* a, int a_ld, const float* b, int b_ld, int relu,
 /* dx = dy * (y > 0) */
 int semseg_relu_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* dx, int dx_ld,
                     int P, int C, void* stream);
+/* nn.ReLU6's upper clamp (mobilenet.py:26,34; the lower clamp is the fused ReLU of the BN kernels): y = min(x, cap);
+   backward dx = dy * (y < cap) -- the open interval of torch's hardtanh backward */
+int semseg_clamp_max(const float* x, int x_ld, float cap, float* y, int y_ld, int P, int C, void* stream);
+int semseg_clamp_max_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float cap, float* dx, int dx_ld,
+                         int P, int C, void* stream);
+/* nn.Dropout2d's per-(n,c) keep mask (models.py:460,464): mask[i] = Bernoulli(1-p) / (1-p), i < n, from a counter-based hash;
+   state = uint64[2] {seed, launch counter} in device memory, the counter is advanced by the kernel (fresh mask per hipGraph
+   replay) */
+int semseg_dropout_mask(float* mask, int n, float p, void* state, void* stream);
 /* strided 2-D copy (torch.cat slices, models.py:424,476,553,575; hrnet.py:434) */
 int semseg_copy2d(const float* src, int src_ld, float* dst, int dst_ld, int P, int C, int accumulate,
                   void* stream);

@@ -531,3 +531,8 @@ def clone_sd(sd, requires_grad=False):
             v.requires_grad_(True)
         out[k] = v
     return out
+
+
+def to_dtype(sd, dtype):
+    """the state dict with its floating-point tensors cast (float64: the anchor runs of the parity tests)"""
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}

@@ -65,6 +65,82 @@ extern "C" int semseg_relu_bwd(const float* dy, int dy_ld, const float* y, int y
     return 0;
 }
 
+// nn.ReLU6's upper clamp (mobilenet.py:26,34; the lower clamp runs fused in the BN kernels): y = min(x, cap);
+// backward dx = dy * (y < cap) -- hardtanh's open interval, as torch's ReLU6 backward
+__global__ void clamp_max_kernel(const float* __restrict__ x, int x_ld, float cap, float* __restrict__ y, int y_ld, int P, int C) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)P * qpr;
+    GRID_STRIDE(i, total) {
+        const int p = (int)(i / qpr);
+        const int c = (int)(i - (size_t)p * qpr) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * x_ld + c);
+        *reinterpret_cast<float4*>(y + (size_t)p * y_ld + c) =
+            make_float4(fminf(v.x, cap), fminf(v.y, cap), fminf(v.z, cap), fminf(v.w, cap));
+    }
+}
+
+__global__ void clamp_max_bwd_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ y, int y_ld, float cap,
+                                     float* __restrict__ dx, int dx_ld, int P, int C) {
+    const int qpr = C / 4;
+    const size_t total = (size_t)P * qpr;
+    GRID_STRIDE(i, total) {
+        const int p = (int)(i / qpr);
+        const int c = (int)(i - (size_t)p * qpr) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c);
+        const float4 v = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c);
+        *reinterpret_cast<float4*>(dx + (size_t)p * dx_ld + c) =
+            make_float4(v.x < cap ? g.x : 0.f, v.y < cap ? g.y : 0.f, v.z < cap ? g.z : 0.f, v.w < cap ? g.w : 0.f);
+    }
+}
+
+extern "C" int semseg_clamp_max(const float* x, int x_ld, float cap, float* y, int y_ld, int P, int C, void* stream) {
+    if (!x || !y || P <= 0 || C <= 0 || (C % 4) || (x_ld % 4) || (y_ld % 4) || x_ld < C || y_ld < C) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(clamp_max_kernel, dim3(stream_blocks((size_t)P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, x_ld, cap,
+                       y, y_ld, P, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int semseg_clamp_max_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float cap, float* dx, int dx_ld, int P,
+                                    int C, void* stream) {
+    if (!dy || !y || !dx || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) || (y_ld % 4) || (dx_ld % 4)) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(clamp_max_bwd_kernel, dim3(stream_blocks((size_t)P * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
+                       y, y_ld, cap, dx, dx_ld, P, C);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// nn.Dropout2d's per-(n, c) Bernoulli keep mask (models.py:460,464): mask[i] = keep ? 1/(1-p) : 0 from a counter-based hash of
+// (seed, launch counter, i).  `state` = {seed, counter} in DEVICE memory; the kernel advances the counter itself, so a captured
+// launch draws a fresh mask on every hipGraph replay.  One block (the mask has N*C <= a few thousand entries).
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, int n, float p, float keep_scale,
+                                                           unsigned long long* __restrict__ state) {
+    const uint64_t seed = state[0], counter = state[1];
+    const uint64_t base = mix64(seed ^ mix64(counter));
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint32_t r = (uint32_t)(mix64(base + (uint64_t)i) >> 40);           // 24 uniform bits
+        const float u = (float)r * (1.0f / 16777216.0f);                          // [0, 1), exactly representable
+        mask[i] = u >= p ? keep_scale : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) state[1] = counter + 1;
+}
+
+extern "C" int semseg_dropout_mask(float* mask, int n, float p, void* state, void* stream) {
+    if (!mask || !state || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask, n, p, 1.0f / (1.0f - p),
+                       (unsigned long long*)state);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool ACC, bool VEC>
 __global__ void copy2d_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld, int P, int C) {
     if (VEC) {

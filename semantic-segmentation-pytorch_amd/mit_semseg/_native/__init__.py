@@ -73,6 +73,9 @@ SIGNATURES = {
     'semseg_weights_prepare_h2': (c_int, [ctypes.POINTER(WPrepTensor), c_int, vp]),
     'semseg_add_act': (c_int, [vp, c_int, vp, c_int, c_int, vp, c_int, c_int, c_int, vp]),
     'semseg_relu_bwd': (c_int, [vp, c_int, vp, c_int, vp, c_int, c_int, c_int, vp]),
+    'semseg_clamp_max': (c_int, [vp, c_int, c_f, vp, c_int, c_int, c_int, vp]),
+    'semseg_clamp_max_bwd': (c_int, [vp, c_int, vp, c_int, c_f, vp, c_int, c_int, c_int, vp]),
+    'semseg_dropout_mask': (c_int, [vp, c_int, c_f, vp, vp]),
     'semseg_copy2d': (c_int, [vp, c_int, vp, c_int, c_int, c_int, c_int, vp]),
     'semseg_scale_nc': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
     'semseg_nchw_to_nhwc': (c_int, [vp, vp, c_int, c_int, c_int, vp]),

@@ -66,6 +66,46 @@ def _label_axis_table(src_size, mid_size, rate, flip):
     return out
 
 
+def batch_geometry(sizes_hw, this_short_size, imgMaxSize, padding_constant):
+    """dataset.py:127-142: per-sample resized widths / heights (int32 truncation) and the padded batch (H, W)"""
+    n = len(sizes_hw)
+    bw, bh = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    for i, (h, w) in enumerate(sizes_hw):
+        this_scale = min(this_short_size / min(h, w), imgMaxSize / max(h, w))
+        bw[i] = w * this_scale
+        bh[i] = h * this_scale
+    batch_w = int(round2nearest_multiple(np.max(bw), padding_constant))
+    batch_h = int(round2nearest_multiple(np.max(bh), padding_constant))
+    return bw, bh, batch_h, batch_w
+
+
+def batch_shape_stream(sizes_wh, counts, imgSizes=(300, 375, 450, 525, 600), imgMaxSize=1000, padding_constant=8,
+                       batch_per_gpu=2, seed=0):
+    """Endless generator of the padded per-GPU batch shapes (H, W) that `TrainDataset` produces for a record list with
+    the given size histogram (`sizes_wh[i]` = (width, height) occurring `counts[i]` times) -- the record grouping
+    (portrait / landscape lists, dataset.py:85-108), the reshuffle at every pass, the short-side draw and the padding rule
+    of dataset.py:110-142, without touching any image.  Synthetic benchmarks / tests of the variable-size path (BASELINE
+    configs[3]) draw their shapes from it; every rank passes its own `seed` (train.py gives each GPU its own loader)."""
+    rng = np.random.RandomState(seed)
+    recs = np.repeat(np.arange(len(counts)), counts)
+    rng.shuffle(recs)
+    groups = ([], [])
+    cur = 0
+    while True:
+        w, h = sizes_wh[recs[cur]]
+        g = groups[0 if h > w else 1]
+        g.append((int(h), int(w)))
+        cur += 1
+        if cur >= len(recs):
+            cur = 0
+            rng.shuffle(recs)
+        if len(g) == batch_per_gpu:
+            short = rng.choice(imgSizes) if isinstance(imgSizes, (list, tuple)) else imgSizes
+            _, _, bh, bw = batch_geometry(g, short, imgMaxSize, padding_constant)
+            del g[:]
+            yield bh, bw
+
+
 class TrainBatchAssembler:
     def __init__(self, imgSizes, imgMaxSize, padding_constant, segm_downsampling_rate, device='cuda'):
         assert padding_constant >= segm_downsampling_rate, \
@@ -76,16 +116,7 @@ class TrainBatchAssembler:
         self._mean_std = (_native.c_f * 6)(*MEAN, *STD)
 
     def geometry(self, sizes_hw, this_short_size):
-        """dataset.py:127-142: per-sample resized widths / heights (int32 truncation) and the padded batch (H, W)"""
-        n = len(sizes_hw)
-        bw, bh = np.zeros(n, np.int32), np.zeros(n, np.int32)
-        for i, (h, w) in enumerate(sizes_hw):
-            this_scale = min(this_short_size / min(h, w), self.imgMaxSize / max(h, w))
-            bw[i] = w * this_scale
-            bh[i] = h * this_scale
-        batch_w = int(round2nearest_multiple(np.max(bw), self.padding_constant))
-        batch_h = int(round2nearest_multiple(np.max(bh), self.padding_constant))
-        return bw, bh, batch_h, batch_w
+        return batch_geometry(sizes_hw, this_short_size, self.imgMaxSize, self.padding_constant)
 
     def assemble(self, images, segms, flips, this_short_size):
         """images: uint8 [H][W][3] tensors (decoded RGB), segms: uint8 [H][W] tensors, host or device; flips: bools.

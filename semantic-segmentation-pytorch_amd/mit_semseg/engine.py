@@ -2,6 +2,7 @@
 poly LR of train.py:130-139) executed as HIP kernels, optionally captured ONCE into a hipGraph and
 replayed (the whole step is capture-safe: no host sync, no allocation outside torch's graph pool, the
 learning rate lives in device memory)."""
+import collections
 import os
 
 import torch
@@ -34,22 +35,20 @@ class FusedSGD:
     """torch.optim.SGD(momentum=0.9, weight_decay on group 0) for both encoder and decoder groups in one
     multi-tensor HIP kernel (train.py:115-127).  lr per group is a device scalar."""
 
-    def __init__(self, groups, momentum=0.9, lr_slots=1):
-        """groups: list of dict(params=[...], lr=float, weight_decay=float).  `lr_slots`: device-resident learning rates
-        per group -- a hipGraph that holds several consecutive steps reads slot i in its i-th step."""
+    def __init__(self, groups, momentum=0.9):
+        """groups: list of dict(params=[...], lr=float, weight_decay=float)."""
         self.groups = groups
         self.momentum = momentum
         self.state = {}
         self.steps = 0
-        self.lr_slot = 0
         for g in groups:
             dev = g['params'][0].device
-            g['lr_t'] = torch.full((lr_slots,), float(g['lr']), device=dev, dtype=torch.float32)
+            g['lr_t'] = torch.full((1,), float(g['lr']), device=dev, dtype=torch.float32)
 
-    def set_lr(self, group_index, lr, slot=0):
+    def set_lr(self, group_index, lr):
         g = self.groups[group_index]
         g['lr'] = lr
-        g['lr_t'][slot:slot + 1].fill_(lr)
+        g['lr_t'].fill_(lr)
 
     def zero_grad(self):
         for g in self.groups:
@@ -57,32 +56,43 @@ class FusedSGD:
                 p.grad = None
 
     def step(self, grad_scale=1.0):
-        first = self.steps == 0
         for g in self.groups:
             ps = [p for p in g['params'] if p.grad is not None]
             if not ps:
                 continue
-            bufs = []
+            bufs, first = [], []
             for p in ps:
                 b = self.state.get(p)
-                if b is None:
+                first.append(b is None)           # per parameter, as torch.optim.SGD: a parameter that gets its first gradient
+                if b is None:                     # at a later step (unfrozen layer, conditional head) starts its buffer then
                     b = torch.empty_like(p.grad)
                     self.state[p] = b
                 bufs.append(b)
-            ops.sgd_step(ps, [p.grad for p in ps], bufs, first, [g['weight_decay']] * len(ps),
-                         g['lr_t'][self.lr_slot:self.lr_slot + 1], self.momentum, grad_scale)
+            ops.sgd_step(ps, [p.grad for p in ps], bufs, first, [g['weight_decay']] * len(ps), g['lr_t'], self.momentum,
+                         grad_scale)
         self.steps += 1
+
+
+def feed_key(feed):
+    """shape signature of a feed dict: one captured graph per signature (per-GPU batches of train.py:170-177 come in many
+    H x W, dataset.py:121-142)"""
+    return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(feed.items()) if torch.is_tensor(v))
 
 
 class TrainStep:
     """One training iteration of train.py:34-48 for a SegmentationModule.
 
-    step(feed) -> (loss, acc) device scalars.  With `graph=True` the first `warmup_eager` calls run eagerly
-    (they size the workspace and the allocator pools), then fwd+bwd+all-reduce+SGD is captured into a
-    hipGraph; later calls copy the batch into static buffers and replay."""
+    step(feed) -> (loss, acc) device scalars.  With `graph=True` the step is captured into a hipGraph PER FEED SHAPE: the
+    first time a shape is seen (and during the first `warmup_eager` steps) the step runs eagerly -- that sizes the workspace,
+    tunes / assigns the conv launch plans of the new geometries and warms the allocator -- the second time it is captured
+    (fwd + bwd + all-reduce + SGD), and from then on the batch is copied into the graph's static buffers and replayed.  The
+    variable-size per-GPU batches of the multi-scale pipeline (BASELINE configs[3]: short side 300...600, long side <= 1000,
+    multiples of 8) therefore converge to replays of their most frequent shapes; at most `max_graphs` graphs are kept (least
+    recently used goes first) and they share ONE allocator pool, so their activation memory is the maximum over the shapes,
+    not the sum (each graph is self-contained: nothing but its (loss, acc) outputs outlives a replay)."""
 
     def __init__(self, segmentation_module, lr_encoder=0.02, lr_decoder=0.02, momentum=0.9, weight_decay=1e-4,
-                 lr_pow=0.9, max_iters=100000, graph=False, group=None, bucket_bytes=64 << 20, graph_steps=None):
+                 lr_pow=0.9, max_iters=100000, graph=False, group=None, bucket_bytes=64 << 20, max_graphs=None):
         self.sm = segmentation_module
         enc, dec = segmentation_module.encoder, segmentation_module.decoder
         groups = []
@@ -105,24 +115,19 @@ class TrainStep:
         self._conv_weights = [m.weight for m in segmentation_module.modules() if type(m) is Conv2d]      # not the grouped ones
         self._weights_ready = False
         self.use_graph = graph
-        # hipGraph replay.  `graph_steps` consecutive training steps are captured into ONE graph: every hipGraphLaunch
-        # costs ~1 ms during which the GPU idles (profiles/r1i_trace_gaps_graph.txt: kernels are back to back inside a
-        # replay, the only holes are between replays), so S steps per launch amortise it S-fold.  step() then returns
-        # the (loss, acc) device scalars of its step, which hold their values once the S-th call of the group has
-        # launched the replay.  SEMSEG_GRAPH_STEPS overrides.
-        self.graph_steps = max(1, int(os.environ.get('SEMSEG_GRAPH_STEPS', graph_steps or 1))) if graph else 1
-        self._graph = None
-        self._static = None           # graph_steps feed dicts
-        self._out = None              # graph_steps (loss, acc)
+        self.max_graphs = int(os.environ.get('SEMSEG_TRAIN_GRAPHS', max_graphs or 16))
+        self._graphs = collections.OrderedDict()      # feed_key -> (graph, static feed, (loss, acc))
+        self._seen = {}                               # feed_key -> eager steps run at this shape
+        self._pool = None
+        self._graph = None                            # the graph of the most recent replay (bench.py reports the launch mode)
         self.warmup_eager = 2
-        if self.graph_steps > 1:
-            self.opt = FusedSGD(groups, momentum, lr_slots=self.graph_steps)
+        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0}
 
-    def adjust_learning_rate(self, slot=0):
+    def adjust_learning_rate(self):
         """train.py:130-139 poly schedule"""
         scale = (1.0 - float(self.iter) / self.max_iters) ** self.lr_pow
         for i, g in enumerate(self.opt.groups):
-            self.opt.set_lr(i, g['base_lr'] * scale, slot)
+            self.opt.set_lr(i, g['base_lr'] * scale)
 
     def _prepare_weights(self):
         if ops.CONV_MODE == 'h2' and ops.FUSE:
@@ -147,53 +152,56 @@ class TrainStep:
         self._prepare_weights()               # planes of the UPDATED weights, for the next step
         return loss.detach(), acc.detach()
 
-    def step(self, feed):
+    def _graph_allowed(self):
         # world > 1: the RCCL all-reduces (SyncBN statistics on the compute stream, gradient buckets on the side stream)
         # can be captured too -- a world-1 RCCL all-reduce survives capture + replay on this stack
         # (tools/probes/rccl_graph_probe.py) -- but the N > 1 capture has not run on a multi-GPU box yet, so it is
-        # opt-in (SEMSEG_DDP_GRAPH=1) and the default data-parallel step launches eagerly.
-        if not self.use_graph or (self.world > 1 and os.environ.get('SEMSEG_DDP_GRAPH', '0') != '1'):
-            self.adjust_learning_rate()
-            self.iter += 1
-            return self._eager(feed)
-        if self._graph is None and self.opt.steps < self.warmup_eager:
-            self.adjust_learning_rate()
-            self.iter += 1
-            return self._eager(feed)
-        S = self.graph_steps
-        if self._graph is None:
-            # capture S consecutive steps; capture records but does not execute, the replays below run them
-            self._static = [{k: v.clone() for k, v in feed.items() if torch.is_tensor(v)} for _ in range(S)]
-            self._graph = torch.cuda.CUDAGraph()
-            self._out = []
-            with torch.cuda.graph(self._graph):
-                for i in range(S):
-                    self.opt.lr_slot = i
-                    self._out.append(self._eager(self._static[i]))
-            self.opt.lr_slot = 0
-            self._sub = 0
-        i = self._sub
-        self.adjust_learning_rate(slot=i)
+        # opt-in (SEMSEG_DDP_GRAPH=1, set by bench.py after its self-test) and the default data-parallel step launches eagerly.
+        return self.use_graph and (self.world == 1 or os.environ.get('SEMSEG_DDP_GRAPH', '0') == '1')
+
+    def step(self, feed):
+        self.adjust_learning_rate()
         self.iter += 1
-        for k, v in self._static[i].items():
+        if not self._graph_allowed():
+            self.stats['eager'] += 1
+            return self._eager(feed)
+        key = feed_key(feed)
+        rec = self._graphs.get(key)
+        if rec is None:
+            seen = self._seen.get(key, 0)
+            if self.opt.steps < self.warmup_eager or seen < 1:
+                self._seen[key] = seen + 1
+                self.stats['eager'] += 1
+                return self._eager(feed)
+            rec = self._capture(key, feed)
+        else:
+            self._graphs.move_to_end(key)
+        graph, static, out = rec
+        for k, v in static.items():
             v.copy_(feed[k])
-        self._sub = (i + 1) % S
-        if self._sub == 0:
-            self._graph.replay()
-        return self._out[i]
+        graph.replay()
+        self._graph = graph
+        self.stats['replayed'] += 1
+        return out
+
+    def _capture(self, key, feed):
+        """capture records but does not execute: the caller replays right away"""
+        while len(self._graphs) >= max(1, self.max_graphs):
+            self._graphs.popitem(last=False)          # least recently used shape: its graph and static buffers are released
+            self.stats['evicted'] += 1
+        static = {k: v.clone() for k, v in feed.items() if torch.is_tensor(v)}
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=self._pool):
+            out = self._eager(static)
+        rec = self._graphs[key] = (graph, static, out)
+        self.stats['captured'] += 1
+        return rec
 
     def flush(self):
-        """graph_steps > 1: a group of steps that has not been replayed yet (fewer than S calls since the last replay) is
-        run eagerly from the staged batches.  Call before reading results / saving weights."""
-        if self._graph is None or self.graph_steps == 1 or self._sub == 0:
-            return
-        n, self._sub = self._sub, 0
-        for i in range(n):
-            self.opt.lr_slot = i
-            loss, acc = self._eager(self._static[i])
-            self._out[i][0].copy_(loss)
-            self._out[i][1].copy_(acc)
-        self.opt.lr_slot = 0
+        """kept for callers of the multi-step-graph API of round 1 (every step now launches when it is called)"""
+        return None
 
 
 class InferenceGraph:

@@ -36,9 +36,33 @@ class _SynchronizedBatchNorm(nn.Module):
         self.register_buffer('_tmp_running_mean', torch.zeros(num_features))
         self.register_buffer('_tmp_running_var', torch.ones(num_features))
         self.register_buffer('_running_iter', torch.ones(1))
+        self._nbt_in_line = 0       # value of num_batches_tracked at which the three buffers above matched running_*
 
     def _as4d(self, x):
         raise NotImplementedError
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        """The fork's multi-GPU branch recomputes `running_* = _tmp_running_* / _running_iter` on every step
+        (batchnorm.py:132-137) with `tmp <- tmp (1-m) + stat`, `iter <- iter (1-m) + 1`.  The kernels here keep the plain EMA
+        `running <- (1-m) running + m stat` (the F.batch_norm path, batchnorm.py:58-61) and do not touch the bookkeeping
+        buffers, so they are brought in line when a checkpoint is written: `_running_iter = 1/m` (the fixed point of its
+        recursion, at which the fork's update IS the plain EMA) and `_tmp_running_* = running_* / m`.  A checkpoint trained here
+        and resumed in the reference's multi-GPU training then continues from these running statistics instead of
+        overwriting them from the init values.  Only done when training steps have run since the buffers were last in line
+        (`num_batches_tracked` moved), so a loaded checkpoint is written back unchanged."""
+        nbt = int(self.num_batches_tracked)
+        if nbt != self._nbt_in_line:
+            with torch.no_grad():
+                it = 1.0 / self.momentum if self.momentum else 1.0
+                self._running_iter.fill_(it)
+                self._tmp_running_mean.copy_(self.running_mean * it)
+                self._tmp_running_var.copy_(self.running_var * it)
+            self._nbt_in_line = nbt
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self._nbt_in_line = int(self.num_batches_tracked)
 
     def forward(self, input, residual=None, relu=False):
         """y = BN(input); the fused form y = relu(BN(input) + residual) is what the blocks call."""

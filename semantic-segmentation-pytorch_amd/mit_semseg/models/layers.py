@@ -113,12 +113,12 @@ class ReLU6(nn.Module):
         super().__init__()
 
     def forward(self, x):
-        return torch.clamp(x, min=0.0, max=6.0)
+        return ops.clamp_max(ops.add_act(x, torch.zeros_like(x), relu=True), 6.0)
 
 
 def conv_bn_relu6(conv, bn, x):
     """conv -> BN -> ReLU6: the fused conv/BN/ReLU unit followed by the upper clamp (elementwise glue)"""
-    return torch.clamp(conv_bn(conv, bn, x, relu=True), max=6.0)
+    return ops.clamp_max(conv_bn(conv, bn, x, relu=True), 6.0)
 
 
 def conv_bn(conv, bn, x, residual=None, relu=False, passthrough=False):
@@ -127,6 +127,13 @@ def conv_bn(conv, bn, x, residual=None, relu=False, passthrough=False):
     h2 path can run it (ops.conv_bn_act), else as the two modules.  passthrough=True returns (y, x'), x' being x routed
     through the node (see ops.conv_bn_act): the blocks hand x' to their shortcut so that its gradient is accumulated in
     this conv's data-gradient kernel."""
+    if passthrough and not ops.PASSTHROUGH and torch.is_grad_enabled() and x.requires_grad:
+        # x has two consumers (this conv and the block's shortcut): fork it so that their two gradients are added by the native
+        # add kernel instead of autograd's torch-side accumulation; the planes this conv splits serve the shortcut's conv too
+        xa, xb = ops.fork(x)
+        y = conv_bn(conv, bn, xa, residual=residual, relu=relu)
+        ops.share_planes(xa, xb)
+        return y, xb
     if conv.bias is None and x.dim() == 4 and type(conv) is Conv2d and isinstance(bn, SynchronizedBatchNorm2d):
         return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                bn.num_batches_tracked, residual=residual, stride=conv.stride[0],
@@ -179,8 +186,7 @@ class Dropout2d(nn.Module):
         if self.mask_override is not None:
             mask = self.mask_override
         else:
-            keep = torch.rand(x.shape[0], x.shape[1], device=x.device) >= self.p
-            mask = keep.float() / (1.0 - self.p)
+            mask = ops.dropout_mask(x.shape[0], x.shape[1], self.p, x.device)
         return ops.scale_nc(x, mask)
 
 

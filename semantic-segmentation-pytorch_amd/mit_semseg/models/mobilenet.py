@@ -6,6 +6,7 @@ import math
 
 import torch.nn as nn
 
+from .. import ops
 from .layers import Conv2d, GroupedConv2d, BatchNorm2d, ReLU6, conv_bn, conv_bn_relu6
 from .utils import load_url
 
@@ -61,8 +62,10 @@ class InvertedResidual(nn.Module):
         self.conv = _Units(*units)
 
     def forward(self, x):
-        y = self.conv(x)
-        return x + y if self.use_res_connect else y
+        if not self.use_res_connect:
+            return self.conv(x)
+        xa, xb = ops.fork(x)
+        return ops.add_act(xb, self.conv(xa))
 
 
 class MobileNetV2(nn.Module):

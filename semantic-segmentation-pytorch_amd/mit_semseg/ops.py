@@ -48,16 +48,22 @@ def _require_cuda(*ts):
 # workspace: one persistent scratch buffer per device (split-K / split-M slabs, BN partial sums)
 # ------------------------------------------------------------------------------------------------
 _WS = {}
+_WS_RETIRED = []        # superseded scratch buffers: captured hipGraphs hold their raw addresses, so they are never freed
 _WS_MIN = 64 << 20
 
 
 def workspace(nbytes, device, tag=''):
     """`tag`: kernels running concurrently on different streams need disjoint scratch (tag 'side': the weight-gradient
-    stream)."""
+    stream).  A buffer that is outgrown stays allocated (`_WS_RETIRED`): a hipGraph captured earlier (TrainStep, one
+    InferenceGraph per shape) has its address baked into split-K / BN-partial launches, and handing the block back to the
+    caching allocator would let a replay scribble over whatever tensor gets it next.  Growth is geometric (x1.5), so the
+    retired blocks add up to at most twice the live one."""
     key = (device.type, device.index if (device.index is not None or device.type != 'cuda') else torch.cuda.current_device(), tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
-        size = max(_WS_MIN, int(nbytes * 1.25))
+        size = max(_WS_MIN, int(nbytes * 1.5))
+        if t is not None:
+            _WS_RETIRED.append(t)
         t = torch.empty(size, dtype=torch.uint8, device=device)
         _WS[key] = t
     return t
@@ -236,6 +242,14 @@ def planes_of(t, scheme, rows, ch):
     if rec is not None and rec[1:4] == (scheme, rows, ch) and rec[4] == t._version and rec[5] == t.data_ptr():
         return rec[0]
     return None
+
+
+def share_planes(src, dst):
+    """`dst` aliases `src` (same storage, e.g. the two outputs of fork()): a consumer that split one of them leaves the planes
+    to the other"""
+    rec = getattr(src, '_semseg_planes', None)
+    if rec is not None and rec[4] == src._version and rec[5] == src.data_ptr() == dst.data_ptr():
+        attach_planes(dst, rec[0], rec[1], rec[2], rec[3])
 
 
 def input_planes(x, scheme):
@@ -497,9 +511,10 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, a
 
 
 # dedicated depthwise 3x3 kernels (csrc/depthwise.hip) instead of the block-diagonal dense expansion of
-# models.layers.GroupedConv2d.  Opt-in until they have executed on a GPU (written after the round's GPU budget was spent;
-# their per-element code is checked on the host, tests/test_depthwise_cpu.py).
-DEPTHWISE_DIRECT = os.environ.get('SEMSEG_DEPTHWISE_DIRECT', '0') == '1'
+# models.layers.GroupedConv2d (960-fold redundant MFMA work for mobilenet.py:48's widest layer).  Default since they passed
+# float64 parity on the MI355X (tests/test_gpu_depthwise.py) and the MobileNetV2 goldens; SEMSEG_DEPTHWISE_DIRECT=0 restores
+# the dense expansion.
+DEPTHWISE_DIRECT = os.environ.get('SEMSEG_DEPTHWISE_DIRECT', '1') == '1'
 
 
 class DepthwiseConv3x3Fn(Function):
@@ -550,7 +565,7 @@ def depthwise_conv3x3(x, weight, stride=1, padding=1, dilation=1):
     return DepthwiseConv3x3Fn.apply(x, weight, int(stride), int(padding), int(dilation))
 
 
-GROUPED_DIRECT = os.environ.get('SEMSEG_GROUPED_DIRECT', '0') == '1'       # csrc/grouped.hip, same status as DEPTHWISE_DIRECT
+GROUPED_DIRECT = os.environ.get('SEMSEG_GROUPED_DIRECT', '1') == '1'       # csrc/grouped.hip; 0: dense expansion
 
 
 class GroupedConv3x3Fn(Function):
@@ -982,6 +997,106 @@ def add_act(a, b, relu=False):
     return AddActFn.apply(a, b, bool(relu))
 
 
+class ClampMaxFn(Function):
+    """y = min(x, cap): the upper clamp of nn.ReLU6 (mobilenet.py:26,34) behind a fused conv -> BN -> ReLU unit."""
+
+    @staticmethod
+    def forward(ctx, x, cap):
+        x, ld = as_nhwc(x.detach())
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h, w, x.device)
+        _native.check(_native.lib().semseg_clamp_max(_p(x), ld, float(cap), _p(y), c, n * h * w, c, _st()), 'clamp_max')
+        ctx.save_for_backward(y)
+        ctx.cap = float(cap)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy, ld = as_nhwc(dy)
+        n, c, h, w = y.shape
+        dx = empty_nhwc(n, c, h, w, y.device)
+        _native.check(_native.lib().semseg_clamp_max_bwd(_p(dy), ld, _p(y), c, ctx.cap, _p(dx), c, n * h * w, c, _st()),
+                      'clamp_max_bwd')
+        return dx, None
+
+
+def clamp_max(x, cap):
+    _require_cuda(x)
+    if x.shape[1] % 4:
+        raise RuntimeError('clamp_max: channel count must be a multiple of 4, got %d' % x.shape[1])
+    return ClampMaxFn.apply(x, float(cap))
+
+
+class ForkFn(Function):
+    """A tensor with TWO consumers (block input -> first conv + shortcut, encoder map -> two heads): returns two aliases of
+    it; backward adds the two gradients with the native add kernel -- otherwise autograd's own accumulation does that sum with
+    a torch kernel (288 launches per R50 step).  A consumer that produced no gradient contributes nothing."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return gb if ga is None else ga
+        L = _native.lib()
+        ga, a_ld = as_nhwc(ga)
+        gb, b_ld = as_nhwc(gb)
+        n, c, h, w = ga.shape
+        out = empty_nhwc(n, c, h, w, ga.device)
+        if c % 4 == 0 and a_ld % 4 == 0 and b_ld % 4 == 0:
+            _native.check(L.semseg_add_act(_p(ga), a_ld, _p(gb), b_ld, 0, _p(out), c, n * h * w, c, _st()), 'add_act')
+        else:
+            _native.check(L.semseg_copy2d(_p(ga), a_ld, _p(out), c, n * h * w, c, 0, _st()), 'copy2d')
+            _native.check(L.semseg_copy2d(_p(gb), b_ld, _p(out), c, n * h * w, c, 1, _st()), 'copy2d')
+        return out
+
+
+def fork(x, n=2):
+    """`n` aliases of `x` for its `n` consumers (gradients are summed natively, see ForkFn); the split-plane / bound records
+    of `x` travel with every alias.  Without autograd (inference) or for tensors that need no gradient `x` itself is returned
+    `n` times."""
+    if n <= 1:
+        return (x,) if n == 1 else ()
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    _require_cuda(x)
+    outs = []
+    rest = x
+    for _ in range(n - 1):
+        a, rest = ForkFn.apply(rest)
+        outs.append(a)
+    outs.append(rest)
+    rec, bound = getattr(x, '_semseg_planes', None), bounds_of(x)
+    for t in outs:
+        if rec is not None and rec[4] == x._version and rec[5] == x.data_ptr():
+            attach_planes(t, rec[0], rec[1], rec[2], rec[3])
+        if bound is not None:
+            attach_absmax(t, bound)
+    return tuple(outs)
+
+
+_DROPOUT_STATE = {}
+
+
+def dropout_mask(n, c, p, device):
+    """[N, C] multipliers of nn.Dropout2d(p) (models.py:460,464): Bernoulli(1-p) / (1-p) per (sample, channel), drawn by a
+    counter-based hash on the device (csrc/pool_resize.hip); the launch counter lives in device memory, so a captured launch
+    draws a fresh mask at every replay.  Seeded from torch's RNG (torch.manual_seed governs it) on first use per device."""
+    key = (device.type, device.index)
+    st = _DROPOUT_STATE.get(key)
+    if st is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        st = _DROPOUT_STATE[key] = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+    mask = torch.empty((n, c), device=device, dtype=torch.float32)
+    _native.check(_native.lib().semseg_dropout_mask(_p(mask), n * c, float(p), _p(st), _st()), 'dropout_mask')
+    return mask
+
+
 class ConcatFn(Function):
     """torch.cat(dim=1) into one NHWC buffer; backward hands out channel-slice VIEWS (no copy)."""
 
@@ -1317,7 +1432,11 @@ def nll_loss_acc(logp, label, ignore_index=-1):
 # ------------------------------------------------------------------------------------------------
 def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum=0.9, grad_scale=1.0):
     """Fused multi-tensor SGD-momentum (train.py:117-126 semantics).  All lists are parallel; `lr_tensor`
-    is a 1-element device tensor (so the poly schedule can change it under hipGraph replay)."""
+    is a 1-element device tensor (so the poly schedule can change it under hipGraph replay).  `first_step`: one flag per
+    tensor (or a single bool for all): the momentum buffer is uninitialised and is SET to the gradient, as torch.optim.SGD
+    does the first time a parameter receives one."""
+    if isinstance(first_step, (bool, int)):
+        first_step = [first_step] * len(params)
     n = len(params)
     arr = (_native.SgdTensor * n)()
     for i, (p, g, b) in enumerate(zip(params, grads, bufs)):
@@ -1328,7 +1447,7 @@ def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum
         arr[i].momentum_buf = b.data_ptr()
         arr[i].numel = p.numel()
         arr[i].weight_decay = float(weight_decays[i])
-        arr[i].first_step = 1 if first_step else 0
+        arr[i].first_step = 1 if first_step[i] else 0
     _native.check(_native.lib().semseg_sgd_step(arr, n, _p(lr_tensor), float(momentum), float(grad_scale), _st()),
                   'sgd_step')
     # the kernel updates the parameters behind torch's back (no version bump): prepared weight planes are stale until

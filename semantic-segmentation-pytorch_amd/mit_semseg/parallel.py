@@ -187,8 +187,21 @@ class NativeDataParallel(nn.Module):
             ops.set_sync_bn_group(group, enabled=world_size(group) > 1)
 
     def scatter(self, batch):
+        """This rank's element of the reference's per-GPU list (data_parallel.py:54-62).  A list must hold ONE dict (this
+        rank's own batch) or one dict per rank of the group.  Anything else is the single-process recipe of the reference
+        (`train.py --gpus 0-7`: one process, a list of 8 per-GPU dicts) run without torchrun -- taking an element of it
+        would silently train on 1/8 of every batch, so it raises."""
         if isinstance(batch, (list, tuple)):
-            return batch[self.rank % len(batch)]
+            world = world_size(self.group)
+            if len(batch) == 1:
+                return batch[0]
+            if len(batch) == world:
+                return batch[self.rank]
+            raise ValueError(
+                'NativeDataParallel got a list of %d per-GPU batches but runs as rank %d of %d process(es)%s: this build is one '
+                'process per GPU -- launch with `python -m torch.distributed.run --nproc-per-node N` and give every rank '
+                'its own batch (a 1-element list) or the full list of N' %
+                (len(batch), self.rank, world, '' if not self.device_ids else ' (device_ids=%s)' % (list(self.device_ids),)))
         return batch
 
     def forward(self, batch, **kwargs):

@@ -20,6 +20,23 @@ ENABLED = os.environ.get('SEMSEG_TUNE', '1') != '0'
 CACHE = os.environ.get('SEMSEG_TUNE_CACHE', '')
 _done = {}          # (scheme, pass, geom) -> (tile, split, ms)
 _cache_loaded = False
+# Variable-size batches (BASELINE configs[3]: every per-GPU batch has its own H x W) would put a full tile x split sweep of every
+# conv of the network in front of every new shape.  The winning plan of a layer depends on its channel configuration and on how
+# many output pixels it has, not on how they are arranged, so a geometry that has not been seen inherits the plan tuned for the
+# same layer in the same HALF-OCTAVE of pixel count (round(2 log2 M)); only the first geometry of a bucket is timed.
+# SEMSEG_TUNE_BUCKETS=0: time every geometry.
+BUCKETS = os.environ.get('SEMSEG_TUNE_BUCKETS', '1') != '0'
+_bucket_plans = {}  # (scheme, pass, C, K, R, S, stride, pad, dil, bucket) -> (tile, split)
+stats = {'timed': 0, 'inherited': 0}
+
+
+def _bucket_key(scheme, pass_id, geom):
+    import math
+    n, h, w, c, k, r, s, stride, pad, dil = geom
+    oh = (h + 2 * pad - dil * (r - 1) - 1) // stride + 1
+    ow = (w + 2 * pad - dil * (s - 1) - 1) // stride + 1
+    m = max(1, n * oh * ow)
+    return (scheme, pass_id, c, k, r, s, stride, pad, dil, int(round(2.0 * math.log2(m))))
 
 
 def _load_cache():
@@ -35,6 +52,7 @@ def _load_cache():
         _done[key] = tuple(v)
         if v[0] >= 0:
             _native.check(_set_plan(L, key[0])(key[1], *key[2:], int(v[0]), int(v[1])), 'set_plan')
+        _bucket_plans.setdefault(_bucket_key(key[0], key[1], key[2:]), (int(v[0]), int(v[1])))
 
 
 def _save_cache():
@@ -109,6 +127,17 @@ def ensure(scheme, pass_id, geom, launch):
         kt = (n * oh * ow + 31) // 32
     tiles = _WTILES[scheme] if pass_id == 2 else _TILES[scheme]
     set_plan = _set_plan(L, scheme)
+    bkey = _bucket_key(scheme, pass_id, geom)
+    if BUCKETS and bkey in _bucket_plans:
+        tile, split = _bucket_plans[bkey]
+        if tile >= 0:
+            while split > 1 and kt // split < 4:              # the same validity rule as the sweep below
+                split = max(s for s in _SPLITS if s < split)
+            _native.check(set_plan(pass_id, *geom, tile, split), 'set_plan')
+        _done[key] = (tile, split if tile >= 0 else 0, None)
+        stats['inherited'] += 1
+        return
+    stats['timed'] += 1
     best = None
     try:
         launch()                                    # heuristic plan first (also warms caches / sizes the workspace)
@@ -134,4 +163,6 @@ def ensure(scheme, pass_id, geom, launch):
         else:
             set_plan(pass_id, *geom, best[0], best[1])
     _done[key] = best
+    if best is not None:
+        _bucket_plans[bkey] = (best[0], best[1])
     _save_cache()

@@ -33,6 +33,26 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
     return (y, x) if passthrough else y
 
 
+def grouped_conv3x3(x, weight, groups, stride=1, padding=1, dilation=1):
+    return F.conv2d(x, weight, None, stride, padding, dilation, groups)
+
+
+def clamp_max(x, cap):
+    return torch.clamp(x, max=cap)
+
+
+def fork(x, n=2):
+    return (x,) * n
+
+
+def share_planes(src, dst):
+    return None
+
+
+def dropout_mask(n, c, p, device):
+    return (torch.rand(n, c, device=device) >= p).float() / (1.0 - p)
+
+
 def add_act(a, b, relu=False):
     y = a + b
     return F.relu(y) if relu else y
@@ -84,10 +104,12 @@ def nll_loss_acc(logp, label, ignore_index=-1):
 def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum=0.9, grad_scale=1.0):
     """train.py:117-126 semantics of the fused kernel: g = grad * scale + wd * p; buf = g (first step) | m * buf + g; p -= lr buf"""
     lr = float(lr_tensor.reshape(-1)[0])
+    if isinstance(first_step, (bool, int)):
+        first_step = [first_step] * len(params)
     with torch.no_grad():
-        for p, g, b, wd in zip(params, grads, bufs, weight_decays):
+        for p, g, b, wd, first in zip(params, grads, bufs, weight_decays, first_step):
             d = g * grad_scale + wd * p
-            if first_step:
+            if first:
                 b.copy_(d)
             else:
                 b.mul_(momentum).add_(d)
@@ -98,7 +120,7 @@ def install(monkeypatch, keep=()):
     """`keep`: names of ops functions to leave in place (they then need a native library, e.g. a host-emulated one)"""
     from mit_semseg import ops
     g = globals()
-    for name in ('conv2d', 'depthwise_conv3x3', 'batch_norm_act', 'conv_bn_act', 'add_act', 'concat', 'scale_nc',
+    for name in ('conv2d', 'depthwise_conv3x3', 'grouped_conv3x3', 'clamp_max', 'fork', 'share_planes', 'dropout_mask', 'batch_norm_act', 'conv_bn_act', 'add_act', 'concat', 'scale_nc',
                  'max_pool_3x3_s2', 'adaptive_avg_pool', 'adaptive_avg_pool_multi', 'interpolate_bilinear', 'log_softmax',
                  'softmax', 'nll_loss_acc', 'sgd_step'):
         if name not in keep:

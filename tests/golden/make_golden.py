@@ -79,6 +79,40 @@ def summarize(t, full_limit=4096):
             'head': f[:16].clone(), 'tail': f[-16:].clone(), 'numel': t.numel()}
 
 
+def sample_index(numel, k=1024):
+    """the seeded element sample the anchor records of large tensors hold (tests/util.py rebuilds the same index set)"""
+    return torch.randint(0, numel, (k,), generator=torch.Generator().manual_seed(numel % (2 ** 31)))
+
+
+# fp32 runs of the unmodified reference that differ only in HOW the same arithmetic is executed (see anchor()): memory format,
+# thread count (= reduction order of the CPU kernels), and an input perturbed below fp32 resolution
+VARIANTS = ('channels_last', 'threads1', 'threads3', 'perturbed')
+PERTURB_REL = 1e-7
+
+
+def anchor(t32s, t64, full_limit=4096):
+    """Float64 ANCHOR of one tensor of the reference + the reference's own fp32 REPRODUCIBILITY BAND around it.
+    A training step through 50-300 BN/ReLU layers is ill-conditioned: backward amplifies rounding (a 1e-7 relative input
+    perturbation -- below fp32 resolution -- moves the fp32 gradients of the seeded ResNet-50 / MobileNetV2 by 0.5 % in L2,
+    independent of the image size), and a ReLU whose pre-activation is ~1e-7 resolves either way depending on the summation
+    order, which shifts every upstream gradient a little.  Two correct fp32 implementations therefore differ by an amount no
+    fixed tolerance describes: on the seeded ResNet-18 case the SAME torch CPU build moves the stem's weight gradient by 2e-5
+    (default), 9e-4 (channels_last tensors) or 2e-3 (one thread) of its scale.  `t32s` = the same tensor from 1 + len(VARIANTS)
+    fp32 runs of the unmodified reference (default; channels_last memory format; 1 and 3 threads; input image multiplied by
+    1 + 1e-7 N(0,1)); the band is their largest deviation from the float64 run, and parity of gradients / updated weights is
+    stated as `|native - ref64| <= c * band` (tests/util.check_vs_anchor)."""
+    t64 = t64.detach().double().flatten()
+    ds = [t.detach().double().flatten() - t64 for t in t32s]
+    rec = {'numel': t64.numel(), 'err_max': max(d.abs().max().item() for d in ds), 'err_l2': max(d.norm().item() for d in ds),
+           'err_max_plain': ds[0].abs().max().item(), 'err_l2_plain': ds[0].norm().item(),
+           'norm': t64.norm().item(), 'absmax': t64.abs().max().item(), 'sum': t64.sum().item()}
+    if t64.numel() <= full_limit:
+        rec['full'] = t64.float().clone()
+    else:
+        rec['sample'] = t64[sample_index(t64.numel())].float().clone()
+    return rec
+
+
 def group_weight(module):
     """train.py:92-112 -- decay on conv/linear weights only."""
     decay, no_decay = [], []
@@ -96,26 +130,51 @@ def group_weight(module):
 
 
 def run_case(name, arch_enc, arch_dec, fc_dim, n, h, w, seg_rate, training, deep_sup_scale,
-             step=False, seg_size=None, seed=0):
+             step=False, seg_size=None, seed=0, grads_full=False, dtype=torch.float32, variant=None):
     torch.manual_seed(304)
     enc, dec = build_reference(arch_enc, arch_dec, fc_dim, use_softmax=seg_size is not None)
     man_e, man_d = manifest_of(enc), manifest_of(dec)
     enc.load_state_dict(O.synth_state_dict(man_e, seed))
     dec.load_state_dict(O.synth_state_dict(man_d, seed + 1))
+    if dtype != torch.float32:
+        enc, dec = enc.to(dtype), dec.to(dtype)
     masks = {}
     if training:
         # conv_last.3 is the main-head Dropout2d, dropout_deepsup the deepsup one (models.py:455-465)
         if hasattr(dec, 'conv_last') and isinstance(dec.conv_last, nn.Sequential) and len(dec.conv_last) == 5:
             masks['main'] = O.synth_dropout_mask(n, 512, seed=seed)
-            dec.conv_last[3] = ReplayDropout(masks['main'])
+            dec.conv_last[3] = ReplayDropout(masks['main'].to(dtype))
         if hasattr(dec, 'dropout_deepsup'):
             masks['deepsup'] = O.synth_dropout_mask(n, fc_dim // 4, seed=seed + 1)
-            dec.dropout_deepsup = ReplayDropout(masks['deepsup'])
+            dec.dropout_deepsup = ReplayDropout(masks['deepsup'].to(dtype))
     crit = nn.NLLLoss(ignore_index=-1)
     sm = SegmentationModule(enc, dec, crit, deep_sup_scale)
     sm.train(training)
     img, lab = O.synth_batch(n, h, w, seg_rate, seed=304 + seed)
-    feed = {'img_data': img, 'seg_label': lab}
+    if variant == 'perturbed':
+        img = img * (1.0 + PERTURB_REL * torch.randn(img.shape, generator=torch.Generator().manual_seed(1001)))
+    if variant == 'channels_last':
+        sm = sm.to(memory_format=torch.channels_last)
+        img = img.contiguous(memory_format=torch.channels_last)
+    feed = {'img_data': img.to(dtype), 'seg_label': lab}
+    if dtype != torch.float32 or variant:
+        # auxiliary runs for anchor(): the float64 run (same modules, weights, batch; double arithmetic) and the perturbed fp32 runs
+        assert step
+        opts = [torch.optim.SGD(group_weight(enc), lr=0.02, momentum=0.9, weight_decay=1e-4),
+                torch.optim.SGD(group_weight(dec), lr=0.02, momentum=0.9, weight_decay=1e-4)]
+        threads = torch.get_num_threads()
+        if variant in ('threads1', 'threads3'):
+            torch.set_num_threads(int(variant[-1]))
+        sm.zero_grad()
+        loss, acc = sm(feed)
+        loss.backward()
+        grads = ({k: p.grad.clone() for k, p in enc.named_parameters()}, {k: p.grad.clone() for k, p in dec.named_parameters()})
+        for op in opts:
+            op.step()
+        torch.set_num_threads(threads)
+        return dict(loss=loss.detach(), grads=grads, after=(
+            {k: v.clone() for k, v in enc.state_dict().items() if v.is_floating_point()},
+            {k: v.clone() for k, v in dec.state_dict().items() if v.is_floating_point()}))
     meta = dict(name=name, arch_encoder=arch_enc, arch_decoder=arch_dec, fc_dim=fc_dim, n=n, h=h, w=w,
                 seg_rate=seg_rate, training=training, deep_sup_scale=deep_sup_scale, step=step,
                 seg_size=seg_size, seed=seed, lr=0.02, torch=torch.__version__)
@@ -147,10 +206,23 @@ def run_case(name, arch_enc, arch_dec, fc_dim, n, h, w, seg_rate, training, deep
     if step:
         out['grads_enc'] = {k: summarize(p.grad) for k, p in enc.named_parameters()}
         out['grads_dec'] = {k: summarize(p.grad) for k, p in dec.named_parameters()}
+        enc_grads = {k: p.grad.clone() for k, p in enc.named_parameters()}
+        dec_grads = {k: p.grad.clone() for k, p in dec.named_parameters()}
         for op in opts:
             op.step()
         out['after_enc'] = {k: summarize(v) for k, v in enc.state_dict().items() if v.is_floating_point()}
         out['after_dec'] = {k: summarize(v) for k, v in dec.state_dict().items() if v.is_floating_point()}
+        aux = dict(name=name, arch_enc=arch_enc, arch_dec=arch_dec, fc_dim=fc_dim, n=n, h=h, w=w, seg_rate=seg_rate,
+                   training=training, deep_sup_scale=deep_sup_scale, step=True, seed=seed)
+        r64 = run_case(dtype=torch.float64, **aux)
+        out['loss64'] = r64['loss'].item()
+        runs = [dict(grads=(dict(enc_grads), dict(dec_grads)),
+                     after=({k: v.clone() for k, v in enc.state_dict().items()}, {k: v.clone() for k, v in dec.state_dict().items()}))]
+        runs += [run_case(variant=v, **aux) for v in VARIANTS]
+        for i, side in enumerate(('enc', 'dec')):
+            out['anchor_grads_' + side] = {k: anchor([r['grads'][i][k] for r in runs], v, 1 << 62 if grads_full else 4096)
+                                           for k, v in r64['grads'][i].items()}
+            out['anchor_after_' + side] = {k: anchor([r['after'][i][k] for r in runs], v) for k, v in r64['after'][i].items()}
     return out
 
 
@@ -175,11 +247,14 @@ CASES = [
     # the remaining arch strings of ModelBuilder (depthwise / grouped convolutions)
     dict(name='mnv2d_c1ds_64_train', arch_enc='mobilenetv2dilated', arch_dec='c1_deepsup', fc_dim=320,
          n=2, h=64, w=64, seg_rate=8, training=True, deep_sup_scale=0.4, step=True),
-    # eval mode: a train step through 101 layers with 2-sample BN statistics in the pyramid branches is chaotic (a 1e-6
-    # relative input perturbation moves the stem gradient by 1.7 %), i.e. not a parity case; the grouped-conv TRAINING path is
-    # pinned by the MobileNetV2 case above
     dict(name='resnext101_upernet_128_eval', arch_enc='resnext101', arch_dec='upernet', fc_dim=2048,
          n=2, h=128, w=128, seg_rate=4, training=False, deep_sup_scale=None),
+    # grouped / depthwise TRAINING steps at sizes where every BN sees >= 1024 values per channel (deepest maps: /8 of 192^2
+    # x 2 images = 1152; /32 of 512^2 x 4 images = 1024); the MobileNetV2 case stores every gradient tensor in full
+    dict(name='mnv2d_c1ds_192_train', arch_enc='mobilenetv2dilated', arch_dec='c1_deepsup', fc_dim=320,
+         n=2, h=192, w=192, seg_rate=8, training=True, deep_sup_scale=0.4, step=True, seed=2, grads_full=True),
+    dict(name='resnext101_c1_512_train', arch_enc='resnext101', arch_dec='c1', fc_dim=2048,
+         n=4, h=512, w=512, seg_rate=32, training=True, deep_sup_scale=None, step=True, seed=3),
 ]
 
 

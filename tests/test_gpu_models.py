@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.util import golden_cases, load_golden, check_summary, HEURISTIC_PLAN_GOLDEN
+from tests.util import golden_cases, load_golden, check_vs_anchor, HEURISTIC_PLAN_GOLDEN
 from oracle import semseg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -91,104 +91,125 @@ def test_native_matches_reference_golden(name, monkeypatch):
     assert abs(acc.item() - g['acc'].item()) < 1e-6
     if not m['step']:
         return
-    # gradients are recorded before the optimizer step in the golden; TrainStep has stepped already, so
-    # compare the post-step state (weights, BN running stats) -- it pins grads, weight decay, momentum and lr
-    for mod, want in ((sm.encoder, g['after_enc']), (sm.decoder, g['after_dec'])):
+    # TrainStep has stepped already: compare the post-step state (weights, BN running stats) -- it pins grads, weight decay,
+    # momentum and lr -- against the reference's float64 anchor with the reference's own fp32 deviation as the yardstick
+    # (tests/util.check_vs_anchor)
+    ratios = []
+    for mod, want in ((sm.encoder, g['anchor_after_enc']), (sm.decoder, g['anchor_after_dec'])):
         sd = mod.state_dict()
         for k in want:
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue
-            check_summary(sd[k].detach().cpu().contiguous(), want[k], 2e-4, 2e-3, 'after-step ' + k)
+            worst, tol = check_vs_anchor(sd[k], want[k], 'after-step ' + k)
+            ratios.append(worst / tol)
+    ratios.sort()
+    print('%s: after-step error / allowed: median %.2f max %.2f over %d tensors' % (name, ratios[len(ratios) // 2], ratios[-1],
+                                                                              len(ratios)))
 
 
-def test_native_gradients_vs_oracle():
-    """Every parameter gradient of one backward (no optimizer step) against the CPU oracle on the same weights /
-    batch / dropout masks (R50dilated+PPM_deepsup, the golden case r50d_ppmds_64_train, whose gradients the
-    oracle reproduces from the unmodified reference to 1e-4: tests/test_oracle_golden.py).
-
-    Metric per tensor: relative L2 error ||g - ref|| / ||ref|| (and max|g - ref| / rms(ref), printed).
-    Why not a plain elementwise bound: with train-mode BN over only 2x8x8 = 128 pixels per channel a ReLU gate
-    whose pre-activation is ~1e-7 can resolve differently under a different (equally valid) fp32 summation
-    order; ONE flipped gate moves the max-error of the next conv's weight gradient by O(0.5 rms) (a single
-    pixel term against a 128-term sum) while the L2 error stays ~1/sqrt(#gates).  The branches without such a
-    flip (deep-supervision head, classifier) must agree to fp32 roundoff elementwise."""
-    g = load_golden('r50d_ppmds_64_train')
+def _native_grads(g, dev):
     m = g['meta']
-    dev = torch.device('cuda:0')
     sm, enc_sd, dec_sd = build_native(g, dev)
     img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=304 + m['seed'])
     loss, acc = sm({'img_data': img.to(dev), 'seg_label': lab.to(dev)})
     loss.backward()
     torch.cuda.synchronize()
-    e, d = O.clone_sd(enc_sd, True), O.clone_sd(dec_sd, True)
-    ref = O.segmentation_forward(e, d, m['arch_encoder'], m['arch_decoder'], img, lab, training=True,
-                                 dropout=g['dropout'], deep_sup_scale=m['deep_sup_scale'])
-    ref['loss'].backward()
-    rows = []
-    for mod, sd, name in ((sm.decoder, d, 'dec'), (sm.encoder, e, 'enc')):
+    return sm
+
+
+@pytest.mark.parametrize('name', ['r18d_ppmds_64_train', 'r50d_ppmds_64_train', 'r50_upernet_128_train', 'hrnetv2_c1_64_train',
+                                  'mnv2d_c1ds_64_train', 'mnv2d_c1ds_192_train'])
+def test_native_gradients_vs_reference_anchor(name, monkeypatch):
+    """EVERY parameter gradient of one backward against the float64 anchor of the unmodified reference
+    (tests/golden/make_golden.py::anchor): elementwise on small tensors and on a seeded 1024-element sample of large ones --
+    for `mnv2d_c1ds_192_train` on EVERY element of every gradient tensor (stored in full).  Yardstick = the reference's own
+    fp32 reproducibility band per tensor: the largest deviation from the float64 run over five fp32 runs of the unmodified
+    reference that differ only in execution (default / channels_last / 1 thread / 3 threads / input perturbed by 1e-7).
+    Backward through these nets is ill-conditioned at ANY image size (ReLU gates whose pre-activation is ~1e-7 resolve either
+    way; the same torch build moves ResNet-18's stem gradient by 2e-5 ... 2e-3 of its scale between those runs), so no fixed
+    elementwise bound separates right from wrong; this one does: a kernel bug moves a gradient by O(1) of its norm."""
+    if name in HEURISTIC_PLAN_GOLDEN or name.startswith('mnv2d'):
+        from mit_semseg import tuner
+        monkeypatch.setattr(tuner, 'ENABLED', False)
+    g = load_golden(name)
+    sm = _native_grads(g, torch.device('cuda:0'))
+    ratios = []
+    for mod, want in ((sm.encoder, g['anchor_grads_enc']), (sm.decoder, g['anchor_grads_dec'])):
         for k, p in mod.named_parameters():
-            r = sd[k].grad.double()
-            got = p.grad.detach().cpu().contiguous().double()
-            rms = r.pow(2).mean().sqrt().item() + 1e-20
-            l2 = (got - r).norm().item() / (r.norm().item() + 1e-20)
-            rows.append((name + '.' + k, (got - r).abs().max().item() / rms, l2))
-    for k, err, l2 in rows:
-        print('%-44s max/rms %.2e   relL2 %.2e' % (k, err, l2))
-    mx = dict((k, err) for k, err, _ in rows)
-    l2 = dict((k, v) for k, _, v in rows)
-    # classifier + deep-supervision branch (no BN/ReLU gate between loss and these tensors, or a well separated
-    # one): fp32 roundoff class, elementwise
-    for k in ('dec.conv_last.4.weight', 'dec.conv_last.4.bias', 'dec.conv_last_deepsup.weight',
-              'dec.conv_last_deepsup.bias', 'dec.cbr_deepsup.0.weight', 'dec.cbr_deepsup.1.weight'):
-        assert mx[k] < 2e-3, (k, mx[k])
-    # main head: at most isolated gate flips
-    for k in ('dec.conv_last.1.weight', 'dec.conv_last.1.bias', 'dec.conv_last.0.weight'):
-        assert l2[k] < 2e-2, (k, l2[k])
-    worst = max(l2.items(), key=lambda kv: kv[1])
-    vals = sorted(l2.values())
-    print('relL2: median %.2e  p90 %.2e  worst %s %.2e' % (vals[len(vals) // 2], vals[int(len(vals) * 0.9)], worst[0], worst[1]))
-    assert vals[len(vals) // 2] < 2e-2, vals[len(vals) // 2]
-    assert worst[1] < 0.25, worst
+            worst, tol = check_vs_anchor(p.grad, want[k], 'grad ' + k)
+            ratios.append((worst / tol, k, want[k]['err_l2'] / (want[k]['norm'] + 1e-30)))
+    ratios.sort()
+    print('%s: gradient error / allowed: median %.2f max %.2f (%s); reference fp32-vs-fp64 relL2 of that tensor %.1e' % (
+        name, ratios[len(ratios) // 2][0], ratios[-1][0], ratios[-1][1], ratios[-1][2]))
 
 
-def test_config1_full_size_vs_oracle():
-    """BASELINE.json configs[1]: ade20k-resnet50dilated-ppm_deepsup, bs 2, 512x512, one full training step.
-    The oracle (torch CPU) runs the same step; log-probs within 1e-3, argmax identical, loss/acc equal, and the
-    updated weights of first/last layers agree."""
+FULL_SIZE = {
+    # BASELINE.json configs[1..4] at their full sizes; (arch_encoder, arch_decoder, fc_dim, deep_sup_scale, seg_rate, H, W,
+    # state-dict keys whose post-step values are compared: first / last / dominant layers of encoder and decoder)
+    'cfg1_r50d_ppmds_512': ('resnet50dilated', 'ppm_deepsup', 2048, 0.4, 8, 512, 512,
+                            ['conv1.weight', 'layer4.2.conv2.weight', 'layer3.0.bn1.weight', 'bn1.running_var'],
+                            ['conv_last.0.weight', 'conv_last.4.bias', 'ppm.0.1.weight']),
+    'cfg2_r50_upernet_512': ('resnet50', 'upernet', 2048, None, 4, 512, 512,
+                             ['conv1.weight', 'layer4.2.conv2.weight', 'layer2.0.bn1.weight', 'bn1.running_var'],
+                             ['conv_last.0.0.weight', 'conv_last.1.bias', 'fpn_out.0.0.0.weight', 'ppm_last_conv.0.weight',
+                              'fpn_in.2.0.weight', 'ppm_conv.0.1.weight']),
+    # configs[3] is variable-size: two non-square batch shapes of the multi-scale rule (dataset.py:121-142), the second with
+    # odd feature-map sizes (57 x 85)
+    'cfg3_r101d_ppmds_376x504': ('resnet101dilated', 'ppm_deepsup', 2048, 0.4, 8, 376, 504,
+                                 ['conv1.weight', 'layer3.22.conv2.weight', 'layer4.2.conv3.weight', 'bn1.running_mean'],
+                                 ['conv_last.0.weight', 'conv_last_deepsup.weight', 'ppm.3.1.weight']),
+    'cfg3_r101d_ppmds_456x680': ('resnet101dilated', 'ppm_deepsup', 2048, 0.4, 8, 456, 680,
+                                 ['conv1.weight', 'layer3.11.conv1.weight', 'layer4.0.downsample.0.weight', 'layer1.0.bn3.running_var'],
+                                 ['conv_last.0.weight', 'cbr_deepsup.0.weight', 'ppm.1.1.weight']),
+    'cfg4_hrnetv2_c1_512': ('hrnetv2', 'c1', 720, None, 4, 512, 512,
+                            ['conv1.weight', 'stage4.2.fuse_layers.0.3.0.weight', 'stage3.1.branches.2.3.conv2.weight',
+                             'stage2.0.branches.0.0.bn1.running_var', 'transition3.3.0.0.weight'],
+                            ['cbr.0.weight', 'cbr.1.weight', 'conv_last.weight', 'conv_last.bias']),
+}
+
+
+@pytest.mark.parametrize('case', sorted(FULL_SIZE))
+def test_full_size_vs_oracle(case):
+    """BASELINE.json configs[1..4] at FULL size (bs 2; 512x512, and two variable-size shapes for configs[3]): one full training
+    step on the device against the oracle (torch CPU) running the same step on the box's host cores: log-probs within 1e-3,
+    argmax identical (outside the oracle's own near-ties), loss / accuracy equal, and the updated weights / BN statistics of
+    first, last and dominant layers agree."""
     from mit_semseg.engine import TrainStep
     import json
+    arch_enc, arch_dec, fc_dim, dss, rate, H, W, enc_keys, dec_keys = FULL_SIZE[case]
     dev = torch.device('cuda:0')
     man = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'manifests.json')))
-    g = dict(meta=dict(arch_encoder='resnet50dilated', arch_decoder='ppm_deepsup', fc_dim=2048, seed=3, training=True,
-                       deep_sup_scale=0.4, seg_size=None),
-             manifest_enc=man['resnet50dilated'], manifest_dec=man['ppm_deepsup@2048'],
-             dropout={'main': O.synth_dropout_mask(2, 512, seed=3), 'deepsup': O.synth_dropout_mask(2, 512, seed=4)})
+    drop = {'main': O.synth_dropout_mask(2, 512, seed=3)} if 'ppm' in arch_dec else {}
+    if arch_dec == 'ppm_deepsup':
+        drop['deepsup'] = O.synth_dropout_mask(2, fc_dim // 4, seed=4)
+    g = dict(meta=dict(arch_encoder=arch_enc, arch_decoder=arch_dec, fc_dim=fc_dim, seed=3, training=True, deep_sup_scale=dss,
+                       seg_size=None),
+             manifest_enc=man[arch_enc], manifest_dec=man['%s@%d' % (arch_dec, fc_dim)], dropout=drop)
     sm, enc_sd, dec_sd = build_native(g, dev)
-    img, lab = O.synth_batch(2, 512, 512, 8, seed=307)
+    img, lab = O.synth_batch(2, H, W, rate, seed=307)
     cap = {}
     hk = sm.decoder.register_forward_hook(lambda mod, i, o: cap.__setitem__('out', o))
     ts = TrainStep(sm, max_iters=10 ** 9)
     loss, acc = ts.step({'img_data': img.to(dev), 'seg_label': lab.to(dev)})
     hk.remove()
     torch.cuda.synchronize()
-    pred = cap['out'][0].detach().cpu().contiguous()
+    out = cap['out']
+    pred = (out[0] if isinstance(out, tuple) else out).detach().cpu().contiguous()
 
     torch.set_num_threads(min(os.cpu_count(), 32))    # torch CPU convs thrash beyond ~32 threads (203 s at 256)
     e, d = O.clone_sd(enc_sd, True), O.clone_sd(dec_sd, True)
-    ref = O.segmentation_forward(e, d, 'resnet50dilated', 'ppm_deepsup', img, lab, training=True, dropout=g['dropout'],
-                                 deep_sup_scale=0.4)
+    ref = O.segmentation_forward(e, d, arch_enc, arch_dec, img, lab, training=True, dropout=drop, deep_sup_scale=dss)
     ref['loss'].backward()
     rp = ref['pred'].detach()
-    print('cfg1: max|dlogp| %.3e  loss %.6f vs %.6f' % ((pred - rp).abs().max().item(), loss.item(), ref['loss'].item()))
+    print('%s: max|dlogp| %.3e  loss %.6f vs %.6f' % (case, (pred - rp).abs().max().item(), loss.item(), ref['loss'].item()))
     torch.testing.assert_close(pred, rp, atol=LOGP_ATOL, rtol=0)
-    argmax_check(pred, rp, 'cfg1')
+    argmax_check(pred, rp, case)
     assert abs(loss.item() - ref['loss'].item()) < 1e-3
     assert abs(acc.item() - ref['acc'].item()) < 1e-6
-    for sd, gr in ((e, None), (d, None)):
+    for sd in (e, d):
         params = {k: v for k, v in sd.items() if v.requires_grad}
         O.sgd_step(params, {k: v.grad for k, v in params.items()}, {}, 0.02)
-    for mod, sd, keys in ((sm.encoder, e, ['conv1.weight', 'layer4.2.conv2.weight', 'layer3.0.bn1.weight', 'bn1.running_var']),
-                          (sm.decoder, d, ['conv_last.0.weight', 'conv_last.4.bias', 'ppm.0.1.weight'])):
+    for mod, sd, keys in ((sm.encoder, e, enc_keys), (sm.decoder, d, dec_keys)):
         got = mod.state_dict()
         for k in keys:
             torch.testing.assert_close(got[k].cpu().contiguous(), sd[k].detach(), atol=2e-5, rtol=1e-3, msg=lambda s, k=k: k + ': ' + s)

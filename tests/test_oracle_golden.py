@@ -5,7 +5,7 @@ import os
 import pytest
 import torch
 
-from tests.util import golden_cases, load_golden, oracle_run, check_summary
+from tests.util import golden_cases, load_golden, oracle_run, check_summary, HEAVY_GOLDEN
 
 # same torch CPU kernels on both sides -> agreement is at rounding level
 ATOL, RTOL = 1e-5, 1e-5
@@ -14,7 +14,8 @@ ATOL, RTOL = 1e-5, 1e-5
 @pytest.mark.parametrize('name', golden_cases())
 def test_oracle_matches_reference(name):
     g = load_golden(name)
-    res, enc, dec, grads = oracle_run(g)
+    heavy = name in HEAVY_GOLDEN
+    res, enc, dec, grads = oracle_run(g, with_step=False if heavy else None)
     if 'prob' in g:
         torch.testing.assert_close(res['prob'], g['prob'], atol=ATOL, rtol=RTOL)
         assert torch.equal(res['prob'].argmax(1), g['prob'].argmax(1))
@@ -27,7 +28,7 @@ def test_oracle_matches_reference(name):
     torch.testing.assert_close(res['acc'], g['acc'], atol=0, rtol=0)
     for f, w in zip(res['feats'], g['feats']):
         check_summary(f, w, 1e-4, 1e-4, 'feat')
-    if not g['meta']['step']:
+    if not g['meta']['step'] or heavy:
         return
     for sd_grads, want in ((grads[0], g['grads_enc']), (grads[1], g['grads_dec'])):
         assert set(sd_grads) == set(want)

@@ -10,7 +10,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 # golden cases whose ~150 convolution geometries (dense forms of grouped convs, 101-layer backbones) no other test uses: they
 # run on the library's heuristic launch plans instead of timing every tile x split candidate
-HEURISTIC_PLAN_GOLDEN = ('mnv2d_c1ds_64_train', 'resnext101_upernet_128_eval')
+HEURISTIC_PLAN_GOLDEN = ('mnv2d_c1ds_64_train', 'mnv2d_c1ds_192_train', 'resnext101_upernet_128_eval', 'resnext101_c1_512_train')
+# 4 x 512 x 512 through ResNeXt-101 (every BN sees >= 1024 values per channel): a training step of it takes the CPU minutes, so
+# the CPU-side tests run its forward only; the GPU test runs the whole step against the stored results of the reference
+HEAVY_GOLDEN = ('resnext101_c1_512_train',)
 
 
 def golden_cases():
@@ -35,6 +38,46 @@ def check_summary(got, want, atol, rtol, what):
     tol = atol * f.numel() ** 0.5 + rtol * want['abssum']
     assert abs(s - want['sum']) <= tol, (what, s, want['sum'], tol)
     assert abs(a - want['abssum']) <= tol, (what, a, want['abssum'], tol)
+
+
+def sample_index(numel, k=1024):
+    """same seeded element sample as tests/golden/make_golden.py::sample_index"""
+    return torch.randint(0, numel, (k,), generator=torch.Generator().manual_seed(numel % (2 ** 31)))
+
+
+ANCHOR_FACTOR = 4.0
+
+
+def check_vs_anchor(got, rec, what, factor=ANCHOR_FACTOR):
+    """`got` against the float64 ANCHOR record of the reference (make_golden.anchor): the native result must be as close to
+    the exact (float64) result of the reference's arithmetic as the reference's OWN fp32 runs are (band = the largest
+    deviation over five executions of the unmodified reference, see anchor()), up to `factor`:
+
+        max|got - ref64|  <=  factor * band_max  + floor        (elementwise, on the full tensor or its sample)
+        ||got - ref64||_2 <=  factor * band_l2 + floor          (full tensors)
+        |sum got - sum ref64| <= 6 * factor * band_l2 + floor   (every tensor: a sum of n errors ~ their 2-norm)
+
+    floor = fp32 representation of the anchor itself (1e-6 of max|ref64|).  Returns (max error, allowed) for reporting."""
+    f = got.detach().double().cpu().flatten()
+    assert f.numel() == rec['numel'], (what, f.numel(), rec['numel'])
+    floor = 1e-6 * rec['absmax'] + 1e-9
+    if 'full' in rec:
+        ref, g = rec['full'].double().flatten(), f
+    else:
+        ref, g = rec['sample'].double(), f[sample_index(rec['numel'])]
+    d = (g - ref).abs()
+    tol = factor * rec['err_max'] + floor
+    worst = d.max().item()
+    assert worst <= tol, '%s: max|native - ref64| %.3e > %.1f x max|ref32 - ref64| %.3e + %.1e' % (
+        what, worst, factor, rec['err_max'], floor)
+    n = rec['numel']
+    if 'full' in rec:
+        l2 = d.norm().item()
+        assert l2 <= factor * rec['err_l2'] + floor * n ** 0.5, '%s: ||native - ref64|| %.3e > %.1f x ||ref32 - ref64|| %.3e' % (
+            what, l2, factor, rec['err_l2'])
+    ds = abs(f.sum().item() - rec['sum'])
+    assert ds <= 6 * factor * rec['err_l2'] + floor * n ** 0.5 + 1e-12 * abs(rec['sum']), (what, 'sum', ds, rec['err_l2'])
+    return worst, tol
 
 
 def oracle_run(g, with_step=None):
