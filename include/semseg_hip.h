@@ -27,6 +27,7 @@ extern "C" {
 
 #define SEMSEG_EINVAL   (-1)   /* bad argument (shape/alignment not supported) */
 #define SEMSEG_EWORKSPACE (-2) /* workspace too small */
+#define SEMSEG_ECOMM   (-3)   /* RCCL not loadable in this process, or an RCCL call failed */
 
 int semseg_abi_version(void);
 
@@ -415,6 +416,22 @@ typedef struct {
  * (buf = g on first_step); p -= lr*buf. */
 int semseg_sgd_step(const semseg_sgd_tensor* tensors_host, int n, const float* lr, float momentum,
                     float grad_scale, void* stream);
+
+/* ---------------- collectives over RCCL / xGMI ------------------------------------
+ * Replace the reference's single-process thread rendezvous: lib/nn/modules/comm.py:46-131 (SyncMaster / SlavePipe queues),
+ * lib/nn/modules/batchnorm.py:98-117 (_data_parallel_master: reduce sum / ssum to device 0, broadcast mean / inv_std) and the
+ * gradient reduction nn.DataParallel performs (train.py:184-190).  One process per GPU; every rank calls the same sequence.
+ * RCCL is bound at run time (the librccl the process already holds); without it these return SEMSEG_ECOMM and everything
+ * else in the library keeps working.  All-reduces are enqueued on `stream` (no host sync; hipGraph-capturable). */
+int semseg_comm_available(void);                       /* 1 if an RCCL library could be bound */
+int semseg_comm_version(void);                         /* ncclGetVersion code, 0 if unavailable */
+int semseg_comm_unique_id(void* id128);                /* rank 0: 128-byte id to hand to the other ranks (host-side rendezvous) */
+int semseg_comm_init(int rank, int world, const void* id128, void** comm_out);     /* collective over all ranks */
+int semseg_comm_allreduce_sum_f32(void* comm, float* buf, size_t count, void* stream);    /* in place: gradient buckets */
+int semseg_comm_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream);   /* in place: BN [sum, sum^2, n] */
+/* `n` payloads in one RCCL group (statistics of independent BN layers: PPM branches, HRNet branches) */
+int semseg_comm_allreduce_sum_f64_multi(void* comm, double* const* bufs, const size_t* counts, int n, void* stream);
+int semseg_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

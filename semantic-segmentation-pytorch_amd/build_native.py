@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'mit_semseg', '_native')
 LIB = os.path.join(OUT_DIR, 'libsemseg_hip.so')
-SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'conv_split.hip', 'weights_prep.hip', 'winograd.hip', 'bn.hip', 'pool_resize.hip', 'head.hip', 'input_pipeline.hip', 'depthwise.hip', 'grouped.hip', 'api.hip']
+SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'conv_split.hip', 'weights_prep.hip', 'winograd.hip', 'bn.hip', 'pool_resize.hip', 'head.hip', 'input_pipeline.hip', 'depthwise.hip', 'grouped.hip', 'comm.hip', 'api.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC,
          '-Wno-unused-result']
@@ -60,7 +60,7 @@ def _build_locked(force, verbose):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        _run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB + tag] + objs, verbose)
+        _run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB + tag] + objs + ['-ldl'], verbose)
         os.replace(LIB + tag, LIB)
     return LIB
 

@@ -122,6 +122,14 @@ SIGNATURES = {
     'semseg_input_resample_v_normalize': (c_int, [vp, c_int, c_int, vp, vp, c_int, c_int, vp, vp, c_int, vp]),
     'semseg_input_label_gather': (c_int, [vp, c_int, vp, vp, c_int, c_int, vp, c_int, vp]),
     'semseg_sgd_step': (c_int, [ctypes.POINTER(SgdTensor), c_int, vp, c_f, c_f, vp]),
+    'semseg_comm_available': (c_int, []),
+    'semseg_comm_version': (c_int, []),
+    'semseg_comm_unique_id': (c_int, [vp]),
+    'semseg_comm_init': (c_int, [c_int, c_int, vp, ctypes.POINTER(vp)]),
+    'semseg_comm_allreduce_sum_f32': (c_int, [vp, vp, c_sz, vp]),
+    'semseg_comm_allreduce_sum_f64': (c_int, [vp, vp, c_sz, vp]),
+    'semseg_comm_allreduce_sum_f64_multi': (c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(c_sz), c_int, vp]),
+    'semseg_comm_destroy': (c_int, [vp]),
 }
 
 

@@ -73,6 +73,83 @@ class FusedSGD:
         self.steps += 1
 
 
+class SegmentedStep:
+    """The data-parallel training step as a CHAIN of hipGraphs with the collectives between them.
+
+    A step of R50dilated+PPM at world > 1 is ~800 kernel launches, 122 SyncBN all-reduces and a handful of gradient-bucket
+    all-reduces; launched eagerly it is host-bound (25-30 ms of launch work against 14.6 ms of kernels).  Capturing the whole
+    step, collectives included, removes the host but puts RCCL inside a hipGraph (opt-in, SEMSEG_DDP_GRAPH=1, behind bench.py's
+    self-test).  This executor keeps RCCL OUT of the graphs: one capture pass runs the step with `ops._SEGMENTS = self`; every
+    collective site (`ops._maybe_allreduce`, `GradientBuckets._launch` / `finish`) ends the segment being captured, records
+    (kind, tensor) and begins the next segment on the same allocator pool.  A replay launches the segments in order and issues
+    the recorded collectives eagerly in between -- ~125 graph launches + ~125 all-reduce calls per step, no per-kernel host
+    work -- on any transport (RCCL, or gloo in the two-ranks-on-one-GPU test).  Backward runs on the calling thread during
+    the capture pass (single-threaded autograd), so begin/end capture never cross threads."""
+
+    def __init__(self):
+        self.items = []           # ('graph', CUDAGraph) | ('allreduce', tensor, group) | ('bucket', flat, buckets) | ('join', None, buckets)
+        self.pool = None
+        self._g = None
+        self.out = None
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self.pool, capture_error_mode='relaxed')
+
+    def _end(self):
+        self._g.capture_end()
+        self.items.append(('graph', self._g, None))
+        self._g = None
+
+    def collective(self, kind, tensor, owner):
+        self._end()
+        self.items.append((kind, tensor, owner))
+        self._begin()
+
+    def capture(self, run, pool):
+        """`run()` executes one eager step on static buffers; returns what it returns"""
+        import gc
+        self.pool = pool
+        gc.collect()
+        torch.cuda.synchronize()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        prev = ops._SEGMENTS
+        try:
+            with torch.cuda.stream(stream), torch.autograd.set_multithreading_enabled(False):
+                ops._SEGMENTS = self
+                self._begin()
+                self.out = run()
+                self._end()
+        finally:
+            ops._SEGMENTS = prev
+            if self._g is not None:            # an exception inside a segment: close the capture before re-raising
+                try:
+                    self._g.capture_end()
+                except Exception:
+                    pass
+                self._g = None
+        torch.cuda.current_stream().wait_stream(stream)
+        return self.out
+
+    def replay(self):
+        for kind, obj, owner in self.items:
+            if kind == 'graph':
+                obj.replay()
+            elif kind == 'allreduce':
+                ops.allreduce_sum(obj, owner)
+            elif kind == 'bucket':
+                if world_size(owner.group) > 1:
+                    owner.reduce_async(obj)
+            else:
+                owner.join()
+        return self.out
+
+    def counts(self):
+        c = collections.Counter(k for k, _, _ in self.items)
+        return dict(c)
+
+
 def feed_key(feed):
     """shape signature of a feed dict: one captured graph per signature (per-GPU batches of train.py:170-177 come in many
     H x W, dataset.py:121-142)"""
@@ -152,17 +229,26 @@ class TrainStep:
         self._prepare_weights()               # planes of the UPDATED weights, for the next step
         return loss.detach(), acc.detach()
 
-    def _graph_allowed(self):
-        # world > 1: the RCCL all-reduces (SyncBN statistics on the compute stream, gradient buckets on the side stream)
-        # can be captured too -- a world-1 RCCL all-reduce survives capture + replay on this stack
-        # (tools/probes/rccl_graph_probe.py) -- but the N > 1 capture has not run on a multi-GPU box yet, so it is
-        # opt-in (SEMSEG_DDP_GRAPH=1, set by bench.py after its self-test) and the default data-parallel step launches eagerly.
-        return self.use_graph and (self.world == 1 or os.environ.get('SEMSEG_DDP_GRAPH', '0') == '1')
+    def launch_mode(self):
+        """'eager' | 'graph' (the whole step is ONE hipGraph) | 'segmented' (SegmentedStep: graphs between the collectives).
+        world > 1: the RCCL all-reduces can be captured with the rest of the step -- a world-1 RCCL all-reduce survives capture +
+        replay on this stack (tools/probes/rccl_graph_probe.py) -- but that has not run on a multi-GPU box, so it is opt-in
+        (SEMSEG_DDP_GRAPH=1, set by bench.py after its self-test); the default at world > 1 is the segmented executor, which
+        keeps the collectives out of the graphs.  SEMSEG_DDP_SEGMENTED=0: eager launches.  SEMSEG_FORCE_SYNC_PATH=1 (tests):
+        the segmented executor on a single rank."""
+        if not self.use_graph:
+            return 'eager'
+        if self.world == 1 and not ops._SYNC_GROUP['force']:
+            return 'graph'
+        if os.environ.get('SEMSEG_DDP_GRAPH', '0') == '1':
+            return 'graph'
+        return 'segmented' if os.environ.get('SEMSEG_DDP_SEGMENTED', '1') != '0' else 'eager'
 
     def step(self, feed):
         self.adjust_learning_rate()
         self.iter += 1
-        if not self._graph_allowed():
+        mode = self.launch_mode()
+        if mode == 'eager':
             self.stats['eager'] += 1
             return self._eager(feed)
         key = feed_key(feed)
@@ -173,7 +259,7 @@ class TrainStep:
                 self._seen[key] = seen + 1
                 self.stats['eager'] += 1
                 return self._eager(feed)
-            rec = self._capture(key, feed)
+            rec = self._capture(key, feed, mode)
         else:
             self._graphs.move_to_end(key)
         graph, static, out = rec
@@ -184,7 +270,7 @@ class TrainStep:
         self.stats['replayed'] += 1
         return out
 
-    def _capture(self, key, feed):
+    def _capture(self, key, feed, mode='graph'):
         """capture records but does not execute: the caller replays right away"""
         while len(self._graphs) >= max(1, self.max_graphs):
             self._graphs.popitem(last=False)          # least recently used shape: its graph and static buffers are released
@@ -192,9 +278,13 @@ class TrainStep:
         static = {k: v.clone() for k, v in feed.items() if torch.is_tensor(v)}
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=self._pool):
-            out = self._eager(static)
+        if mode == 'segmented':
+            graph = SegmentedStep()
+            out = graph.capture(lambda: self._eager(static), self._pool)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=self._pool):
+                out = self._eager(static)
         rec = self._graphs[key] = (graph, static, out)
         self.stats['captured'] += 1
         return rec

@@ -630,7 +630,10 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
 # ------------------------------------------------------------------------------------------------
 # batch norm (+ residual add + ReLU), optional cross-rank statistics
 # ------------------------------------------------------------------------------------------------
-_SYNC_GROUP = {'group': None, 'enabled': False}
+_SYNC_GROUP = {'group': None, 'enabled': False, 'force': os.environ.get('SEMSEG_FORCE_SYNC_PATH', '0') == '1'}
+# engine.SegmentedStep while its capture pass runs: a collective then ENDS the hipGraph segment being captured, is recorded and
+# the next segment begins -- at replay the collectives are issued eagerly between the segment launches
+_SEGMENTS = None
 
 
 def set_sync_bn_group(group, enabled=True):
@@ -642,17 +645,34 @@ def set_sync_bn_group(group, enabled=True):
 
 def _sync_active():
     """True when BN statistics have to be all-reduced across ranks (SyncBN on a world of more than one rank)."""
+    if _SYNC_GROUP['force']:          # tests: the unfused SyncBN kernel sequence (and segment boundaries) on a single rank
+        return True
     if not _SYNC_GROUP['enabled']:
         return False
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_GROUP['group']) > 1
 
 
+def allreduce_sum(buf, group=None):
+    """sum of `buf` over the ranks of `group`, in place, on the current stream: the native RCCL communicator when one is up
+    (mit_semseg.comm: semseg_comm_allreduce_sum through the C ABI), else torch.distributed"""
+    from . import comm
+    if comm.allreduce_sum(buf, group):
+        return
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+
+
 def _maybe_allreduce(buf):
+    if _SEGMENTS is not None:
+        if _sync_active():
+            _SEGMENTS.collective('allreduce', buf, _SYNC_GROUP['group'])
+        return
     if _SYNC_GROUP['enabled']:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_GROUP['group']) > 1:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=_SYNC_GROUP['group'])
+            allreduce_sum(buf, _SYNC_GROUP['group'])
 
 
 class BatchNormActFn(Function):

@@ -138,19 +138,37 @@ class GradientBuckets:
             for p, d in zip(moved, dsts):
                 p.grad = d
 
-    def _launch(self, b):
-        b['launched'] = True
-        self._stage(b)
-        if world_size(self.group) <= 1:
-            return
-        if self.comm_stream is not None and b['flat'].is_cuda:
+    def reduce_async(self, flat):
+        """all-reduce of one staged bucket, overlapped with whatever the compute stream does next: on `comm_stream` behind
+        an event recorded on the compute stream (GPU), or as an async work object (CPU tests)"""
+        if self.comm_stream is not None and flat.is_cuda:
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group)
+                ops.allreduce_sum(flat, self.group)
         else:
-            self._works.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def join(self):
+        """the compute stream waits for every bucket all-reduce launched so far"""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.comm_stream is not None and self.buckets and self.buckets[0]['flat'].is_cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def _launch(self, b):
+        b['launched'] = True
+        self._stage(b)
+        if ops._SEGMENTS is not None:
+            # segmented hipGraph capture (engine.SegmentedStep): the staging copies above belong to the segment being
+            # captured; the all-reduce itself is issued eagerly between segment replays
+            ops._SEGMENTS.collective('bucket', b['flat'], self)
+            return
+        if world_size(self.group) <= 1:
+            return
+        self.reduce_async(b['flat'])
 
     def all_reduce(self):
         """Launch every bucket that the hooks have not launched yet (no hooks / parameters without gradient)."""
@@ -160,11 +178,10 @@ class GradientBuckets:
 
     def finish(self):
         self.all_reduce()
-        for w in self._works:
-            w.wait()
-        self._works = []
-        if self.comm_stream is not None and self.buckets and self.buckets[0]['flat'].is_cuda:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if ops._SEGMENTS is not None:
+            ops._SEGMENTS.collective('join', None, self)
+        else:
+            self.join()
         self.armed = False
 
 
@@ -185,6 +202,10 @@ class NativeDataParallel(nn.Module):
         self.rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
         if sync_bn:
             ops.set_sync_bn_group(group, enabled=world_size(group) > 1)
+        # collectives through the C ABI's own RCCL communicator (csrc/comm.hip) when the group runs on RCCL: one ctypes call per
+        # all-reduce instead of a c10d work object.  Collective + self-tested; any failure leaves torch.distributed in charge.
+        from . import comm
+        self.native_comm = comm.init(group) if world_size(group) > 1 else False
 
     def scatter(self, batch):
         """This rank's element of the reference's per-GPU list (data_parallel.py:54-62).  A list must hold ONE dict (this

@@ -103,3 +103,115 @@ def test_two_ranks_one_gpu_match_oracle_on_joint_batch():
             got = r0['sd'][prefix + k]
             torch.testing.assert_close(got.reshape(v.shape).float(), v.detach().float(), atol=2e-4, rtol=2e-3,
                                        msg=lambda m, k=k: prefix + k + ': ' + m)
+
+
+def _train_r18(dev, steps, graph, force_sync):
+    """`steps` training steps of R18dilated+PPM_deepsup on a fixed batch; returns the final state dict + launch statistics"""
+    from mit_semseg.models import ModelBuilder, SegmentationModule
+    from mit_semseg.engine import TrainStep
+    from mit_semseg import ops
+    enc_sd, dec_sd, img, lab, masks = _joint_case()
+    with tempfile.TemporaryDirectory() as d:
+        pe, pd = os.path.join(d, 'e.pth'), os.path.join(d, 'd.pth')
+        torch.save(enc_sd, pe)
+        torch.save(dec_sd, pd)
+        enc = ModelBuilder.build_encoder('resnet18dilated', fc_dim=512, weights=pe)
+        dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=512, num_class=150, weights=pd)
+    dec.conv_last[3].mask_override = masks['main'][:2].to(dev)
+    dec.dropout_deepsup.mask_override = masks['deepsup'][:2].to(dev)
+    sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), 0.4).to(dev).train()
+    prev = ops._SYNC_GROUP['force']
+    ops._SYNC_GROUP['force'] = force_sync
+    try:
+        ts = TrainStep(sm, lr_encoder=LR, lr_decoder=LR, max_iters=10 ** 9, graph=graph)
+        feed = {'img_data': img[:2].to(dev), 'seg_label': lab[:2].to(dev)}
+        losses = []
+        for _ in range(steps):
+            loss, acc = ts.step(feed)
+            losses.append(loss.clone())
+        torch.cuda.synchronize()
+    finally:
+        ops._SYNC_GROUP['force'] = prev
+    return {k: v.detach().cpu().clone() for k, v in sm.state_dict().items()}, [l.item() for l in losses], ts
+
+
+def test_segmented_graph_step_equals_eager_single_rank():
+    """engine.SegmentedStep (hipGraph segments between the collective sites, collectives issued between the replays) on ONE
+    rank with the SyncBN kernel sequence forced: 5 steps (2 eager, capture + 3 replays) end in exactly the weights, BN
+    statistics and losses of 5 eager steps -- same kernels, same order, so bit-identical."""
+    dev = torch.device('cuda:0')
+    want, wl, _ = _train_r18(dev, 5, graph=False, force_sync=True)
+    got, gl, ts = _train_r18(dev, 5, graph=True, force_sync=True)
+    seg = ts._graph
+    from mit_semseg.engine import SegmentedStep
+    assert isinstance(seg, SegmentedStep), type(seg)
+    c = seg.counts()
+    print('segmented step: %s; stats %s' % (c, ts.stats))
+    assert c.get('allreduce', 0) >= 2 * 29 and c['graph'] == c['allreduce'] + c.get('bucket', 0) + c.get('join', 0) + 1
+    assert ts.stats['replayed'] == 3 and ts.stats['captured'] == 1
+    assert gl == wl, (gl, wl)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def _worker_steps(rank, world, port, out_dir, graph):
+    for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from mit_semseg.models import ModelBuilder, SegmentationModule
+        from mit_semseg.parallel import NativeDataParallel
+        from mit_semseg.engine import TrainStep, SegmentedStep
+        from mit_semseg import tuner
+        import time
+        tuner.ENABLED = False            # heuristic launch plans: the eager and the graph processes must sum in the same order
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        enc_sd, dec_sd, img, lab, masks = _joint_case()
+        with tempfile.TemporaryDirectory() as d:
+            pe, pd = os.path.join(d, 'e.pth'), os.path.join(d, 'd.pth')
+            torch.save(enc_sd, pe)
+            torch.save(dec_sd, pd)
+            enc = ModelBuilder.build_encoder('resnet18dilated', fc_dim=512, weights=pe)
+            dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=512, num_class=150, weights=pd)
+        sl = slice(2 * rank, 2 * rank + 2)
+        dec.conv_last[3].mask_override = masks['main'][sl].to(dev)
+        dec.dropout_deepsup.mask_override = masks['deepsup'][sl].to(dev)
+        sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), 0.4).to(dev).train()
+        NativeDataParallel(sm)
+        ts = TrainStep(sm, lr_encoder=LR, lr_decoder=LR, max_iters=10 ** 9, bucket_bytes=8 << 20, graph=graph)
+        feed = {'img_data': img[sl].to(dev), 'seg_label': lab[sl].to(dev)}
+        for _ in range(4):
+            loss, acc = ts.step(feed)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            loss, acc = ts.step(feed)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        if graph:
+            assert isinstance(ts._graph, SegmentedStep) and ts.stats['replayed'] == 12, ts.stats
+        sd = {k: v.detach().cpu().contiguous() for k, v in sm.state_dict().items()}
+        torch.save(dict(loss=loss.cpu(), sd=sd, ms=ms, counts=ts._graph.counts() if graph else None),
+                   os.path.join(out_dir, 'g%d_rank%d.pt' % (int(graph), rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_segmented_graphs_equal_eager():
+    """Two ranks on the one GPU (gloo transport), 14 data-parallel steps each: the segmented-graph executor (gradient buckets on
+    the side stream, SyncBN all-reduces between segment replays) ends in exactly the replicas of the eager data-parallel
+    step -- same kernels and the same reduction order, so bit-identical -- and the ranks agree with each other."""
+    res = {}
+    for graph in (False, True):
+        with tempfile.TemporaryDirectory() as out_dir:
+            mp.spawn(_worker_steps, args=(2, _free_port(), out_dir, graph), nprocs=2, join=True)
+            res[graph] = [torch.load(os.path.join(out_dir, 'g%d_rank%d.pt' % (int(graph), r)), weights_only=False) for r in (0, 1)]
+    print('2 ranks on 1 GPU: eager %.2f ms/step, segmented graphs %.2f ms/step; segments %s' % (
+        res[False][0]['ms'], res[True][0]['ms'], res[True][0]['counts']))
+    for k in res[False][0]['sd']:
+        assert torch.equal(res[True][0]['sd'][k], res[True][1]['sd'][k]), ('ranks differ', k)
+        assert torch.equal(res[True][0]['sd'][k], res[False][0]['sd'][k]), ('segmented != eager', k)

@@ -152,7 +152,7 @@ def test_resnext_golden_with_direct_grouped_kernels_emulated(monkeypatch, tmp_pa
         fn = getattr(emu, name)
         fn.restype, fn.argtypes = _native.SIGNATURES[name]
         setattr(lib, name, fn)
-    cpu_twin.install(monkeypatch)
+    cpu_twin.install(monkeypatch, keep=('grouped_conv3x3',))      # the REAL Function, on the emulated kernels
     monkeypatch.setattr(_native, 'lib', lambda: lib)
     monkeypatch.setattr(ops, '_st', lambda: ctypes.c_void_p(0))
     monkeypatch.setattr(ops, '_WS', {})

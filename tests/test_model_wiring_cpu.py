@@ -41,6 +41,8 @@ def test_new_backbone_wiring_matches_oracle(arch, training, monkeypatch):
     monkeypatch.setattr(layers, 'conv_bn_relu6', lambda c, b, x: torch.clamp(_cpu_conv_bn(c, b, x, relu=True), max=6.0))
     monkeypatch.setattr(mobilenet, 'conv_bn_relu6', layers.conv_bn_relu6)
     monkeypatch.setattr(ops, 'max_pool_3x3_s2', lambda x: F.max_pool2d(x, 3, 2, 1))
+    monkeypatch.setattr(ops, 'fork', lambda x, n=2: (x,) * n)                       # identity shortcuts (mobilenet.py:72-75)
+    monkeypatch.setattr(ops, 'add_act', lambda a, b, relu=False: F.relu(a + b) if relu else a + b)
     man = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'manifests.json')))[arch]
     sd = O.synth_state_dict(man, seed=5)
     if arch == 'mobilenetv2dilated':
