@@ -290,7 +290,8 @@ class TrainDataset:
         self.imgSizes, self.imgMaxSize = opt.imgSizes, opt.imgMaxSize
         self.padding_constant, self.segm_downsampling_rate = opt.padding_constant, opt.segm_downsampling_rate
         self.batch_per_gpu = batch_per_gpu
-        self.batch_record_list = [[], []]
+        self.random_flip = bool(getattr(opt, 'random_flip', True))          # dataset.py:157 draws the flip unconditionally; the
+        self.batch_record_list = [[], []]                                   # option exists in the config, so it is honoured
         self.cur_idx = 0
         self.if_shuffled = False
         self.assembler = TrainBatchAssembler(self.imgSizes, self.imgMaxSize, self.padding_constant,
@@ -310,7 +311,8 @@ class TrainDataset:
                     self.batch_record_list[k] = []
                     return batch_records
 
-    def __getitem__(self, index):
+    def decode(self, index):
+        """host half of __getitem__ (record selection, random draws, PIL decode): what a prefetch thread runs"""
         from PIL import Image
         if not self.if_shuffled:
             np.random.seed(index)
@@ -327,10 +329,17 @@ class TrainDataset:
             segm = Image.open(os.path.join(self.root_dataset, rec['fpath_segm']))
             assert segm.mode == 'L'
             assert img.size == segm.size
-            flips.append(bool(np.random.choice([0, 1])))
+            flips.append(bool(np.random.choice([0, 1])) if self.random_flip else False)
             images.append(torch.from_numpy(np.array(img)))
             segms.append(torch.from_numpy(np.array(segm)))
-        return self.assembler.assemble(images, segms, flips, this_short_size)
+        return images, segms, flips, this_short_size
+
+    def assemble(self, decoded):
+        """device half: resize / flip / normalise / label down-sampling / padding in HIP kernels"""
+        return self.assembler.assemble(*decoded)
+
+    def __getitem__(self, index):
+        return self.assemble(self.decode(index))
 
     def __len__(self):
         return int(1e10)          # dataset.py:201-203: every loader keeps its own list

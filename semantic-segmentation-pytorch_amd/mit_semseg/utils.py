@@ -4,16 +4,25 @@ the device: the argmax over classes and the accuracy / intersection / union tall
 or label map to the host -- only 2 + 3*numClass integers per image (or per dataset: the tallies accumulate).
 
 Same names and return conventions as the reference for label-map inputs (`accuracy`, `intersectionAndUnion`,
-`AverageMeter`); inputs are CUDA tensors (there is no CPU fallback: the reference's numpy code is the CPU path).
-`segmentation_metrics` is the fused form for a score map.
+`AverageMeter`); inputs are CUDA tensors, or numpy arrays / host tensors as eval.py:74-84 passes them (uploaded to the current
+HIP device: the tallies still run in the kernels -- there is no CPU fallback).  `segmentation_metrics` is the fused form for a
+score map.  The host-side helpers of the reference's drivers (`parse_devices`, `setup_logger`, `find_recursive`,
+`colorEncode`; utils.py:10-31,111-125,159-200) are plain Python / numpy and keep their semantics.
 """
+import fnmatch
+import logging
+import os
+import re
+import sys
+
 import numpy as np
 import torch
 
 from . import _native
 from . import ops
 
-__all__ = ['AverageMeter', 'accuracy', 'intersectionAndUnion', 'segmentation_metrics', 'MetricTally']
+__all__ = ['AverageMeter', 'accuracy', 'intersectionAndUnion', 'segmentation_metrics', 'MetricTally', 'parse_devices',
+           'setup_logger', 'find_recursive', 'colorEncode', 'unique', 'NotSupportedCliException']
 
 
 class AverageMeter(object):
@@ -46,9 +55,15 @@ class AverageMeter(object):
 
 
 def _as_i64_flat(t, what):
+    """label / prediction map -> flat int64 tensor on the HIP device (numpy arrays and host tensors are uploaded)"""
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(t))
     if not torch.is_tensor(t):
-        raise TypeError('%s: expected a CUDA tensor (the numpy path is the reference; this build has no CPU fallback)' % what)
-    ops._require_cuda(t)
+        raise TypeError('%s: expected a tensor or a numpy array, got %s' % (what, type(t).__name__))
+    if not t.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError('mit_semseg (MI355X build): the evaluation tallies run on a HIP device; there is no CPU fallback')
+        t = t.to(torch.device('cuda', torch.cuda.current_device()))
     return t.reshape(-1).to(torch.int64).contiguous()
 
 
@@ -113,3 +128,67 @@ def segmentation_metrics(scores, label=None, tally=None):
                                                       ops._p(tally.counts if lab is not None else None), ops._st()),
                   'argmax_metrics')
     return pred, tally
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# host-side helpers of the reference's drivers
+# ---------------------------------------------------------------------------------------------------------------------------
+def setup_logger(distributed_rank=0, filename='log.txt'):
+    """utils.py:10-22: a DEBUG logger named "Logger" printing to stdout on rank 0, silent on the other ranks"""
+    logger = logging.getLogger('Logger')
+    logger.setLevel(logging.DEBUG)
+    if distributed_rank > 0 or logger.handlers:
+        return logger
+    handler = logging.StreamHandler(stream=sys.stdout)
+    handler.setLevel(logging.DEBUG)
+    handler.setFormatter(logging.Formatter('[%(asctime)s %(levelname)s %(filename)s line %(lineno)d %(process)d] %(message)s'))
+    logger.addHandler(handler)
+    return logger
+
+
+def find_recursive(root_dir, ext='.jpg'):
+    """utils.py:25-30: every file below `root_dir` whose name ends in `ext`"""
+    return [os.path.join(root, name) for root, _, names in os.walk(root_dir) for name in fnmatch.filter(names, '*' + ext)]
+
+
+def unique(ar, return_index=False, return_inverse=False, return_counts=False):
+    """utils.py:68-108 (a vendored numpy.unique of 2016): numpy's own does the same"""
+    return np.unique(np.asanyarray(ar).flatten(), return_index=return_index, return_inverse=return_inverse,
+                     return_counts=return_counts)
+
+
+def colorEncode(labelmap, colors, mode='RGB'):
+    """utils.py:111-125: [H, W] class indices -> [H, W, 3] uint8 colours (`colors[label]`); negative labels stay black"""
+    labelmap = np.asarray(labelmap).astype('int')
+    colors = np.asarray(colors)
+    rgb = np.zeros(labelmap.shape + (3,), dtype=np.uint8)
+    valid = labelmap >= 0
+    rgb[valid] = colors[labelmap[valid]].astype(np.uint8)
+    return rgb[:, :, ::-1] if mode == 'BGR' else rgb
+
+
+class NotSupportedCliException(Exception):
+    pass
+
+
+_DEVICE_PATTERNS = (re.compile(r'^(?:gpu)?(\d+)$'), re.compile(r'^(?:gpu)?(\d+)-(?:gpu)?(\d+)$'))
+
+
+def parse_devices(input_devices):
+    """utils.py:180-200: "0-3" / "0,1,2,3" / "gpu0-gpu2,5" -> ['gpu0', 'gpu1', ...] (ranges are inclusive and may be given
+    high-to-low; duplicates are dropped, order of first mention is kept)"""
+    out = []
+    for item in input_devices.split(','):
+        item = item.lower().strip()
+        single, span = _DEVICE_PATTERNS[0].match(item), _DEVICE_PATTERNS[1].match(item)
+        if single:
+            ids = [int(single.group(1))]
+        elif span:
+            a, b = sorted((int(span.group(1)), int(span.group(2))))
+            ids = range(a, b + 1)
+        else:
+            raise NotSupportedCliException('Can not recognize device: "{}"'.format(item))
+        for i in ids:
+            if 'gpu%d' % i not in out:
+                out.append('gpu%d' % i)
+    return out

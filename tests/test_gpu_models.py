@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.util import golden_cases, load_golden, check_vs_anchor, HEURISTIC_PLAN_GOLDEN
+from tests.util import golden_cases, load_golden, anchor_ratio, check_anchor_ratios, HEURISTIC_PLAN_GOLDEN
 from oracle import semseg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -93,18 +93,15 @@ def test_native_matches_reference_golden(name, monkeypatch):
         return
     # TrainStep has stepped already: compare the post-step state (weights, BN running stats) -- it pins grads, weight decay,
     # momentum and lr -- against the reference's float64 anchor with the reference's own fp32 deviation as the yardstick
-    # (tests/util.check_vs_anchor)
+    # (tests/util.anchor_ratio / check_anchor_ratios)
     ratios = []
-    for mod, want in ((sm.encoder, g['anchor_after_enc']), (sm.decoder, g['anchor_after_dec'])):
+    for mod, want, side in ((sm.encoder, g['anchor_after_enc'], 'enc.'), (sm.decoder, g['anchor_after_dec'], 'dec.')):
         sd = mod.state_dict()
         for k in want:
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue
-            worst, tol = check_vs_anchor(sd[k], want[k], 'after-step ' + k)
-            ratios.append(worst / tol)
-    ratios.sort()
-    print('%s: after-step error / allowed: median %.2f max %.2f over %d tensors' % (name, ratios[len(ratios) // 2], ratios[-1],
-                                                                              len(ratios)))
+            ratios.append((anchor_ratio(sd[k], want[k], 'after-step ' + k), side + k))
+    print(check_anchor_ratios(ratios, name + ' after-step state'))
 
 
 def _native_grads(g, dev):
@@ -134,13 +131,10 @@ def test_native_gradients_vs_reference_anchor(name, monkeypatch):
     g = load_golden(name)
     sm = _native_grads(g, torch.device('cuda:0'))
     ratios = []
-    for mod, want in ((sm.encoder, g['anchor_grads_enc']), (sm.decoder, g['anchor_grads_dec'])):
+    for mod, want, side in ((sm.encoder, g['anchor_grads_enc'], 'enc.'), (sm.decoder, g['anchor_grads_dec'], 'dec.')):
         for k, p in mod.named_parameters():
-            worst, tol = check_vs_anchor(p.grad, want[k], 'grad ' + k)
-            ratios.append((worst / tol, k, want[k]['err_l2'] / (want[k]['norm'] + 1e-30)))
-    ratios.sort()
-    print('%s: gradient error / allowed: median %.2f max %.2f (%s); reference fp32-vs-fp64 relL2 of that tensor %.1e' % (
-        name, ratios[len(ratios) // 2][0], ratios[-1][0], ratios[-1][1], ratios[-1][2]))
+            ratios.append((anchor_ratio(p.grad, want[k], 'grad ' + k), side + k))
+    print(check_anchor_ratios(ratios, name + ' gradients'))
 
 
 FULL_SIZE = {
@@ -200,19 +194,34 @@ def test_full_size_vs_oracle(case):
     e, d = O.clone_sd(enc_sd, True), O.clone_sd(dec_sd, True)
     ref = O.segmentation_forward(e, d, arch_enc, arch_dec, img, lab, training=True, dropout=drop, deep_sup_scale=dss)
     ref['loss'].backward()
+    # a second fp32 execution of the same oracle step (channels_last tensors: other kernels / summation orders inside torch):
+    # how far two correct fp32 runs are apart is the yardstick for the updated weights below (ill-conditioned backward, see
+    # tests/golden/make_golden.py::anchor)
+    cl = lambda sd: {k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v) for k, v in sd.items()}  # noqa: E731
+    e2, d2 = O.clone_sd(cl(enc_sd), True), O.clone_sd(cl(dec_sd), True)
+    ref2 = O.segmentation_forward(e2, d2, arch_enc, arch_dec, img.contiguous(memory_format=torch.channels_last), lab, training=True,
+                                  dropout=drop, deep_sup_scale=dss)
+    ref2['loss'].backward()
     rp = ref['pred'].detach()
     print('%s: max|dlogp| %.3e  loss %.6f vs %.6f' % (case, (pred - rp).abs().max().item(), loss.item(), ref['loss'].item()))
     torch.testing.assert_close(pred, rp, atol=LOGP_ATOL, rtol=0)
     argmax_check(pred, rp, case)
     assert abs(loss.item() - ref['loss'].item()) < 1e-3
     assert abs(acc.item() - ref['acc'].item()) < 1e-6
-    for sd in (e, d):
+    for sd in (e, d, e2, d2):
         params = {k: v for k, v in sd.items() if v.requires_grad}
         O.sgd_step(params, {k: v.grad for k, v in params.items()}, {}, 0.02)
-    for mod, sd, keys in ((sm.encoder, e, enc_keys), (sm.decoder, d, dec_keys)):
+    worst = (0.0, '')
+    for mod, sd, sd2, keys in ((sm.encoder, e, e2, enc_keys), (sm.decoder, d, d2, dec_keys)):
         got = mod.state_dict()
         for k in keys:
-            torch.testing.assert_close(got[k].cpu().contiguous(), sd[k].detach(), atol=2e-5, rtol=1e-3, msg=lambda s, k=k: k + ': ' + s)
+            a, b, g_ = sd[k].detach().double(), sd2[k].detach().double().contiguous(), got[k].cpu().contiguous().double()
+            spread = (a - b).abs().max().item()                       # two fp32 executions of the oracle
+            tol = 2e-5 + 8.0 * spread
+            err = min((g_ - a).abs().max().item(), (g_ - b).abs().max().item())
+            worst = max(worst, (err / tol, k))
+            assert err <= tol, '%s: |native - oracle| %.3e > 2e-5 + 8 x %.3e (spread of two fp32 oracle runs)' % (k, err, spread)
+    print('%s: updated weights, worst error / allowed %.2f (%s)' % (case, worst[0], worst[1]))
 
 
 def test_inference_graph_replay_equals_eager():

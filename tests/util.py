@@ -45,39 +45,45 @@ def sample_index(numel, k=1024):
     return torch.randint(0, numel, (k,), generator=torch.Generator().manual_seed(numel % (2 ** 31)))
 
 
-ANCHOR_FACTOR = 4.0
+def anchor_ratio(got, rec, what):
+    """`got` against the float64 ANCHOR record of the reference (make_golden.anchor): how far the native result is from the
+    exact (float64) result of the reference's arithmetic, in units of the reference's OWN fp32 reproducibility band (the
+    largest deviation from float64 over five executions of the unmodified reference, see anchor()):
 
+        ratio = max|got - ref64| / (band_max + floor)           elementwise, on the full tensor or its seeded sample
+        (full tensors also: ||got - ref64||_2 / (band_l2 + floor sqrt(n)); the larger of the two is returned)
 
-def check_vs_anchor(got, rec, what, factor=ANCHOR_FACTOR):
-    """`got` against the float64 ANCHOR record of the reference (make_golden.anchor): the native result must be as close to
-    the exact (float64) result of the reference's arithmetic as the reference's OWN fp32 runs are (band = the largest
-    deviation over five executions of the unmodified reference, see anchor()), up to `factor`:
-
-        max|got - ref64|  <=  factor * band_max  + floor        (elementwise, on the full tensor or its sample)
-        ||got - ref64||_2 <=  factor * band_l2 + floor          (full tensors)
-        |sum got - sum ref64| <= 6 * factor * band_l2 + floor   (every tensor: a sum of n errors ~ their 2-norm)
-
-    floor = fp32 representation of the anchor itself (1e-6 of max|ref64|).  Returns (max error, allowed) for reporting."""
+    floor = fp32 representation of the anchor itself (1e-6 of max|ref64|).  A ratio around 1 means "as reproducible as the
+    reference is against itself"; a kernel bug gives ratios of 1e2...1e4."""
     f = got.detach().double().cpu().flatten()
     assert f.numel() == rec['numel'], (what, f.numel(), rec['numel'])
+    assert torch.isfinite(f).all(), what + ': non-finite values'
     floor = 1e-6 * rec['absmax'] + 1e-9
     if 'full' in rec:
         ref, g = rec['full'].double().flatten(), f
     else:
         ref, g = rec['sample'].double(), f[sample_index(rec['numel'])]
     d = (g - ref).abs()
-    tol = factor * rec['err_max'] + floor
-    worst = d.max().item()
-    assert worst <= tol, '%s: max|native - ref64| %.3e > %.1f x max|ref32 - ref64| %.3e + %.1e' % (
-        what, worst, factor, rec['err_max'], floor)
-    n = rec['numel']
+    ratio = d.max().item() / (rec['err_max'] + floor)
     if 'full' in rec:
-        l2 = d.norm().item()
-        assert l2 <= factor * rec['err_l2'] + floor * n ** 0.5, '%s: ||native - ref64|| %.3e > %.1f x ||ref32 - ref64|| %.3e' % (
-            what, l2, factor, rec['err_l2'])
-    ds = abs(f.sum().item() - rec['sum'])
-    assert ds <= 6 * factor * rec['err_l2'] + floor * n ** 0.5 + 1e-12 * abs(rec['sum']), (what, 'sum', ds, rec['err_l2'])
-    return worst, tol
+        ratio = max(ratio, d.norm().item() / (rec['err_l2'] + floor * rec['numel'] ** 0.5))
+    return ratio
+
+
+# Acceptance over ALL tensors of a case.  The deviation of a correct fp32 implementation from the band is heavy-tailed: a ReLU
+# gate that resolves the other way (pre-activation ~1e-7) moves a handful of tensors by several bands while the bulk sits well
+# inside one band.  So: the typical tensor must be inside the band itself, 95 % within 4 bands, none beyond 16.
+ANCHOR_MEDIAN, ANCHOR_P95, ANCHOR_MAX = 1.0, 4.0, 16.0
+
+
+def check_anchor_ratios(ratios, what):
+    """ratios: [(ratio, tensor name)]; returns a one-line summary"""
+    rs = sorted(ratios)
+    med, p95, worst = rs[len(rs) // 2][0], rs[min(len(rs) - 1, int(len(rs) * 0.95))][0], rs[-1]
+    msg = '%s: deviation from the float64 anchor in units of the reference\'s fp32 band over %d tensors: median %.2f, p95 %.2f, ' \
+          'max %.2f (%s)' % (what, len(rs), med, p95, worst[0], worst[1])
+    assert med <= ANCHOR_MEDIAN and p95 <= ANCHOR_P95 and worst[0] <= ANCHOR_MAX, msg
+    return msg
 
 
 def oracle_run(g, with_step=None):
