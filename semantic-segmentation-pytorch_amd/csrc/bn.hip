@@ -425,9 +425,10 @@ extern "C" size_t semseg_bn_mm_workspace_bytes(int P, int C) {
 
 // as bn_stats_partial_kernel + per-channel min / max of z:  mm[by][0][c] = min, mm[by][1][c] = max
 constexpr int ROWS_IN_FLIGHT = 8;
-__global__ __launch_bounds__(256) void bn_stats_mm_partial_kernel(const float* __restrict__ z, int P, int C, int cx, int py,
-                                                                  int rows_per_block, double* __restrict__ partial,
-                                                                  float* __restrict__ mm) {
+#define SEMSEG_BN_TICKETS 1024      /* ticket counters (uint32) a caller provides to the *_fused entry points */
+__device__ __forceinline__ void bn_stats_mm_partial_body(const float* __restrict__ z, int P, int C, int cx, int py,
+                                                         int rows_per_block, double* __restrict__ partial,
+                                                         float* __restrict__ mm) {
     extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][8] floats
     float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
     const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
@@ -492,6 +493,12 @@ __global__ __launch_bounds__(256) void bn_stats_mm_partial_kernel(const float* _
             of[C + c + e] = mx[e];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_mm_partial_kernel(const float* __restrict__ z, int P, int C, int cx, int py,
+                                                                  int rows_per_block, double* __restrict__ partial,
+                                                                  float* __restrict__ mm) {
+    bn_stats_mm_partial_body(z, P, C, cx, py, rows_per_block, partial, mm);
 }
 
 // column sums of the fp64 partials (as colsum_finish_kernel) + column min (j < C) / max (j >= C) of the float partials
@@ -707,14 +714,12 @@ extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const floa
 // as bn_bwd_partial_kernel + per-channel max |g|:  gm[by][c]
 // GATE: 0 = no ReLU, 1 = ReLU gate recomputed from z (gscale/gshift), 2 = ReLU gate read from y
 template <int GATE>
-__global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __restrict__ dy, int dy_ld,
-                                                                const float* __restrict__ y, int y_ld,
-                                                                const float* __restrict__ z, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd, int relu, int P, int C,
-                                                                int cx, int py, int rows_per_block,
-                                                                double* __restrict__ partial, float* __restrict__ gm,
-                                                                const float* __restrict__ gscale,
-                                                                const float* __restrict__ gshift) {
+__device__ __forceinline__ void bn_bwd_mm_partial_body(const float* __restrict__ dy, int dy_ld, const float* __restrict__ y,
+                                                       int y_ld, const float* __restrict__ z, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, int relu, int P, int C, int cx, int py,
+                                                       int rows_per_block, double* __restrict__ partial,
+                                                       float* __restrict__ gm, const float* __restrict__ gscale,
+                                                       const float* __restrict__ gshift) {
     extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][4] floats
     float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
     const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
@@ -788,6 +793,19 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
             of[c + e] = __uint_as_float(m[e]);
         }
     }
+}
+
+template <int GATE>
+__global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __restrict__ dy, int dy_ld,
+                                                                const float* __restrict__ y, int y_ld,
+                                                                const float* __restrict__ z, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int relu, int P, int C,
+                                                                int cx, int py, int rows_per_block,
+                                                                double* __restrict__ partial, float* __restrict__ gm,
+                                                                const float* __restrict__ gscale,
+                                                                const float* __restrict__ gshift) {
+    bn_bwd_mm_partial_body<GATE>(dy, dy_ld, y, y_ld, z, mean, invstd, relu, P, C, cx, py, rows_per_block, partial, gm, gscale,
+                                 gshift);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_mm_finish_kernel(const double* __restrict__ partial, const float* __restrict__ gm,
@@ -999,17 +1017,25 @@ extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y
 // per-channel finalize / bound work and leave one bound per block (16 channels) for the apply kernel's prologue
 // (h2_exponent_from): 3 launches per BN pass instead of 4.  Block = 16 channels x 16 partial lanes.
 // ================================================================================================
-__global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
-    const double* __restrict__ partial, const float* __restrict__ mm, int nparts, int C, double count,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
-    float* __restrict__ running_var, float momentum, float eps, int relu, const float* __restrict__ res_absmax,
-    double* __restrict__ stats, float* __restrict__ zmm, float* __restrict__ mean, float* __restrict__ invstd,
-    float* __restrict__ scale, float* __restrict__ shift, int64_t* __restrict__ num_batches_tracked,
-    uint32_t* __restrict__ blockbound) {
-    __shared__ double rs[16][17], rq[16][17];
-    __shared__ float rlo[16][17], rhi[16][17];
+struct FwdFinish {
+    const double* partial; const float* mm; int nparts, C; double count;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps; int relu;
+    const float* res_absmax; double* stats; float* zmm; float* mean; float* invstd; float* scale; float* shift;
+    int64_t* num_batches_tracked; uint32_t* blockbound;
+};
+
+// finish + finalize of 16 channels (group `vb`) by one 256-thread block: 16 channels x 16 partial lanes.  `sm` = 6528 bytes of
+// shared memory.  Ends with a block-wide barrier, so it can be called in a loop.
+__device__ __forceinline__ void bn_fwd_finish_group(const FwdFinish& a, int vb, unsigned char* sm) {
+    double (*rs)[17] = reinterpret_cast<double (*)[17]>(sm);
+    double (*rq)[17] = rs + 16;
+    float (*rlo)[17] = reinterpret_cast<float (*)[17]>(rq + 16);
+    float (*rhi)[17] = rlo + 16;
+    const double* __restrict__ partial = a.partial;
+    const float* __restrict__ mm = a.mm;
+    const int nparts = a.nparts, C = a.C;
     const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int c = vb * 16 + cl;
     const int C2 = 2 * C;
     double su = 0.0, sq = 0.0;
     float lo = INFINITY, hi = -INFINITY;
@@ -1044,47 +1070,82 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
             su += rs[i][cl]; sq += rq[i][cl];
             lo = fminf(lo, rlo[i][cl]); hi = fmaxf(hi, rhi[i][cl]);
         }
-        stats[c] = su; stats[C + c] = sq;
-        zmm[c] = lo; zmm[C + c] = hi;
-        const double n = count;
+        a.stats[c] = su; a.stats[C + c] = sq;
+        a.zmm[c] = lo; a.zmm[C + c] = hi;
+        const double n = a.count;
         const double mu = su / n;
         double var = sq / n - mu * mu;
         if (var < 0.0) var = 0.0;
-        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float is = (float)(1.0 / sqrt(var + (double)a.eps));
         const float muf = (float)mu;
-        mean[c] = muf;
-        invstd[c] = is;
-        const float sc = gamma[c] * is;
-        const float sh = beta[c] - muf * sc;
-        scale[c] = sc;
-        shift[c] = sh;
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
-        if (running_var) {
+        a.mean[c] = muf;
+        a.invstd[c] = is;
+        const float sc = a.gamma[c] * is;
+        const float sh = a.beta[c] - muf * sc;
+        a.scale[c] = sc;
+        a.shift[c] = sh;
+        if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * muf;
+        if (a.running_var) {
             const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
         }
-        const float rmax = res_absmax ? res_absmax[0] : 0.f;
+        const float rmax = a.res_absmax ? a.res_absmax[0] : 0.f;
         const float e0 = fmaf(lo, sc, sh), e1 = fmaf(hi, sc, sh);
         const float bh = fmaxf(e0, e1) + rmax, bl = fminf(e0, e1) - rmax;
-        const float b = relu ? fmaxf(bh, 0.f) : fmaxf(fabsf(bh), fabsf(bl));
+        const float b = a.relu ? fmaxf(bh, 0.f) : fmaxf(fabsf(bh), fabsf(bl));
         const bool bad = !(b == b) || !(e0 == e0) || !(e1 == e1);
         bits = bad ? 0x7fc00000u : __float_as_uint(b);
     }
-    bits = block_max_u32(bits);
+    bits = block_max_u32(bits);                   // contains two barriers: the shared arrays are free again afterwards
     if (threadIdx.x == 0) {
-        blockbound[blockIdx.x] = bits;
-        if (blockIdx.x == 0) {
-            stats[C2] = count;
-            if (num_batches_tracked) num_batches_tracked[0] += 1;
+        a.blockbound[vb] = bits;
+        if (vb == 0) {
+            a.stats[C2] = a.count;
+            if (a.num_batches_tracked) a.num_batches_tracked[0] += 1;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(FwdFinish a) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[6528];
+    bn_fwd_finish_group(a, blockIdx.x, sm);
+}
+
+// The LAST block of a column of the partial-sum grid to arrive (ticket counter per column, left at zero again) finishes the
+// channels of its column itself -- the finish kernel launch (5-6 us of launch latency + drain per BN layer and pass) is gone.
+// Writers publish their partial rows with a device-scope fence before taking the ticket; the finisher fences again before it
+// reads them.  The finish code and its summation order are those of the separate kernel (bit-identical results).
+template <class FINISH_ARGS, class FN>
+__device__ __forceinline__ void finish_by_last_block(uint32_t* __restrict__ tickets, int C, int cx, unsigned char* sm,
+                                                     const FINISH_ARGS& a, FN fn) {
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1u) == gridDim.y - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int per = cx * 4;                               // channels per column (a multiple of 16 unless the grid has ONE column)
+    const int g0 = (blockIdx.x * per) / 16, g1 = min((C + 15) / 16, ((int)(blockIdx.x + 1) * per + 15) / 16);
+    for (int vb = g0; vb < g1; ++vb) fn(a, vb, sm);
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_mm_partial_finish_kernel(const float* __restrict__ z, int P, int C, int cx,
+                                                                         int py, int rows_per_block,
+                                                                         uint32_t* __restrict__ tickets, FwdFinish a) {
+    extern __shared__ double red[];
+    bn_stats_mm_partial_body(z, P, C, cx, py, rows_per_block, const_cast<double*>(a.partial), const_cast<float*>(a.mm));
+    finish_by_last_block(tickets, C, cx, reinterpret_cast<unsigned char*>(red), a,
+                         [](const FwdFinish& f, int vb, unsigned char* sm) { bn_fwd_finish_group(f, vb, sm); });
 }
 
 extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var,
                                          int64_t* num_batches_tracked, float momentum, float eps, int relu,
                                          const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
-                                         void* blockbound, void* workspace, size_t workspace_bytes, void* stream) {
+                                         void* blockbound, void* workspace, size_t workspace_bytes, void* tickets,
+                                         void* stream) {
     if (!z || !stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || !blockbound || P <= 0 || C <= 0 ||
         (C % 4) || !aligned16(z))
         return SEMSEG_EINVAL;
@@ -1095,30 +1156,44 @@ extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* s
     double* partial = (double*)workspace;
     float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
+    const FwdFinish fin{partial, mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
+                        res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound};
+    if (tickets && g.gx <= SEMSEG_BN_TICKETS && smem >= 6528) {
+        // one launch: the last block of every column finishes its channels (finish_by_last_block)
+        hipLaunchKernelGGL(bn_stats_mm_partial_finish_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
+                           g.rows_per_block, (uint32_t*)tickets, fin);
+        SEMSEG_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
                        g.rows_per_block, partial, mm);
     SEMSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_fwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
-                       (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                       res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound);
+    hipLaunchKernelGGL(bn_fwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, fin);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
-    const double* __restrict__ partial, const float* __restrict__ gm, int nparts, int C, const double* __restrict__ count,
-    const float* __restrict__ zmm, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, int training, double* __restrict__ sums, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, uint32_t* __restrict__ blockbound) {
-    __shared__ double rs[16][17], rq[16][17];
-    __shared__ uint32_t rg[16][17];
+struct BwdFinish {
+    const double* partial; const float* gm; int nparts, C; const double* count;
+    const float* zmm; const float* mean; const float* invstd; const float* gamma; int training;
+    double* sums; float* dgamma; float* dbeta; uint32_t* blockbound;
+};
+
+// as bn_fwd_finish_group for the backward sums; `sm` = 5440 bytes
+__device__ __forceinline__ void bn_bwd_finish_group(const BwdFinish& a, int vb, unsigned char* sm) {
+    double (*rs)[17] = reinterpret_cast<double (*)[17]>(sm);
+    double (*rq)[17] = rs + 16;
+    uint32_t (*rg)[17] = reinterpret_cast<uint32_t (*)[17]>(rq + 16);
+    const double* __restrict__ partial = a.partial;
+    const float* __restrict__ gm = a.gm;
+    const int nparts = a.nparts, C = a.C;
     const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int c = vb * 16 + cl;
     const int C2 = 2 * C;
     double su = 0.0, sq = 0.0;
     uint32_t gmx = 0;
     if (c < C) {
-        constexpr int U = 8;                   // as bn_fwd_finish_fused_kernel
+        constexpr int U = 8;                   // as bn_fwd_finish_group
         for (int b = lane; b < nparts; b += U * 16) {
             double ps[U], pq[U];
             float pg[U];
@@ -1146,22 +1221,42 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
             su += rs[i][cl]; sq += rq[i][cl];
             gmx = max(gmx, rg[i][cl]);
         }
-        sums[c] = su; sums[C + c] = sq;
-        if (dbeta) dbeta[c] = (float)su;
-        if (dgamma) dgamma[c] = (float)sq;
-        const float is = invstd[c];
+        a.sums[c] = su; a.sums[C + c] = sq;
+        if (a.dbeta) a.dbeta[c] = (float)su;
+        if (a.dgamma) a.dgamma[c] = (float)sq;
+        const float is = a.invstd[c];
         float b = __uint_as_float(gmx);
-        if (training) {
-            const float inv_n = (float)(1.0 / count[0]);
+        if (a.training) {
+            const float inv_n = (float)(1.0 / a.count[0]);
             const float m = fabsf((float)su * inv_n), x = fabsf((float)sq * inv_n);
-            const float xh = fmaxf(fabsf(zmm[c] - mean[c]), fabsf(zmm[C + c] - mean[c])) * is;
+            const float xh = fmaxf(fabsf(a.zmm[c] - a.mean[c]), fabsf(a.zmm[C + c] - a.mean[c])) * is;
             b = b + m + xh * x;
         }
-        b = fabsf(gamma[c]) * is * b * 1.0009765625f;
+        b = fabsf(a.gamma[c]) * is * b * 1.0009765625f;
         bits = absbits(b);
     }
     bits = block_max_u32(bits);
-    if (threadIdx.x == 0) blockbound[blockIdx.x] = bits;
+    if (threadIdx.x == 0) a.blockbound[vb] = bits;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(BwdFinish a) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[5440];
+    bn_bwd_finish_group(a, blockIdx.x, sm);
+}
+
+template <int GATE>
+__global__ __launch_bounds__(256) void bn_bwd_mm_partial_finish_kernel(const float* __restrict__ dy, int dy_ld,
+                                                                       const float* __restrict__ y, int y_ld,
+                                                                       const float* __restrict__ z, int relu, int P, int cx,
+                                                                       int py, int rows_per_block,
+                                                                       const float* __restrict__ gscale,
+                                                                       const float* __restrict__ gshift,
+                                                                       uint32_t* __restrict__ tickets, BwdFinish a) {
+    extern __shared__ double red[];
+    bn_bwd_mm_partial_body<GATE>(dy, dy_ld, y, y_ld, z, a.mean, a.invstd, relu, P, a.C, cx, py, rows_per_block,
+                                 const_cast<double*>(a.partial), const_cast<float*>(a.gm), gscale, gshift);
+    finish_by_last_block(tickets, a.C, cx, reinterpret_cast<unsigned char*>(red), a,
+                         [](const BwdFinish& f, int vb, unsigned char* sm) { bn_bwd_finish_group(f, vb, sm); });
 }
 
 extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
@@ -1169,7 +1264,7 @@ extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const floa
                                           const float* gate_shift, int relu, int P, int C, const double* stats_count,
                                           const float* zmm, const float* gamma, int training, double* sums, float* dgamma,
                                           float* dbeta, void* blockbound, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
+                                          void* tickets, void* stream) {
     if (!dy || !z || !mean || !invstd || !sums || !gamma || !blockbound || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) ||
         dy_ld < C)
         return SEMSEG_EINVAL;
@@ -1183,6 +1278,19 @@ extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const floa
     double* partial = (double*)workspace;
     float* gm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
+    const BwdFinish fin{partial, gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
+                        (uint32_t*)blockbound};
+    if (tickets && g.gx <= SEMSEG_BN_TICKETS && smem >= 5440) {
+#define LAUNCH_FUSED(GATE)                                                                                                 \
+    hipLaunchKernelGGL(bn_bwd_mm_partial_finish_kernel<GATE>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, \
+                       relu, P, g.cx, g.py, g.rows_per_block, gate_scale, gate_shift, (uint32_t*)tickets, fin)
+        if (!relu) LAUNCH_FUSED(0);
+        else if (gate_scale) LAUNCH_FUSED(1);
+        else LAUNCH_FUSED(2);
+#undef LAUNCH_FUSED
+        SEMSEG_LAUNCH_CHECK();
+        return 0;
+    }
 #define LAUNCH_PARTIAL(GATE)                                                                                              \
     hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<GATE>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, \
                        invstd, relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, gate_scale, gate_shift)
@@ -1191,9 +1299,7 @@ extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const floa
     else LAUNCH_PARTIAL(2);
 #undef LAUNCH_PARTIAL
     SEMSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
-                       (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
-                       (uint32_t*)blockbound);
+    hipLaunchKernelGGL(bn_bwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, fin);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }

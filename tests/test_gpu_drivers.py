@@ -44,12 +44,20 @@ def test_train_checkpoint_resume_eval_test(tmp_path):
     data = str(tmp_path / 'data')
     _dataset(data)
     ckpt = str(tmp_path / 'ckpt')
+    # MODEL.weights_encoder '' means "download the ImageNet weights" (models.py:65), as in the reference: start from a seeded
+    # backbone file instead (the oracle recipe of SURVEY 8c)
+    sys.path.insert(0, PKG)
+    from mit_semseg.models import resnet
+    from mit_semseg.models.models import ResnetDilated
+    torch.manual_seed(1)
+    enc0 = str(tmp_path / 'enc0.pth')
+    torch.save(ResnetDilated(resnet.resnet18(pretrained=False), dilate_scale=8).state_dict(), enc0)
     env = dict(os.environ, SEMSEG_TUNE='0', PYTHONPATH=PKG + os.pathsep + os.environ.get('PYTHONPATH', ''))
     common = ['--cfg', 'preset:ade20k-resnet18dilated-ppm_deepsup']
     opts = ['DIR', ckpt, 'DATASET.root_dataset', data, 'DATASET.list_train', os.path.join(data, 'train.odgt'),
             'DATASET.list_val', os.path.join(data, 'val.odgt'), 'DATASET.imgSizes', '(64, 96)', 'DATASET.imgMaxSize', '160',
             'TRAIN.epoch_iters', '3', 'TRAIN.num_epoch', '2', 'TRAIN.disp_iter', '1']
-    out = _run('train.py', common + ['--gpus', '0'] + opts, env)
+    out = _run('train.py', common + ['--gpus', '0'] + opts + ['MODEL.weights_encoder', enc0], env)
     assert 'Training Done!' in out and out.count('Epoch: [') == 6, out[-2000:]
     for e in (1, 2):
         for part in ('encoder', 'decoder', 'history'):
