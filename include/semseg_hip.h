@@ -253,6 +253,10 @@ int semseg_clamp_max_bwd(const float* dy, int dy_ld, const float* y, int y_ld, f
    state = uint64[2] {seed, launch counter} in device memory, the counter is advanced by the kernel (fresh mask per hipGraph
    replay) */
 int semseg_dropout_mask(float* mask, int n, float p, void* state, void* stream);
+/* inference head fused (models.py:480-484,578-582; eval.py:66-71): out[N,OH,OW,C] (+)= weight * softmax_C(bilinear(logits
+   [N,IH,IW,C], align_corners=False) at (OH, OW)); accumulate != 0 adds to `out` (the multi-scale average, weight = 1/#scales) */
+int semseg_upsample_softmax(const float* logits, int x_ld, float* out, int out_ld, int accumulate, float weight,
+                            int N, int IH, int IW, int OH, int OW, int C, void* stream);
 /* strided 2-D copy (torch.cat slices, models.py:424,476,553,575; hrnet.py:434) */
 int semseg_copy2d(const float* src, int src_ld, float* dst, int dst_ld, int P, int C, int accumulate,
                   void* stream);

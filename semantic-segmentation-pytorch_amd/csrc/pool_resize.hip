@@ -780,6 +780,88 @@ extern "C" int semseg_bilinear_fwd(const float* x, int x_ld, float* y, int y_ld,
     return 0;
 }
 
+// Inference head in ONE pass (models.py:480-484 / eval.py:66-71): out[n, oh, ow, :] (+)= weight * softmax_c(bilinear(logits)(oh, ow, :))
+// -- the bilinear up-sampling of the class logits to segSize, the softmax over the classes and the multi-scale average
+// `scores = scores + scores_tmp / len(imgSizes)`.  One wave per output pixel: lane l holds classes l, l+64, ... (K per lane),
+// the four source pixels are read as contiguous class vectors, max / sum by wave shuffles, the probabilities are written as one
+// contiguous class vector.  Versus bilinear_fwd + softmax_fwd + a scale and an add pass: the full-resolution class map is
+// written once (read once more when accumulating) instead of written three times and read three times.
+template <int K, bool ACC>
+__global__ __launch_bounds__(256) void upsample_softmax_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ out,
+                                                               int out_ld, int N, int IH, int IW, int OH, int OW, int C, float sh,
+                                                               float sw, float weight) {
+    const int lane = threadIdx.x & 63;
+    const size_t P = (size_t)N * OH * OW;
+    for (size_t op = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); op < P; op += (size_t)gridDim.x * 4) {
+        const int ow = (int)(op % OW);
+        const int oh = (int)((op / OW) % OH);
+        const int n = (int)(op / ((size_t)OW * OH));
+        int h0, h1, w0, w1;
+        float lh0, lh1, lw0, lw1;
+        bl_coord(oh, sh, IH, h0, h1, lh0, lh1);
+        bl_coord(ow, sw, IW, w0, w1, lw0, lw1);
+        const float* b = x + (size_t)n * IH * IW * x_ld;
+        const float* r00 = b + ((size_t)h0 * IW + w0) * x_ld;
+        const float* r01 = b + ((size_t)h0 * IW + w1) * x_ld;
+        const float* r10 = b + ((size_t)h1 * IW + w0) * x_ld;
+        const float* r11 = b + ((size_t)h1 * IW + w1) * x_ld;
+        float v[K];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane + 64 * k;
+            // the association of bilinear_fwd_kernel (= torch upsample_bilinear2d)
+            v[k] = (c < C) ? lh0 * (lw0 * r00[c] + lw1 * r01[c]) + lh1 * (lw0 * r10[c] + lw1 * r11[c]) : -INFINITY;
+            m = fmaxf(m, v[k]);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            v[k] = (lane + 64 * k < C) ? expf(v[k] - m) : 0.f;
+            sum += v[k];
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        float* o = out + op * out_ld;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                const float pr = (v[k] * inv) * weight;        // softmax, then `/ len(imgSizes)` as eval.py:70 (weight = 1/n)
+                o[c] = ACC ? o[c] + pr : pr;
+            }
+        }
+    }
+}
+
+extern "C" int semseg_upsample_softmax(const float* logits, int x_ld, float* out, int out_ld, int accumulate, float weight, int N,
+                                       int IH, int IW, int OH, int OW, int C, void* stream) {
+    if (!logits || !out || N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || C <= 0 || C > 1024 || x_ld < C || out_ld < C)
+        return SEMSEG_EINVAL;
+    const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+    const size_t P = (size_t)N * OH * OW;
+    const int blocks = (int)(ceil_div_sz(P, 4) < 16384 ? ceil_div_sz(P, 4) : 16384);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(KK)                                                                                                          \
+    do {                                                                                                                    \
+        if (accumulate) hipLaunchKernelGGL((upsample_softmax_kernel<KK, true>), dim3(blocks), dim3(256), 0, st, logits, x_ld, out, \
+                                           out_ld, N, IH, IW, OH, OW, C, sh, sw, weight);                                   \
+        else hipLaunchKernelGGL((upsample_softmax_kernel<KK, false>), dim3(blocks), dim3(256), 0, st, logits, x_ld, out, out_ld, N, \
+                                IH, IW, OH, OW, C, sh, sw, weight);                                                          \
+    } while (0)
+    const int K = ceil_div(C, 64);
+    if (K <= 1) LAUNCH(1);
+    else if (K <= 2) LAUNCH(2);
+    else if (K <= 3) LAUNCH(3);
+    else if (K <= 4) LAUNCH(4);
+    else if (K <= 8) LAUNCH(8);
+    else LAUNCH(16);
+#undef LAUNCH
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 // gather-form backward: block.x = one input pixel, block.y = a chunk of 4*ql channels; the 256/ql pixel lanes sweep the
 // window of output pixels that can touch this input pixel, fixed-order LDS combine.  ql = 16 (64 channels, 16 pixel
 // lanes) for ordinary maps; ql = 4 (16 channels, 64 pixel lanes) when the input map is tiny and every input pixel

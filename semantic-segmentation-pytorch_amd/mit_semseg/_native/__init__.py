@@ -76,6 +76,7 @@ SIGNATURES = {
     'semseg_clamp_max': (c_int, [vp, c_int, c_f, vp, c_int, c_int, c_int, vp]),
     'semseg_clamp_max_bwd': (c_int, [vp, c_int, vp, c_int, c_f, vp, c_int, c_int, c_int, vp]),
     'semseg_dropout_mask': (c_int, [vp, c_int, c_f, vp, vp]),
+    'semseg_upsample_softmax': (c_int, [vp, c_int, vp, c_int, c_int, c_f] + [c_int] * 6 + [vp]),
     'semseg_copy2d': (c_int, [vp, c_int, vp, c_int, c_int, c_int, c_int, vp]),
     'semseg_scale_nc': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
     'semseg_nchw_to_nhwc': (c_int, [vp, vp, c_int, c_int, c_int, vp]),

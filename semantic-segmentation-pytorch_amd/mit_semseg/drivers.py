@@ -273,10 +273,7 @@ def test_worker(rank, world, cfg, gpus, port, list_test):
     for i in range(len(dataset)):
         item = dataset[i]
         h, w = item['img_ori'].shape[0], item['img_ori'].shape[1]
-        scores = None
-        for img in item['img_data']:
-            s = run(img, (h, w)) / len(item['img_data'])
-            scores = s if scores is None else scores + s
+        scores = run.multi_scale(item['img_data'], (h, w))
         pred, _ = utils.segmentation_metrics(scores)
         pred = pred[0].cpu().numpy().astype(np.int32)
         preds.append(pred)

@@ -296,39 +296,74 @@ class TrainStep:
 
 class InferenceGraph:
     """segmentation_module(feed, segSize=...) of the inference branch (models.py:480-484, eval.py:66-71) captured into one
-    hipGraph per (input shape, segSize) and replayed: an eager forward of R50dilated+PPM is ~350 launches and host-bound
+    hipGraph per (input shape, segSize, role) and replayed: an eager forward of R50dilated+PPM is ~350 launches and host-bound
     (4.0 ms per 512x512 image, tools/bench_infer.py), the replay is bound by its kernels.
 
         run = InferenceGraph(segmentation_module)
-        prob = run(img, segSize=(H, W))        # [N, num_class, H, W] probabilities; valid until the next call
-    """
+        prob = run(img, segSize=(H, W))                     # [N, num_class, H, W] probabilities; valid until the next call
+        scores = run.multi_scale([img_300, img_375, ...], (H, W))      # eval.py:59-71: mean of the per-scale probabilities
+
+    `multi_scale` keeps ONE score buffer per segSize; the fused head kernel of the first scale writes `p / n` into it, the
+    others add theirs (ops.head_output) -- no full-resolution temporaries, no scale / add passes."""
 
     def __init__(self, segmentation_module, max_graphs=8):
         self.sm = segmentation_module.eval()
         self.max_graphs = max_graphs
-        self._graphs = {}           # (img shape, segSize) -> (graph, static image, static output)
+        self._graphs = {}           # (img shape, segSize, accumulate, weight) -> (graph, static image, output)
+        self._scores = {}           # (N, segSize) -> score buffer of multi_scale
 
-    def _eager(self, img, segSize):
+    def _eager(self, img, segSize, head=None):
         with torch.no_grad():
-            return self.sm({'img_data': img}, segSize=segSize)
+            if head is None:
+                return self.sm({'img_data': img}, segSize=segSize)
+            with ops.head_output(*head):
+                return self.sm({'img_data': img}, segSize=segSize)
 
-    def __call__(self, img, segSize):
-        segSize = (int(segSize[0]), int(segSize[1]))
-        key = (tuple(img.shape), segSize)
+    def _run(self, img, segSize, head=None):
+        key = (tuple(img.shape), segSize, None if head is None else (head[0].data_ptr(), head[1], head[2]))
         rec = self._graphs.get(key)
         if rec is None:
             if len(self._graphs) >= self.max_graphs:
-                return self._eager(img, segSize)          # multi-scale evaluation with many distinct sizes: stay eager
-            self._eager(img, segSize)                      # first call: tunes the conv plans, builds the weight planes
+                return self._eager(img, segSize, head)     # multi-scale evaluation with many distinct sizes: stay eager
+            if head is not None and head[2]:
+                keep = head[0].clone()                     # the warm-up call below must not count twice
+            self._eager(img, segSize, head)                # first call: tunes the conv plans, builds the weight planes
+            if head is not None and head[2]:
+                head[0].copy_(keep)
             static = img.clone()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self._eager(static, segSize)
+                out = self._eager(static, segSize, head)
             rec = self._graphs[key] = (graph, static, out)
         graph, static, out = rec
         static.copy_(img)
         graph.replay()
         return out
+
+    def __call__(self, img, segSize):
+        return self._run(img, (int(segSize[0]), int(segSize[1])))
+
+    def multi_scale(self, imgs, segSize):
+        """scores = sum_i softmax(upsample(logits(imgs[i]))) / len(imgs) at segSize (eval.py:59-71, test.py:66-78); the returned
+        buffer is reused by the next call with the same segSize"""
+        segSize = (int(segSize[0]), int(segSize[1]))
+        n = int(imgs[0].shape[0])
+        dev = imgs[0].device
+        num_class = self._num_class(dev)
+        key = (n, segSize)
+        buf = self._scores.get(key)
+        if buf is None:
+            if len(self._scores) >= 4 * self.max_graphs:
+                self._scores.clear()
+            buf = self._scores[key] = ops.empty_nhwc(n, num_class, segSize[0], segSize[1], dev)
+        w = 1.0 / len(imgs)
+        for i, img in enumerate(imgs):
+            self._run(img, segSize, (buf, w, i > 0))
+        return buf
+
+    def _num_class(self, dev):
+        """output channels of the decoder's classifier (its last convolution; the deep-supervision twin has the same width)"""
+        return [m.out_channels for m in self.sm.decoder.modules() if hasattr(m, 'out_channels')][-1]
 
 
 def evaluate(segmentation_module, loader, num_class, device=None, tally=None, use_graph=True, on_item=None, group=None,
@@ -353,17 +388,20 @@ def evaluate(segmentation_module, loader, num_class, device=None, tally=None, us
             item = item[0]                                    # user_scattered_collate batches of one (eval.py:51)
         label = item['seg_label'][0].to(device)
         seg_size = (int(label.shape[0]), int(label.shape[1]))
-        imgs = item['img_data']
-        scores = None
-        for img in imgs:
-            img = img.to(device)
-            if run is not None:
-                s = run(img, seg_size)
-            else:
-                with torch.no_grad():
+        imgs = [img.to(device) for img in item['img_data']]
+        if run is not None:
+            scores = run.multi_scale(imgs, seg_size)          # p_0 / n, then += p_i / n in the fused head kernel
+        else:
+            scores = None
+            for i, img in enumerate(imgs):
+                ctx = ops.head_output(scores, 1.0 / len(imgs), i > 0)
+                with torch.no_grad(), ctx:
                     s = segmentation_module({'img_data': img}, segSize=seg_size)
-            s = s / len(imgs)                                 # a new tensor: the graph's output buffer is reused next call
-            scores = s if scores is None else scores + s      # 0 + s == s exactly: same sums as the reference's zeros start
+                if ctx.used:
+                    scores = s                                    # weighted + accumulated by the fused head kernel
+                else:                                             # a decoder that is not this build's: eval.py:70 literally
+                    s = s / len(imgs)
+                    scores = s if scores is None else scores + s
         pred, tally = utils.segmentation_metrics(scores, label, tally)
         if on_item is not None:
             on_item(item, pred)

@@ -214,8 +214,7 @@ class MobileNetV2Dilated(nn.Module):
 def _head_output(x, use_softmax, segSize):
     """models.py:480-484 / :492: inference = bilinear up-sample of the logits + softmax; training = log_softmax."""
     if use_softmax:
-        x = ops.interpolate_bilinear(x, segSize)
-        return ops.softmax(x)
+        return ops.upsample_softmax(x, segSize)          # bilinear up-sampling + softmax in one kernel
     return ops.log_softmax(x)
 
 

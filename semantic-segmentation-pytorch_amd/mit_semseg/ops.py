@@ -1424,6 +1424,48 @@ def softmax(z):
     return out
 
 
+# destination of the inference head (engine.InferenceGraph.multi_scale / engine.evaluate): `out` = the score map to write or to
+# accumulate into, `weight` = 1 / number of scales (eval.py:70), `accumulate` = add to what `out` holds
+_HEAD = {'out': None, 'weight': 1.0, 'accumulate': False, 'used': False}
+
+
+class head_output:
+    """with ops.head_output(out, weight, accumulate): segmentation_module(feed, segSize=...) -- the decoder's fused
+    up-sample + softmax kernel then writes `weight * probabilities` into `out` (or adds them to it) instead of a new tensor"""
+
+    def __init__(self, out, weight=1.0, accumulate=False):
+        self.cfg = {'out': out, 'weight': float(weight), 'accumulate': bool(accumulate), 'used': False}
+        self.used = False
+
+    def __enter__(self):
+        self.prev = dict(_HEAD)
+        _HEAD.update(self.cfg)
+        return self
+
+    def __exit__(self, *exc):
+        self.used = _HEAD['used']          # False: the module inside did not go through ops.upsample_softmax (foreign decoder)
+        _HEAD.update(self.prev)
+
+
+def upsample_softmax(z, size):
+    """Inference head (models.py:480-484): softmax over the classes of the logits bilinearly up-sampled to `size`, one fused
+    kernel (csrc/pool_resize.hip semseg_upsample_softmax).  Returns [N, C, H, W] probabilities (times the weight of an enclosing
+    ops.head_output context, into its buffer)."""
+    z, ld = as_nhwc(z.detach())
+    n, c, h, w = z.shape
+    oh, ow = int(size[0]), int(size[1])
+    out, weight, acc = _HEAD['out'], _HEAD['weight'], _HEAD['accumulate']
+    if out is not None:
+        if tuple(out.shape) != (n, c, oh, ow) or nhwc_ld(out) != c or out.dtype != torch.float32 or not out.is_cuda:
+            raise RuntimeError('head_output buffer %s does not fit the score map %s' % (tuple(out.shape), (n, c, oh, ow)))
+    else:
+        out, acc = empty_nhwc(n, c, oh, ow, z.device), False
+    _native.check(_native.lib().semseg_upsample_softmax(_p(z), ld, _p(out), c, int(acc), float(weight), n, h, w, oh, ow, c,
+                                                        _st()), 'upsample_softmax')
+    _HEAD['used'] = True
+    return out
+
+
 class NLLAccFn(Function):
     """nn.NLLLoss(ignore_index) (train.py:154) + pixel_acc (models.py:12-18) in one pass.
     Returns (loss, acc) 0-dim tensors; only `loss` is differentiable."""

@@ -85,6 +85,20 @@ def interpolate_bilinear(x, size, base=None, relu=False):
     return F.relu(y) if relu else y
 
 
+def upsample_softmax(z, size):
+    from mit_semseg import ops
+    y = F.softmax(F.interpolate(z, size=(int(size[0]), int(size[1])), mode='bilinear', align_corners=False), dim=1)
+    out, w, acc = ops._HEAD['out'], ops._HEAD['weight'], ops._HEAD['accumulate']
+    ops._HEAD['used'] = True
+    if out is None:
+        return y * w if w != 1.0 else y
+    if acc:
+        out += y * w
+    else:
+        out.copy_(y * w)
+    return out
+
+
 def log_softmax(z):
     return F.log_softmax(z, dim=1)
 
@@ -121,7 +135,7 @@ def install(monkeypatch, keep=()):
     from mit_semseg import ops
     g = globals()
     for name in ('conv2d', 'depthwise_conv3x3', 'grouped_conv3x3', 'clamp_max', 'fork', 'share_planes', 'dropout_mask', 'batch_norm_act', 'conv_bn_act', 'add_act', 'concat', 'scale_nc',
-                 'max_pool_3x3_s2', 'adaptive_avg_pool', 'adaptive_avg_pool_multi', 'interpolate_bilinear', 'log_softmax',
+                 'max_pool_3x3_s2', 'adaptive_avg_pool', 'adaptive_avg_pool_multi', 'interpolate_bilinear', 'upsample_softmax', 'log_softmax',
                  'softmax', 'nll_loss_acc', 'sgd_step'):
         if name not in keep:
             monkeypatch.setattr(ops, name, g[name])

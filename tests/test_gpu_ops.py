@@ -824,3 +824,32 @@ def test_conv_bn_act_winograd_wgrad_matches_direct(monkeypatch):
     assert e < 1e-5, e
     e = ((dw1.double().cpu() - wd.grad).norm() / wd.grad.norm()).item()
     assert e < 3e-3, e
+
+
+@pytest.mark.parametrize('n,c,ih,iw,oh,ow', [(1, 150, 8, 10, 35, 45), (2, 150, 64, 64, 64, 64), (1, 7, 5, 3, 9, 12), (1, 64, 6, 6, 13, 7),
+                                             (1, 200, 4, 5, 17, 9), (1, 150, 47, 63, 376, 504)], ids=str)
+def test_upsample_softmax_fused(n, c, ih, iw, oh, ow):
+    """the fused inference head (models.py:480-484 + the multi-scale average of eval.py:66-71): weight * softmax(bilinear(logits))
+    written, then a second scale accumulated, against torch's interpolate + softmax in float64"""
+    from mit_semseg import ops
+    d = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(c * 1000 + oh)
+    z1 = torch.randn(n, c, ih, iw, generator=g) * 4
+    z2 = torch.randn(n, c, ih + 2, iw + 1, generator=g) * 4
+
+    def ref(z):
+        return F.softmax(F.interpolate(z.double(), size=(oh, ow), mode='bilinear', align_corners=False), dim=1)
+    single = ops.upsample_softmax(z1.to(d).contiguous(memory_format=torch.channels_last), (oh, ow))
+    torch.testing.assert_close(single.cpu().double(), ref(z1), atol=2e-6, rtol=1e-5)
+    buf = ops.empty_nhwc(n, c, oh, ow, d)
+    with ops.head_output(buf, 0.5, False) as h1:
+        out = ops.upsample_softmax(z1.to(d), (oh, ow))                      # NCHW-contiguous logits: converted on the way in
+    assert out.data_ptr() == buf.data_ptr()
+    with ops.head_output(buf, 0.5, True) as h2:
+        ops.upsample_softmax(z2.to(d).contiguous(memory_format=torch.channels_last), (oh, ow))
+    torch.cuda.synchronize()
+    assert h1.used and h2.used
+    want = 0.5 * ref(z1) + 0.5 * ref(z2)
+    torch.testing.assert_close(buf.cpu().double(), want, atol=2e-6, rtol=1e-5)
+    assert torch.equal(buf.cpu().argmax(1), want.float().argmax(1)) or (want.topk(2, dim=1)[0].diff(dim=1).abs().min() < 1e-5)
+    assert abs(buf.sum().item() - n * oh * ow) < 1e-3 * n * oh * ow

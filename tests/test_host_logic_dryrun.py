@@ -99,4 +99,4 @@ def test_inference_host_logic(stub):
     with torch.no_grad():
         prob = sm({'img_data': torch.randn(1, 3, 64, 80)}, segSize=(70, 90))
     assert tuple(prob.shape) == (1, 150, 70, 90)
-    assert 'semseg_softmax_fwd' in stub.calls and 'semseg_bn_eval_coeffs' in stub.calls
+    assert 'semseg_upsample_softmax' in stub.calls and 'semseg_bn_eval_coeffs' in stub.calls
