@@ -221,21 +221,17 @@ int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y, int y_ld,
 /* Single-rank fused forms (no all-reduce between the partial sums and their use): 3 launches per BN pass instead of 4.
  * semseg_bn_fwd_stats_fused = semseg_bn_stats_mm + semseg_bn_finalize_mm, leaving ceil(C/16) per-block bounds (uint32 bit
  * patterns) in `blockbound` for semseg_bn_apply_h2.  semseg_bn_bwd_reduce_fused = semseg_bn_bwd_reduce_mm + the per-channel
- * part of semseg_bn_bwd_bound, leaving the bounds for semseg_bn_bwd_apply_h2.
- * `tickets` (may be NULL): SEMSEG_BN_TICKETS (1024) uint32 counters in device memory, ZERO on entry and left zero on exit, shared
- * by consecutive launches of one stream.  With tickets the partial-sum kernel's last-arriving block of each channel column
- * finishes that column itself (2 launches per BN pass instead of 3); without, a separate finish kernel runs.  Results are
- * bit-identical either way. */
+ * part of semseg_bn_bwd_bound, leaving the bounds for semseg_bn_bwd_apply_h2. */
 int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                               float momentum, float eps, int relu, const float* res_absmax,
                               float* mean, float* invstd, float* scale, float* shift, void* blockbound,
-                              void* workspace, size_t workspace_bytes, void* tickets, void* stream);
+                              void* workspace, size_t workspace_bytes, void* stream);
 int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
                                const float* mean, const float* invstd, const float* gate_scale, const float* gate_shift,
                                int relu, int P, int C, const double* stats_count, const float* zmm, const float* gamma,
                                int training, double* sums, float* dgamma, float* dbeta, void* blockbound,
-                               void* workspace, size_t workspace_bytes, void* tickets, void* stream);
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------- elementwise helpers ------------------------------------------------------ */
 /* out = act(a + b) (hrnet.py:231-248 fuse sums); a,b,out [P,C] with their own ld */

@@ -999,343 +999,6 @@ extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y
 // per-channel finalize / bound work and leave one bound per block (16 channels) for the apply kernel's prologue
 // (h2_exponent_from): 3 launches per BN pass instead of 4.  Block = 16 channels x 16 partial lanes.
 // ================================================================================================
-
-// ================================================================================================
-// Last-block finish: ONE launch per BN statistics pass.  The partial-sum grid is (channel columns, row chunks); the LAST block of
-// a column to arrive (ticket counter per column, left at zero again) reduces that column's partial rows itself -- one thread per
-// channel, all its loads independent -- instead of a separate finish kernel (5-6 us of launch latency + drain per BN layer and
-// pass, 122 launches per R50 step).  Writers publish their partial rows with a device-scope fence before taking the ticket; the
-// finisher fences again before it reads them.  The per-channel sums are formed in the association of the finish kernels (16
-// residue-class sums of the partial rows, added in order), so the results are bit-identical to the two-launch form.
-// ================================================================================================
-#define SEMSEG_BN_TICKETS 1024      /* ticket counters (uint32) a caller provides to the *_fused entry points */
-
-__device__ __forceinline__ void bn_stats_mm_partial_body(const float* __restrict__ z, int P, int C, int cx, int py,
-                                                                  int rows_per_block, double* __restrict__ partial,
-                                                                  float* __restrict__ mm) {
-    extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][8] floats
-    float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
-    const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
-    const int quad = blockIdx.x * cx + tx;
-    const int c = quad * 4;
-    const int row0 = blockIdx.y * rows_per_block;
-    const int row1 = min(P, row0 + rows_per_block);
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-    float4 hi = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    const bool active = (ty < py) && (c < C);
-    if (active) {
-        auto acc = [&](const float4 v) {
-            const double x = v.x, y = v.y, zz = v.z, w = v.w;
-            a0 += x; a1 += y; a2 += zz; a3 += w;
-            q0 = fma(x, x, q0); q1 = fma(y, y, q1); q2 = fma(zz, zz, q2); q3 = fma(w, w, q3);
-            lo.x = fminf(lo.x, v.x); lo.y = fminf(lo.y, v.y); lo.z = fminf(lo.z, v.z); lo.w = fminf(lo.w, v.w);
-            hi.x = fmaxf(hi.x, v.x); hi.y = fmaxf(hi.y, v.y); hi.z = fmaxf(hi.z, v.z); hi.w = fmaxf(hi.w, v.w);
-        };
-        // ROWS_IN_FLIGHT loads are issued before the first is consumed (a thread walks only ~8 rows: one load per
-        // iteration makes the pass latency-bound); the accumulation order is that of the plain loop
-        int p = row0 + ty;
-        for (; p + (ROWS_IN_FLIGHT - 1) * py < row1; p += ROWS_IN_FLIGHT * py) {
-            float4 v[ROWS_IN_FLIGHT];
-#pragma unroll
-            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) v[u] = *reinterpret_cast<const float4*>(z + (size_t)(p + u * py) * C + c);
-#pragma unroll
-            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) acc(v[u]);
-        }
-        for (; p < row1; p += py) acc(*reinterpret_cast<const float4*>(z + (size_t)p * C + c));
-    }
-    if (ty < py) {
-        double* r = red + ((size_t)ty * cx + tx) * 8;
-        r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
-        r[4] = q0; r[5] = q1; r[6] = q2; r[7] = q3;
-        float* f = redf + ((size_t)ty * cx + tx) * 8;
-        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
-        f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
-    }
-    __syncthreads();
-    if (ty == 0 && c < C) {
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        for (int y = 0; y < py; ++y) {
-            const double* r = red + ((size_t)y * cx + tx) * 8;
-            const float* f = redf + ((size_t)y * cx + tx) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += r[e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                mn[e] = fminf(mn[e], f[e]);
-                mx[e] = fmaxf(mx[e], f[4 + e]);
-            }
-        }
-        double* o = partial + (size_t)blockIdx.y * 2 * C;
-        float* of = mm + (size_t)blockIdx.y * 2 * C;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[c + e] = a[e];
-            o[C + c + e] = a[4 + e];
-            of[c + e] = mn[e];
-            of[C + c + e] = mx[e];
-        }
-    }
-}
-
-
-template <int GATE>
-__device__ __forceinline__ void bn_bwd_mm_partial_body(const float* __restrict__ dy, int dy_ld,
-                                                                const float* __restrict__ y, int y_ld,
-                                                                const float* __restrict__ z, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd, int relu, int P, int C,
-                                                                int cx, int py, int rows_per_block,
-                                                                double* __restrict__ partial, float* __restrict__ gm,
-                                                                const float* __restrict__ gscale,
-                                                                const float* __restrict__ gshift) {
-    extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][4] floats
-    float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
-    const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
-    const int c = (blockIdx.x * cx + tx) * 4;
-    const int row0 = blockIdx.y * rows_per_block;
-    const int row1 = min(P, row0 + rows_per_block);
-    float4 s = f4zero(), sx = f4zero(), gx = f4zero();
-    if (ty < py && c < C) {
-        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
-        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        constexpr bool gate_z = GATE == 1, gate_y = GATE == 2;
-        auto acc = [&](float4 g, const float4 v, const float4 yin) {
-            if (GATE != 0) {
-                const float4 yy = gate_z ? relu_gate_from_z(v, gscale + c, gshift + c) : yin;
-                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-            }
-            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
-            sx.x += g.x * ((v.x - mu.x) * is.x); sx.y += g.y * ((v.y - mu.y) * is.y);
-            sx.z += g.z * ((v.z - mu.z) * is.z); sx.w += g.w * ((v.w - mu.w) * is.w);
-            // NaN-propagating max (fmaxf would drop a NaN gradient)
-            gx.x = (fabsf(g.x) > gx.x || g.x != g.x) ? fabsf(g.x) : gx.x;
-            gx.y = (fabsf(g.y) > gx.y || g.y != g.y) ? fabsf(g.y) : gx.y;
-            gx.z = (fabsf(g.z) > gx.z || g.z != g.z) ? fabsf(g.z) : gx.z;
-            gx.w = (fabsf(g.w) > gx.w || g.w != g.w) ? fabsf(g.w) : gx.w;
-        };
-        // 4 rows (8-12 loads) in flight, accumulation order of the plain loop (see bn_stats_mm_partial_kernel)
-        constexpr int U = 4;
-        int p = row0 + ty;
-        for (; p + (U - 1) * py < row1; p += U * py) {
-            float4 g[U], v[U], yy[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                g[u] = *reinterpret_cast<const float4*>(dy + (size_t)(p + u * py) * dy_ld + c);
-                v[u] = *reinterpret_cast<const float4*>(z + (size_t)(p + u * py) * C + c);
-                yy[u] = gate_y ? *reinterpret_cast<const float4*>(y + (size_t)(p + u * py) * y_ld + c) : f4zero();
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc(g[u], v[u], yy[u]);
-        }
-        for (; p < row1; p += py)
-            acc(*reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c), *reinterpret_cast<const float4*>(z + (size_t)p * C + c),
-                gate_y ? *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c) : f4zero());
-    }
-    if (ty < py) {
-        double* r = red + ((size_t)ty * cx + tx) * 8;
-        r[0] = s.x; r[1] = s.y; r[2] = s.z; r[3] = s.w;
-        r[4] = sx.x; r[5] = sx.y; r[6] = sx.z; r[7] = sx.w;
-        float* f = redf + ((size_t)ty * cx + tx) * 4;
-        f[0] = gx.x; f[1] = gx.y; f[2] = gx.z; f[3] = gx.w;
-    }
-    __syncthreads();
-    if (ty == 0 && c < C) {
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t m[4] = {0, 0, 0, 0};             // bit patterns: monotone for |g| >= 0, NaN sorts above inf
-        for (int yy = 0; yy < py; ++yy) {
-            const double* r = red + ((size_t)yy * cx + tx) * 8;
-            const float* f = redf + ((size_t)yy * cx + tx) * 4;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += r[e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = max(m[e], absbits(f[e]));
-        }
-        double* o = partial + (size_t)blockIdx.y * 2 * C;
-        float* of = gm + (size_t)blockIdx.y * C;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[c + e] = a[e];
-            o[C + c + e] = a[4 + e];
-            of[c + e] = __uint_as_float(m[e]);
-        }
-    }
-}
-
-
-struct FwdFinish {
-    const double* partial; const float* mm; int nparts, C; double count;
-    const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps; int relu;
-    const float* res_absmax; double* stats; float* zmm; float* mean; float* invstd; float* scale; float* shift;
-    int64_t* num_batches_tracked; uint32_t* blockbound;
-};
-struct BwdFinish {
-    const double* partial; const float* gm; int nparts, C; const double* count;
-    const float* zmm; const float* mean; const float* invstd; const float* gamma; int training;
-    double* sums; float* dgamma; float* dbeta; uint32_t* blockbound;
-};
-
-// true in exactly one block per column: the last one to get here.  All threads of the block return the same value.
-__device__ __forceinline__ bool last_block_of_column(uint32_t* __restrict__ tickets) {
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1u) == gridDim.y - 1;
-    __syncthreads();
-    const bool last = s_last != 0;
-    if (last) __threadfence();
-    return last;
-}
-
-// max over each group of 16 consecutive lanes (the 16 channels of one `blockbound` entry)
-__device__ __forceinline__ uint32_t group16_max(uint32_t v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-    return v;
-}
-
-__device__ __forceinline__ void bn_fwd_finish_column(const FwdFinish& a, int cx) {
-    const int C = a.C, C2 = 2 * C, nparts = a.nparts;
-    const int c = blockIdx.x * cx * 4 + threadIdx.x;
-    const bool live = threadIdx.x < cx * 4 && c < C;
-    uint32_t bits = 0;
-    if (live) {
-        const double* __restrict__ partial = a.partial;
-        const float* __restrict__ mm = a.mm;
-        double as[16], aq[16];
-        float lo = INFINITY, hi = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { as[u] = 0.0; aq[u] = 0.0; }
-        for (int b0 = 0; b0 < nparts; b0 += 16) {
-            double ps[16], pq[16];
-            float pl[16], ph[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const size_t o = (size_t)min(b0 + u, nparts - 1) * C2;
-                ps[u] = partial[o + c]; pq[u] = partial[o + C + c];
-                pl[u] = mm[o + c]; ph[u] = mm[o + C + c];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const bool in = b0 + u < nparts;
-                as[u] = in ? as[u] + ps[u] : as[u]; aq[u] = in ? aq[u] + pq[u] : aq[u];
-                lo = in ? fminf(lo, pl[u]) : lo; hi = in ? fmaxf(hi, ph[u]) : hi;
-            }
-        }
-        double su = 0.0, sq = 0.0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { su += as[u]; sq += aq[u]; }      // the order of the finish kernel's 16-lane combine
-        a.stats[c] = su; a.stats[C + c] = sq;
-        a.zmm[c] = lo; a.zmm[C + c] = hi;
-        const double n = a.count;
-        const double mu = su / n;
-        double var = sq / n - mu * mu;
-        if (var < 0.0) var = 0.0;
-        const float is = (float)(1.0 / sqrt(var + (double)a.eps));
-        const float muf = (float)mu;
-        a.mean[c] = muf;
-        a.invstd[c] = is;
-        const float sc = a.gamma[c] * is;
-        const float sh = a.beta[c] - muf * sc;
-        a.scale[c] = sc;
-        a.shift[c] = sh;
-        if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * muf;
-        if (a.running_var) {
-            const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
-        }
-        const float rmax = a.res_absmax ? a.res_absmax[0] : 0.f;
-        const float e0 = fmaf(lo, sc, sh), e1 = fmaf(hi, sc, sh);
-        const float bh = fmaxf(e0, e1) + rmax, bl = fminf(e0, e1) - rmax;
-        const float b = a.relu ? fmaxf(bh, 0.f) : fmaxf(fabsf(bh), fabsf(bl));
-        const bool bad = !(b == b) || !(e0 == e0) || !(e1 == e1);
-        bits = bad ? 0x7fc00000u : __float_as_uint(b);
-    }
-    bits = group16_max(bits);
-    if (live && (threadIdx.x & 15) == 0) a.blockbound[c >> 4] = bits;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.stats[C2] = a.count;
-        if (a.num_batches_tracked) a.num_batches_tracked[0] += 1;
-    }
-}
-
-__device__ __forceinline__ void bn_bwd_finish_column(const BwdFinish& a, int cx) {
-    const int C = a.C, C2 = 2 * C, nparts = a.nparts;
-    const int c = blockIdx.x * cx * 4 + threadIdx.x;
-    const bool live = threadIdx.x < cx * 4 && c < C;
-    uint32_t bits = 0;
-    if (live) {
-        const double* __restrict__ partial = a.partial;
-        const float* __restrict__ gm = a.gm;
-        double as[16], aq[16];
-        uint32_t gmx = 0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { as[u] = 0.0; aq[u] = 0.0; }
-        for (int b0 = 0; b0 < nparts; b0 += 16) {
-            double ps[16], pq[16];
-            float pg[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const size_t r = (size_t)min(b0 + u, nparts - 1);
-                ps[u] = partial[r * C2 + c]; pq[u] = partial[r * C2 + C + c];
-                pg[u] = gm[r * C + c];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const bool in = b0 + u < nparts;
-                as[u] = in ? as[u] + ps[u] : as[u]; aq[u] = in ? aq[u] + pq[u] : aq[u];
-                gmx = in ? max(gmx, absbits(pg[u])) : gmx;
-            }
-        }
-        double su = 0.0, sq = 0.0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { su += as[u]; sq += aq[u]; }
-        a.sums[c] = su; a.sums[C + c] = sq;
-        if (a.dbeta) a.dbeta[c] = (float)su;
-        if (a.dgamma) a.dgamma[c] = (float)sq;
-        const float is = a.invstd[c];
-        float b = __uint_as_float(gmx);
-        if (a.training) {
-            const float inv_n = (float)(1.0 / a.count[0]);
-            const float m = fabsf((float)su * inv_n), x = fabsf((float)sq * inv_n);
-            const float xh = fmaxf(fabsf(a.zmm[c] - a.mean[c]), fabsf(a.zmm[C + c] - a.mean[c])) * is;
-            b = b + m + xh * x;
-        }
-        b = fabsf(a.gamma[c]) * is * b * 1.0009765625f;
-        bits = absbits(b);
-    }
-    bits = group16_max(bits);
-    if (live && (threadIdx.x & 15) == 0) a.blockbound[c >> 4] = bits;
-}
-
-__global__ __launch_bounds__(256) void bn_stats_mm_partial_finish_kernel(const float* __restrict__ z, int P, int C, int cx,
-                                                                         int py, int rows_per_block,
-                                                                         uint32_t* __restrict__ tickets, FwdFinish a) {
-    bn_stats_mm_partial_body(z, P, C, cx, py, rows_per_block, const_cast<double*>(a.partial), const_cast<float*>(a.mm));
-    if (!last_block_of_column(tickets)) return;
-    bn_fwd_finish_column(a, cx);
-    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
-}
-
-template <int GATE>
-__global__ __launch_bounds__(256) void bn_bwd_mm_partial_finish_kernel(const float* __restrict__ dy, int dy_ld,
-                                                                       const float* __restrict__ y, int y_ld,
-                                                                       const float* __restrict__ z, int relu, int P, int cx,
-                                                                       int py, int rows_per_block,
-                                                                       const float* __restrict__ gscale,
-                                                                       const float* __restrict__ gshift,
-                                                                       uint32_t* __restrict__ tickets, BwdFinish a) {
-    bn_bwd_mm_partial_body<GATE>(dy, dy_ld, y, y_ld, z, a.mean, a.invstd, relu, P, a.C, cx, py, rows_per_block,
-                                 const_cast<double*>(a.partial), const_cast<float*>(a.gm), gscale, gshift);
-    if (!last_block_of_column(tickets)) return;
-    bn_bwd_finish_column(a, cx);
-    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
-}
-
 __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     const double* __restrict__ partial, const float* __restrict__ mm, int nparts, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
@@ -1421,8 +1084,7 @@ extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* s
                                          const float* beta, float* running_mean, float* running_var,
                                          int64_t* num_batches_tracked, float momentum, float eps, int relu,
                                          const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
-                                         void* blockbound, void* workspace, size_t workspace_bytes, void* tickets,
-                                         void* stream) {
+                                         void* blockbound, void* workspace, size_t workspace_bytes, void* stream) {
     if (!z || !stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || !blockbound || P <= 0 || C <= 0 ||
         (C % 4) || !aligned16(z))
         return SEMSEG_EINVAL;
@@ -1433,14 +1095,6 @@ extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* s
     double* partial = (double*)workspace;
     float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
-    if (tickets && g.gx <= SEMSEG_BN_TICKETS) {
-        const FwdFinish fin{partial, mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                            res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound};
-        hipLaunchKernelGGL(bn_stats_mm_partial_finish_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
-                           g.rows_per_block, (uint32_t*)tickets, fin);
-        SEMSEG_LAUNCH_CHECK();
-        return 0;
-    }
     hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
                        g.rows_per_block, partial, mm);
     SEMSEG_LAUNCH_CHECK();
@@ -1515,7 +1169,7 @@ extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const floa
                                           const float* gate_shift, int relu, int P, int C, const double* stats_count,
                                           const float* zmm, const float* gamma, int training, double* sums, float* dgamma,
                                           float* dbeta, void* blockbound, void* workspace, size_t workspace_bytes,
-                                          void* tickets, void* stream) {
+                                          void* stream) {
     if (!dy || !z || !mean || !invstd || !sums || !gamma || !blockbound || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) ||
         dy_ld < C)
         return SEMSEG_EINVAL;
@@ -1529,19 +1183,6 @@ extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const floa
     double* partial = (double*)workspace;
     float* gm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
-    if (tickets && g.gx <= SEMSEG_BN_TICKETS) {
-        const BwdFinish fin{partial, gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
-                            (uint32_t*)blockbound};
-#define LAUNCH_FUSED(GATE)                                                                                                 \
-    hipLaunchKernelGGL(bn_bwd_mm_partial_finish_kernel<GATE>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, \
-                       relu, P, g.cx, g.py, g.rows_per_block, gate_scale, gate_shift, (uint32_t*)tickets, fin)
-        if (!relu) LAUNCH_FUSED(0);
-        else if (gate_scale) LAUNCH_FUSED(1);
-        else LAUNCH_FUSED(2);
-#undef LAUNCH_FUSED
-        SEMSEG_LAUNCH_CHECK();
-        return 0;
-    }
 #define LAUNCH_PARTIAL(GATE)                                                                                              \
     hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<GATE>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, \
                        invstd, relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, gate_scale, gate_shift)

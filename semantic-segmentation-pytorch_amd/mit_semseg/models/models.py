@@ -139,9 +139,16 @@ class Resnet(nn.Module):
     def forward(self, x, return_feature_maps=False):
         x = run_deep_stem(self, x)
         conv_out = []
-        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+        stages = (self.layer1, self.layer2, self.layer3, self.layer4)
+        for i, stage in enumerate(stages):
             x = stage(x)
-            conv_out.append(x)
+            if return_feature_maps and i + 1 < len(stages):
+                # a stage output feeds the next stage AND a decoder head (deep supervision, FPN laterals): fork it, so that
+                # the two gradients are summed by the native add kernel (a fork output nobody uses costs nothing)
+                keep, x = ops.fork(x)
+                conv_out.append(keep)
+            else:
+                conv_out.append(x)
         return conv_out if return_feature_maps else [x]
 
 
@@ -298,7 +305,8 @@ class PPM(nn.Module):
     def _pyramid(self, conv5):
         size = conv5.shape[2:]
         # all pyramid scales pooled in one pass over conv5 (ops.adaptive_avg_pool_multi)
-        pooled = ops.adaptive_avg_pool_multi(conv5, [b._modules['0'].output_size for b in self.ppm])
+        conv5, c5 = ops.fork(conv5)                  # two consumers: the pyramid pooling and the concat
+        pooled = ops.adaptive_avg_pool_multi(c5, [b._modules['0'].output_size for b in self.ppm])
         return ops.concat([conv5] + [ops.interpolate_bilinear(b.after_pool(p), size) for b, p in zip(self.ppm, pooled)])
 
     def forward(self, conv_out, segSize=None):
@@ -344,9 +352,9 @@ class UPerNet(nn.Module):
             Conv2d(fpn_dim, num_class, kernel_size=1))
 
     def forward(self, conv_out, segSize=None):
-        conv5 = conv_out[-1]
+        conv5, c5 = ops.fork(conv_out[-1])            # two consumers: the pyramid pooling and the concat
         size = conv5.shape[2:]
-        pooled = ops.adaptive_avg_pool_multi(conv5, [pool.output_size for pool in self.ppm_pooling])    # one pass over conv5
+        pooled = ops.adaptive_avg_pool_multi(c5, [pool.output_size for pool in self.ppm_pooling])    # one pass over conv5
         ppm_out = [conv5] + [conv(ops.interpolate_bilinear(p, size)) for p, conv in zip(pooled, self.ppm_conv)]
         f = self.ppm_last_conv(ops.concat(ppm_out))
         fpn_feature_list = [f]

@@ -69,23 +69,6 @@ def workspace(nbytes, device, tag=''):
     return t
 
 
-_TICKETS = {}
-# SEMSEG_BN_TICKETS=0: the fused BN statistics entry points run their separate finish kernels (A/B of the last-block finish)
-BN_TICKETS = os.environ.get('SEMSEG_BN_TICKETS', '1') != '0'
-
-
-def tickets(device, tag=''):
-    """1024 zeroed uint32 ticket counters per device (and stream tag): the `tickets` argument of the fused BN entry points
-    (the last-arriving block of a reduction grid finishes it; the kernels leave the counters at zero)."""
-    if not BN_TICKETS:
-        return None
-    key = (device.type, device.index if (device.index is not None or device.type != 'cuda') else torch.cuda.current_device(), tag)
-    t = _TICKETS.get(key)
-    if t is None:
-        t = _TICKETS[key] = torch.zeros(1024, dtype=torch.int32, device=device)
-    return t
-
-
 # ------------------------------------------------------------------------------------------------
 # layout helpers
 # ------------------------------------------------------------------------------------------------
@@ -869,8 +852,7 @@ class ConvBNActFn(Function):
             _native.check(L.semseg_bn_fwd_stats_fused(_p(z), P, k, _p(stats), _p(zmm), _p(g), _p(b), _p(running_mean),
                                                       _p(running_var), _p(nbt), float(momentum), float(eps), int(relu),
                                                       _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
-                                                      _p(bb), _p(ws), ws.numel(), _p(tickets(dev)), _st()),
-                          'bn_fwd_stats_fused')
+                                                      _p(bb), _p(ws), ws.numel(), _st()), 'bn_fwd_stats_fused')
             _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), _p(yp),
                                                P, k, _p(bb), _p(absmax), _st()), 'bn_apply_h2')
         else:
@@ -925,8 +907,8 @@ class ConvBNActFn(Function):
             bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
             _native.check(L.semseg_bn_bwd_reduce_fused(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gsc),
                                                        _p(gsh), int(relu), P, k, _p(count), _p(zmm), _p(gamma), 1, _p(sums),
-                                                       _p(dgamma), _p(dbeta), _p(bb), _p(ws), ws.numel(), _p(tickets(dev)),
-                                                       _st()), 'bn_bwd_reduce_fused')
+                                                       _p(dgamma), _p(dbeta), _p(bb), _p(ws), ws.numel(), _st()),
+                          'bn_bwd_reduce_fused')
         else:
             bb = None
             if gate:                                      # the unfused reduce reads y: rebuild the gate tensor once

@@ -400,20 +400,7 @@ def test_bn_h2_forward_kernels(n, c, h, w, relu, res):
     _native.check(L.semseg_bn_fwd_stats_fused(ops._p(z), P, c, ops._p(stats_f), ops._p(zmm_f), ops._p(gamma), ops._p(beta),
                                               ops._p(rm3), ops._p(rv3), ops._p(nbt), 0.1, 1e-5, int(relu), ops._p(rabs),
                                               ops._p(coef_f[0]), ops._p(coef_f[1]), ops._p(coef_f[2]), ops._p(coef_f[3]),
-                                              ops._p(bb), ops._p(ws), ws.numel(), ops._p(ops.tickets(d)), st), 'fwd_stats_fused')
-    # the same entry point WITHOUT ticket counters (separate finish kernel instead of the last-block finish): identical bits
-    stats_g = torch.empty(2 * c + 1, dtype=torch.float64, device=d)
-    zmm_g, coef_g, bb_g = torch.empty(2 * c, device=d), torch.empty(4, c, device=d), torch.empty_like(bb)
-    rm4, rv4 = torch.zeros(c, device=d), torch.ones(c, device=d)
-    _native.check(L.semseg_bn_fwd_stats_fused(ops._p(z), P, c, ops._p(stats_g), ops._p(zmm_g), ops._p(gamma), ops._p(beta),
-                                              ops._p(rm4), ops._p(rv4), ops._p(None), 0.1, 1e-5, int(relu), ops._p(rabs),
-                                              ops._p(coef_g[0]), ops._p(coef_g[1]), ops._p(coef_g[2]), ops._p(coef_g[3]),
-                                              ops._p(bb_g), ops._p(ws), ws.numel(), ops._p(None), st), 'fwd_stats_fused')
-    torch.cuda.synchronize()
-    assert torch.equal(stats_g, stats_f) and torch.equal(zmm_g, zmm_f) and torch.equal(coef_g, coef_f) and torch.equal(bb_g, bb)
-    assert torch.equal(rm4, rm3) and torch.equal(rv4, rv3)
-    if ops.tickets(d) is not None:
-        assert int(ops.tickets(d).abs().max()) == 0                     # the counters are left at zero
+                                              ops._p(bb), ops._p(ws), ws.numel(), st), 'fwd_stats_fused')
     _native.check(L.semseg_bn_apply_h2(ops._p(z), ops._p(coef_f[2]), ops._p(coef_f[3]), ops._p(r), c, int(relu), ops._p(y_f),
                                        ops._p(yp_f), P, c, ops._p(bb), ops._p(absmax_f), st), 'apply_h2_fused')
     torch.cuda.synchronize()
@@ -499,16 +486,7 @@ def test_bn_h2_backward_kernels(n, c, h, w, relu, dres, training):
     _native.check(L.semseg_bn_bwd_reduce_fused(ops._p(dy), c, ops._p(None if gate else y), c, ops._p(z), ops._p(mean), ops._p(invstd),
                                                ops._p(gsc), ops._p(gsh), int(relu), P, c, ops._p(count), ops._p(zmm), ops._p(gamma),
                                                int(training), ops._p(sums_f), ops._p(dg_f), ops._p(db_f), ops._p(bb), ops._p(ws),
-                                               ws.numel(), ops._p(ops.tickets(d)), st), 'reduce_fused')
-    sums_g, dg_g, db_g, bb_g = torch.empty_like(sums_f), torch.empty_like(dg_f), torch.empty_like(db_f), torch.empty_like(bb)
-    _native.check(L.semseg_bn_bwd_reduce_fused(ops._p(dy), c, ops._p(None if gate else y), c, ops._p(z), ops._p(mean), ops._p(invstd),
-                                               ops._p(gsc), ops._p(gsh), int(relu), P, c, ops._p(count), ops._p(zmm), ops._p(gamma),
-                                               int(training), ops._p(sums_g), ops._p(dg_g), ops._p(db_g), ops._p(bb_g), ops._p(ws),
-                                               ws.numel(), ops._p(None), st), 'reduce_fused')
-    torch.cuda.synchronize()
-    assert torch.equal(sums_g, sums_f) and torch.equal(dg_g, dg_f) and torch.equal(db_g, db_f) and torch.equal(bb_g, bb)
-    if ops.tickets(d) is not None:
-        assert int(ops.tickets(d).abs().max()) == 0
+                                               ws.numel(), st), 'reduce_fused')
     _native.check(L.semseg_bn_bwd_apply_h2(ops._p(dy), c, ops._p(None if gate else y), c, ops._p(z), ops._p(mean), ops._p(invstd),
                                            ops._p(gamma), ops._p(sums_f), ops._p(count), int(training), int(relu), ops._p(dzp_f),
                                            ops._p(dres_f), P, c, ops._p(gsc), ops._p(gsh), ops._p(bb), st), 'apply_h2_fused')
@@ -840,7 +818,7 @@ def test_upsample_softmax_fused(n, c, ih, iw, oh, ow):
     def ref(z):
         return F.softmax(F.interpolate(z.double(), size=(oh, ow), mode='bilinear', align_corners=False), dim=1)
     single = ops.upsample_softmax(z1.to(d).contiguous(memory_format=torch.channels_last), (oh, ow))
-    torch.testing.assert_close(single.cpu().double(), ref(z1), atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(single.cpu().double(), ref(z1), atol=2e-5, rtol=1e-4)     # fp32 exp / sum of 150 terms
     buf = ops.empty_nhwc(n, c, oh, ow, d)
     with ops.head_output(buf, 0.5, False) as h1:
         out = ops.upsample_softmax(z1.to(d), (oh, ow))                      # NCHW-contiguous logits: converted on the way in
@@ -850,6 +828,6 @@ def test_upsample_softmax_fused(n, c, ih, iw, oh, ow):
     torch.cuda.synchronize()
     assert h1.used and h2.used
     want = 0.5 * ref(z1) + 0.5 * ref(z2)
-    torch.testing.assert_close(buf.cpu().double(), want, atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(buf.cpu().double(), want, atol=2e-5, rtol=1e-4)
     assert torch.equal(buf.cpu().argmax(1), want.float().argmax(1)) or (want.topk(2, dim=1)[0].diff(dim=1).abs().min() < 1e-5)
     assert abs(buf.sum().item() - n * oh * ow) < 1e-3 * n * oh * ow
