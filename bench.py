@@ -230,10 +230,14 @@ def cpu_baseline(cfg, steps=3):
 
 
 def ddp_graph_selftest(timeout_s=150):
-    """world > 1: decide whether the real run may capture its RCCL all-reduces into the step's hipGraph.  Every rank runs
-    tools/probes/ddp_graph_selftest.py (a small model through exactly that code path) in a CHILD process, on its own
-    rendezvous port, BEFORE this process touches the GPU or RCCL; a child that fails or does not finish in time is killed and
-    counts as a failure.  Returns True if this rank's child passed (the ranks agree on the outcome afterwards)."""
+    """world > 1: decide what the real run may rely on.  Every rank runs tools/probes/ddp_graph_selftest.py (a small model through
+    exactly the data-parallel code paths) in a CHILD process, on its own rendezvous port, BEFORE this process touches the GPU or
+    RCCL; a child that fails or does not finish in time is killed.  Returns the stages this rank's child reached:
+      'comm'       the C ABI's own RCCL communicator came up and summed correctly (else the real run sets SEMSEG_NATIVE_COMM=0
+                   and the collectives go through torch.distributed),
+      'segmented'  the segmented hipGraph executor trained (else SEMSEG_DDP_SEGMENTED=0: eager launches),
+      'graph'      the whole step, RCCL included, replayed as ONE hipGraph (then SEMSEG_DDP_GRAPH=1).
+    The ranks agree on the outcome afterwards (minimum over ranks)."""
     import subprocess
     import tempfile
     env = dict(os.environ)
@@ -241,25 +245,29 @@ def ddp_graph_selftest(timeout_s=150):
     env.pop('TORCHELASTIC_USE_AGENT_STORE', None)       # rank 0 of the children opens its own store on the new port
     env.pop('SEMSEG_TUNE_CACHE', None)
     script = os.path.join(ROOT, 'tools', 'probes', 'ddp_graph_selftest.py')
-    ok, why = False, 'not started'
+    out, rc, why = '', None, 'not started'
     with tempfile.TemporaryFile() as log:
         try:
             p = subprocess.Popen([sys.executable, script], env=env, stdout=log, stderr=subprocess.STDOUT)
             try:
                 rc = p.wait(timeout=timeout_s)
-                ok, why = rc == 0, 'exit code %d' % rc
+                why = 'exit code %d' % rc
             except subprocess.TimeoutExpired:
                 p.kill()                                 # the exact child started above
                 p.wait()
                 why = 'no result within %d s (killed)' % timeout_s
         except OSError as e:
             why = str(e)
-        if not ok and env.get('RANK', '0') == '0':
-            log.seek(0)
-            tail = log.read()[-1500:].decode('utf-8', 'replace')
-            print('[bench] data-parallel hipGraph self-test did not pass (%s); launching eagerly.\n%s' % (why, tail),
-                  file=sys.stderr, flush=True)
-    return ok
+        log.seek(0)
+        out = log.read().decode('utf-8', 'replace')
+    # the markers are printed by rank 0's child only; a non-zero rank infers its stages from its own exit code, and the
+    # all-reduce(min) in main() combines them
+    stages = {'comm': 'COMM_OK' in out or (env.get('RANK', '0') != '0' and rc == 0),
+              'segmented': 'SEGMENTED_OK' in out or (env.get('RANK', '0') != '0' and rc == 0),
+              'graph': rc == 0}
+    if rc != 0 and env.get('RANK', '0') == '0':
+        print('[bench] data-parallel self-test: %s; stages reached %s\n%s' % (why, stages, out[-1500:]), file=sys.stderr, flush=True)
+    return stages
 
 
 def main():
@@ -290,6 +298,8 @@ def main():
     if int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'SEMSEG_DDP_GRAPH' not in os.environ and not args.no_graph and \
             not os.environ.get('SEMSEG_DIST_BACKEND') and not os.environ.get('SEMSEG_BENCH_DEVICE'):
         selftest_ok = ddp_graph_selftest()
+        if not selftest_ok['comm']:
+            os.environ['SEMSEG_NATIVE_COMM'] = '0'      # before NativeDataParallel is built: torch.distributed carries the collectives
     rank, world, local = init_distributed()
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     if os.environ.get('SEMSEG_BENCH_DEVICE'):          # several ranks on one GPU (gloo): functional check of the N>1 path
@@ -297,9 +307,14 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     if selftest_ok is not None:
-        flag = torch.tensor([1 if selftest_ok else 0], device=dev, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # every rank's child must have passed
-        if int(flag.item()) == 1:
+        flag = torch.tensor([int(selftest_ok[k]) for k in ('comm', 'segmented', 'graph')], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # every rank's child must have reached the stage
+        selftest_ok = dict(zip(('comm', 'segmented', 'graph'), (bool(v) for v in flag.tolist())))
+        if not selftest_ok['comm']:
+            os.environ['SEMSEG_NATIVE_COMM'] = '0'
+        if not selftest_ok['segmented']:
+            os.environ['SEMSEG_DDP_SEGMENTED'] = '0'
+        if selftest_ok['graph']:
             os.environ['SEMSEG_DDP_GRAPH'] = '1'
     sm = build_model(dev, cfg)
     if world > 1:
@@ -362,11 +377,14 @@ def main():
                                            'included: first sights and graph captures are timed)'))
                                        if cfg.get('variable') else '512x512x3', cfg['rate']),
                        'global_batch': 2 * world, 'parallelism': 'dp%d' % world,
-                       'launch': ('hipGraph replay' if timed['replayed'] == args.steps else
+                       'launch': (('segmented hipGraphs (%s)' % step._graph.counts() if type(step._graph).__name__ == 'SegmentedStep'
+                                   else 'hipGraph replay') if timed['replayed'] == args.steps else
                                   'eager' if timed['replayed'] == 0 else
                                   'per-shape hipGraphs: %(replayed)d of the timed steps replayed (%(captured)d captured in the '
                                   'timed region), %(eager)d eager (first sight of a shape)' % timed),
                        'ddp_graph_selftest': selftest_ok,
+                       'collectives': ('C ABI RCCL communicator (semseg_comm_*)' if world > 1 and __import__('mit_semseg.comm').comm.active()
+                                       else 'torch.distributed' if world > 1 else None),
                        'conv_path': ops_mode(),
                        'images_per_sec_per_gpu': round(per_gpu, 3),
                        'step_conv_tflops_per_gpu': round(per_gpu * gflop_img * 1e-3, 2),

@@ -19,7 +19,11 @@ import torch
 from . import _native
 
 _COMMS = {}          # id(group) -> dict(handle, rank, world)
-ENABLED = os.environ.get('SEMSEG_NATIVE_COMM', '1') != '0'
+
+
+def enabled():
+    """SEMSEG_NATIVE_COMM=0 (read when the communicator would be built): collectives stay with torch.distributed"""
+    return os.environ.get('SEMSEG_NATIVE_COMM', '1') != '0'
 
 
 def _key(group):
@@ -35,7 +39,7 @@ def init(group=None, selftest=True):
     one process per GPU, current device set).  Collective.  Every rank learns whether ALL ranks succeeded; on any failure the
     communicator is torn down everywhere and False is returned (torch.distributed then carries the collectives)."""
     import torch.distributed as dist
-    if not ENABLED or not (dist.is_available() and dist.is_initialized()):
+    if not enabled() or not (dist.is_available() and dist.is_initialized()):
         return False
     if _key(group) in _COMMS:
         return True

@@ -215,3 +215,86 @@ def test_two_ranks_segmented_graphs_equal_eager():
     for k in res[False][0]['sd']:
         assert torch.equal(res[True][0]['sd'][k], res[True][1]['sd'][k]), ('ranks differ', k)
         assert torch.equal(res[True][0]['sd'][k], res[False][0]['sd'][k]), ('segmented != eager', k)
+
+
+def test_per_shape_train_graphs_equal_eager_and_evict():
+    """BASELINE configs[3] (variable-size per-GPU batches, dataset.py:121-142): TrainStep keeps one hipGraph per batch shape.
+    A sequence that alternates between three shapes (first sight eager, second sight captured, then replays; `max_graphs=2`
+    forces an eviction and a re-capture) ends in exactly the weights / BN statistics / losses of the same sequence launched
+    eagerly."""
+    from mit_semseg.models import ModelBuilder, SegmentationModule
+    from mit_semseg.engine import TrainStep
+    from oracle import semseg_oracle as O
+    dev = torch.device('cuda:0')
+    enc_sd, dec_sd, _, _, _ = _joint_case()
+    shapes = [(64, 64), (72, 104), (64, 64), (72, 104), (64, 64), (96, 64), (72, 104), (96, 64), (64, 64), (96, 64), (64, 64)]
+    feeds = {}
+    for hw in set(shapes):
+        img, lab = O.synth_batch(2, hw[0], hw[1], 8, seed=hw[0] * 1000 + hw[1])
+        feeds[hw] = {'img_data': img.to(dev), 'seg_label': lab.to(dev)}
+
+    def run(graph):
+        with tempfile.TemporaryDirectory() as d:
+            pe, pd = os.path.join(d, 'e.pth'), os.path.join(d, 'd.pth')
+            torch.save(enc_sd, pe)
+            torch.save(dec_sd, pd)
+            enc = ModelBuilder.build_encoder('resnet18dilated', fc_dim=512, weights=pe)
+            dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=512, num_class=150, weights=pd)
+        dec.conv_last[3].p = 0.0                  # no dropout draw: the two runs must see the same arithmetic
+        dec.dropout_deepsup.p = 0.0
+        sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), 0.4).to(dev).train()
+        ts = TrainStep(sm, lr_encoder=LR, lr_decoder=LR, max_iters=1000, graph=graph, max_graphs=2)
+        losses = [ts.step(feeds[hw])[0].clone() for hw in shapes]
+        torch.cuda.synchronize()
+        return {k: v.detach().cpu().clone() for k, v in sm.state_dict().items()}, [l.item() for l in losses], ts.stats
+
+    got, gl, stats = run(True)
+    want, wl, _ = run(False)
+    print('per-shape graphs: %s' % stats)
+    assert stats['captured'] >= 4 and stats['evicted'] >= 1 and stats['replayed'] >= 5, stats
+    assert gl == wl, (gl, wl)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_comm_abi_single_rank_rccl():
+    """semseg_comm_* (csrc/comm.hip) against a real RCCL on the box: unique id, a 1-rank communicator, in-place all-reduces of both
+    payload types on the current stream (sum over one rank = identity), the grouped form, and the same all-reduce captured in a
+    hipGraph and replayed (what SEMSEG_DDP_GRAPH=1 relies on)."""
+    import ctypes
+    from mit_semseg import _native
+    L = _native.lib()
+    assert L.semseg_comm_available() == 1 and L.semseg_comm_version() > 0
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    idbuf = (ctypes.c_ubyte * 128)()
+    assert L.semseg_comm_unique_id(idbuf) == 0 and any(idbuf)
+    comm = ctypes.c_void_p()
+    assert L.semseg_comm_init(0, 1, idbuf, ctypes.byref(comm)) == 0 and comm.value
+    try:
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        a = torch.randn(4097, dtype=torch.float64, device=dev)
+        b = torch.randn(1 << 20, dtype=torch.float32, device=dev)
+        a0, b0 = a.clone(), b.clone()
+        assert L.semseg_comm_allreduce_sum_f64(comm, ctypes.c_void_p(a.data_ptr()), a.numel(), st) == 0
+        assert L.semseg_comm_allreduce_sum_f32(comm, ctypes.c_void_p(b.data_ptr()), b.numel(), st) == 0
+        bufs = [torch.randn(2 * c + 1, dtype=torch.float64, device=dev) for c in (64, 512, 2048)]
+        ref = [t.clone() for t in bufs]
+        ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in bufs])
+        counts = (ctypes.c_size_t * 3)(*[t.numel() for t in bufs])
+        assert L.semseg_comm_allreduce_sum_f64_multi(comm, ptrs, counts, 3, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a, a0) and torch.equal(b, b0) and all(torch.equal(x, y) for x, y in zip(bufs, ref))
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            sst = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            b.mul_(2.0)
+            assert L.semseg_comm_allreduce_sum_f32(comm, ctypes.c_void_p(b.data_ptr()), b.numel(), sst) == 0
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(b, b0 * 8.0)
+        assert L.semseg_comm_allreduce_sum_f32(comm, ctypes.c_void_p(0), 5, st) == -1       # SEMSEG_EINVAL
+    finally:
+        assert L.semseg_comm_destroy(comm) == 0

@@ -31,10 +31,24 @@ def main():
     enc = ResnetDilated(resnet.resnet18(pretrained=False), dilate_scale=8)
     dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=512, num_class=150)
     sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), 0.4).to(dev).train()
-    NativeDataParallel(sm)
+    dp = NativeDataParallel(sm)                         # brings up the C ABI's own RCCL communicator (self-tested sums)
+    if rank == 0:
+        print('COMM_%s native RCCL communicator through the C ABI: %s' % ('OK' if dp.native_comm else 'OFF', dp.native_comm), flush=True)
     g = torch.Generator().manual_seed(1000 + rank)
     feed = {'img_data': torch.randn(2, 3, 64, 64, generator=g).to(dev),
             'seg_label': torch.randint(-1, 150, (2, 8, 8), generator=g).to(dev)}
+    # stage 1: the default data-parallel launch mode (SegmentedStep: hipGraph segments, collectives between the replays)
+    os.environ['SEMSEG_DDP_GRAPH'] = '0'
+    ts0 = TrainStep(sm, max_iters=1000, graph=True, bucket_bytes=8 << 20)
+    for _ in range(5):
+        loss, acc = ts0.step(feed)
+    torch.cuda.synchronize()
+    assert ts0.launch_mode() == 'segmented' and ts0.stats['replayed'] >= 2 and torch.isfinite(loss).item()
+    dist.barrier()
+    if rank == 0:
+        print('SEGMENTED_OK loss %.5f' % loss.item(), flush=True)
+    # stage 2: RCCL captured inside ONE hipGraph
+    os.environ['SEMSEG_DDP_GRAPH'] = '1'
     ts = TrainStep(sm, max_iters=1000, graph=True, bucket_bytes=8 << 20)
     assert ts.buckets is not None and len(ts.buckets.buckets) > 1
     loss = None
@@ -65,7 +79,7 @@ def main():
     dist.all_reduce(ref)                          # also proves an eager collective still works after the replays
     dist.barrier()
     if rank == 0:
-        print('ddp graph selftest ok: world %d, loss %.5f' % (world, loss.item()), flush=True)
+        print('GRAPH_OK ddp graph selftest ok: world %d, loss %.5f' % (world, loss.item()), flush=True)
     dist.destroy_process_group()
 
 
