@@ -108,6 +108,10 @@ int semseg_conv2d_s3_set_plan(int pass, int N, int H, int W, int C, int K, int R
  * fp32 summation order differs); tests/test_gpu_ops.py::test_h2_conv_every_tile_pinned runs each one. */
 size_t semseg_split_h2_bytes(int rows, int C);
 int semseg_split_h2(const float* x, int x_ld, void* xs, int rows, int C, void* stream);
+/* out[0] = max |x| over the fp32 window [rows][0..C) with row stride x_ld (a NaN anywhere gives NaN); workspace >= 4 KiB.
+ * The bound the Winograd input transform needs when no producer kernel carried one (evaluation-mode forward). */
+int semseg_absmax(const float* x, int x_ld, int rows, int C, float* out, void* workspace, size_t workspace_bytes,
+                  void* stream);
 size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

@@ -301,6 +301,33 @@ extern "C" int semseg_split_h2(const float* x, int x_ld, void* xs, int rows, int
     return 0;
 }
 
+// max |x| of an fp32 [rows][x_ld] window as ONE device scalar (the bound the Winograd input transform scales by when no producer
+// kernel left one: the evaluation-mode forward, where BN applies running statistics and carries no min / max)
+__global__ __launch_bounds__(256) void absmax_finish_kernel(const uint32_t* __restrict__ partial, int npartial,
+                                                            float* __restrict__ out) {
+    uint32_t m = 0;
+    for (int i = threadIdx.x; i < npartial; i += 256) m = max(m, partial[i]);
+    m = block_max_u32(m);
+    if (threadIdx.x == 0) out[0] = __uint_as_float(m);
+}
+
+extern "C" int semseg_absmax(const float* x, int x_ld, int rows, int C, float* out, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || x_ld < C) return SEMSEG_EINVAL;
+    const size_t total_c = (size_t)rows * ((C + 7) >> 3);
+    const int nb = (int)min((size_t)H2_MAX_PARTIALS, ceil_div_sz(total_c, 1024));
+    if (!workspace || workspace_bytes < (size_t)nb * sizeof(uint32_t)) return SEMSEG_EWORKSPACE;
+    uint32_t* partial = (uint32_t*)workspace;
+    if ((x_ld % 4 == 0) && aligned16(x))
+        hipLaunchKernelGGL(absmax_partial_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, x_ld, rows, C, partial);
+    else
+        hipLaunchKernelGGL(absmax_partial_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, x_ld, rows, C, partial);
+    SEMSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)partial, nb, out);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient implicit GEMM on split operands
 // ------------------------------------------------------------------------------------------------

@@ -622,9 +622,31 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     if CONV_MODE == 'f32':
         return Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
     _require_cuda(x)
+    if not torch.is_grad_enabled() and bias is None and int(stride) == 1 and int(padding) == int(dilation) and \
+            _wino_eligible(*weight.shape):
+        # evaluation-mode forward of the >= 1024-channel 3x3 convs (conv_last / cbr_deepsup of the PPM heads, models.py:456,
+        # 519): Winograd F(2x2, 3x3) as in training; the |x| bound the input transform scales by comes from an absmax pass
+        # over x (15 us for the 4096-channel concat) since the eval-mode BN kernels carry none
+        weight_planes(weight, 'h2')                     # builds the planes of this parameter state (incl. the Winograd ones)
+        u = weight_wino(weight)
+        if u is not None:
+            return _winograd_eval(x, weight, u, int(dilation))
     xp = input_planes(x, CONV_MODE)
     wp, wtp = weight_planes(weight, CONV_MODE)
     return Conv2dSplitFn.apply(x, weight, bias, xp, wp, wtp, int(stride), int(padding), int(dilation), CONV_MODE)
+
+
+def _winograd_eval(x, weight, u_planes, dil):
+    L = _native.lib()
+    x, x_ld = as_nhwc(x.detach())
+    n, c, h, wd = x.shape
+    k = int(weight.shape[0])
+    bound = torch.empty((1,), device=x.device, dtype=torch.float32)
+    ws = workspace(4096, x.device)
+    _native.check(L.semseg_absmax(_p(x), x_ld, n * h * wd, c, _p(bound), _p(ws), ws.numel(), _st()), 'absmax')
+    z = empty_nhwc(n, k, h, wd, x.device)
+    _winograd_fwd(L, x, (bound,), u_planes, z, (n, h, wd, c, k, 3, 3, 1, dil, dil))
+    return z
 
 
 # ------------------------------------------------------------------------------------------------

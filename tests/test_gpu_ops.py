@@ -831,3 +831,42 @@ def test_upsample_softmax_fused(n, c, ih, iw, oh, ow):
     torch.testing.assert_close(buf.cpu().double(), want, atol=2e-5, rtol=1e-4)
     assert torch.equal(buf.cpu().argmax(1), want.float().argmax(1)) or (want.topk(2, dim=1)[0].diff(dim=1).abs().min() < 1e-5)
     assert abs(buf.sum().item() - n * oh * ow) < 1e-3 * n * oh * ow
+
+
+@pytest.mark.parametrize('rows,c,ld', [(4096, 4096, 4096), (300, 150, 150), (77, 24, 40), (1, 3, 3)], ids=str)
+def test_absmax_scalar(rows, c, ld):
+    """semseg_absmax (the |x| bound of the evaluation-mode Winograd forward): exact maximum, NaN propagates"""
+    from mit_semseg import ops, _native
+    d = torch.device('cuda:0')
+    x = torch.randn(rows, ld, device=d) * 3
+    out = torch.empty(1, device=d)
+    ws = ops.workspace(4096, d)
+    L = _native.lib()
+    _native.check(L.semseg_absmax(ops._p(x), ld, rows, c, ops._p(out), ops._p(ws), ws.numel(), ops._st()), 'absmax')
+    assert out.item() == x[:, :c].abs().max().item()
+    x[rows // 2, c - 1] = float('nan')
+    _native.check(L.semseg_absmax(ops._p(x), ld, rows, c, ops._p(out), ops._p(ws), ws.numel(), ops._st()), 'absmax')
+    assert out.item() != out.item()
+
+
+def test_eval_mode_winograd_forward_matches_direct(monkeypatch):
+    """conv2d under no_grad for a >= 1024-channel 3x3 conv goes through the Winograd path (absmax bound + transforms + batched GEMM)
+    and agrees with the direct h2 convolution and with float64"""
+    from mit_semseg import ops
+    from mit_semseg.models.layers import Conv2d
+    d = torch.device('cuda:0')
+    torch.manual_seed(0)
+    conv = Conv2d(1024, 256, 3, padding=2, dilation=2, bias=False).to(d)
+    x = torch.randn(1, 1024, 24, 40, device=d).contiguous(memory_format=torch.channels_last)
+    calls = []
+    orig = ops._winograd_eval
+    monkeypatch.setattr(ops, '_winograd_eval', lambda *a: (calls.append(1), orig(*a))[1])
+    with torch.no_grad():
+        y = conv(x)
+        monkeypatch.setattr(ops, 'WINOGRAD', False)
+        y_direct = conv(x)
+    assert len(calls) == 1
+    ref = F.conv2d(x.double().cpu(), conv.weight.detach().double().cpu(), None, 1, 2, 2)
+    scale = ref.abs().max().item()
+    assert (y.cpu().double() - ref).abs().max().item() < 2e-5 * scale
+    assert (y_direct.cpu().double() - ref).abs().max().item() < 2e-5 * scale
