@@ -296,6 +296,7 @@ WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '1024'))
 # the weight gradient of the same layers in the Winograd domain (dU[f] = dM[f]^T V[f], V kept from the forward pass):
 # in-box A/B (gpurun wg1) 16.50 -> 16.02 ms per step.  SEMSEG_WINOGRAD_WGRAD=0 disables.
 WINOGRAD_WGRAD = os.environ.get('SEMSEG_WINOGRAD_WGRAD', '1') != '0'
+WINOGRAD_EVAL = os.environ.get('SEMSEG_WINOGRAD_EVAL', '0') == '1'
 
 
 def _wino_eligible(k, c, r, s):
@@ -622,11 +623,12 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     if CONV_MODE == 'f32':
         return Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
     _require_cuda(x)
-    if not torch.is_grad_enabled() and bias is None and int(stride) == 1 and int(padding) == int(dilation) and \
-            _wino_eligible(*weight.shape):
-        # evaluation-mode forward of the >= 1024-channel 3x3 convs (conv_last / cbr_deepsup of the PPM heads, models.py:456,
-        # 519): Winograd F(2x2, 3x3) as in training; the |x| bound the input transform scales by comes from an absmax pass
-        # over x (15 us for the 4096-channel concat) since the eval-mode BN kernels carry none
+    if WINOGRAD_EVAL and not torch.is_grad_enabled() and bias is None and int(stride) == 1 and int(padding) == int(dilation) \
+            and _wino_eligible(*weight.shape):
+        # evaluation-mode forward of the >= 1024-channel 3x3 convs (conv_last of the PPM heads, models.py:456,519): Winograd
+        # F(2x2, 3x3) as in training; the |x| bound the input transform scales by comes from an absmax pass over x since the
+        # eval-mode BN kernels carry none.  Opt-in (SEMSEG_WINOGRAD_EVAL=1): at the single-image batches of eval.py / test.py it
+        # measures the same 3.19 ms per 512x512 image as the direct convolution (profiles/r3g_bench_infer_*.jsonl)
         weight_planes(weight, 'h2')                     # builds the planes of this parameter state (incl. the Winograd ones)
         u = weight_wino(weight)
         if u is not None:

@@ -268,12 +268,12 @@ def test_sharded_evaluate_equals_single_process():
 
 def test_bench_ddp_graph_selftest_fails_closed(monkeypatch):
     """bench.ddp_graph_selftest: a child that cannot finish (here: its peer never shows up) is killed at the time limit and
-    counts as a failure -- the data-parallel run then stays on the eager path"""
+    no stage counts as reached -- the data-parallel run then uses torch.distributed collectives and eager launches"""
     import time
     import bench
     for k, v in dict(RANK='0', WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29713',
                      TORCHELASTIC_USE_AGENT_STORE='True').items():
         monkeypatch.setenv(k, v)
     t = time.time()
-    assert bench.ddp_graph_selftest(timeout_s=6) is False
+    assert bench.ddp_graph_selftest(timeout_s=6) == {'comm': False, 'segmented': False, 'graph': False}
     assert time.time() - t < 30

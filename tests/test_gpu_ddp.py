@@ -158,6 +158,10 @@ def _worker_steps(rank, world, port, out_dir, graph):
     for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
         if p not in sys.path:
             sys.path.insert(0, p)
+    # two processes on ONE GPU oversubscribe its hardware queues: with the runtime's default queue count a replay of 71 small
+    # graphs takes 0.5-1.2 s per step (the processes' queues are multiplexed in coarse time slices); with 2 queues per process
+    # it takes 37 ms against 45 ms eager (gpurun r3g).  One rank per GPU -- the deployment -- is not affected.
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '2')
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:

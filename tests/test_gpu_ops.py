@@ -861,6 +861,7 @@ def test_eval_mode_winograd_forward_matches_direct(monkeypatch):
     calls = []
     orig = ops._winograd_eval
     monkeypatch.setattr(ops, '_winograd_eval', lambda *a: (calls.append(1), orig(*a))[1])
+    monkeypatch.setattr(ops, 'WINOGRAD_EVAL', True)                   # opt-in path (SEMSEG_WINOGRAD_EVAL=1)
     with torch.no_grad():
         y = conv(x)
         monkeypatch.setattr(ops, 'WINOGRAD', False)
