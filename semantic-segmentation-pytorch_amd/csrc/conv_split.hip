@@ -101,7 +101,7 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
 // software-pipelined fragment reads.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 6 : 1) : (sch == SchH2::ID ? 10 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 6 : 1) : (sch == SchH2::ID ? 14 : 3); }
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
@@ -675,11 +675,13 @@ __device__ __forceinline__ void wait_vm_barrier() {
 }
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
-__global__ __launch_bounds__(512) void igemm_dma_kernel(const SParams p) {
+__global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams p) {
     constexpr int NP = SCH::NP;
     typedef typename SCH::frag frag;
-    constexpr int NW = 8;                              // waves
-    static_assert(WGM * WGN == NW, "wave grid");
+    // waves: 8 (4x2 / 2x4) for the round-1 tiles; 4 (2x2: 128x128 / 128x64 per wave -- a third less LDS read traffic per MFMA, one
+    // wave per SIMD with up to 512 registers) and 16 (4x4: 64x64 per wave, four waves per SIMD to hide the waits) since round 2
+    constexpr int NW = WGM * WGN;
+    static_assert(NW == 4 || NW == 8 || NW == 16, "wave grid");
     constexpr int WM = BM / WGM, WN = BN / WGN;        // wave tile
     constexpr int FM = WM / 32, FN = WN / 32;
     constexpr int AG = BM / 16 / NW;                   // 16-row groups of A per wave
@@ -1005,8 +1007,9 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[11][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
-                                   {256, 128}, {256, 256}, {128, 128}, {256, 128}};
+static const int kTiles[15][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
+                                   {256, 128}, {256, 256}, {128, 128}, {256, 128}, {256, 256}, {256, 128}, {256, 128},
+                                   {256, 256}};
 
 // Launch plan: same wave-quantisation model as plan_igemm (conv_igemm.hip) -- tile x split-K candidates, cost =
 // waves * (k-tiles per block * tile cost + fixed) + split-K slab traffic.  The LDS-DMA tiles (3..5) are chosen by the
@@ -1079,7 +1082,7 @@ static int launch_dma(const SParams& p, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
-    hipLaunchKernelGGL((igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(512), smem, st, p);
+    hipLaunchKernelGGL((igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(64 * WGM * WGN), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -1134,6 +1137,18 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
         case 10:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 128, 4, 2, 13>(p, st);
+            break;
+        case 11:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 256, 2, 2, 12>(p, st);      // 4 waves, 128x128 per wave
+            break;
+        case 12:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 128, 2, 2, 12>(p, st);      // 4 waves, 128x64 per wave
+            break;
+        case 13:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 128, 2, 2, 13>(p, st);
+            break;
+        case 14:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 256, 4, 4, 12>(p, st);      // 16 waves, 64x64 per wave
             break;
     }
     if (rc) return rc;

@@ -133,7 +133,7 @@ def main():
                     cfgs += [('t%d_s%d' % (t, sp), {pre + '_TILE': str(t), pre + '_SPLIT': str(sp)})
                              for t in wtiles for sp in (1, 2, 4, 8, 16)]
                 elif which != 'split':
-                    tiles = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10) if args.mode == 'h2' else (0, 1, 2, 3)
+                    tiles = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14) if args.mode == 'h2' else (0, 1, 2, 3)
                     cfgs += [('t%d_s%d' % (t, sp), {pre2 + '_TILE': str(t), pre2 + '_SPLITK': str(sp)})
                              for t in tiles for sp in (1, 2, 4, 8)]
             ref = None
