@@ -101,7 +101,7 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
 // software-pipelined fragment reads.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 6 : 1) : (sch == SchH2::ID ? 14 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 7 : 1) : (sch == SchH2::ID ? 14 : 3); }
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
@@ -1582,10 +1582,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int FM = WM / 32, FN = WN / 32;
     constexpr int CBA = BM / 128, CBB = BN / 128;          // 128-channel column blocks per operand
-    constexpr int GPW = 8 / NW;                            // 4-row groups per wave
-    constexpr int LPT = GPW * NP * (CBA + CBB);            // DMA pieces per wave per k-tile
+    // 16 waves (round 2; four per SIMD hide the DMA / LDS waits better than two, as in igemm_dma_kernel): the 8 four-row groups
+    // of a k-tile go to waves 0-7 for the dy operand and to waves 8-15 for the x operand -- every wave still issues the same
+    // number of DMA pieces (the vmcnt accounting depends on it), which needs CBA == CBB
+    constexpr bool SPLIT_AB = NW == 16;
+    constexpr int GPW = SPLIT_AB ? 1 : 8 / NW;             // 4-row groups per wave
+    constexpr int LPT = SPLIT_AB ? NP * CBA : GPW * NP * (CBA + CBB);            // DMA pieces per wave per k-tile
     constexpr int A_BYTES = NP * CBA * 32 * 256, B_BYTES = NP * CBB * 32 * 256, BUF_BYTES = A_BYTES + B_BYTES;
-    static_assert(BM % 128 == 0 && BN % 128 == 0 && (NW == 4 || NW == 8) && FM >= 1 && FN >= 1, "tile");
+    static_assert(BM % 128 == 0 && BN % 128 == 0 && (NW == 4 || NW == 8 || NW == 16) && FM >= 1 && FN >= 1, "tile");
+    static_assert(!SPLIT_AB || CBA == CBB, "16 waves: equal operand widths");
     static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3 || NSLOT == 12) && 2 * LPT < 64, "tile");
 
     extern __shared__ __align__(16) unsigned char smem_w[];
@@ -1630,7 +1635,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
         const bool live = mt < m_end;                      // wave-uniform
 #pragma unroll
         for (int gi = 0; gi < GPW; ++gi) {
-            const int g = wave + NW * gi;                  // wave-uniform 4-row group
+            const int g = SPLIT_AB ? (wave & 7) : wave + NW * gi;                  // wave-uniform 4-row group
+            const bool do_a = !SPLIT_AB || wave < 8, do_b = !SPLIT_AB || wave >= 8;          // wave-uniform
             const int mr = mt + 4 * g + lrow;
             const bool rowok = live && (mr < m_end);
             const int m = min(mr, p.M - 1);
@@ -1648,6 +1654,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
             const uint32_t brow = (uint32_t)blockIdx.z * (uint32_t)p.batch_rows;
             const uint32_t a_off = ((uint32_t)m + brow) * a_row_b + a_col_b;
             const uint32_t b_off = ((uint32_t)((n * p.H + ih) * p.W + iw) + brow) * b_row_b + b_col_b;
+            if (do_a) {
 #pragma unroll
             for (int cb = 0; cb < CBA; ++cb)
 #pragma unroll
@@ -1657,6 +1664,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         rs_a, (lds_void*)(uintptr_t)(abuf + ((h * CBA + cb) * 32 + 4 * g) * 256), 16, vo, 0, 0, 0);
                 }
+            }
+            if (do_b) {
 #pragma unroll
             for (int cb = 0; cb < CBB; ++cb)
 #pragma unroll
@@ -1666,6 +1675,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         rs_b, (lds_void*)(uintptr_t)(bbuf + ((h * CBB + cb) * 32 + 4 * g) * 256), 16, vo, 0, 0, 0);
                 }
+            }
         }
     };
 
@@ -1830,19 +1840,19 @@ struct WPlan {
 // wgrad tiles (k x c): 0 = 128x128, 1 = 64x64 (register staged); h2 only: 2 = 128x128 LDS-DMA 2-slot (4 waves),
 // 3 = 256x128 LDS-DMA 3-slot ring (8 waves), 4 = 256x256 LDS-DMA 2-slot (8 waves), 5 / 6 = 2 / 4 software pipelined -- chosen by
 // the tuner / overrides only
-static const int kWTiles[7][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}};
+static const int kWTiles[8][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256}};
 
 // tuning overrides: SEMSEG_W3_TILE=0..3, SEMSEG_W3_SPLIT=n
 static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_split = 0) {
     WPlan pl;
     const int mtiles = ceil_div(M, 32);
-    const double tile_cost[7] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0};
-    const int slots[7] = {512, 1024, 512, 256, 256, 512, 256};
+    const double tile_cost[8] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0};
+    const int slots[8] = {512, 1024, 512, 256, 256, 512, 256, 256};
     const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_W3_TILE", -1);
     const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_W3_SPLIT", 0);
     double best = 1e30;
     int best_t = 1, best_s = 1;
-    for (int t = 0; t < 7; ++t) {
+    for (int t = 0; t < 8; ++t) {
         if (force_tile >= 0 && t != force_tile) continue;
         if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
@@ -1968,6 +1978,9 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
             break;
         case 6:
             if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 256, 256, 2, 4, 12>(p, st);
+            break;
+        case 7:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 256, 256, 4, 4, 12>(p, st);     // 16 waves
             break;
     }
     if (rc) return rc;

@@ -73,11 +73,15 @@ _WSPLITS = _SPLITS + tuple(s for s in (96, 128, 192, 256) if s <= _WGRAD_MAX_SPL
 # 14 = 256x256 on 16 waves.  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).
 _TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)}
 # weight-gradient tile ids: 0 = 128x128, 1 = 64x64 register staged; h2 only: 2 = 128x128 LDS-DMA, 3 = 256x128 LDS-DMA ring
-_WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4, 5, 6)}
+_WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4, 5, 6, 7)}
 _ALLOW = os.environ.get('SEMSEG_TUNE_TILES', '')
 if _ALLOW:
     _allow = tuple(int(t) for t in _ALLOW.split(','))
     _TILES = {k: tuple(t for t in v if t in _allow) for k, v in _TILES.items()}
+_WALLOW = os.environ.get('SEMSEG_TUNE_WTILES', '')          # the same for the weight-gradient tiles
+if _WALLOW:
+    _wallow = tuple(int(t) for t in _WALLOW.split(','))
+    _WTILES = {k: tuple(t for t in v if t in _wallow) for k, v in _WTILES.items()}
 
 
 def _set_plan(L, scheme):
