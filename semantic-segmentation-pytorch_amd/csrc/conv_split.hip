@@ -1290,6 +1290,7 @@ extern "C" int semseg_winograd_gemm_h2(const void* v_planes, const void* u_plane
         case 8: return launch_dma<SchH2, 256, 256, 2, 4, 12>(p, st);
         case 9: return launch_dma<SchH2, 128, 128, 4, 2, 12>(p, st);
         case 10: return launch_dma<SchH2, 256, 128, 4, 2, 13>(p, st);
+        case 14: return launch_dma<SchH2, 256, 256, 4, 4, 12>(p, st);
         default: return SEMSEG_EINVAL;
     }
 }
@@ -2034,7 +2035,9 @@ extern "C" int semseg_winograd_wgrad_gemm_h2(const void* v_planes, const void* d
         if (!workspace || workspace_bytes < (size_t)p.splits * slab * sizeof(float)) return SEMSEG_EWORKSPACE;
         p.partial = (float*)workspace;
     }
-    const int rc = big ? launch_wgrad_dma<SchH2, 256, 256, 2, 4, 2>(p, st) : launch_wgrad_dma<SchH2, 128, 128, 2, 2, 2>(p, st);
+    static const int w16 = env_int("SEMSEG_WINO_W16", 0);          // 16-wave form of the 256x256 tile
+    const int rc = big ? (w16 ? launch_wgrad_dma<SchH2, 256, 256, 4, 4, 12>(p, st) : launch_wgrad_dma<SchH2, 256, 256, 2, 4, 2>(p, st))
+                       : launch_wgrad_dma<SchH2, 128, 128, 2, 2, 2>(p, st);
     if (rc) return rc;
     if (p.splits > 1) {
         const int blocks = (int)min((size_t)2048, ceil_div_sz(slab / 4, 256));
