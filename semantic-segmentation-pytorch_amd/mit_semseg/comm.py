@@ -8,8 +8,14 @@ events, Python), through this wrapper one ctypes call enqueues ncclAllReduce on 
 stays GPU-bound.  torch.distributed remains the RENDEZVOUS (it carries the 128-byte unique id from rank 0 to the others) and
 the fallback transport (gloo in the CPU tests, or when RCCL cannot be bound).
 
-    comm.init(group)          # collective; returns True when the native communicator is up on every rank
+    comm.init(group)          # collective; returns True when the native communicators are up on every rank
     comm.allreduce_sum(t)     # in place on the current stream; False -> caller falls back to torch.distributed
+
+TWO communicators per group: RCCL serialises the operations of ONE communicator in issue order and does not allow two of them in
+flight from different streams, but the data-parallel step has exactly that -- latency-critical SyncBN payloads on the compute stream
+while a 64 MiB gradient bucket is being reduced on the side stream.  Channel 'sync' serves the compute stream, channel 'bucket' the
+gradient buckets (torch.distributed avoids the problem by funnelling every collective of a group through one internal stream, which
+would put each SyncBN all-reduce of backward behind the bucket in flight).
 """
 import ctypes
 import os
@@ -18,7 +24,8 @@ import torch
 
 from . import _native
 
-_COMMS = {}          # id(group) -> dict(handle, rank, world)
+_COMMS = {}          # id(group) -> dict(rank, world, sync=handle, bucket=handle)
+CHANNELS = ('sync', 'bucket')
 
 
 def enabled():
@@ -48,46 +55,52 @@ def init(group=None, selftest=True):
         return False
     L = _native.lib()
     dev = torch.device('cuda', torch.cuda.current_device())
+    handles = {}
     ok = bool(L.semseg_comm_available())
-    idbuf = (ctypes.c_ubyte * 128)()
-    if ok and rank == 0:
-        ok = L.semseg_comm_unique_id(idbuf) == 0
-    # rendezvous over the existing process group: rank 0's id (and whether it has one) to everybody
-    t = torch.zeros(129, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        t[:128] = torch.tensor(list(idbuf), dtype=torch.uint8)
-        t[128] = 1 if ok else 0
-    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    host = t.cpu()
-    handle = ctypes.c_void_p()
-    if int(host[128]) == 1 and ok:
-        ids = (ctypes.c_ubyte * 128)(*host[:128].tolist())
-        ok = L.semseg_comm_init(rank, world, ids, ctypes.byref(handle)) == 0
-    else:
-        ok = False
-    if ok and selftest:
-        # every rank contributes rank+1: the sum must be world (world+1) / 2 in both payload types
-        a = torch.full((257,), float(rank + 1), dtype=torch.float64, device=dev)
-        b = torch.full((1031,), float(rank + 1), dtype=torch.float32, device=dev)
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        ok = L.semseg_comm_allreduce_sum_f64(handle, ctypes.c_void_p(a.data_ptr()), a.numel(), st) == 0 and \
-            L.semseg_comm_allreduce_sum_f32(handle, ctypes.c_void_p(b.data_ptr()), b.numel(), st) == 0
-        torch.cuda.synchronize()
-        want = world * (world + 1) / 2.0
-        ok = ok and bool((a == want).all()) and bool((b == want).all())
+    for ch in CHANNELS:
+        idbuf = (ctypes.c_ubyte * 128)()
+        have = ok
+        if have and rank == 0:
+            have = L.semseg_comm_unique_id(idbuf) == 0
+        # rendezvous over the existing process group: rank 0's id (and whether it has one) to everybody
+        t = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t[:128] = torch.tensor(list(idbuf), dtype=torch.uint8)
+            t[128] = 1 if have else 0
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        host = t.cpu()
+        handle = ctypes.c_void_p()
+        if int(host[128]) == 1 and ok:
+            ids = (ctypes.c_ubyte * 128)(*host[:128].tolist())
+            ok = L.semseg_comm_init(rank, world, ids, ctypes.byref(handle)) == 0
+        else:
+            ok = False
+        if handle:
+            handles[ch] = handle
+        if ok and selftest:
+            # every rank contributes rank+1: the sum must be world (world+1) / 2 in both payload types
+            a = torch.full((257,), float(rank + 1), dtype=torch.float64, device=dev)
+            b = torch.full((1031,), float(rank + 1), dtype=torch.float32, device=dev)
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            ok = L.semseg_comm_allreduce_sum_f64(handle, ctypes.c_void_p(a.data_ptr()), a.numel(), st) == 0 and \
+                L.semseg_comm_allreduce_sum_f32(handle, ctypes.c_void_p(b.data_ptr()), b.numel(), st) == 0
+            torch.cuda.synchronize()
+            want = world * (world + 1) / 2.0
+            ok = ok and bool((a == want).all()) and bool((b == want).all())
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     if int(flag.item()) != 1:
-        if handle:
-            L.semseg_comm_destroy(handle)
+        for h in handles.values():
+            L.semseg_comm_destroy(h)
         return False
-    _COMMS[_key(group)] = dict(handle=handle, rank=rank, world=world)
+    _COMMS[_key(group)] = dict(rank=rank, world=world, **handles)
     return True
 
 
-def allreduce_sum(buf, group=None):
-    """In-place sum over the ranks on the CURRENT stream; returns False if no native communicator serves `group` (or the dtype
-    is not one the ABI carries) -- the caller then uses torch.distributed."""
+def allreduce_sum(buf, group=None, channel='sync'):
+    """In-place sum over the ranks on the CURRENT stream through the communicator of `channel` ('sync': the compute stream's
+    SyncBN payloads; 'bucket': the gradient buckets on their side stream); returns False if no native communicator serves
+    `group` (or the dtype is not one the ABI carries) -- the caller then uses torch.distributed."""
     rec = _COMMS.get(_key(group))
     if rec is None or not buf.is_cuda or not buf.is_contiguous():
         return False
@@ -99,16 +112,19 @@ def allreduce_sum(buf, group=None):
         fn = L.semseg_comm_allreduce_sum_f32
     else:
         return False
-    _native.check(fn(rec['handle'], ctypes.c_void_p(buf.data_ptr()), buf.numel(), st), 'comm_allreduce_sum')
+    _native.check(fn(rec[channel], ctypes.c_void_p(buf.data_ptr()), buf.numel(), st), 'comm_allreduce_sum')
     return True
 
 
 def destroy(group=None):
     rec = _COMMS.pop(_key(group), None)
     if rec is not None:
-        _native.lib().semseg_comm_destroy(rec['handle'])
+        for ch in CHANNELS:
+            _native.lib().semseg_comm_destroy(rec[ch])
 
 
 def destroy_all():
     for k in list(_COMMS):
-        _native.lib().semseg_comm_destroy(_COMMS.pop(k)['handle'])
+        destroy_key = _COMMS.pop(k)
+        for ch in CHANNELS:
+            _native.lib().semseg_comm_destroy(destroy_key[ch])

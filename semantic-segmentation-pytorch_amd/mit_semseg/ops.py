@@ -677,11 +677,11 @@ def _sync_active():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_GROUP['group']) > 1
 
 
-def allreduce_sum(buf, group=None):
-    """sum of `buf` over the ranks of `group`, in place, on the current stream: the native RCCL communicator when one is up
-    (mit_semseg.comm: semseg_comm_allreduce_sum through the C ABI), else torch.distributed"""
+def allreduce_sum(buf, group=None, channel='sync'):
+    """sum of `buf` over the ranks of `group`, in place, on the current stream: the native RCCL communicator of `channel` when
+    one is up (mit_semseg.comm: semseg_comm_allreduce_sum through the C ABI), else torch.distributed"""
     from . import comm
-    if comm.allreduce_sum(buf, group):
+    if comm.allreduce_sum(buf, group, channel):
         return
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

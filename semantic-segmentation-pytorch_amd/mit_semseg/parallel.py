@@ -146,7 +146,7 @@ class GradientBuckets:
             ev.record()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                ops.allreduce_sum(flat, self.group)
+                ops.allreduce_sum(flat, self.group, channel='bucket')
         else:
             self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
