@@ -101,7 +101,7 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
 // software-pipelined fragment reads.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 7 : 1) : (sch == SchH2::ID ? 14 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 7 : 1) : (sch == SchH2::ID ? 17 : 3); }
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
@@ -1007,9 +1007,9 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[15][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
+static const int kTiles[18][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
                                    {256, 128}, {256, 256}, {128, 128}, {256, 128}, {256, 256}, {256, 128}, {256, 128},
-                                   {256, 256}};
+                                   {256, 256}, {64, 64}, {128, 64}, {64, 64}};
 
 // Launch plan: same wave-quantisation model as plan_igemm (conv_igemm.hip) -- tile x split-K candidates, cost =
 // waves * (k-tiles per block * tile cost + fixed) + split-K slab traffic.  The LDS-DMA tiles (3..5) are chosen by the
@@ -1149,6 +1149,18 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
         case 14:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 256, 4, 4, 12>(p, st);      // 16 waves, 64x64 per wave
+            break;
+        // small tiles on the LDS-DMA ring (4 waves): the register-staged igemm_rs_kernel keeps ONE k-tile in flight and pays two
+        // barriers per tile -- on the short-M layers (HRNet's 192 / 384-channel branches, layer1 / layer2) a 64x64 block multiplies
+        // for 0.1 us per k-tile and waits ~1 us for the next; the ring keeps two tiles in flight behind one barrier
+        case 15:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 64, 64, 2, 2, 13>(p, st);
+            break;
+        case 16:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 64, 2, 2, 13>(p, st);
+            break;
+        case 17:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 64, 64, 2, 2, 12>(p, st);
             break;
     }
     if (rc) return rc;

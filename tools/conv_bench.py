@@ -33,6 +33,14 @@ LAYERS = [
     ('l2_conv2',      2, 128, 64, 64, 128,   3, 1, 1, 1, 3),
     ('ppm_1x1_s6',    2, 2048, 6, 6, 512,    1, 1, 0, 1, 1),
     ('cls',           2, 512, 64, 64, 150,   1, 1, 0, 1, 2),
+    # HRNetV2-W48 branches (hrnet.py: 4 x BasicBlock per branch and module)
+    ('hr_48',         2, 48, 128, 128, 48,   3, 1, 1, 1, 64),
+    ('hr_96',         2, 96,  64, 64, 96,    3, 1, 1, 1, 64),
+    ('hr_192',        2, 192, 32, 32, 192,   3, 1, 1, 1, 56),
+    ('hr_384',        2, 384, 16, 16, 384,   3, 1, 1, 1, 24),
+    ('l1_conv1',      2, 256, 128, 128, 64,  1, 1, 0, 1, 2),
+    ('l1_conv3',      2, 64, 128, 128, 256,  1, 1, 0, 1, 3),
+    ('l2_conv3',      2, 128, 64, 64, 512,   1, 1, 0, 1, 4),
 ]
 
 
@@ -133,9 +141,9 @@ def main():
                     cfgs += [('t%d_s%d' % (t, sp), {pre + '_TILE': str(t), pre + '_SPLIT': str(sp)})
                              for t in wtiles for sp in (1, 2, 4, 8, 16)]
                 elif which != 'split':
-                    tiles = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14) if args.mode == 'h2' else (0, 1, 2, 3)
+                    tiles = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17) if args.mode == 'h2' else (0, 1, 2, 3)
                     cfgs += [('t%d_s%d' % (t, sp), {pre2 + '_TILE': str(t), pre2 + '_SPLITK': str(sp)})
-                             for t in tiles for sp in (1, 2, 4, 8)]
+                             for t in tiles for sp in (1, 2, 4, 8, 16)]
             ref = None
             if args.verify and which != 'split':
                 for kk in list(os.environ):
