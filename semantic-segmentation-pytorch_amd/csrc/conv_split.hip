@@ -101,7 +101,7 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
 // software-pipelined fragment reads.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 7 : 1) : (sch == SchH2::ID ? 17 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 9 : 1) : (sch == SchH2::ID ? 18 : 3); }
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
@@ -1007,9 +1007,9 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[18][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
+static const int kTiles[19][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
                                    {256, 128}, {256, 256}, {128, 128}, {256, 128}, {256, 256}, {256, 128}, {256, 128},
-                                   {256, 256}, {64, 64}, {128, 64}, {64, 64}};
+                                   {256, 256}, {64, 64}, {128, 64}, {64, 64}, {128, 128}};
 
 // Launch plan: same wave-quantisation model as plan_igemm (conv_igemm.hip) -- tile x split-K candidates, cost =
 // waves * (k-tiles per block * tile cost + fixed) + split-K slab traffic.  The LDS-DMA tiles (3..5) are chosen by the
@@ -1161,6 +1161,9 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
         case 17:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 64, 64, 2, 2, 12>(p, st);
+            break;
+        case 18:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 2, 2, 13>(p, st);      // 4 waves, 64x64 per wave, 3-slot ring
             break;
     }
     if (rc) return rc;
@@ -1853,19 +1856,20 @@ struct WPlan {
 // wgrad tiles (k x c): 0 = 128x128, 1 = 64x64 (register staged); h2 only: 2 = 128x128 LDS-DMA 2-slot (4 waves),
 // 3 = 256x128 LDS-DMA 3-slot ring (8 waves), 4 = 256x256 LDS-DMA 2-slot (8 waves), 5 / 6 = 2 / 4 software pipelined -- chosen by
 // the tuner / overrides only
-static const int kWTiles[8][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256}};
+static const int kWTiles[10][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
+                                    {128, 128}, {128, 128}};
 
 // tuning overrides: SEMSEG_W3_TILE=0..3, SEMSEG_W3_SPLIT=n
 static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_split = 0) {
     WPlan pl;
     const int mtiles = ceil_div(M, 32);
-    const double tile_cost[8] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0};
-    const int slots[8] = {512, 1024, 512, 256, 256, 512, 256, 256};
+    const double tile_cost[10] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0, 1.0, 1.0};
+    const int slots[10] = {512, 1024, 512, 256, 256, 512, 256, 256, 512, 512};
     const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_W3_TILE", -1);
     const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_W3_SPLIT", 0);
     double best = 1e30;
     int best_t = 1, best_s = 1;
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < 10; ++t) {
         if (force_tile >= 0 && t != force_tile) continue;
         if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
@@ -1994,6 +1998,12 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
             break;
         case 7:
             if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 256, 256, 4, 4, 12>(p, st);     // 16 waves
+            break;
+        case 8:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 2, 12>(p, st);     // 8 waves, 32x64 per wave
+            break;
+        case 9:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 4, 12>(p, st);     // 16 waves, 32x32 per wave
             break;
     }
     if (rc) return rc;

@@ -597,7 +597,7 @@ PLAN_CASES = [
 
 
 @pytest.mark.parametrize('case', PLAN_CASES, ids=str)
-@pytest.mark.parametrize('pass_id,tile', [(0, t) for t in range(18)] + [(1, t) for t in range(18)] + [(2, t) for t in range(8)])
+@pytest.mark.parametrize('pass_id,tile', [(0, t) for t in range(19)] + [(1, t) for t in range(19)] + [(2, t) for t in range(10)])
 @pytest.mark.parametrize('split', [1, 3])
 def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
     from mit_semseg import ops, _native, tuner
