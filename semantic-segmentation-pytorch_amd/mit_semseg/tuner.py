@@ -144,10 +144,12 @@ def ensure(scheme, pass_id, geom, launch):
         return
     stats['timed'] += 1
     best = None
+    ranked = []                                     # (ms, tile, split) of every candidate that ran
     try:
         launch()                                    # heuristic plan first (also warms caches / sizes the workspace)
         base = _time(launch, 2)
         best = (-1, 0, base)
+        ranked.append((base, -1, 0))
         for tile in tiles:
             for split in (_WSPLITS if pass_id == 2 else _SPLITS):
                 if split > 1 and kt // split < 4:
@@ -158,10 +160,28 @@ def ensure(scheme, pass_id, geom, launch):
                     ms = _time(launch, 2)
                 except RuntimeError:
                     continue
+                ranked.append((ms, tile, split))
                 if ms < best[2]:
                     best = (tile, split, ms)
                 if ms > 3.0 * best[2] and split >= 4:
                     break
+        # play-off: with ~200 candidates per geometry a 5 % timing outlier picks the wrong plan now and then; the three
+        # fastest are timed again (more launches per round) and the best mean of the two measurements wins
+        ranked.sort()
+        finals = []
+        for ms, tile, split in ranked[:3]:
+            if tile < 0:
+                set_plan(pass_id, *geom, -1, 0)
+            else:
+                _native.check(set_plan(pass_id, *geom, tile, split), 'set_plan')
+            try:
+                launch()
+                finals.append((0.5 * (ms + _time(launch, 4)), tile, split))
+            except RuntimeError:
+                continue
+        if finals:
+            ms, tile, split = min(finals)
+            best = (tile, split, ms)
     finally:
         if best is None or best[0] < 0:
             set_plan(pass_id, *geom, -1, 0)
