@@ -237,17 +237,6 @@ int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const float* y, int y
                                int training, double* sums, float* dgamma, float* dbeta, void* blockbound,
                                void* workspace, size_t workspace_bytes, void* stream);
 
-/* semseg_conv2d_fwd_h2 (bias-free) + semseg_bn_fwd_stats_fused of its dense output z [N*OH*OW][K] in one entry point (the conv ->
- * BN node of resnet.py:72-92 on one rank): when the convolution runs split-K, its partial slabs are summed inside the
- * statistics pass (fixed order) -- one launch and one full read of z less; results are bit-identical to the two calls.
- * Workspace: semseg_conv2d_fwd_bnstats_h2_workspace_bytes(geometry). */
-size_t semseg_conv2d_fwd_bnstats_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
-int semseg_conv2d_fwd_bnstats_h2(const void* xs, const void* ws, float* z, int N, int H, int W, int C, int K, int R, int S,
-                                 int stride, int pad, int dil, double* stats, float* zmm, const float* gamma, const float* beta,
-                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                                 float eps, int relu, const float* res_absmax, float* mean, float* invstd, float* scale,
-                                 float* shift, void* blockbound, void* workspace, size_t workspace_bytes, void* stream);
-
 /* ---------------- elementwise helpers ------------------------------------------------------ */
 /* out = act(a + b) (hrnet.py:231-248 fuse sums); a,b,out [P,C] with their own ld */
 int semseg_add_act(const float* a, int a_ld, const float* b, int b_ld, int relu, float* out, int out_ld,

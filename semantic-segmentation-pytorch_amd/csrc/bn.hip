@@ -1080,115 +1080,6 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     }
 }
 
-// bn_stats_mm_partial_kernel over z = sum_s partial[s] (split-K slabs of the convolution that produced z), which it also writes:
-// the separate split_gemm_reduce launch and one full read of z disappear.  Slab sum in the order of split_gemm_reduce_kernel,
-// statistics in the order of bn_stats_mm_partial_kernel: bit-identical to the two-kernel form.
-__global__ __launch_bounds__(256) void bn_stats_mm_partial_reduce_kernel(const float* __restrict__ slabs, int splits,
-                                                                         float* __restrict__ z, int P, int C, int cx, int py,
-                                                                         int rows_per_block, double* __restrict__ partial,
-                                                                         float* __restrict__ mm) {
-    extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][8] floats
-    float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
-    const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
-    const int quad = blockIdx.x * cx + tx;
-    const int c = quad * 4;
-    const int row0 = blockIdx.y * rows_per_block;
-    const int row1 = min(P, row0 + rows_per_block);
-    const size_t total = (size_t)P * C;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-    float4 hi = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    const bool active = (ty < py) && (c < C);
-    if (active) {
-        auto acc = [&](const float4 v) {
-            const double x = v.x, y = v.y, zz = v.z, w = v.w;
-            a0 += x; a1 += y; a2 += zz; a3 += w;
-            q0 = fma(x, x, q0); q1 = fma(y, y, q1); q2 = fma(zz, zz, q2); q3 = fma(w, w, q3);
-            lo.x = fminf(lo.x, v.x); lo.y = fminf(lo.y, v.y); lo.z = fminf(lo.z, v.z); lo.w = fminf(lo.w, v.w);
-            hi.x = fmaxf(hi.x, v.x); hi.y = fmaxf(hi.y, v.y); hi.z = fmaxf(hi.z, v.z); hi.w = fmaxf(hi.w, v.w);
-        };
-        auto reduce_row = [&](int p) {
-            const size_t o = (size_t)p * C + c;
-            float4 s = *reinterpret_cast<const float4*>(slabs + o);
-            for (int zz = 1; zz < splits; ++zz) {
-                const float4 t = *reinterpret_cast<const float4*>(slabs + (size_t)zz * total + o);
-                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-            }
-            *reinterpret_cast<float4*>(z + o) = s;
-            return s;
-        };
-        constexpr int U = 4;                        // rows in flight (each row is `splits` loads)
-        int p = row0 + ty;
-        for (; p + (U - 1) * py < row1; p += U * py) {
-            float4 v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = reduce_row(p + u * py);
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc(v[u]);
-        }
-        for (; p < row1; p += py) acc(reduce_row(p));
-    }
-    if (ty < py) {
-        double* r = red + ((size_t)ty * cx + tx) * 8;
-        r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
-        r[4] = q0; r[5] = q1; r[6] = q2; r[7] = q3;
-        float* f = redf + ((size_t)ty * cx + tx) * 8;
-        f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w;
-        f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
-    }
-    __syncthreads();
-    if (ty == 0 && c < C) {
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        for (int y = 0; y < py; ++y) {
-            const double* r = red + ((size_t)y * cx + tx) * 8;
-            const float* f = redf + ((size_t)y * cx + tx) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += r[e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                mn[e] = fminf(mn[e], f[e]);
-                mx[e] = fmaxf(mx[e], f[4 + e]);
-            }
-        }
-        double* o = partial + (size_t)blockIdx.y * 2 * C;
-        float* of = mm + (size_t)blockIdx.y * 2 * C;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[c + e] = a[e];
-            o[C + c + e] = a[4 + e];
-            of[c + e] = mn[e];
-            of[C + c + e] = mx[e];
-        }
-    }
-}
-
-int semseg_internal_bn_stats_of_conv(const float* slabs, int splits, float* z, int P, int C, const SemsegBnStats& a,
-                                     hipStream_t st) {
-    if (!z || !a.stats || !a.zmm || !a.gamma || !a.beta || !a.mean || !a.invstd || !a.scale || !a.shift || !a.blockbound ||
-        P <= 0 || C <= 0 || (C % 4) || !aligned16(z) || (slabs && !aligned16(slabs)))
-        return SEMSEG_EINVAL;
-    const ColGeom g = col_geom(P, C);
-    const size_t need = (size_t)g.gy * 2 * C * (sizeof(double) + sizeof(float));
-    if (!a.workspace || a.workspace_bytes < need) return SEMSEG_EWORKSPACE;
-    double* partial = (double*)a.workspace;
-    float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
-    const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
-    if (slabs && splits > 1)
-        hipLaunchKernelGGL(bn_stats_mm_partial_reduce_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, slabs, splits, z, P, C, g.cx,
-                           g.py, g.rows_per_block, partial, mm);
-    else
-        hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, (const float*)z, P, C, g.cx, g.py,
-                           g.rows_per_block, partial, mm);
-    SEMSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_fwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
-                       (const float*)mm, g.gy, C, (double)P, a.gamma, a.beta, a.running_mean, a.running_var, a.momentum, a.eps,
-                       a.relu, a.res_absmax, a.stats, a.zmm, a.mean, a.invstd, a.scale, a.shift, a.num_batches_tracked,
-                       (uint32_t*)a.blockbound);
-    SEMSEG_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var,
                                          int64_t* num_batches_tracked, float momentum, float eps, int relu,

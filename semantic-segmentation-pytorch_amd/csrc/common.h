@@ -58,15 +58,3 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (b >> 3);
 }
-
-// ---- internal (not part of the C ABI): single-rank BN statistics of a conv output, csrc/bn.hip, called from csrc/conv_split.hip
-struct SemsegBnStats {
-    double* stats; float* zmm; const float* gamma; const float* beta; float* running_mean; float* running_var;
-    int64_t* num_batches_tracked; float momentum, eps; int relu; const float* res_absmax;
-    float* mean; float* invstd; float* scale; float* shift; void* blockbound;
-    void* workspace; size_t workspace_bytes;         // semseg_bn_mm_workspace_bytes(P, C)
-};
-// z[p][c] = sum_s partial[s][p][c] (the fixed-order split-K reduce; partial == nullptr: z is read as it is) + the statistics
-// pass (sum, sum^2, min, max) over z in the SAME sweep + the finish / finalize kernel of semseg_bn_fwd_stats_fused
-int semseg_internal_bn_stats_of_conv(const float* partial, int splits, float* z, int P, int C, const SemsegBnStats& a,
-                                     hipStream_t st);

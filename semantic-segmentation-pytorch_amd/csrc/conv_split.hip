@@ -1089,7 +1089,7 @@ static int launch_dma(const SParams& p, hipStream_t st) {
 
 template <class SCH>
 static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* workspace, size_t workspace_bytes,
-                    hipStream_t st, const SemsegBnStats* bn = nullptr) {
+                    hipStream_t st) {
     const size_t in_plane = in_rows * p.pitch, w_plane = (size_t)p.Cout * p.T * p.pitch;
     if (2 * SCH::NP * in_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
         2 * SCH::NP * w_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31))
@@ -1167,11 +1167,6 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
     }
     if (rc) return rc;
-    if (bn) {
-        // the conv feeds a single-rank training-mode BN: its statistics pass does the split-K reduce on the way (bn.hip)
-        if (p.out_ld != p.Cout || p.bias || p.addend || p.batches > 1) return SEMSEG_EINVAL;
-        return semseg_internal_bn_stats_of_conv(pl.splits > 1 ? p.partial : nullptr, pl.splits, p.out, p.M, p.Cout, *bn, st);
-    }
     if (pl.splits > 1) {
         const size_t total = (size_t)p.M * p.Cout;
         const bool vec = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && aligned16(p.out) && aligned16(p.partial) &&
@@ -1200,7 +1195,7 @@ static inline int out_dim(int in, int k, int stride, int pad, int dil) {
 template <class SCH>
 static int conv_fwd(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                    void* workspace, size_t workspace_bytes, void* stream, const SemsegBnStats* bn = nullptr) {
+                    void* workspace, size_t workspace_bytes, void* stream) {
     if (!xs || !ws || !y || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0 || y_ld < K) return SEMSEG_EINVAL;
     if (!aligned16(xs) || !aligned16(ws)) return SEMSEG_EINVAL;
     const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
@@ -1219,7 +1214,7 @@ static int conv_fwd(const void* xs, const void* ws, const float* bias, float* y,
     }
     int ov_tile = -1, ov_split = 0;
     lookup_plan(SCH::ID, 0, N, H, W, C, K, R, S, stride, pad, dil, &ov_tile, &ov_split);
-    return run_gemm<SCH>(p, (size_t)N * H * W, ov_tile, ov_split, workspace, workspace_bytes, (hipStream_t)stream, bn);
+    return run_gemm<SCH>(p, (size_t)N * H * W, ov_tile, ov_split, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 template <class SCH>
@@ -2113,32 +2108,4 @@ extern "C" size_t semseg_conv2d_s3_workspace_bytes(int N, int H, int W, int C, i
 extern "C" size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                                                    int dil) {
     return split_conv_workspace_bytes(SchH2::ID, N, H, W, C, K, R, S, stride, pad, dil);
-}
-
-// conv forward (h2) + the single-rank BN statistics of its output in one entry point: semseg_conv2d_fwd_h2 followed by
-// semseg_bn_fwd_stats_fused, except that a split-K convolution's reduce launch is folded into the statistics pass.
-// Workspace: the conv part first, the BN partial sums behind it (256-byte aligned).
-static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-extern "C" size_t semseg_bn_mm_workspace_bytes(int P, int C);
-extern "C" size_t semseg_conv2d_fwd_bnstats_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride,
-                                                               int pad, int dil) {
-    const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
-    if (OH <= 0 || OW <= 0) return 0;
-    return align256(split_conv_workspace_bytes(SchH2::ID, N, H, W, C, K, R, S, stride, pad, dil)) +
-           semseg_bn_mm_workspace_bytes(N * OH * OW, K);
-}
-extern "C" int semseg_conv2d_fwd_bnstats_h2(const void* xs, const void* ws, float* z, int N, int H, int W, int C, int K, int R,
-                                            int S, int stride, int pad, int dil, double* stats, float* zmm, const float* gamma,
-                                            const float* beta, float* running_mean, float* running_var,
-                                            int64_t* num_batches_tracked, float momentum, float eps, int relu,
-                                            const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
-                                            void* blockbound, void* workspace, size_t workspace_bytes, void* stream) {
-    const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
-    if (OH <= 0 || OW <= 0 || !workspace) return SEMSEG_EINVAL;
-    const size_t conv_b = align256(split_conv_workspace_bytes(SchH2::ID, N, H, W, C, K, R, S, stride, pad, dil));
-    const size_t bn_b = semseg_bn_mm_workspace_bytes(N * OH * OW, K);
-    if (workspace_bytes < conv_b + bn_b) return SEMSEG_EWORKSPACE;
-    const SemsegBnStats bn{stats, zmm, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu,
-                           res_absmax, mean, invstd, scale, shift, blockbound, (char*)workspace + conv_b, bn_b};
-    return conv_fwd<SchH2>(xs, ws, nullptr, z, K, N, H, W, C, K, R, S, stride, pad, dil, workspace, conv_b, stream, &bn);
 }

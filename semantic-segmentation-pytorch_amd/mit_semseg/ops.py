@@ -297,8 +297,6 @@ WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '1024'))
 # in-box A/B (gpurun wg1) 16.50 -> 16.02 ms per step.  SEMSEG_WINOGRAD_WGRAD=0 disables.
 WINOGRAD_WGRAD = os.environ.get('SEMSEG_WINOGRAD_WGRAD', '1') != '0'
 WINOGRAD_EVAL = os.environ.get('SEMSEG_WINOGRAD_EVAL', '0') == '1'
-# conv forward + BN statistics through one entry point (the split-K reduce folded into the statistics pass)
-CONV_STATS = os.environ.get('SEMSEG_CONV_STATS', '1') != '0'
 
 
 def _wino_eligible(k, c, r, s):
@@ -859,11 +857,7 @@ class ConvBNActFn(Function):
                 _native.check(sch.fn(L, 'fwd')(_p(xp), _p(wsp), _p(None), _p(z), k, *geom, _p(ws), ws.numel(), _st()),
                               'conv2d_fwd_h2')
             tuner.ensure('h2', 0, geom, launch)
-            # one rank: the conv and the statistics pass of its BN go through ONE entry point, which folds a split-K reduce into
-            # the statistics sweep (csrc/bn.hip bn_stats_mm_partial_reduce_kernel); SEMSEG_CONV_STATS=0: the two separate calls
-            conv_stats = CONV_STATS and not _sync_active() and emit and (residual is None or res_absmax is not None)
-            if not conv_stats:
-                launch()
+            launch()
         stats = torch.empty((2 * k + 1,), device=dev, dtype=torch.float64)
         zmm = torch.empty((2 * k,), device=dev, dtype=torch.float32)
         ws = workspace(L.semseg_bn_mm_workspace_bytes(P, k), dev)
@@ -879,18 +873,10 @@ class ConvBNActFn(Function):
         if single and yp is not None:
             # one rank: finish + finalize in one kernel; the apply kernel derives the exponent from the per-block bounds
             bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
-            if wino is None and conv_stats:
-                wsf = workspace(L.semseg_conv2d_fwd_bnstats_h2_workspace_bytes(*geom), dev)
-                _native.check(L.semseg_conv2d_fwd_bnstats_h2(_p(xp), _p(wsp), _p(z), *geom, _p(stats), _p(zmm), _p(g), _p(b),
-                                                             _p(running_mean), _p(running_var), _p(nbt), float(momentum),
-                                                             float(eps), int(relu), _p(res_absmax), _p(coef[0]), _p(coef[1]),
-                                                             _p(coef[2]), _p(coef[3]), _p(bb), _p(wsf), wsf.numel(), _st()),
-                              'conv2d_fwd_bnstats_h2')
-            else:
-                _native.check(L.semseg_bn_fwd_stats_fused(_p(z), P, k, _p(stats), _p(zmm), _p(g), _p(b), _p(running_mean),
-                                                          _p(running_var), _p(nbt), float(momentum), float(eps), int(relu),
-                                                          _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
-                                                          _p(bb), _p(ws), ws.numel(), _st()), 'bn_fwd_stats_fused')
+            _native.check(L.semseg_bn_fwd_stats_fused(_p(z), P, k, _p(stats), _p(zmm), _p(g), _p(b), _p(running_mean),
+                                                      _p(running_var), _p(nbt), float(momentum), float(eps), int(relu),
+                                                      _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
+                                                      _p(bb), _p(ws), ws.numel(), _st()), 'bn_fwd_stats_fused')
             _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), _p(yp),
                                                P, k, _p(bb), _p(absmax), _st()), 'bn_apply_h2')
         else:

@@ -871,46 +871,3 @@ def test_eval_mode_winograd_forward_matches_direct(monkeypatch):
     scale = ref.abs().max().item()
     assert (y.cpu().double() - ref).abs().max().item() < 2e-5 * scale
     assert (y_direct.cpu().double() - ref).abs().max().item() < 2e-5 * scale
-
-
-@pytest.mark.parametrize('case,tile,split', [((2, 256, 24, 24, 384, 3, 1, 2, 2), 9, 4), ((2, 512, 16, 16, 256, 1, 1, 0, 1), 2, 3),
-                                             ((2, 64, 40, 40, 128, 3, 1, 1, 1), 14, 1), ((2, 96, 32, 32, 96, 3, 1, 1, 1), 15, 2),
-                                             ((2, 128, 17, 19, 64, 1, 2, 0, 1), -1, 0)], ids=str)
-@pytest.mark.parametrize('res', [False, True])
-def test_conv_bnstats_entry_equals_two_calls(case, tile, split, res, monkeypatch):
-    """semseg_conv2d_fwd_bnstats_h2 (conv forward + single-rank BN statistics; a split-K reduce folded into the statistics sweep)
-    against semseg_conv2d_fwd_h2 + semseg_bn_fwd_stats_fused under the same pinned plan: z, the sums, min / max, coefficients,
-    running statistics and the per-block bounds are bit-identical"""
-    from mit_semseg import ops, _native, tuner
-    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
-    monkeypatch.setattr(tuner, 'ENABLED', False)
-    n, c, h, w, k, ks, stride, pad, dil = case
-    geom = (n, h, w, c, k, ks, ks, stride, pad, dil)
-    L = _native.lib()
-    if tile >= 0:
-        _native.check(L.semseg_conv2d_h2_set_plan(0, *geom, tile, split), 'set_plan')
-    try:
-        g = torch.Generator().manual_seed(hash(case) & 0xffff)
-        x = cl(torch.randn(n, c, h, w, generator=g))
-        wt = torch.nn.Parameter(cl(torch.randn(k, c, ks, ks, generator=g) / (c * ks * ks) ** 0.5))
-        gam, bet = (torch.rand(k, generator=g) + 0.5).to(dev()), (torch.randn(k, generator=g) * 0.1).to(dev())
-        oh = (h + 2 * pad - dil * (ks - 1) - 1) // stride + 1
-        ow = (w + 2 * pad - dil * (ks - 1) - 1) // stride + 1
-        r = cl(torch.randn(n, k, oh, ow, generator=g)) if res else None
-        if r is not None:
-            ops.attach_absmax(r, r.abs().max().reshape(1))
-        outs = {}
-        for flag in (False, True):
-            monkeypatch.setattr(ops, 'CONV_STATS', flag)
-            rm, rv, nbt = torch.zeros(k, device=dev()), torch.ones(k, device=dev()), torch.zeros((), dtype=torch.long, device=dev())
-            y = ops.conv_bn_act(x, wt, gam, bet, rm, rv, nbt, residual=r, stride=stride, padding=pad, dilation=dil, training=True,
-                                relu=True)
-            torch.cuda.synchronize()
-            planes = ops.planes_of(y, 'h2', n * oh * ow, k)
-            outs[flag] = (y.detach().clone(), rm, rv, int(nbt.item()), planes.clone(), ops.absmax_of(y).clone())
-        a, b = outs[False], outs[True]
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3] == 1
-        assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
-    finally:
-        if tile >= 0:
-            L.semseg_conv2d_h2_set_plan(0, *geom, -1, 0)

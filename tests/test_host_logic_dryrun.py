@@ -80,8 +80,7 @@ def test_train_step_host_logic(stub, cfg, mode, monkeypatch):
             'h2': ('semseg_split_h2', 'semseg_conv2d_fwd_h2', 'semseg_conv2d_dgrad_h2', 'semseg_conv2d_wgrad_h2',
                    'semseg_bias_grad')}[mode]
     # h2: conv -> BN pairs run as the fused node (BN kernels that emit / consume split planes, multi-tensor weight prep)
-    # (the conv forward and the BN statistics of its output share one entry point)
-    bn = ('semseg_conv2d_fwd_bnstats_h2', 'semseg_bn_apply_h2', 'semseg_bn_bwd_reduce_fused', 'semseg_bn_bwd_apply_h2',
+    bn = ('semseg_bn_fwd_stats_fused', 'semseg_bn_apply_h2', 'semseg_bn_bwd_reduce_fused', 'semseg_bn_bwd_apply_h2',
           'semseg_weights_prepare_h2') if mode == 'h2' else \
          ('semseg_bn_stats', 'semseg_bn_apply', 'semseg_bn_bwd_reduce', 'semseg_bn_bwd_apply')
     for must in conv + bn + ('semseg_log_softmax_fwd', 'semseg_nll_acc_fwd', 'semseg_nll_bwd', 'semseg_sgd_step'):
