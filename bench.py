@@ -232,7 +232,7 @@ def cpu_baseline(cfg, steps=3):
         return {'value': None, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
 
 
-def ddp_graph_selftest(timeout_s=150):
+def ddp_graph_selftest(timeout_s=240):
     """world > 1: decide what the real run may rely on.  Every rank runs tools/probes/ddp_graph_selftest.py (a small model through
     exactly the data-parallel code paths) in a CHILD process, on its own rendezvous port, BEFORE this process touches the GPU or
     RCCL; a child that fails or does not finish in time is killed.  Returns the stages this rank's child reached:
@@ -247,6 +247,7 @@ def ddp_graph_selftest(timeout_s=150):
     env['MASTER_PORT'] = str(int(env.get('MASTER_PORT', '29500')) + 17)
     env.pop('TORCHELASTIC_USE_AGENT_STORE', None)       # rank 0 of the children opens its own store on the new port
     env.pop('SEMSEG_TUNE_CACHE', None)
+    env['SEMSEG_TUNE'] = '0'                 # the library's heuristic launch plans: the child checks mechanisms, not speed
     script = os.path.join(ROOT, 'tools', 'probes', 'ddp_graph_selftest.py')
     out, rc, why = '', None, 'not started'
     with tempfile.TemporaryFile() as log:
