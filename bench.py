@@ -232,12 +232,17 @@ def cpu_baseline(cfg, steps=3):
         return {'value': None, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
 
 
+STAGES = ('comm', 'peer', 'segmented', 'graph')
+
+
 def ddp_graph_selftest(timeout_s=240):
     """world > 1: decide what the real run may rely on.  Every rank runs tools/probes/ddp_graph_selftest.py (a small model through
     exactly the data-parallel code paths) in a CHILD process, on its own rendezvous port, BEFORE this process touches the GPU or
     RCCL; a child that fails or does not finish in time is killed.  Returns the stages this rank's child reached:
       'comm'       the C ABI's own RCCL communicator came up and summed correctly (else the real run sets SEMSEG_NATIVE_COMM=0
                    and the collectives go through torch.distributed),
+      'peer'       the one-node peer exchange of the SyncBN payloads (csrc/peer.hip: IPC-mapped inboxes, xGMI peer stores) came
+                   up on every rank and summed correctly (else SEMSEG_PEER=0: RCCL / torch.distributed carry them),
       'segmented'  the segmented hipGraph executor trained (else SEMSEG_DDP_SEGMENTED=0: eager launches),
       'graph'      the whole step, RCCL included, replayed as ONE hipGraph (then SEMSEG_DDP_GRAPH=1).
     The ranks agree on the outcome afterwards (minimum over ranks)."""
@@ -267,11 +272,21 @@ def ddp_graph_selftest(timeout_s=240):
     # the markers are printed by rank 0's child only; a non-zero rank infers its stages from its own exit code, and the
     # all-reduce(min) in main() combines them
     stages = {'comm': 'COMM_OK' in out or (env.get('RANK', '0') != '0' and rc == 0),
+              'peer': 'PEER_OK' in out or (env.get('RANK', '0') != '0' and rc == 0),
               'segmented': 'SEGMENTED_OK' in out or (env.get('RANK', '0') != '0' and rc == 0),
               'graph': rc == 0}
     if rc != 0 and env.get('RANK', '0') == '0':
         print('[bench] data-parallel self-test: %s; stages reached %s\n%s' % (why, stages, out[-1500:]), file=sys.stderr, flush=True)
     return stages
+
+
+def collectives_used(world):
+    if world == 1:
+        return None
+    from mit_semseg import comm
+    buckets = 'C ABI RCCL communicator (semseg_comm_*)' if comm.active() else 'torch.distributed'
+    syncbn = 'xGMI peer exchange kernel (semseg_peer_*)' if comm.peer_active() else buckets
+    return {'syncbn': syncbn, 'gradient_buckets': buckets}
 
 
 def main():
@@ -304,6 +319,8 @@ def main():
         selftest_ok = ddp_graph_selftest()
         if not selftest_ok['comm']:
             os.environ['SEMSEG_NATIVE_COMM'] = '0'      # before NativeDataParallel is built: torch.distributed carries the collectives
+        if not selftest_ok['peer']:
+            os.environ['SEMSEG_PEER'] = '0'
     rank, world, local = init_distributed()
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     if os.environ.get('SEMSEG_BENCH_DEVICE'):          # several ranks on one GPU (gloo): functional check of the N>1 path
@@ -311,11 +328,13 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     if selftest_ok is not None:
-        flag = torch.tensor([int(selftest_ok[k]) for k in ('comm', 'segmented', 'graph')], device=dev, dtype=torch.int32)
+        flag = torch.tensor([int(selftest_ok[k]) for k in STAGES], device=dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # every rank's child must have reached the stage
-        selftest_ok = dict(zip(('comm', 'segmented', 'graph'), (bool(v) for v in flag.tolist())))
+        selftest_ok = dict(zip(STAGES, (bool(v) for v in flag.tolist())))
         if not selftest_ok['comm']:
             os.environ['SEMSEG_NATIVE_COMM'] = '0'
+        if not selftest_ok['peer']:
+            os.environ['SEMSEG_PEER'] = '0'
         if not selftest_ok['segmented']:
             os.environ['SEMSEG_DDP_SEGMENTED'] = '0'
         if selftest_ok['graph']:
@@ -387,8 +406,7 @@ def main():
                                   'per-shape hipGraphs: %(replayed)d of the timed steps replayed (%(captured)d captured in the '
                                   'timed region), %(eager)d eager (first sight of a shape)' % timed),
                        'ddp_graph_selftest': selftest_ok,
-                       'collectives': ('C ABI RCCL communicator (semseg_comm_*)' if world > 1 and __import__('mit_semseg.comm').comm.active()
-                                       else 'torch.distributed' if world > 1 else None),
+                       'collectives': collectives_used(world),
                        'conv_path': ops_mode(),
                        'images_per_sec_per_gpu': round(per_gpu, 3),
                        'step_conv_tflops_per_gpu': round(per_gpu * gflop_img * 1e-3, 2),

@@ -441,6 +441,24 @@ int semseg_comm_allreduce_sum_f64(void* comm, double* buf, size_t count, void* s
 int semseg_comm_allreduce_sum_f64_multi(void* comm, double* const* bufs, const size_t* counts, int n, void* stream);
 int semseg_comm_destroy(void* comm);
 
+/* ---------------- one-node peer exchange for the SyncBN payloads (csrc/peer.hip) ----------------
+ * The same replacement target as above (comm.py:46-131, batchnorm.py:98-117), for the latency-bound part: an all-reduce(sum)
+ * of <= max_doubles doubles as ONE small kernel -- every rank stores its payload (data + tag in each 8-byte word) into every
+ * peer's uncached inbox over xGMI and sums, in rank order, what arrives in its own.  No RCCL, no host step, capturable into a
+ * hipGraph like any other kernel; the result is bit-identical on all ranks.
+ *   create (every rank, current device) -> handle (64-byte hipIpcMemHandle_t of the inbox; the host side carries it to the
+ *   other ranks) -> attach (one per peer; attach_local for contexts of the same process) -> allreduce ... -> destroy (after a
+ *   host-side barrier).  world <= semseg_peer_max_world() ranks of ONE node.  A rank that waits longer than timeout_s poisons
+ *   its result with NaN and raises semseg_peer_status() (SEMSEG_ECOMM) instead of hanging. */
+int semseg_peer_max_world(void);
+int semseg_peer_create(int rank, int world, int max_doubles, double timeout_s, void** peer_out);
+int semseg_peer_handle(void* peer, void* handle64);
+int semseg_peer_attach(void* peer, int src_rank, const void* handle64);
+int semseg_peer_attach_local(void* peer, int src_rank, void* other_peer);
+int semseg_peer_allreduce_sum_f64(void* peer, double* buf, size_t count, void* stream);   /* in place, on `stream` */
+int semseg_peer_status(void* peer);                    /* 0, or SEMSEG_ECOMM once an exchange timed out (no device sync) */
+int semseg_peer_destroy(void* peer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,14 @@ SIGNATURES = {
     'semseg_comm_allreduce_sum_f64': (c_int, [vp, vp, c_sz, vp]),
     'semseg_comm_allreduce_sum_f64_multi': (c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(c_sz), c_int, vp]),
     'semseg_comm_destroy': (c_int, [vp]),
+    'semseg_peer_max_world': (c_int, []),
+    'semseg_peer_create': (c_int, [c_int, c_int, c_int, ctypes.c_double, ctypes.POINTER(vp)]),
+    'semseg_peer_handle': (c_int, [vp, vp]),
+    'semseg_peer_attach': (c_int, [vp, c_int, vp]),
+    'semseg_peer_attach_local': (c_int, [vp, c_int, vp]),
+    'semseg_peer_allreduce_sum_f64': (c_int, [vp, vp, c_sz, vp]),
+    'semseg_peer_status': (c_int, [vp]),
+    'semseg_peer_destroy': (c_int, [vp]),
 }
 
 

@@ -98,9 +98,12 @@ def init(group=None, selftest=True):
 
 
 def allreduce_sum(buf, group=None, channel='sync'):
-    """In-place sum over the ranks on the CURRENT stream through the communicator of `channel` ('sync': the compute stream's
-    SyncBN payloads; 'bucket': the gradient buckets on their side stream); returns False if no native communicator serves
+    """In-place sum over the ranks on the CURRENT stream: channel 'sync' (the compute stream's SyncBN payloads) through the
+    one-node peer exchange when it is up, else -- and channel 'bucket', the gradient buckets on their side stream, always --
+    through the RCCL communicator of the channel; returns False if no native communicator serves
     `group` (or the dtype is not one the ABI carries) -- the caller then uses torch.distributed."""
+    if channel == 'sync' and _PEERS and peer_allreduce_sum(buf, group):
+        return True
     rec = _COMMS.get(_key(group))
     if rec is None or not buf.is_cuda or not buf.is_contiguous():
         return False
@@ -114,6 +117,122 @@ def allreduce_sum(buf, group=None, channel='sync'):
         return False
     _native.check(fn(rec[channel], ctypes.c_void_p(buf.data_ptr()), buf.numel(), st), 'comm_allreduce_sum')
     return True
+
+
+# ------------------------------------------------------------------------------------------------
+# one-node peer exchange (csrc/peer.hip): the SyncBN payloads as ONE small kernel over xGMI peer stores
+# ------------------------------------------------------------------------------------------------
+_PEERS = {}          # id(group) -> dict(handle, rank, world, cap)
+PEER_MAX_DOUBLES = 2 * 4096 + 1          # [sum, sum^2, n] of a 4096-channel BN
+
+
+def peer_enabled():
+    """SEMSEG_PEER=0 (read when the exchange would be built): SyncBN payloads stay with RCCL / torch.distributed"""
+    return os.environ.get('SEMSEG_PEER', '1') != '0'
+
+
+def peer_active(group=None):
+    return _key(group) in _PEERS
+
+
+def _same_host(group):
+    import socket
+    import torch.distributed as dist
+    names = [None] * dist.get_world_size(group)
+    dist.all_gather_object(names, socket.gethostname(), group=group)
+    return len(set(names)) == 1
+
+
+def peer_init(group=None, max_doubles=PEER_MAX_DOUBLES, selftest=True):
+    """Bring up the peer exchange among the ranks of `group` (all on ONE node, at most semseg_peer_max_world() of them; any
+    torch.distributed backend -- it only carries the 64-byte IPC handles).  Collective.  Every rank creates its inbox on its
+    current device, the handles travel by all_gather, every rank maps the others' inboxes; a known-sum self-test over more
+    exchanges than the protocol has slots; unanimous or torn down everywhere (False: RCCL / torch.distributed then carry the payloads)."""
+    import torch.distributed as dist
+    if not peer_enabled() or not (dist.is_available() and dist.is_initialized()) or not torch.cuda.is_available():
+        return False
+    if _key(group) in _PEERS:
+        return True
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    L = _native.lib()
+    if world <= 1 or world > L.semseg_peer_max_world() or not _same_host(group):
+        return False
+    timeout_s = float(os.environ.get('SEMSEG_PEER_TIMEOUT_S', '120'))
+    handle = ctypes.c_void_p()
+    ok = L.semseg_peer_create(rank, world, max_doubles, timeout_s, ctypes.byref(handle)) == 0
+    mine = (ctypes.c_ubyte * 64)()
+    ok = ok and L.semseg_peer_handle(handle, mine) == 0
+    handles = [None] * world
+    dist.all_gather_object(handles, bytes(mine) if ok else None, group=group)
+    ok = ok and all(h is not None for h in handles)
+    if ok:
+        for r, h in enumerate(handles):
+            if r != rank and L.semseg_peer_attach(handle, r, (ctypes.c_ubyte * 64)(*h)) != 0:
+                ok = False
+                break
+    # every rank knows whether every rank could map every inbox BEFORE anybody launches an exchange (an exchange with a rank
+    # that is not taking part would only end by its timeout)
+    ok = _unanimous(ok, group)
+    if ok and selftest:
+        dev = torch.device('cuda', torch.cuda.current_device())
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        want = world * (world + 1) / 2.0
+        for n in (3, 257, max_doubles, 1025, 64, 2049, 5):       # 7 exchanges > 4 slots: reuse is exercised
+            a = torch.full((n,), float(rank + 1), dtype=torch.float64, device=dev)
+            a[0] = 1.0 / (rank + 1)                                # an order-sensitive sum: bit-identical on all ranks or not at all
+            ok = ok and L.semseg_peer_allreduce_sum_f64(handle, ctypes.c_void_p(a.data_ptr()), n, st) == 0
+            torch.cuda.synchronize()
+            first = 0.0
+            for r in range(world):
+                first = first + 1.0 / (r + 1)
+            ok = ok and L.semseg_peer_status(handle) == 0 and bool((a[1:] == want).all()) and float(a[0].item()) == first
+        ok = _unanimous(ok, group)
+    if not ok:
+        if handle:
+            dist.barrier(group=group)
+            L.semseg_peer_destroy(handle)
+        return False
+    _PEERS[_key(group)] = dict(handle=handle, rank=rank, world=world, cap=max_doubles)
+    return True
+
+
+def _unanimous(ok, group):
+    import torch.distributed as dist
+    votes = [None] * dist.get_world_size(group)
+    dist.all_gather_object(votes, bool(ok), group=group)
+    return all(votes)
+
+
+def peer_allreduce_sum(buf, group=None):
+    """In-place sum of a float64 payload over the ranks, one kernel on the CURRENT stream (capturable); False if the peer exchange
+    does not serve `group` or the payload does not fit."""
+    rec = _PEERS.get(_key(group))
+    if rec is None or buf.dtype != torch.float64 or not buf.is_cuda or not buf.is_contiguous() or buf.numel() > rec['cap']:
+        return False
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _native.check(_native.lib().semseg_peer_allreduce_sum_f64(rec['handle'], ctypes.c_void_p(buf.data_ptr()), buf.numel(), st),
+                  'peer_allreduce_sum')
+    return True
+
+
+def peer_check(group=None):
+    """Raise if an exchange of `group` ever timed out (the kernel then poisoned its result with NaN); reads a host-mapped word,
+    no device synchronisation -- call it where the host looks at the loss anyway."""
+    rec = _PEERS.get(_key(group))
+    if rec is not None and _native.lib().semseg_peer_status(rec['handle']) != 0:
+        raise RuntimeError('peer exchange: a rank waited longer than SEMSEG_PEER_TIMEOUT_S for the payload of another rank '
+                           '(a rank died, or the ranks no longer issue the same sequence of SyncBN layers)')
+
+
+def peer_destroy(group=None):
+    """Collective: nobody unmaps an inbox another rank may still be writing to."""
+    rec = _PEERS.pop(_key(group), None)
+    if rec is not None:
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier(group=group)
+        _native.lib().semseg_peer_destroy(rec['handle'])
 
 
 def destroy(group=None):

@@ -245,6 +245,9 @@ class TrainStep:
         return 'segmented' if os.environ.get('SEMSEG_DDP_SEGMENTED', '1') != '0' else 'eager'
 
     def step(self, feed):
+        if self.world > 1:
+            from . import comm
+            comm.peer_check(self.group)       # a host-mapped word, no device sync: raises once a peer exchange has timed out
         self.adjust_learning_rate()
         self.iter += 1
         mode = self.launch_mode()

@@ -691,6 +691,9 @@ def allreduce_sum(buf, group=None, channel='sync'):
 def _maybe_allreduce(buf):
     if _SEGMENTS is not None:
         if _sync_active():
+            from . import comm
+            if comm.peer_active(_SYNC_GROUP['group']) and comm.peer_allreduce_sum(buf, _SYNC_GROUP['group']):
+                return          # the peer exchange is an ordinary kernel: it stays INSIDE the segment being captured
             _SEGMENTS.collective('allreduce', buf, _SYNC_GROUP['group'])
         return
     if _SYNC_GROUP['enabled']:

@@ -275,5 +275,5 @@ def test_bench_ddp_graph_selftest_fails_closed(monkeypatch):
                      TORCHELASTIC_USE_AGENT_STORE='True').items():
         monkeypatch.setenv(k, v)
     t = time.time()
-    assert bench.ddp_graph_selftest(timeout_s=6) == {'comm': False, 'segmented': False, 'graph': False}
+    assert bench.ddp_graph_selftest(timeout_s=6) == {'comm': False, 'peer': False, 'segmented': False, 'graph': False}
     assert time.time() - t < 30

@@ -41,12 +41,12 @@ def _joint_case():
     return enc_sd, dec_sd, img, lab, masks
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, peer):
     for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0')
+                      LOCAL_RANK='0', SEMSEG_PEER='1' if peer else '0', SEMSEG_PEER_TIMEOUT_S='20')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from mit_semseg.models import ModelBuilder, SegmentationModule
@@ -66,6 +66,7 @@ def _worker(rank, world, port, out_dir):
         dec.dropout_deepsup.mask_override = masks['deepsup'][sl].to(dev)
         sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), 0.4).to(dev).train()
         dp = NativeDataParallel(sm)                      # SyncBN on
+        assert dp.peer_exchange == peer, 'peer exchange (csrc/peer.hip, IPC-mapped inboxes) did not come up'
         ts = TrainStep(sm, lr_encoder=LR, lr_decoder=LR, max_iters=10 ** 9, bucket_bytes=8 << 20)
         assert ts.buckets is not None and len(ts.buckets.buckets) > 1
         feed = {'img_data': img[sl].to(dev), 'seg_label': lab[sl].to(dev)}
@@ -74,14 +75,20 @@ def _worker(rank, world, port, out_dir):
         torch.cuda.synchronize()
         sd = {k: v.detach().cpu().contiguous() for k, v in sm.state_dict().items()}
         torch.save(dict(loss=mloss.cpu(), acc=macc.cpu(), sd=sd), os.path.join(out_dir, 'rank%d.pt' % rank))
+        from mit_semseg import comm
+        comm.peer_check()
+        comm.peer_destroy()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_oracle_on_joint_batch():
+@pytest.mark.parametrize('peer', [True, False], ids=['peer_exchange', 'gloo_allreduce'])
+def test_two_ranks_one_gpu_match_oracle_on_joint_batch(peer):
+    """peer=True: the SyncBN payloads travel through csrc/peer.hip (each rank's inbox mapped into the other process by
+    hipIpcOpenMemHandle, one exchange kernel per BN pass); peer=False: through torch.distributed (gloo)."""
     from oracle import semseg_oracle as O
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_worker, args=(2, _free_port(), out_dir), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), out_dir, peer), nprocs=2, join=True)
         r0 = torch.load(os.path.join(out_dir, 'rank0.pt'), weights_only=False)
         r1 = torch.load(os.path.join(out_dir, 'rank1.pt'), weights_only=False)
     # replicas stay identical: same reduced gradients, same BN statistics on both ranks
@@ -154,7 +161,7 @@ def test_segmented_graph_step_equals_eager_single_rank():
         assert torch.equal(got[k], want[k]), k
 
 
-def _worker_steps(rank, world, port, out_dir, graph):
+def _worker_steps(rank, world, port, out_dir, graph, peer):
     for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -162,12 +169,14 @@ def _worker_steps(rank, world, port, out_dir, graph):
     # graphs takes 0.5-1.2 s per step (the processes' queues are multiplexed in coarse time slices); with 2 queues per process
     # it takes 37 ms against 45 ms eager (gpurun r3g).  One rank per GPU -- the deployment -- is not affected.
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '2')
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      SEMSEG_PEER='1' if peer else '0', SEMSEG_PEER_TIMEOUT_S='20')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from mit_semseg.models import ModelBuilder, SegmentationModule
         from mit_semseg.parallel import NativeDataParallel
         from mit_semseg.engine import TrainStep, SegmentedStep
+        from mit_semseg import comm
         from mit_semseg import tuner
         import time
         tuner.ENABLED = False            # heuristic launch plans: the eager and the graph processes must sum in the same order
@@ -184,7 +193,7 @@ def _worker_steps(rank, world, port, out_dir, graph):
         dec.conv_last[3].mask_override = masks['main'][sl].to(dev)
         dec.dropout_deepsup.mask_override = masks['deepsup'][sl].to(dev)
         sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), 0.4).to(dev).train()
-        NativeDataParallel(sm)
+        assert NativeDataParallel(sm).peer_exchange == peer
         ts = TrainStep(sm, lr_encoder=LR, lr_decoder=LR, max_iters=10 ** 9, bucket_bytes=8 << 20, graph=graph)
         feed = {'img_data': img[sl].to(dev), 'seg_label': lab[sl].to(dev)}
         for _ in range(4):
@@ -201,21 +210,29 @@ def _worker_steps(rank, world, port, out_dir, graph):
         sd = {k: v.detach().cpu().contiguous() for k, v in sm.state_dict().items()}
         torch.save(dict(loss=loss.cpu(), sd=sd, ms=ms, counts=ts._graph.counts() if graph else None),
                    os.path.join(out_dir, 'g%d_rank%d.pt' % (int(graph), rank)))
+        comm.peer_check()
+        comm.peer_destroy()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_segmented_graphs_equal_eager():
+@pytest.mark.parametrize('peer', [True, False], ids=['peer_exchange', 'gloo_allreduce'])
+def test_two_ranks_segmented_graphs_equal_eager(peer):
     """Two ranks on the one GPU (gloo transport), 14 data-parallel steps each: the segmented-graph executor (gradient buckets on
     the side stream, SyncBN all-reduces between segment replays) ends in exactly the replicas of the eager data-parallel
-    step -- same kernels and the same reduction order, so bit-identical -- and the ranks agree with each other."""
+    step -- same kernels and the same reduction order, so bit-identical -- and the ranks agree with each other.
+    peer=True: the SyncBN exchanges are csrc/peer.hip kernels INSIDE the captured segments (replayed with the rest), so only the
+    gradient buckets are left between the segments."""
     res = {}
     for graph in (False, True):
         with tempfile.TemporaryDirectory() as out_dir:
-            mp.spawn(_worker_steps, args=(2, _free_port(), out_dir, graph), nprocs=2, join=True)
+            mp.spawn(_worker_steps, args=(2, _free_port(), out_dir, graph, peer), nprocs=2, join=True)
             res[graph] = [torch.load(os.path.join(out_dir, 'g%d_rank%d.pt' % (int(graph), r)), weights_only=False) for r in (0, 1)]
     print('2 ranks on 1 GPU: eager %.2f ms/step, segmented graphs %.2f ms/step; segments %s' % (
         res[False][0]['ms'], res[True][0]['ms'], res[True][0]['counts']))
+    if peer:
+        c = res[True][0]['counts']
+        assert c.get('allreduce', 0) == 0 and c['graph'] == c['bucket'] + 2, c       # segments end only at the gradient buckets and the join
     for k in res[False][0]['sd']:
         assert torch.equal(res[True][0]['sd'][k], res[True][1]['sd'][k]), ('ranks differ', k)
         assert torch.equal(res[True][0]['sd'][k], res[False][0]['sd'][k]), ('segmented != eager', k)
@@ -302,3 +319,88 @@ def test_comm_abi_single_rank_rccl():
         assert L.semseg_comm_allreduce_sum_f32(comm, ctypes.c_void_p(0), 5, st) == -1       # SEMSEG_EINVAL
     finally:
         assert L.semseg_comm_destroy(comm) == 0
+
+
+def test_peer_exchange_abi_two_contexts_one_process():
+    """semseg_peer_* (csrc/peer.hip) with both "ranks" in this process (attach_local), each on its own stream: every exchange
+    returns the rank-ordered sum, bit-identical on both ranks, over more exchanges than the protocol has slots, eagerly and as
+    replayed hipGraphs (the device-resident exchange counter keeps counting); error codes; a rank without a partner times out,
+    poisons its result and raises the status instead of hanging."""
+    import ctypes
+    from mit_semseg import _native
+    L = _native.lib()
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    assert L.semseg_peer_max_world() >= 8
+    cap = 2 * 2048 + 1
+    peers = [ctypes.c_void_p(), ctypes.c_void_p()]
+    for r in (0, 1):
+        assert L.semseg_peer_create(r, 2, cap, 10.0, ctypes.byref(peers[r])) == 0 and peers[r].value
+    # two streams of ONE process must sit on different hardware queues (rank 0's kernel waits for rank 1's): a high-priority
+    # stream never shares a queue with a normal one.  (The deployment has one context per process; processes never share queues.)
+    streams = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)]
+    try:
+        x = torch.zeros(8, dtype=torch.float64, device=dev)
+        sst = ctypes.c_void_p(streams[0].cuda_stream)
+        assert L.semseg_peer_allreduce_sum_f64(peers[0], ctypes.c_void_p(x.data_ptr()), 8, sst) == -1     # peer 1 not attached yet
+        assert L.semseg_peer_attach_local(peers[0], 1, peers[1]) == 0 and L.semseg_peer_attach_local(peers[1], 0, peers[0]) == 0
+        assert L.semseg_peer_attach_local(peers[0], 1, peers[1]) == -1                                     # twice
+        assert L.semseg_peer_allreduce_sum_f64(peers[0], ctypes.c_void_p(x.data_ptr()), cap + 1, sst) == -1
+        h = (ctypes.c_ubyte * 64)()
+        assert L.semseg_peer_handle(peers[0], h) == 0 and any(h)
+
+        def exchange(bufs):
+            for r in (0, 1):
+                with torch.cuda.stream(streams[r]):
+                    st = ctypes.c_void_p(streams[r].cuda_stream)
+                    assert L.semseg_peer_allreduce_sum_f64(peers[r], ctypes.c_void_p(bufs[r].data_ptr()), bufs[r].numel(), st) == 0
+
+        g = torch.Generator().manual_seed(5)
+        for n in (1, 3, 129, 1025, cap, 2, 4097, 513, 77):            # 9 exchanges, 4 slots
+            a = [(torch.randn(n, dtype=torch.float64, generator=g) * 10 ** float(torch.randint(-3, 4, (1,), generator=g))).to(dev)
+                 for _ in (0, 1)]
+            want = a[0] + a[1]                                         # rank order 0, 1
+            torch.cuda.synchronize()
+            exchange(a)
+            torch.cuda.synchronize()
+            assert torch.equal(a[0], want) and torch.equal(a[1], want), (n, a[0][:4].tolist(), a[1][:4].tolist(), want[:4].tolist(),
+                                                                         L.semseg_peer_status(peers[0]), L.semseg_peer_status(peers[1]))
+        # captured + replayed: one graph per rank, each on its stream; the payload is regenerated inside the graph
+        src = [torch.randn(1025, dtype=torch.float64, device=dev) for _ in (0, 1)]
+        buf = [torch.empty_like(s) for s in src]
+        graphs = []
+        torch.cuda.synchronize()
+        for r in (0, 1):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=streams[r]):
+                buf[r].copy_(src[r])
+                st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                assert L.semseg_peer_allreduce_sum_f64(peers[r], ctypes.c_void_p(buf[r].data_ptr()), 1025, st) == 0
+            graphs.append(gr)
+        for it in range(6):
+            for r in (0, 1):
+                src[r].add_(float(it))
+            torch.cuda.synchronize()
+            for r in (0, 1):
+                with torch.cuda.stream(streams[r]):
+                    graphs[r].replay()
+            torch.cuda.synchronize()
+            assert torch.equal(buf[0], src[0] + src[1]) and torch.equal(buf[1], buf[0]), it
+        assert L.semseg_peer_status(peers[0]) == 0 and L.semseg_peer_status(peers[1]) == 0
+    finally:
+        torch.cuda.synchronize()
+        for p in peers:
+            assert L.semseg_peer_destroy(p) == 0
+    # a rank whose partner never shows up: 0.2 s, NaN, status raised, no hang
+    lone, ghost = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.semseg_peer_create(0, 2, 64, 0.2, ctypes.byref(lone)) == 0 and L.semseg_peer_create(1, 2, 64, 0.2, ctypes.byref(ghost)) == 0
+    try:
+        assert L.semseg_peer_attach_local(lone, 1, ghost) == 0
+        y = torch.ones(16, dtype=torch.float64, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert L.semseg_peer_allreduce_sum_f64(lone, ctypes.c_void_p(y.data_ptr()), 16, st) == 0
+        torch.cuda.synchronize()
+        assert L.semseg_peer_status(lone) == -3 and bool(torch.isnan(y).any())            # SEMSEG_ECOMM
+    finally:
+        L.semseg_peer_destroy(lone)
+        L.semseg_peer_destroy(ghost)

@@ -1,7 +1,7 @@
 """Self-test of the hipGraph data-parallel step, one process per GPU (launched by bench.py on every rank before the real run,
 or by hand under torchrun): a small model (ResNet18dilated + PPM_deepsup, 2 x 64 x 64 per rank) trains a few steps with
-SEMSEG_DDP_GRAPH=1 -- SyncBN statistics all-reduces on the compute stream and the gradient buckets on the side stream are
-CAPTURED with the rest of the step and replayed.  Passes (exit 0) only if the graph was really used, the loss is finite and
+SEMSEG_DDP_GRAPH=1 -- the SyncBN exchanges on the compute stream (csrc/peer.hip kernels when the peer exchange came up, RCCL
+all-reduces otherwise) and the gradient buckets on the side stream are CAPTURED with the rest of the step and replayed.  Passes (exit 0) only if the graph was really used, the loss is finite and
 the replicas stay bit-identical (their parameters could not agree if any captured all-reduce were dropped or stale: every
 rank trains on different data).  bench.py enables the graph path for the real run only when every rank's self-test passed
 inside its time limit; anything else -- an exception, a hang that the parent kills -- leaves the eager path in place."""
@@ -34,6 +34,18 @@ def main():
     dp = NativeDataParallel(sm)                         # brings up the C ABI's own RCCL communicator (self-tested sums)
     if rank == 0:
         print('COMM_%s native RCCL communicator through the C ABI: %s' % ('OK' if dp.native_comm else 'OFF', dp.native_comm), flush=True)
+    if rank == 0:       # peer_init is unanimous by construction (every rank mapped every inbox and summed correctly, or nobody uses it)
+        print('PEER_%s one-node peer exchange of the SyncBN payloads (csrc/peer.hip): %s' % ('OK' if dp.peer_exchange else 'OFF', dp.peer_exchange),
+              flush=True)
+
+    def replicas_identical():
+        sums = torch.stack([p.detach().double().abs().sum() for p in sm.parameters()] +
+                           [b.detach().double().abs().sum() for n, b in sm.named_buffers() if n.endswith('running_var')])
+        hi, lo = sums.clone(), sums.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        assert torch.equal(hi, lo), 'replicas diverged: max |hi - lo| = %g' % (hi - lo).abs().max().item()
+
     g = torch.Generator().manual_seed(1000 + rank)
     feed = {'img_data': torch.randn(2, 3, 64, 64, generator=g).to(dev),
             'seg_label': torch.randint(-1, 150, (2, 8, 8), generator=g).to(dev)}
@@ -44,6 +56,9 @@ def main():
         loss, acc = ts0.step(feed)
     torch.cuda.synchronize()
     assert ts0.launch_mode() == 'segmented' and ts0.stats['replayed'] >= 2 and torch.isfinite(loss).item()
+    from mit_semseg import comm
+    comm.peer_check()
+    replicas_identical()        # every rank trains on different data: equal replicas <=> every exchange delivered every payload
     dist.barrier()
     if rank == 0:
         print('SEGMENTED_OK loss %.5f' % loss.item(), flush=True)
@@ -57,12 +72,8 @@ def main():
     torch.cuda.synchronize()
     assert ts._graph is not None, 'the step did not run as a graph'
     assert torch.isfinite(loss).item(), 'loss is not finite'
-    sums = torch.stack([p.detach().double().abs().sum() for p in sm.parameters()] +
-                       [b.detach().double().abs().sum() for n, b in sm.named_buffers() if n.endswith('running_var')])
-    hi, lo = sums.clone(), sums.clone()
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    assert torch.equal(hi, lo), 'replicas diverged: max |hi - lo| = %g' % (hi - lo).abs().max().item()
+    comm.peer_check()
+    replicas_identical()
     # bucket-sized message through a graph as well (the real run reduces 64 MiB gradient buckets)
     big = torch.ones(16 << 20, device=dev, dtype=torch.float32)
     dist.all_reduce(big)
@@ -80,6 +91,7 @@ def main():
     dist.barrier()
     if rank == 0:
         print('GRAPH_OK ddp graph selftest ok: world %d, loss %.5f' % (world, loss.item()), flush=True)
+    comm.peer_destroy()
     dist.destroy_process_group()
 
 
