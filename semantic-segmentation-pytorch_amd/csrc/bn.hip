@@ -9,6 +9,7 @@
 // can all-reduce them between `stats` and `finalize` -- this is what replaces the reference's
 // SyncMaster/SlavePipe rendezvous (batchnorm.py:63-117, comm.py).
 #include "common.h"
+#include "peer_dev.h"
 #include "split_layout.h"
 #include <stdlib.h>
 
@@ -999,20 +1000,27 @@ extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y
 // per-channel finalize / bound work and leave one bound per block (16 channels) for the apply kernel's prologue
 // (h2_exponent_from): 3 launches per BN pass instead of 4.  Block = 16 channels x 16 partial lanes.
 // ================================================================================================
+// PEER (SyncBN over the one-node peer exchange, csrc/peer_dev.h): the per-channel [sum, sum^2] and the pixel count leave for the
+// peers' inboxes as soon as the block has them and come back summed over the ranks -- the all-reduce of batchnorm.py:98-117
+// INSIDE the finish kernel; min / max and the bounds stay rank-local (they only choose an exponent).
+template <bool PEER>
 __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     const double* __restrict__ partial, const float* __restrict__ mm, int nparts, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, int relu, const float* __restrict__ res_absmax,
     double* __restrict__ stats, float* __restrict__ zmm, float* __restrict__ mean, float* __restrict__ invstd,
     float* __restrict__ scale, float* __restrict__ shift, int64_t* __restrict__ num_batches_tracked,
-    uint32_t* __restrict__ blockbound) {
+    uint32_t* __restrict__ blockbound, semseg_peer::PeerArgs pa) {
     __shared__ double rs[16][17], rq[16][17];
     __shared__ float rlo[16][17], rhi[16][17];
+    __shared__ double xs[3][16];
+    __shared__ unsigned s_q;
     const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const int C2 = 2 * C;
     double su = 0.0, sq = 0.0;
     float lo = INFINITY, hi = -INFINITY;
+    if (PEER && threadIdx.x == 0) s_q = *pa.seq;
     if (c < C) {
         // 8 partial rows (32 loads) in flight per round; rows past the end are clamped loads whose values are not used.
         // Additions in the order of the plain loop (bit-identical sums).
@@ -1038,15 +1046,36 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     rs[lane][cl] = su; rq[lane][cl] = sq; rlo[lane][cl] = lo; rhi[lane][cl] = hi;
     __syncthreads();
     uint32_t bits = 0;
+    double n = count;
     if (lane == 0 && c < C) {
         su = 0.0; sq = 0.0; lo = INFINITY; hi = -INFINITY;
         for (int i = 0; i < 16; ++i) {            // same summation order as colsum_block
             su += rs[i][cl]; sq += rq[i][cl];
             lo = fminf(lo, rlo[i][cl]); hi = fmaxf(hi, rhi[i][cl]);
         }
+        if (PEER) { xs[0][cl] = su; xs[1][cl] = sq; }
+    }
+    if (PEER) {
+        // threads (lane 0, cl) / (lane 1, cl) carry sum / sum^2 of channel cl through the exchange, thread (lane 2, 0) the pixel
+        // count (pushed by block 0 only, gathered by every block)
+        __syncthreads();
+        const unsigned q = s_q;
+        if (lane < 3 && (lane < 2 ? c < C : cl == 0)) {
+            const int idx = lane == 2 ? C2 : lane * C + c;
+            const double own = lane == 2 ? count : xs[lane][cl];
+            if (lane < 2 || blockIdx.x == 0) semseg_peer::push(pa, q, idx, own);
+            bool timed_out = false;
+            const double tot = semseg_peer::gather_sum(pa, q, idx, own, wall_clock64(), timed_out);
+            if (timed_out) atomicOr(pa.status, 1u);
+            xs[lane][lane == 2 ? 0 : cl] = tot;
+        }
+        __syncthreads();
+        n = xs[2][0];
+    }
+    if (lane == 0 && c < C) {
+        if (PEER) { su = xs[0][cl]; sq = xs[1][cl]; }
         stats[c] = su; stats[C + c] = sq;
         zmm[c] = lo; zmm[C + c] = hi;
-        const double n = count;
         const double mu = su / n;
         double var = sq / n - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -1074,17 +1103,20 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     if (threadIdx.x == 0) {
         blockbound[blockIdx.x] = bits;
         if (blockIdx.x == 0) {
-            stats[C2] = count;
+            stats[C2] = n;
             if (num_batches_tracked) num_batches_tracked[0] += 1;
         }
+        if (PEER) semseg_peer::advance(pa, s_q, gridDim.x);
     }
 }
 
-extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
-                                         const float* beta, float* running_mean, float* running_var,
-                                         int64_t* num_batches_tracked, float momentum, float eps, int relu,
-                                         const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
-                                         void* blockbound, void* workspace, size_t workspace_bytes, void* stream) {
+static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float momentum, float eps, int relu,
+                                   const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
+                                   void* blockbound, void* workspace, size_t workspace_bytes, void* stream, void* peer) {
+    semseg_peer::PeerArgs pa = {};
+    if (peer && (!semseg_peer::peer_args(peer, &pa) || 2 * C + 1 > pa.cap)) return SEMSEG_EINVAL;
     if (!z || !stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || !blockbound || P <= 0 || C <= 0 ||
         (C % 4) || !aligned16(z))
         return SEMSEG_EINVAL;
@@ -1098,25 +1130,58 @@ extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* s
     hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
                        g.rows_per_block, partial, mm);
     SEMSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_fwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
-                       (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                       res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound);
+    if (peer)
+        hipLaunchKernelGGL(bn_fwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+                           (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
+                           res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound, pa);
+    else
+        hipLaunchKernelGGL(bn_fwd_finish_fused_kernel<false>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+                           (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
+                           res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound, pa);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
 
+extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var,
+                                         int64_t* num_batches_tracked, float momentum, float eps, int relu,
+                                         const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
+                                         void* blockbound, void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_fwd_stats_fused_impl(z, P, C, stats, zmm, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                   relu, res_absmax, mean, invstd, scale, shift, blockbound, workspace, workspace_bytes, stream,
+                                   nullptr);
+}
+
+extern "C" int semseg_bn_fwd_stats_fused_peer(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
+                                              const float* beta, float* running_mean, float* running_var,
+                                              int64_t* num_batches_tracked, float momentum, float eps, int relu,
+                                              const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
+                                              void* blockbound, void* workspace, size_t workspace_bytes, void* stream,
+                                              void* peer) {
+    if (!peer) return SEMSEG_EINVAL;
+    return bn_fwd_stats_fused_impl(z, P, C, stats, zmm, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                   relu, res_absmax, mean, invstd, scale, shift, blockbound, workspace, workspace_bytes, stream,
+                                   peer);
+}
+
+// PEER: as bn_fwd_finish_fused_kernel -- [sum g, sum g xhat] summed over the ranks inside the kernel; dgamma / dbeta stay the
+// rank's own sums (parameter gradients are reduced with the gradient buckets), max|g| stays rank-local.
+template <bool PEER>
 __global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
     const double* __restrict__ partial, const float* __restrict__ gm, int nparts, int C, const double* __restrict__ count,
     const float* __restrict__ zmm, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, int training, double* __restrict__ sums, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, uint32_t* __restrict__ blockbound) {
+    float* __restrict__ dbeta, uint32_t* __restrict__ blockbound, semseg_peer::PeerArgs pa) {
     __shared__ double rs[16][17], rq[16][17];
     __shared__ uint32_t rg[16][17];
+    __shared__ double xs[2][16];
+    __shared__ unsigned s_q;
     const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const int C2 = 2 * C;
     double su = 0.0, sq = 0.0;
     uint32_t gmx = 0;
+    if (PEER && threadIdx.x == 0) s_q = *pa.seq;
     if (c < C) {
         constexpr int U = 8;                   // as bn_fwd_finish_fused_kernel
         for (int b = lane; b < nparts; b += U * 16) {
@@ -1146,9 +1211,27 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
             su += rs[i][cl]; sq += rq[i][cl];
             gmx = max(gmx, rg[i][cl]);
         }
-        sums[c] = su; sums[C + c] = sq;
         if (dbeta) dbeta[c] = (float)su;
         if (dgamma) dgamma[c] = (float)sq;
+        if (PEER) { xs[0][cl] = su; xs[1][cl] = sq; }
+    }
+    if (PEER) {
+        __syncthreads();
+        const unsigned q = s_q;
+        if (lane < 2 && c < C) {
+            const int idx = lane * C + c;
+            const double own = xs[lane][cl];
+            semseg_peer::push(pa, q, idx, own);
+            bool timed_out = false;
+            const double tot = semseg_peer::gather_sum(pa, q, idx, own, wall_clock64(), timed_out);
+            if (timed_out) atomicOr(pa.status, 1u);
+            xs[lane][cl] = tot;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && c < C) {
+        if (PEER) { su = xs[0][cl]; sq = xs[1][cl]; }
+        sums[c] = su; sums[C + c] = sq;
         const float is = invstd[c];
         float b = __uint_as_float(gmx);
         if (training) {
@@ -1161,15 +1244,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
         bits = absbits(b);
     }
     bits = block_max_u32(bits);
-    if (threadIdx.x == 0) blockbound[blockIdx.x] = bits;
+    if (threadIdx.x == 0) {
+        blockbound[blockIdx.x] = bits;
+        if (PEER) semseg_peer::advance(pa, s_q, gridDim.x);
+    }
 }
 
-extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
-                                          const float* mean, const float* invstd, const float* gate_scale,
-                                          const float* gate_shift, int relu, int P, int C, const double* stats_count,
-                                          const float* zmm, const float* gamma, int training, double* sums, float* dgamma,
-                                          float* dbeta, void* blockbound, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
+static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                                    const float* mean, const float* invstd, const float* gate_scale,
+                                    const float* gate_shift, int relu, int P, int C, const double* stats_count,
+                                    const float* zmm, const float* gamma, int training, double* sums, float* dgamma,
+                                    float* dbeta, void* blockbound, void* workspace, size_t workspace_bytes,
+                                    void* stream, void* peer) {
+    semseg_peer::PeerArgs pa = {};
+    if (peer && (!semseg_peer::peer_args(peer, &pa) || 2 * C > pa.cap)) return SEMSEG_EINVAL;
     if (!dy || !z || !mean || !invstd || !sums || !gamma || !blockbound || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) ||
         dy_ld < C)
         return SEMSEG_EINVAL;
@@ -1191,9 +1279,35 @@ extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const floa
     else LAUNCH_PARTIAL(2);
 #undef LAUNCH_PARTIAL
     SEMSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finish_fused_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
-                       (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
-                       (uint32_t*)blockbound);
+    if (peer)
+        hipLaunchKernelGGL(bn_bwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+                           (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
+                           (uint32_t*)blockbound, pa);
+    else
+        hipLaunchKernelGGL(bn_bwd_finish_fused_kernel<false>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+                           (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
+                           (uint32_t*)blockbound, pa);
     SEMSEG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                                          const float* mean, const float* invstd, const float* gate_scale,
+                                          const float* gate_shift, int relu, int P, int C, const double* stats_count,
+                                          const float* zmm, const float* gamma, int training, double* sums, float* dgamma,
+                                          float* dbeta, void* blockbound, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    return bn_bwd_reduce_fused_impl(dy, dy_ld, y, y_ld, z, mean, invstd, gate_scale, gate_shift, relu, P, C, stats_count, zmm, gamma,
+                                    training, sums, dgamma, dbeta, blockbound, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int semseg_bn_bwd_reduce_fused_peer(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                                               const float* mean, const float* invstd, const float* gate_scale,
+                                               const float* gate_shift, int relu, int P, int C, const double* stats_count,
+                                               const float* zmm, const float* gamma, int training, double* sums, float* dgamma,
+                                               float* dbeta, void* blockbound, void* workspace, size_t workspace_bytes,
+                                               void* stream, void* peer) {
+    if (!peer) return SEMSEG_EINVAL;
+    return bn_bwd_reduce_fused_impl(dy, dy_ld, y, y_ld, z, mean, invstd, gate_scale, gate_shift, relu, P, C, stats_count, zmm, gamma,
+                                    training, sums, dgamma, dbeta, blockbound, workspace, workspace_bytes, stream, peer);
 }

@@ -21,22 +21,14 @@
 //     slowest rank's payload of exchange q to leave q), so kSlots >= 2 rules out overwriting unread words.
 //   * a rank that waits longer than `timeout_s` raises the context's status (host-mapped word, semseg_peer_status) and
 //     poisons its result with NaN instead of hanging the GPU.
-#include "common.h"
+#include "peer_dev.h"
 #include <string.h>
+
+using namespace semseg_peer;
 
 namespace {
 
-constexpr int kMaxWorld = 8;        // one node
-constexpr int kSlots = 4;
 constexpr int kThreads = 1024;
-
-struct PeerArgs {                   // passed by value to the kernel (baked into a captured graph: set up before capture)
-    unsigned long long* inbox[kMaxWorld];     // inbox[r]: rank r's inbox in THIS process' address space
-    unsigned* seq;                            // device: exchange counter of this rank
-    unsigned* status;                         // host-mapped: != 0 after a timeout
-    long long timeout_ticks;                  // wall_clock64 ticks (100 MHz)
-    int rank, world, cap;
-};
 
 struct Peer {
     PeerArgs a;
@@ -46,79 +38,30 @@ struct Peer {
     bool opened[kMaxWorld];
 };
 
-__device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 __global__ __launch_bounds__(kThreads) void peer_allreduce_f64_kernel(PeerArgs a, double* __restrict__ buf, int n) {
     __shared__ unsigned s_seq;
     if (threadIdx.x == 0) s_seq = *a.seq;
     __syncthreads();
     const unsigned q = s_seq;
-    const unsigned tag = q % 0xFFFFFFFEu + 1u;
-    const size_t lane_words = 2 * (size_t)a.cap;
-    const size_t slot_base = (size_t)(q % kSlots) * a.world * lane_words;
-    const unsigned long long hi_tag = (unsigned long long)tag << 32;
-
-    // push my payload to every peer (nearest-rank-first rotation spreads the first stores over the links)
-    for (int i = threadIdx.x; i < n; i += kThreads) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(buf[i]);
-        const unsigned long long w0 = hi_tag | (bits & 0xFFFFFFFFull), w1 = hi_tag | (bits >> 32);
-        const size_t at = slot_base + (size_t)a.rank * lane_words + 2 * (size_t)i;
-        for (int p = 1; p < a.world; ++p) {
-            int r = a.rank + p;
-            if (r >= a.world) r -= a.world;
-            st_sys(a.inbox[r] + at, w0);
-            st_sys(a.inbox[r] + at + 1, w1);
-        }
-    }
-    // sum in rank order; the words of all peers are requested together, re-polled until tagged
-    const unsigned long long* mine = a.inbox[a.rank] + slot_base;
+    for (int i = threadIdx.x; i < n; i += kThreads) push(a, q, i, buf[i]);
     const long long t0 = wall_clock64();
     bool timed_out = false;
-    for (int i = threadIdx.x; i < n; i += kThreads) {
-        unsigned long long w0[kMaxWorld], w1[kMaxWorld];
-        unsigned pending = 0;
-#pragma unroll
-        for (int r = 0; r < kMaxWorld; ++r)
-            if (r < a.world && r != a.rank) pending |= 1u << r;
-        while (pending) {
-#pragma unroll
-            for (int r = 0; r < kMaxWorld; ++r)
-                if (pending >> r & 1u) {
-                    const unsigned long long* src = mine + (size_t)r * lane_words + 2 * (size_t)i;
-                    w0[r] = ld_sys(src);
-                    w1[r] = ld_sys(src + 1);
-                }
-#pragma unroll
-            for (int r = 0; r < kMaxWorld; ++r)
-                if ((pending >> r & 1u) && (unsigned)(w0[r] >> 32) == tag && (unsigned)(w1[r] >> 32) == tag) pending &= ~(1u << r);
-            if (pending && wall_clock64() - t0 > a.timeout_ticks) {
-                timed_out = true;
-                break;
-            }
-        }
-        double acc = 0.0;
-        const double own = buf[i];
-#pragma unroll
-        for (int r = 0; r < kMaxWorld; ++r)
-            if (r < a.world) {
-                const double v = r == a.rank ? own
-                                             : __longlong_as_double((long long)((w1[r] << 32) | (w0[r] & 0xFFFFFFFFull)));
-                acc = r == 0 ? v : acc + v;
-            }
-        buf[i] = timed_out ? __longlong_as_double(0x7FF8000000000000ll) : acc;
-        if (timed_out) break;
-    }
+    for (int i = threadIdx.x; i < n && !timed_out; i += kThreads) buf[i] = gather_sum(a, q, i, buf[i], t0, timed_out);
     if (timed_out) atomicOr(a.status, 1u);
     __syncthreads();
-    if (threadIdx.x == 0) *a.seq = q + 1;
+    if (threadIdx.x == 0) advance(a, q, 1);
 }
 
 }  // namespace
+
+bool semseg_peer::peer_args(void* peer, PeerArgs* out) {
+    Peer* p = (Peer*)peer;
+    if (!p || !out) return false;
+    for (int r = 0; r < p->a.world; ++r)
+        if (!p->a.inbox[r]) return false;
+    *out = p->a;
+    return true;
+}
 
 extern "C" int semseg_peer_max_world(void) { return kMaxWorld; }
 
@@ -142,7 +85,8 @@ extern "C" int semseg_peer_create(int rank, int world, int max_doubles, double t
         }
     }
     bool ok = hipMemset(p->own_inbox, 0, p->inbox_bytes) == hipSuccess;
-    ok = ok && hipMalloc((void**)&p->a.seq, sizeof(unsigned)) == hipSuccess && hipMemset(p->a.seq, 0, sizeof(unsigned)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&p->a.seq, 2 * sizeof(unsigned)) == hipSuccess && hipMemset(p->a.seq, 0, 2 * sizeof(unsigned)) == hipSuccess;
+    if (ok) p->a.done = p->a.seq + 1;
     ok = ok && hipHostMalloc((void**)&p->status_host, sizeof(unsigned), hipHostMallocMapped) == hipSuccess;
     if (ok) {
         *p->status_host = 0;

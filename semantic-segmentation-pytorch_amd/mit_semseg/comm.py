@@ -135,6 +135,13 @@ def peer_active(group=None):
     return _key(group) in _PEERS
 
 
+def peer_handle(group=None, doubles=0):
+    """the context (ctypes handle) for the entry points that exchange inside their own kernels
+    (semseg_bn_fwd_stats_fused_peer / semseg_bn_bwd_reduce_fused_peer); None if the exchange is not up or the payload does not fit"""
+    rec = _PEERS.get(_key(group))
+    return rec['handle'] if rec is not None and doubles <= rec['cap'] else None
+
+
 def _same_host(group):
     import socket
     import torch.distributed as dist

@@ -658,6 +658,7 @@ _SYNC_GROUP = {'group': None, 'enabled': False, 'force': os.environ.get('SEMSEG_
 # engine.SegmentedStep while its capture pass runs: a collective then ENDS the hipGraph segment being captured, is recorded and
 # the next segment begins -- at replay the collectives are issued eagerly between the segment launches
 _SEGMENTS = None
+PEER_FUSED = os.environ.get('SEMSEG_PEER_FUSED', '1') != '0'
 
 
 def set_sync_bn_group(group, enabled=True):
@@ -675,6 +676,15 @@ def _sync_active():
         return False
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_GROUP['group']) > 1
+
+
+def _sync_peer(doubles):
+    """the peer-exchange context (csrc/peer.hip) that serves the SyncBN group, if it is up and carries `doubles` per exchange;
+    SEMSEG_PEER_FUSED=0 keeps the exchange a kernel of its own between the unfused BN entry points"""
+    if not PEER_FUSED or not _SYNC_GROUP['enabled']:
+        return None
+    from . import comm
+    return comm.peer_handle(_SYNC_GROUP['group'], doubles)
 
 
 def allreduce_sum(buf, group=None, channel='sync'):
@@ -872,14 +882,19 @@ class ConvBNActFn(Function):
         absmax = torch.empty((1,), device=dev, dtype=torch.float32) if bound_ok else None
         yp = torch.empty(L.semseg_split_h2_bytes(P, k), dtype=torch.uint8, device=dev) if (emit and bound_ok) else None
         y = empty_nhwc(n, k, oh, ow, dev)
-        single = not _sync_active()
-        if single and yp is not None:
-            # one rank: finish + finalize in one kernel; the apply kernel derives the exponent from the per-block bounds
+        sync = _sync_active()
+        peer = _sync_peer(2 * k + 1) if sync else None
+        if (not sync or peer is not None) and yp is not None:
+            # one rank: finish + finalize in one kernel; the apply kernel derives the exponent from the per-block bounds.
+            # SyncBN over the peer exchange: the same kernel exchanges its sums with the other ranks on the way (csrc/peer_dev.h)
             bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
-            _native.check(L.semseg_bn_fwd_stats_fused(_p(z), P, k, _p(stats), _p(zmm), _p(g), _p(b), _p(running_mean),
-                                                      _p(running_var), _p(nbt), float(momentum), float(eps), int(relu),
-                                                      _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
-                                                      _p(bb), _p(ws), ws.numel(), _st()), 'bn_fwd_stats_fused')
+            args = (_p(z), P, k, _p(stats), _p(zmm), _p(g), _p(b), _p(running_mean), _p(running_var), _p(nbt), float(momentum),
+                    float(eps), int(relu), _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(bb), _p(ws),
+                    ws.numel(), _st())
+            if peer is None:
+                _native.check(L.semseg_bn_fwd_stats_fused(*args), 'bn_fwd_stats_fused')
+            else:
+                _native.check(L.semseg_bn_fwd_stats_fused_peer(*args, peer), 'bn_fwd_stats_fused_peer')
             _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), _p(yp),
                                                P, k, _p(bb), _p(absmax), _st()), 'bn_apply_h2')
         else:
@@ -930,12 +945,16 @@ class ConvBNActFn(Function):
         dres = empty_nhwc(n, k, oh, ow, dev) if (has_res and ctx.needs_input_grad[4]) else None
         gate = relu and not has_res                       # ReLU gate from z (forward's own fmaf), y was not saved
         gsc, gsh = (coef[2], coef[3]) if gate else (None, None)
-        if not _sync_active():
+        sync = _sync_active()
+        peer = _sync_peer(2 * k + 1) if sync else None
+        if not sync or peer is not None:
             bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
-            _native.check(L.semseg_bn_bwd_reduce_fused(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gsc),
-                                                       _p(gsh), int(relu), P, k, _p(count), _p(zmm), _p(gamma), 1, _p(sums),
-                                                       _p(dgamma), _p(dbeta), _p(bb), _p(ws), ws.numel(), _st()),
-                          'bn_bwd_reduce_fused')
+            args = (_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gsc), _p(gsh), int(relu), P, k, _p(count),
+                    _p(zmm), _p(gamma), 1, _p(sums), _p(dgamma), _p(dbeta), _p(bb), _p(ws), ws.numel(), _st())
+            if peer is None:
+                _native.check(L.semseg_bn_bwd_reduce_fused(*args), 'bn_bwd_reduce_fused')
+            else:
+                _native.check(L.semseg_bn_bwd_reduce_fused_peer(*args, peer), 'bn_bwd_reduce_fused_peer')
         else:
             bb = None
             if gate:                                      # the unfused reduce reads y: rebuild the gate tensor once

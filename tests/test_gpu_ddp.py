@@ -41,16 +41,20 @@ def _joint_case():
     return enc_sd, dec_sd, img, lab, masks
 
 
-def _worker(rank, world, port, out_dir, peer):
+def _worker(rank, world, port, out_dir, mode):
+    peer = mode != 'gloo_allreduce'
     for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', SEMSEG_PEER='1' if peer else '0', SEMSEG_PEER_TIMEOUT_S='20')
+                      LOCAL_RANK='0', SEMSEG_PEER='1' if peer else '0', SEMSEG_PEER_TIMEOUT_S='20',
+                      SEMSEG_PEER_FUSED='0' if mode == 'peer_kernel' else '1')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from mit_semseg.models import ModelBuilder, SegmentationModule
         from mit_semseg.parallel import NativeDataParallel, mean_over_ranks
+        from mit_semseg import tuner
+        tuner.ENABLED = False            # heuristic launch plans: the three modes must sum in the same order
         from mit_semseg.engine import TrainStep
         dev = torch.device('cuda:0')
         torch.cuda.set_device(dev)
@@ -82,15 +86,22 @@ def _worker(rank, world, port, out_dir, peer):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('peer', [True, False], ids=['peer_exchange', 'gloo_allreduce'])
-def test_two_ranks_one_gpu_match_oracle_on_joint_batch(peer):
-    """peer=True: the SyncBN payloads travel through csrc/peer.hip (each rank's inbox mapped into the other process by
-    hipIpcOpenMemHandle, one exchange kernel per BN pass); peer=False: through torch.distributed (gloo)."""
+def test_two_ranks_one_gpu_match_oracle_on_joint_batch():
+    """The SyncBN payloads travel (a) `peer_fused`: through csrc/peer.hip INSIDE the fused BN finish kernels (each rank's inbox
+    mapped into the other process by hipIpcOpenMemHandle; semseg_bn_fwd_stats_fused_peer / semseg_bn_bwd_reduce_fused_peer),
+    (b) `peer_kernel`: through the stand-alone exchange kernel between the unfused BN entry points, (c) `gloo_allreduce`: through
+    torch.distributed.  Two ranks add commutatively, so the three are the same arithmetic: bit-identical replicas, and each
+    matches the oracle's joint batch."""
     from oracle import semseg_oracle as O
-    with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_worker, args=(2, _free_port(), out_dir, peer), nprocs=2, join=True)
-        r0 = torch.load(os.path.join(out_dir, 'rank0.pt'), weights_only=False)
-        r1 = torch.load(os.path.join(out_dir, 'rank1.pt'), weights_only=False)
+    runs = {}
+    for mode in ('peer_fused', 'peer_kernel', 'gloo_allreduce'):
+        with tempfile.TemporaryDirectory() as out_dir:
+            mp.spawn(_worker, args=(2, _free_port(), out_dir, mode), nprocs=2, join=True)
+            runs[mode] = [torch.load(os.path.join(out_dir, 'rank%d.pt' % r), weights_only=False) for r in (0, 1)]
+    for mode in ('peer_kernel', 'gloo_allreduce'):
+        for k in runs['peer_fused'][0]['sd']:
+            assert torch.equal(runs['peer_fused'][0]['sd'][k], runs[mode][0]['sd'][k]), ('peer_fused != ' + mode, k)
+    r0, r1 = runs['peer_fused']
     # replicas stay identical: same reduced gradients, same BN statistics on both ranks
     for k in r0['sd']:
         assert torch.equal(r0['sd'][k], r1['sd'][k]), k
