@@ -56,21 +56,39 @@ class GradientBuckets:
     every `p.grad` as a VIEW of a reduced bucket (sum over ranks; the 1/world factor is folded into the SGD
     kernel's grad_scale)."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None, comm_stream=None, overlap=True):
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, comm_stream=None, overlap=True, tail_bytes=None):
         self.group = group
         self.params = [p for p in reversed(list(params)) if p.requires_grad]
         self.buckets = []          # dict(flat, items=[(param, offset, numel)], pending, launched)
-        cur, cur_n = [], 0
+        groups, cur, cur_n = [], [], 0
         cap = max(1, bucket_bytes // 4)
         for p in self.params:
             n = p.numel()
             if cur and cur_n + n > cap:
-                self.buckets.append(self._make_bucket(cur, cur_n))
+                groups.append(cur)
                 cur, cur_n = [], 0
-            cur.append((p, cur_n, n))
+            cur.append(p)
             cur_n += n
         if cur:
-            self.buckets.append(self._make_bucket(cur, cur_n))
+            groups.append(cur)
+        # The LAST bucket (the first layers of the network) is complete only when backward is, so its all-reduce overlaps with
+        # nothing: keep it small -- what backward produces in its last fraction of a millisecond -- and let everything before
+        # it travel while backward is still running.
+        tail = max(1, (bucket_bytes // 16 if tail_bytes is None else tail_bytes) // 4)
+        if groups and len(groups[-1]) > 1 and sum(p.numel() for p in groups[-1]) > tail:
+            last, keep, n = groups.pop(), [], 0
+            while len(last) > 1 and n + last[-1].numel() <= tail:
+                n += last[-1].numel()
+                keep.insert(0, last.pop())
+            groups.append(last)
+            if keep:
+                groups.append(keep)
+        for grp in groups:
+            items, off = [], 0
+            for p in grp:
+                items.append((p, off, p.numel()))
+                off += p.numel()
+            self.buckets.append(self._make_bucket(items, off))
         self.comm_stream = comm_stream
         self._works = []
         self._bucket_of = {}
