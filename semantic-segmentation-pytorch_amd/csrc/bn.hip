@@ -902,58 +902,91 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
         reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
     const float inv_n = TRAIN ? (float)(1.0 / count[0]) : 0.f;
+    // A thread keeps ONE group of 8 channels and walks down the rows: the per-channel terms (1/std, gamma, mean, the two batch
+    // means, the gate's scale / shift: 26 loads) are fetched once instead of once per 8 outputs, and only dy / z (/ y) stream.
+    // Consecutive threads own consecutive channel groups of a row, then the next row -- the coalescing of a flat index.
     const int G = Cp >> 3;
-    const size_t total = (size_t)P * G;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int p = (int)(i / G);
-        const int c = (int)(i - (size_t)p * G) << 3;
-        f16x8 p0, p1;
-        if (c < C) {
-            float o[8];
+    const size_t threads = (size_t)gridDim.x * blockDim.x;
+    const size_t rows_step = threads / G;                 // rows covered per sweep; the last threads % G threads idle
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rows_step == 0 || tid >= rows_step * G) return;
+    const int c = (int)(tid % G) << 3;
+    const int prow = (int)(tid / G);
+    if (c >= C) {                                          // padding groups of the plane pitch: zeros
+        f16x8 zf;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int cc = c + 4 * h;
-                float4 g = *reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + cc);
-                float4 v = f4zero();
-                if (TRAIN || (RELU && gscale)) v = *reinterpret_cast<const float4*>(z + (size_t)p * C + cc);
-                if (RELU) {
-                    float4 yy;
-                    if (gscale) yy = relu_gate_from_z(v, gscale + cc, gshift + cc);
-                    else yy = *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + cc);
-                    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-                    g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-                }
-                if (DRES) *reinterpret_cast<float4*>(dres + (size_t)p * C + cc) = g;
-                const float4 is = *reinterpret_cast<const float4*>(invstd + cc);
-                const float4 ga = *reinterpret_cast<const float4*>(gamma + cc);
-                float4 t;
-                if (TRAIN) {
-                    const float4 mu = *reinterpret_cast<const float4*>(mean + cc);
-                    const float m0 = (float)sums[cc] * inv_n, m1 = (float)sums[cc + 1] * inv_n;
-                    const float m2 = (float)sums[cc + 2] * inv_n, m3 = (float)sums[cc + 3] * inv_n;
-                    const float x0 = (float)sums[C + cc] * inv_n, x1 = (float)sums[C + cc + 1] * inv_n;
-                    const float x2 = (float)sums[C + cc + 2] * inv_n, x3 = (float)sums[C + cc + 3] * inv_n;
-                    t.x = ga.x * is.x * (g.x - m0 - (v.x - mu.x) * is.x * x0);
-                    t.y = ga.y * is.y * (g.y - m1 - (v.y - mu.y) * is.y * x1);
-                    t.z = ga.z * is.z * (g.z - m2 - (v.z - mu.z) * is.z * x2);
-                    t.w = ga.w * is.w * (g.w - m3 - (v.w - mu.w) * is.w * x3);
-                } else {
-                    t.x = ga.x * is.x * g.x; t.y = ga.y * is.y * g.y; t.z = ga.z * is.z * g.z; t.w = ga.w * is.w * g.w;
-                }
-                o[4 * h] = t.x; o[4 * h + 1] = t.y; o[4 * h + 2] = t.z; o[4 * h + 3] = t.w;
-            }
+        for (int e = 0; e < 8; ++e) zf[e] = (_Float16)0.f;
+        for (size_t p = prow; p < (size_t)P; p += rows_step) {
+            const size_t po = p * pitch + c;
+            *reinterpret_cast<f16x8*>(planes + po) = zf;
+            *reinterpret_cast<f16x8*>(planes + plane + po) = zf;
+        }
+        return;
+    }
+    float is[8], ga[8], mu[8], m[8], x[8], gs[8], gh[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                _Float16 a, r;
-                h2_split_of(o[e] * sc2, a, r);
-                p0[e] = a;
-                p1[e] = r;
-            }
+    for (int h = 0; h < 2; ++h) {
+        const int cc = c + 4 * h;
+        const float4 is4 = *reinterpret_cast<const float4*>(invstd + cc);
+        const float4 ga4 = *reinterpret_cast<const float4*>(gamma + cc);
+        is[4 * h] = is4.x; is[4 * h + 1] = is4.y; is[4 * h + 2] = is4.z; is[4 * h + 3] = is4.w;
+        ga[4 * h] = ga4.x; ga[4 * h + 1] = ga4.y; ga[4 * h + 2] = ga4.z; ga[4 * h + 3] = ga4.w;
+        if (TRAIN) {
+            const float4 mu4 = *reinterpret_cast<const float4*>(mean + cc);
+            mu[4 * h] = mu4.x; mu[4 * h + 1] = mu4.y; mu[4 * h + 2] = mu4.z; mu[4 * h + 3] = mu4.w;
+            const double2 sa = *reinterpret_cast<const double2*>(sums + cc), sb = *reinterpret_cast<const double2*>(sums + cc + 2);
+            const double2 xa = *reinterpret_cast<const double2*>(sums + C + cc), xb = *reinterpret_cast<const double2*>(sums + C + cc + 2);
+            m[4 * h] = (float)sa.x * inv_n; m[4 * h + 1] = (float)sa.y * inv_n; m[4 * h + 2] = (float)sb.x * inv_n; m[4 * h + 3] = (float)sb.y * inv_n;
+            x[4 * h] = (float)xa.x * inv_n; x[4 * h + 1] = (float)xa.y * inv_n; x[4 * h + 2] = (float)xb.x * inv_n; x[4 * h + 3] = (float)xb.y * inv_n;
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { p0[e] = (_Float16)0.f; p1[e] = (_Float16)0.f; }
+            for (int e = 0; e < 4; ++e) { mu[4 * h + e] = 0.f; m[4 * h + e] = 0.f; x[4 * h + e] = 0.f; }
         }
-        const size_t po = (size_t)p * pitch + c;
+        if (RELU && gscale) {
+            const float4 s4 = *reinterpret_cast<const float4*>(gscale + cc), h4 = *reinterpret_cast<const float4*>(gshift + cc);
+            gs[4 * h] = s4.x; gs[4 * h + 1] = s4.y; gs[4 * h + 2] = s4.z; gs[4 * h + 3] = s4.w;
+            gh[4 * h] = h4.x; gh[4 * h + 1] = h4.y; gh[4 * h + 2] = h4.z; gh[4 * h + 3] = h4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gs[4 * h + e] = 0.f; gh[4 * h + e] = 0.f; }
+        }
+    }
+    const bool gate_z = RELU && gscale;
+#pragma unroll 4
+    for (size_t p = prow; p < (size_t)P; p += rows_step) {
+        float g[8], v[8], yy[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dy + p * dy_ld + c + 4 * h);
+            g[4 * h] = g4.x; g[4 * h + 1] = g4.y; g[4 * h + 2] = g4.z; g[4 * h + 3] = g4.w;
+            float4 v4 = f4zero();
+            if (TRAIN || gate_z) v4 = *reinterpret_cast<const float4*>(z + p * C + c + 4 * h);
+            v[4 * h] = v4.x; v[4 * h + 1] = v4.y; v[4 * h + 2] = v4.z; v[4 * h + 3] = v4.w;
+            if (RELU && !gate_z) {
+                const float4 y4 = *reinterpret_cast<const float4*>(y + p * y_ld + c + 4 * h);
+                yy[4 * h] = y4.x; yy[4 * h + 1] = y4.y; yy[4 * h + 2] = y4.z; yy[4 * h + 3] = y4.w;
+            }
+        }
+        f16x8 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float ge = g[e];
+            if (RELU) {
+                const float ye = gate_z ? fmaf(v[e], gs[e], gh[e]) : yy[e];        // relu_gate_from_z: the forward's own fmaf
+                ge = ye > 0.f ? ge : 0.f;
+            }
+            g[e] = ge;
+            const float t = TRAIN ? ga[e] * is[e] * (ge - m[e] - (v[e] - mu[e]) * is[e] * x[e]) : ga[e] * is[e] * ge;
+            _Float16 a, r;
+            h2_split_of(t * sc2, a, r);
+            p0[e] = a;
+            p1[e] = r;
+        }
+        if (DRES) {
+            *reinterpret_cast<float4*>(dres + p * C + c) = make_float4(g[0], g[1], g[2], g[3]);
+            *reinterpret_cast<float4*>(dres + p * C + c + 4) = make_float4(g[4], g[5], g[6], g[7]);
+        }
+        const size_t po = p * pitch + c;
         *reinterpret_cast<f16x8*>(planes + po) = p0;
         *reinterpret_cast<f16x8*>(planes + plane + po) = p1;
     }
@@ -976,6 +1009,10 @@ extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y
     int* hdr = const_cast<int*>(h2_exp_ptr(dz_planes, (size_t)P, C));
     int blocks = stream_blocks((size_t)P * (Cp / 8));
     if (blockbound && blocks > 2048) blocks = 2048;
+    // a thread keeps its channel group: 4 rows per thread amortise its per-channel loads (never below 1024 blocks = 4 per CU)
+    const int quarter = (int)ceil_div_sz((size_t)P * (Cp / 8), 4 * 256);
+    const int target = quarter > 1024 ? quarter : 1024;
+    if (blocks > target) blocks = target;
     const int nbound = ceil_div(C, 16);
 #define LAUNCH(T, R, D) hipLaunchKernelGGL((bn_bwd_apply_h2_kernel<T, R, D>), dim3(blocks), dim3(256), 0, st, dy, dy_ld, y, y_ld, z, mean, invstd, gamma, sums, stats_count, (uint16_t*)dz_planes, plane, pitch, hdr, dres, P, C, Cp, gate_scale, gate_shift, (const uint32_t*)blockbound, nbound)
     const int key = (training ? 4 : 0) | (relu ? 2 : 0) | (dres ? 1 : 0);
