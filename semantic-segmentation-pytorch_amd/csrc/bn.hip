@@ -639,44 +639,57 @@ __global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restric
     const float sc2 = pow2i(ex);
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
         reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    // a thread keeps ONE group of 8 channels (scale / shift loaded once) and walks down the rows; consecutive threads own
+    // consecutive channel groups of a row, then the next row -- the coalescing of a flat index
     const int G = Cp >> 3;
-    const size_t total = (size_t)P * G;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int p = (int)(i / G);
-        const int c = (int)(i - (size_t)p * G) << 3;
-        f16x8 p0, p1;
-        if (c < C) {                               // C % 8 == 0: the 8 channels are all real
-            float o[8];
+    const size_t threads = (size_t)gridDim.x * blockDim.x;
+    const size_t rows_step = threads / G;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rows_step == 0 || tid >= rows_step * G) return;
+    const int c = (int)(tid % G) << 3;
+    const int prow = (int)(tid / G);
+    if (c >= C) {                                  // padding groups of the plane pitch: zeros
+        f16x8 zf;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * C + c + 4 * h);
-                const float4 sc = *reinterpret_cast<const float4*>(scale + c + 4 * h);
-                const float4 sh = *reinterpret_cast<const float4*>(shift + c + 4 * h);
-                float4 t;
-                t.x = fmaf(v.x, sc.x, sh.x); t.y = fmaf(v.y, sc.y, sh.y);
-                t.z = fmaf(v.z, sc.z, sh.z); t.w = fmaf(v.w, sc.w, sh.w);
-                if (RES) {
-                    const float4 r = *reinterpret_cast<const float4*>(res + (size_t)p * res_ld + c + 4 * h);
-                    t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
-                }
-                if (RELU) {
-                    t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
-                }
-                *reinterpret_cast<float4*>(y + (size_t)p * C + c + 4 * h) = t;
-                o[4 * h] = t.x; o[4 * h + 1] = t.y; o[4 * h + 2] = t.z; o[4 * h + 3] = t.w;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                _Float16 a, r;
-                h2_split_of(o[e] * sc2, a, r);
-                p0[e] = a;
-                p1[e] = r;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { p0[e] = (_Float16)0.f; p1[e] = (_Float16)0.f; }
+        for (int e = 0; e < 8; ++e) zf[e] = (_Float16)0.f;
+        for (size_t p = prow; p < (size_t)P; p += rows_step) {
+            const size_t po = p * pitch + c;
+            *reinterpret_cast<f16x8*>(planes + po) = zf;
+            *reinterpret_cast<f16x8*>(planes + plane + po) = zf;
         }
-        const size_t po = (size_t)p * pitch + c;
+        return;
+    }
+    const float4 sc0 = *reinterpret_cast<const float4*>(scale + c), sc1 = *reinterpret_cast<const float4*>(scale + c + 4);
+    const float4 sh0 = *reinterpret_cast<const float4*>(shift + c), sh1 = *reinterpret_cast<const float4*>(shift + c + 4);
+#pragma unroll 4
+    for (size_t p = prow; p < (size_t)P; p += rows_step) {
+        float o[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 v = *reinterpret_cast<const float4*>(z + p * C + c + 4 * h);
+            const float4 sc = h ? sc1 : sc0, sh = h ? sh1 : sh0;
+            float4 t;
+            t.x = fmaf(v.x, sc.x, sh.x); t.y = fmaf(v.y, sc.y, sh.y);
+            t.z = fmaf(v.z, sc.z, sh.z); t.w = fmaf(v.w, sc.w, sh.w);
+            if (RES) {
+                const float4 r = *reinterpret_cast<const float4*>(res + p * res_ld + c + 4 * h);
+                t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+            }
+            if (RELU) {
+                t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(y + p * C + c + 4 * h) = t;
+            o[4 * h] = t.x; o[4 * h + 1] = t.y; o[4 * h + 2] = t.z; o[4 * h + 3] = t.w;
+        }
+        f16x8 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 a, r;
+            h2_split_of(o[e] * sc2, a, r);
+            p0[e] = a;
+            p1[e] = r;
+        }
+        const size_t po = p * pitch + c;
         *reinterpret_cast<f16x8*>(planes + po) = p0;
         *reinterpret_cast<f16x8*>(planes + plane + po) = p1;
     }
@@ -695,6 +708,11 @@ extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const floa
     int* hdr = const_cast<int*>(h2_exp_ptr(y_planes, (size_t)P, C));
     int blocks = stream_blocks((size_t)P * (Cp / 8));
     if (blockbound && blocks > 2048) blocks = 2048;      // every block redoes the bound reduction: keep them long-lived
+    {   // 4 rows per thread amortise the per-channel loads (never below 1024 blocks = 4 per CU)
+        const int quarter = (int)ceil_div_sz((size_t)P * (Cp / 8), 4 * 256);
+        const int target = quarter > 1024 ? quarter : 1024;
+        if (blocks > target) blocks = target;
+    }
     const int nbound = ceil_div(C, 16);
 #define LAUNCH(R, A) hipLaunchKernelGGL((bn_apply_h2_kernel<R, A>), dim3(blocks), dim3(256), 0, st, z, scale, shift, residual, res_ld, y, (uint16_t*)y_planes, plane, pitch, hdr, P, C, Cp, (const uint32_t*)blockbound, nbound, absmax_out)
     if (residual) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
