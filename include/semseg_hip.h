@@ -236,6 +236,13 @@ int semseg_bn_bwd_reduce_fused(const float* dy, int dy_ld, const float* y, int y
                                int relu, int P, int C, const double* stats_count, const float* zmm, const float* gamma,
                                int training, double* sums, float* dgamma, float* dbeta, void* blockbound,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* semseg_bn_fwd_stats_fused + the bound of |y| itself in absmax_out[0] (max over the per-block bounds): for a BN whose output is
+ * not written as planes (no ReLU: shortcut / fuse-layer BNs, resnet.py:84-88, hrnet.py:188-205) -- semseg_bn_apply follows. */
+int semseg_bn_fwd_stats_fused_bound(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                    float momentum, float eps, int relu, const float* res_absmax,
+                                    float* mean, float* invstd, float* scale, float* shift, void* blockbound,
+                                    void* workspace, size_t workspace_bytes, void* stream, float* absmax_out);
 /* SyncBN forms of the two (batchnorm.py:63-117: the statistics are those of the batch over ALL ranks): `peer` is a context of
  * the one-node peer exchange below (semseg_peer_create, every peer attached).  The finish kernel pushes the per-channel
  * [sum, sum^2] (+ this rank's pixel count P) / [sum g, sum g xhat] to the peers' inboxes and continues with the sums over the
@@ -246,7 +253,7 @@ int semseg_bn_fwd_stats_fused_peer(const float* z, int P, int C, double* stats, 
                                    const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                    float momentum, float eps, int relu, const float* res_absmax,
                                    float* mean, float* invstd, float* scale, float* shift, void* blockbound,
-                                   void* workspace, size_t workspace_bytes, void* stream, void* peer);
+                                   void* workspace, size_t workspace_bytes, void* stream, void* peer, float* absmax_out /* nullable */);
 int semseg_bn_bwd_reduce_fused_peer(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
                                     const float* mean, const float* invstd, const float* gate_scale, const float* gate_shift,
                                     int relu, int P, int C, const double* stats_count, const float* zmm, const float* gamma,

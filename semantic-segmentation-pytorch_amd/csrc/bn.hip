@@ -428,8 +428,10 @@ extern "C" size_t semseg_bn_mm_workspace_bytes(int P, int C) {
 constexpr int ROWS_IN_FLIGHT = 8;
 __global__ __launch_bounds__(256) void bn_stats_mm_partial_kernel(const float* __restrict__ z, int P, int C, int cx, int py,
                                                                   int rows_per_block, double* __restrict__ partial,
-                                                                  float* __restrict__ mm) {
+                                                                  float* __restrict__ mm, float* __restrict__ zero_word) {
     extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][8] floats
+    // the fused finish kernel max-reduces its blocks' bounds into this word with atomics: start it at +0
+    if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) zero_word[0] = 0.f;
     float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
     const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
     const int quad = blockIdx.x * cx + tx;
@@ -539,7 +541,7 @@ extern "C" int semseg_bn_stats_mm(const float* z, int P, int C, double* stats, f
     float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
     hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
-                       g.rows_per_block, partial, mm);
+                       g.rows_per_block, partial, mm, (float*)nullptr);
     SEMSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_mm_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)partial,
                        (const float*)mm, g.gy, C, stats, zmm, (double)P);
@@ -1065,7 +1067,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     float* __restrict__ running_var, float momentum, float eps, int relu, const float* __restrict__ res_absmax,
     double* __restrict__ stats, float* __restrict__ zmm, float* __restrict__ mean, float* __restrict__ invstd,
     float* __restrict__ scale, float* __restrict__ shift, int64_t* __restrict__ num_batches_tracked,
-    uint32_t* __restrict__ blockbound, semseg_peer::PeerArgs pa) {
+    uint32_t* __restrict__ blockbound, float* __restrict__ absmax_out, semseg_peer::PeerArgs pa) {
     __shared__ double rs[16][17], rq[16][17];
     __shared__ float rlo[16][17], rhi[16][17];
     __shared__ double xs[3][16];
@@ -1157,6 +1159,8 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     bits = block_max_u32(bits);
     if (threadIdx.x == 0) {
         blockbound[blockIdx.x] = bits;
+        // bit patterns of non-negative floats order like the floats, the NaN pattern above all of them (zeroed by the partial kernel)
+        if (absmax_out) atomicMax(reinterpret_cast<unsigned*>(absmax_out), bits);
         if (blockIdx.x == 0) {
             stats[C2] = n;
             if (num_batches_tracked) num_batches_tracked[0] += 1;
@@ -1169,7 +1173,8 @@ static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, 
                                    const float* beta, float* running_mean, float* running_var,
                                    int64_t* num_batches_tracked, float momentum, float eps, int relu,
                                    const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
-                                   void* blockbound, void* workspace, size_t workspace_bytes, void* stream, void* peer) {
+                                   void* blockbound, void* workspace, size_t workspace_bytes, void* stream, void* peer,
+                                   float* absmax_out) {
     semseg_peer::PeerArgs pa = {};
     if (peer && (!semseg_peer::peer_args(peer, &pa) || 2 * C + 1 > pa.cap)) return SEMSEG_EINVAL;
     if (!z || !stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || !blockbound || P <= 0 || C <= 0 ||
@@ -1183,16 +1188,18 @@ static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, 
     float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
     hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
-                       g.rows_per_block, partial, mm);
+                       g.rows_per_block, partial, mm, absmax_out);
     SEMSEG_LAUNCH_CHECK();
     if (peer)
         hipLaunchKernelGGL(bn_fwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
                            (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                           res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound, pa);
+                           res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound,
+                           absmax_out, pa);
     else
         hipLaunchKernelGGL(bn_fwd_finish_fused_kernel<false>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
                            (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
-                           res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound, pa);
+                           res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound,
+                           absmax_out, pa);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -1204,7 +1211,20 @@ extern "C" int semseg_bn_fwd_stats_fused(const float* z, int P, int C, double* s
                                          void* blockbound, void* workspace, size_t workspace_bytes, void* stream) {
     return bn_fwd_stats_fused_impl(z, P, C, stats, zmm, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                                    relu, res_absmax, mean, invstd, scale, shift, blockbound, workspace, workspace_bytes, stream,
-                                   nullptr);
+                                   nullptr, nullptr);
+}
+
+// + the bound of |y| itself in absmax_out (for outputs that are not written as planes: semseg_bn_apply follows, not _apply_h2)
+extern "C" int semseg_bn_fwd_stats_fused_bound(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
+                                               const float* beta, float* running_mean, float* running_var,
+                                               int64_t* num_batches_tracked, float momentum, float eps, int relu,
+                                               const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
+                                               void* blockbound, void* workspace, size_t workspace_bytes, void* stream,
+                                               float* absmax_out) {
+    if (!absmax_out) return SEMSEG_EINVAL;
+    return bn_fwd_stats_fused_impl(z, P, C, stats, zmm, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                   relu, res_absmax, mean, invstd, scale, shift, blockbound, workspace, workspace_bytes, stream,
+                                   nullptr, absmax_out);
 }
 
 extern "C" int semseg_bn_fwd_stats_fused_peer(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
@@ -1212,11 +1232,11 @@ extern "C" int semseg_bn_fwd_stats_fused_peer(const float* z, int P, int C, doub
                                               int64_t* num_batches_tracked, float momentum, float eps, int relu,
                                               const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
                                               void* blockbound, void* workspace, size_t workspace_bytes, void* stream,
-                                              void* peer) {
+                                              void* peer, float* absmax_out) {
     if (!peer) return SEMSEG_EINVAL;
     return bn_fwd_stats_fused_impl(z, P, C, stats, zmm, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                                    relu, res_absmax, mean, invstd, scale, shift, blockbound, workspace, workspace_bytes, stream,
-                                   peer);
+                                   peer, absmax_out);
 }
 
 // PEER: as bn_fwd_finish_fused_kernel -- [sum g, sum g xhat] summed over the ranks inside the kernel; dgamma / dbeta stay the

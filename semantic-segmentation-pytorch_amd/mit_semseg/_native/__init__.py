@@ -72,7 +72,9 @@ SIGNATURES = {
     'semseg_bn_bwd_reduce_fused': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, c_int,
                                            vp, vp, vp, vp, vp, c_sz, vp]),
     'semseg_bn_fwd_stats_fused_peer': (c_int, [vp, c_int, c_int, vp, vp, vp, vp, vp, vp, vp, c_f, c_f, c_int, vp, vp, vp, vp, vp,
-                                          vp, vp, c_sz, vp] + [vp]),
+                                               vp, vp, c_sz, vp] + [vp, vp]),
+    'semseg_bn_fwd_stats_fused_bound': (c_int, [vp, c_int, c_int, vp, vp, vp, vp, vp, vp, vp, c_f, c_f, c_int, vp, vp, vp, vp, vp,
+                                                vp, vp, c_sz, vp] + [vp]),
     'semseg_bn_bwd_reduce_fused_peer': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, c_int,
                                            vp, vp, vp, vp, vp, c_sz, vp] + [vp]),
     'semseg_weights_prepare_h2': (c_int, [ctypes.POINTER(WPrepTensor), c_int, vp]),

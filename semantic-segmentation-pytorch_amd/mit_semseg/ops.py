@@ -659,6 +659,8 @@ _SYNC_GROUP = {'group': None, 'enabled': False, 'force': os.environ.get('SEMSEG_
 # the next segment begins -- at replay the collectives are issued eagerly between the segment launches
 _SEGMENTS = None
 PEER_FUSED = os.environ.get('SEMSEG_PEER_FUSED', '1') != '0'
+# BN outputs that are not written as planes (no ReLU): 0 = the four-launch unfused forward (A/B switch)
+BN_BOUND_FUSED = os.environ.get('SEMSEG_BN_BOUND_FUSED', '1') != '0'
 
 
 def set_sync_bn_group(group, enabled=True):
@@ -884,19 +886,26 @@ class ConvBNActFn(Function):
         y = empty_nhwc(n, k, oh, ow, dev)
         sync = _sync_active()
         peer = _sync_peer(2 * k + 1) if sync else None
-        if (not sync or peer is not None) and yp is not None:
+        if (not sync or peer is not None) and (yp is not None or (absmax is not None and BN_BOUND_FUSED)):
             # one rank: finish + finalize in one kernel; the apply kernel derives the exponent from the per-block bounds.
             # SyncBN over the peer exchange: the same kernel exchanges its sums with the other ranks on the way (csrc/peer_dev.h)
             bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
             args = (_p(z), P, k, _p(stats), _p(zmm), _p(g), _p(b), _p(running_mean), _p(running_var), _p(nbt), float(momentum),
                     float(eps), int(relu), _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(bb), _p(ws),
                     ws.numel(), _st())
-            if peer is None:
-                _native.check(L.semseg_bn_fwd_stats_fused(*args), 'bn_fwd_stats_fused')
+            bound = None if yp is not None else _p(absmax)       # no planes: the bound of |y| comes from the finish kernel itself
+            if peer is not None:
+                _native.check(L.semseg_bn_fwd_stats_fused_peer(*args, peer, bound), 'bn_fwd_stats_fused_peer')
+            elif bound is not None:
+                _native.check(L.semseg_bn_fwd_stats_fused_bound(*args, bound), 'bn_fwd_stats_fused_bound')
             else:
-                _native.check(L.semseg_bn_fwd_stats_fused_peer(*args, peer), 'bn_fwd_stats_fused_peer')
-            _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), _p(yp),
-                                               P, k, _p(bb), _p(absmax), _st()), 'bn_apply_h2')
+                _native.check(L.semseg_bn_fwd_stats_fused(*args), 'bn_fwd_stats_fused')
+            if yp is not None:
+                _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), _p(yp),
+                                                   P, k, _p(bb), _p(absmax), _st()), 'bn_apply_h2')
+            else:
+                _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), k, P, k,
+                                                _st()), 'bn_apply')
         else:
             _native.check(L.semseg_bn_stats_mm(_p(z), P, k, _p(stats), _p(zmm), _p(ws), ws.numel(), _st()), 'bn_stats_mm')
             _maybe_allreduce(stats)

@@ -277,3 +277,25 @@ def test_bench_ddp_graph_selftest_fails_closed(monkeypatch):
     t = time.time()
     assert bench.ddp_graph_selftest(timeout_s=6) == {'comm': False, 'peer': False, 'segmented': False, 'graph': False}
     assert time.time() - t < 30
+
+
+def test_gradient_buckets_small_tail():
+    """The last bucket (the first layers of the network: complete only when backward is) is kept small, every parameter is in
+    exactly one bucket, and the buckets follow the reverse registration order."""
+    import torch
+    from mit_semseg.parallel import GradientBuckets
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (10, 20, 30, 400, 50, 60, 700, 80)]       # registration order: first layer first
+    gb = GradientBuckets(ps, bucket_bytes=4 * 1000, overlap=False)                                # tail = 1/16 of a bucket = 62 elements
+    sizes = [b['flat'].numel() for b in gb.buckets]
+    order = [p for b in gb.buckets for p, _, _ in b['items']]
+    assert order == list(reversed(ps)) and sum(sizes) == sum(p.numel() for p in ps)
+    assert sizes[-1] <= 62 and sizes[-1] == 10 + 20 + 30 and len(gb.buckets) == 3, sizes
+    # one parameter alone, or a tail that is small already: nothing to split
+    assert len(GradientBuckets(ps[:1], bucket_bytes=4 * 1000, overlap=False).buckets) == 1
+    gb2 = GradientBuckets(ps, bucket_bytes=4 * 1000, overlap=False, tail_bytes=4 * 10 ** 6)
+    assert [b['flat'].numel() for b in gb2.buckets] == [80 + 700 + 60 + 50, 400 + 30 + 20 + 10]
+    for b in gb.buckets:                       # offsets are contiguous inside a bucket
+        off = 0
+        for p, o, n in b['items']:
+            assert o == off and n == p.numel()
+            off += n

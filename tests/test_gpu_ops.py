@@ -403,7 +403,17 @@ def test_bn_h2_forward_kernels(n, c, h, w, relu, res):
                                               ops._p(bb), ops._p(ws), ws.numel(), st), 'fwd_stats_fused')
     _native.check(L.semseg_bn_apply_h2(ops._p(z), ops._p(coef_f[2]), ops._p(coef_f[3]), ops._p(r), c, int(relu), ops._p(y_f),
                                        ops._p(yp_f), P, c, ops._p(bb), ops._p(absmax_f), st), 'apply_h2_fused')
+    # ... and the form for outputs without planes: the bound itself comes from the finish kernel (max over its blocks)
+    stats_b, zmm_b, coef_b = torch.empty_like(stats_f), torch.empty_like(zmm_f), torch.empty_like(coef_f)
+    absmax_b = torch.full((1,), 7e30, device=d)
+    bb_b = torch.empty_like(bb)
+    _native.check(L.semseg_bn_fwd_stats_fused_bound(ops._p(z), P, c, ops._p(stats_b), ops._p(zmm_b), ops._p(gamma), ops._p(beta),
+                                                    ops._p(None), ops._p(None), ops._p(None), 0.1, 1e-5, int(relu), ops._p(rabs),
+                                                    ops._p(coef_b[0]), ops._p(coef_b[1]), ops._p(coef_b[2]), ops._p(coef_b[3]),
+                                                    ops._p(bb_b), ops._p(ws), ws.numel(), st, ops._p(absmax_b)), 'fwd_stats_fused_bound')
     torch.cuda.synchronize()
+    assert torch.equal(stats_b, stats_f) and torch.equal(coef_b, coef_f) and torch.equal(bb_b, bb)
+    assert absmax_b.item() == absmax_f.item() == absmax.item()
     assert torch.equal(stats_f, stats) and torch.equal(zmm_f, zmm) and int(nbt.item()) == 1
     for a, b in ((coef_f, coef), (rm3, rm2), (rv3, rv2), (y_f, y)):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
