@@ -123,7 +123,10 @@ class HighResolutionModule(nn.Module):
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        x = ops.run_branches(list(self.branches), x)      # independent until the exchange below: side streams (ops.run_branches)
+        # The accumulation chains of the exchange are independent of each other as well, but a step whose capture forks them onto
+        # the branch streams too makes hipStreamEndCapture crash on this ROCm (gpurun r3x; eager launches are fine): they stay
+        # on the current stream.
         fused = []
         for i in range(len(self.fuse_layers)):
             # same left-to-right summation order as hrnet.py:232-248

@@ -52,12 +52,100 @@ _WS_RETIRED = []        # superseded scratch buffers: captured hipGraphs hold th
 _WS_MIN = 64 << 20
 
 
+# Independent sub-networks on separate HIP streams (HRNet's parallel branches, hrnet.py:225-227): the launch-bound kernels of the
+# low-resolution branches overlap with the high-resolution branch, in eager launches and -- captured as parallel chains -- in the
+# step's hipGraph.  Autograd runs every backward node on the stream of its forward, so backward overlaps the same way.
+BRANCH_STREAMS = os.environ.get('SEMSEG_BRANCH_STREAMS', '1') != '0'
+_BRANCH_POOL = {}       # device index -> [torch.cuda.Stream]
+_BRANCH_TAG = {}        # raw stream handle -> workspace tag
+
+
+def _branch_streams(device, count):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _BRANCH_POOL.setdefault(idx, [])
+    while len(pool) < count:
+        st = torch.cuda.Stream(device=device)
+        _BRANCH_TAG[st.cuda_stream] = 'branch%d' % len(pool)
+        pool.append(st)
+    return pool[:count]
+
+
+def run_branches(fns, args):
+    """[f(a) for f, a in zip(fns, args)] with f_1 ... f_n-1 on side streams (f_0, the largest, stays on the current stream);
+    joined before returning.  Off when SyncBN is active (the ranks must issue their exchanges in ONE order) and during a
+    segmented capture."""
+    x0 = args[0]
+    while isinstance(x0, (list, tuple)):                  # an argument may be a list of tensors (every branch reads all of them)
+        x0 = x0[0]
+    if not (BRANCH_STREAMS and len(fns) > 1 and torch.is_tensor(x0) and x0.is_cuda) or _sync_active() or _SEGMENTS is not None:
+        return [f(a) for f, a in zip(fns, args)]
+    main = torch.cuda.current_stream(x0.device)
+    if main.cuda_stream in _BRANCH_TAG:                  # nested use: stay sequential on this branch's stream
+        return [f(a) for f, a in zip(fns, args)]
+    pool = _branch_streams(x0.device, len(fns) - 1)
+    _presplit_shared(args)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    outs = [None] * len(fns)
+    for i in range(1, len(fns)):
+        pool[i - 1].wait_event(fork)
+        _crosses_to(args[i], pool[i - 1])                # allocated on this stream, read (and saved for backward) on the branch's
+        with torch.cuda.stream(pool[i - 1]):
+            outs[i] = fns[i](args[i])
+    outs[0] = fns[0](args[0])
+    for i in range(1, len(fns)):
+        done = torch.cuda.Event()
+        done.record(pool[i - 1])
+        main.wait_event(done)
+        _crosses_to(outs[i], main)                       # allocated on the branch stream, consumed on this one
+    return outs
+
+
+def _presplit_shared(args):
+    """A tensor that several branches read gets its split planes HERE, before the fork: input_planes() leaves the planes of a
+    conv input on the tensor for its next consumer, and a branch on another stream must not pick up planes whose split kernel
+    it is not ordered after."""
+    if not FUSE or CONV_MODE not in SCHEMES:
+        return
+    count, first = {}, {}
+    for a in args:
+        for t in (a if isinstance(a, (list, tuple)) else (a,)):
+            if torch.is_tensor(t) and t.is_cuda and t.dim() == 4:
+                count[id(t)] = count.get(id(t), 0) + 1
+                first[id(t)] = t
+    for k, c in count.items():
+        if c > 1:
+            input_planes(first[k], CONV_MODE)
+
+
+def _crosses_to(t, stream):
+    """tensor `t` -- and the split planes / bound scalars that travel with it -- is used on `stream`, which is not the stream it
+    was allocated on: tell the caching allocator, or the block could be handed out again while that stream still reads it"""
+    if isinstance(t, (list, tuple)):
+        for e in t:
+            _crosses_to(e, stream)
+        return
+    if not torch.is_tensor(t) or not t.is_cuda:
+        return
+    t.record_stream(stream)
+    rec = getattr(t, '_semseg_planes', None)
+    if rec is not None and torch.is_tensor(rec[0]):
+        rec[0].record_stream(stream)
+    rec = getattr(t, '_semseg_absmax', None)
+    if rec is not None:
+        for b in rec[0]:
+            if torch.is_tensor(b):
+                b.record_stream(stream)
+
+
 def workspace(nbytes, device, tag=''):
     """`tag`: kernels running concurrently on different streams need disjoint scratch (tag 'side': the weight-gradient
     stream).  A buffer that is outgrown stays allocated (`_WS_RETIRED`): a hipGraph captured earlier (TrainStep, one
     InferenceGraph per shape) has its address baked into split-K / BN-partial launches, and handing the block back to the
     caching allocator would let a replay scribble over whatever tensor gets it next.  Growth is geometric (x1.5), so the
     retired blocks add up to at most twice the live one."""
+    if _BRANCH_TAG and device.type == 'cuda':           # a branch stream of run_branches: its own scratch
+        tag = _BRANCH_TAG.get(torch.cuda.current_stream(device).cuda_stream, tag)
     key = (device.type, device.index if (device.index is not None or device.type != 'cuda') else torch.cuda.current_device(), tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
