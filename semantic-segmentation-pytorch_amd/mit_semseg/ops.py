@@ -55,7 +55,7 @@ _WS_MIN = 64 << 20
 # Independent sub-networks on separate HIP streams (HRNet's parallel branches, hrnet.py:225-227): the launch-bound kernels of the
 # low-resolution branches overlap with the high-resolution branch, in eager launches and -- captured as parallel chains -- in the
 # step's hipGraph.  Autograd runs every backward node on the stream of its forward, so backward overlaps the same way.
-BRANCH_STREAMS = os.environ.get('SEMSEG_BRANCH_STREAMS', '1') != '0'
+BRANCH_STREAMS = os.environ.get('SEMSEG_BRANCH_STREAMS', '1') != '0'       # '2': in no_grad (inference) passes as well
 _BRANCH_POOL = {}       # device index -> [torch.cuda.Stream]
 _BRANCH_TAG = {}        # raw stream handle -> workspace tag
 
@@ -79,6 +79,8 @@ def run_branches(fns, args):
         x0 = x0[0]
     if not (BRANCH_STREAMS and len(fns) > 1 and torch.is_tensor(x0) and x0.is_cuda) or _sync_active() or _SEGMENTS is not None:
         return [f(a) for f, a in zip(fns, args)]
+    if not torch.is_grad_enabled() and os.environ.get('SEMSEG_BRANCH_STREAMS', '1') != '2':
+        return [f(a) for f, a in zip(fns, args)]         # measured on the training step only (a forked hipGraph pays ~4 us per kernel)
     main = torch.cuda.current_stream(x0.device)
     if main.cuda_stream in _BRANCH_TAG:                  # nested use: stay sequential on this branch's stream
         return [f(a) for f, a in zip(fns, args)]
