@@ -269,12 +269,10 @@ def ddp_graph_selftest(timeout_s=240):
             why = str(e)
         log.seek(0)
         out = log.read().decode('utf-8', 'replace')
-    # the markers are printed by rank 0's child only; a non-zero rank infers its stages from its own exit code, and the
-    # all-reduce(min) in main() combines them
-    stages = {'comm': 'COMM_OK' in out or (env.get('RANK', '0') != '0' and rc == 0),
-              'peer': 'PEER_OK' in out or (env.get('RANK', '0') != '0' and rc == 0),
-              'segmented': 'SEGMENTED_OK' in out or (env.get('RANK', '0') != '0' and rc == 0),
-              'graph': rc == 0}
+    # every rank's child prints the markers of the stages it passed into its own log (a child that dies in a later stage -- the
+    # whole-step graph is the risky one -- keeps the earlier ones); the all-reduce(min) in main() combines the ranks
+    stages = {'comm': 'COMM_OK' in out, 'peer': 'PEER_OK' in out, 'segmented': 'SEGMENTED_OK' in out,
+              'graph': rc == 0 and 'GRAPH_OK' in out}
     if rc != 0 and env.get('RANK', '0') == '0':
         print('[bench] data-parallel self-test: %s; stages reached %s\n%s' % (why, stages, out[-1500:]), file=sys.stderr, flush=True)
     return stages
@@ -337,7 +335,11 @@ def main():
             os.environ['SEMSEG_PEER'] = '0'
         if not selftest_ok['segmented']:
             os.environ['SEMSEG_DDP_SEGMENTED'] = '0'
-        if selftest_ok['graph']:
+        # One hipGraph for the whole step needs the gradient buckets' side stream INSIDE the graph, and a graph with parallel
+        # chains dispatches ~4 us per kernel slower than a linear one (profiles/r3i-m_ab_tile_forms.txt: +3.4 ms on this step).
+        # With the peer exchange up the segmented executor has only the buckets between its (linear) segments, so it is the better
+        # mode; without it the alternative is 122 host-issued collectives per step, and the single graph is preferred.
+        if selftest_ok['graph'] and not (selftest_ok['peer'] and selftest_ok['segmented']):
             os.environ['SEMSEG_DDP_GRAPH'] = '1'
     sm = build_model(dev, cfg)
     if world > 1:

@@ -32,11 +32,11 @@ def main():
     dec = ModelBuilder.build_decoder('ppm_deepsup', fc_dim=512, num_class=150)
     sm = SegmentationModule(enc, dec, nn.NLLLoss(ignore_index=-1), 0.4).to(dev).train()
     dp = NativeDataParallel(sm)                         # brings up the C ABI's own RCCL communicator (self-tested sums)
-    if rank == 0:
-        print('COMM_%s native RCCL communicator through the C ABI: %s' % ('OK' if dp.native_comm else 'OFF', dp.native_comm), flush=True)
-    if rank == 0:       # peer_init is unanimous by construction (every rank mapped every inbox and summed correctly, or nobody uses it)
-        print('PEER_%s one-node peer exchange of the SyncBN payloads (csrc/peer.hip): %s' % ('OK' if dp.peer_exchange else 'OFF', dp.peer_exchange),
-              flush=True)
+    # every rank: its own parent reads its own child's log
+    print('COMM_%s native RCCL communicator through the C ABI: %s' % ('OK' if dp.native_comm else 'OFF', dp.native_comm), flush=True)
+    # peer_init is unanimous by construction (every rank mapped every inbox and summed correctly, or nobody uses it)
+    print('PEER_%s one-node peer exchange of the SyncBN payloads (csrc/peer.hip): %s' % ('OK' if dp.peer_exchange else 'OFF', dp.peer_exchange),
+          flush=True)
 
     def replicas_identical():
         sums = torch.stack([p.detach().double().abs().sum() for p in sm.parameters()] +
@@ -60,8 +60,7 @@ def main():
     comm.peer_check()
     replicas_identical()        # every rank trains on different data: equal replicas <=> every exchange delivered every payload
     dist.barrier()
-    if rank == 0:
-        print('SEGMENTED_OK loss %.5f' % loss.item(), flush=True)
+    print('SEGMENTED_OK loss %.5f' % loss.item(), flush=True)
     # stage 2: RCCL captured inside ONE hipGraph
     os.environ['SEMSEG_DDP_GRAPH'] = '1'
     ts = TrainStep(sm, max_iters=1000, graph=True, bucket_bytes=8 << 20)
@@ -89,8 +88,7 @@ def main():
     ref = torch.tensor([loss.item()], device=dev, dtype=torch.float64)
     dist.all_reduce(ref)                          # also proves an eager collective still works after the replays
     dist.barrier()
-    if rank == 0:
-        print('GRAPH_OK ddp graph selftest ok: world %d, loss %.5f' % (world, loss.item()), flush=True)
+    print('GRAPH_OK ddp graph selftest ok: world %d, loss %.5f' % (world, loss.item()), flush=True)
     comm.peer_destroy()
     dist.destroy_process_group()
 
