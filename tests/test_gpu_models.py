@@ -241,3 +241,34 @@ def test_inference_graph_replay_equals_eager():
         torch.cuda.synchronize()
         assert torch.equal(got, want), seed
 
+
+
+def test_hrnet_branch_streams_equal_one_stream(monkeypatch):
+    """ops.run_branches: HRNetV2's parallel branches on side HIP streams (hrnet.py:225-227) train to exactly the weights of the
+    one-stream step -- same kernels, same order inside every branch -- with eager launches and as a captured hipGraph whose
+    branches are parallel chains; the scratch of the branch streams is their own."""
+    from mit_semseg import ops, tuner
+    from mit_semseg.engine import TrainStep
+    monkeypatch.setattr(tuner, 'ENABLED', False)          # heuristic launch plans: the runs must sum in the same order
+    g = load_golden('hrnetv2_c1_64_train')
+    m = g['meta']
+    dev = torch.device('cuda:0')
+    img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=m['seed'] + 2)
+    feed = {'img_data': img.to(dev), 'seg_label': lab.to(dev)}
+    res = {}
+    for streams, graph in ((False, False), (True, False), (True, True)):
+        monkeypatch.setattr(ops, 'BRANCH_STREAMS', streams)
+        sm, _, _ = build_native(g, dev)
+        ts = TrainStep(sm, max_iters=1000, graph=graph)
+        for _ in range(4):
+            loss, acc = ts.step(feed)
+        torch.cuda.synchronize()
+        if graph:
+            assert ts.stats['replayed'] >= 2
+        res[(streams, graph)] = ({k: v.detach().clone() for k, v in sm.state_dict().items()}, loss.item())
+    assert ops._BRANCH_POOL and any(k[2].startswith('branch') for k in ops._WS)       # the branch streams really ran, on their own scratch
+    base = res[(False, False)]
+    for key in ((True, False), (True, True)):
+        assert res[key][1] == base[1], (key, res[key][1], base[1])
+        for k, v in base[0].items():
+            assert torch.equal(res[key][0][k], v), (key, k)
