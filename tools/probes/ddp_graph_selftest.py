@@ -25,6 +25,8 @@ def main():
     from mit_semseg.engine import TrainStep
     rank, world, local = init_distributed()
     assert world > 1, 'run with one process per GPU (WORLD_SIZE > 1)'
+    if os.environ.get('SEMSEG_BENCH_DEVICE'):          # several ranks on one GPU (gloo transport): functional check of this script
+        local = int(os.environ['SEMSEG_BENCH_DEVICE'])
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     torch.manual_seed(304)
