@@ -336,9 +336,10 @@ def main():
         if not selftest_ok['segmented']:
             os.environ['SEMSEG_DDP_SEGMENTED'] = '0'
         # One hipGraph for the whole step needs the gradient buckets' side stream INSIDE the graph, and a graph with parallel
-        # chains dispatches ~4 us per kernel slower than a linear one (profiles/r3i-m_ab_tile_forms.txt: +3.4 ms on this step).
-        # With the peer exchange up the segmented executor has only the buckets between its (linear) segments, so it is the better
-        # mode; without it the alternative is 122 host-issued collectives per step, and the single graph is preferred.
+        # chains is submitted node by node (profiles/r3i-m_ab_tile_forms.txt: +3.4 ms on this step).  With the peer exchange up
+        # the segmented executor has only the buckets between its (linear) segments, so it is the better mode (the child does not
+        # even try the single graph then); without it the alternative is 122 host-issued collectives per step, and the single
+        # graph is preferred when it works.
         if selftest_ok['graph'] and not (selftest_ok['peer'] and selftest_ok['segmented']):
             os.environ['SEMSEG_DDP_GRAPH'] = '1'
     sm = build_model(dev, cfg)

@@ -1,10 +1,14 @@
-"""Self-test of the hipGraph data-parallel step, one process per GPU (launched by bench.py on every rank before the real run,
-or by hand under torchrun): a small model (ResNet18dilated + PPM_deepsup, 2 x 64 x 64 per rank) trains a few steps with
-SEMSEG_DDP_GRAPH=1 -- the SyncBN exchanges on the compute stream (csrc/peer.hip kernels when the peer exchange came up, RCCL
-all-reduces otherwise) and the gradient buckets on the side stream are CAPTURED with the rest of the step and replayed.  Passes (exit 0) only if the graph was really used, the loss is finite and
-the replicas stay bit-identical (their parameters could not agree if any captured all-reduce were dropped or stale: every
-rank trains on different data).  bench.py enables the graph path for the real run only when every rank's self-test passed
-inside its time limit; anything else -- an exception, a hang that the parent kills -- leaves the eager path in place."""
+"""Self-test of the data-parallel step, one process per GPU (launched by bench.py on every rank in a child process before the real
+run, or by hand under torchrun): a small model (ResNet18dilated + PPM_deepsup, 2 x 64 x 64 per rank, every rank on different data)
+goes through exactly the production code paths, in stages, and prints a marker per stage it passed:
+  COMM_OK       the C ABI's own RCCL communicators came up and summed correctly (NativeDataParallel -> comm.init),
+  PEER_OK       the one-node peer exchange of the SyncBN sums came up on every rank and summed correctly (comm.peer_init),
+  SEGMENTED_OK  the segmented hipGraph executor trained 5 steps, no exchange timed out, the replicas are bit-identical (they could
+                not be if any exchange or all-reduce were dropped or stale),
+  GRAPH_OK      the whole step incl. the RCCL all-reduces replayed as ONE hipGraph with identical replicas -- only tried when the
+                peer exchange is NOT up (GRAPH_SKIPPED otherwise: the real run then stays segmented, see bench.py).
+bench.py enables for the real run what every rank's child reached; an exception, or a hang that the parent kills at its time limit,
+leaves the later stages off."""
 import os
 import sys
 
@@ -63,6 +67,13 @@ def main():
     replicas_identical()        # every rank trains on different data: equal replicas <=> every exchange delivered every payload
     dist.barrier()
     print('SEGMENTED_OK loss %.5f' % loss.item(), flush=True)
+    if dp.peer_exchange and os.environ.get('SEMSEG_SELFTEST_GRAPH', '0') != '1':
+        # with the peer exchange up the real run stays segmented (a hipGraph with the buckets' side stream inside it is submitted
+        # node by node): the whole-step graph is not needed, so it is not risked either
+        print('GRAPH_SKIPPED the segmented executor with the peer exchange is the preferred mode', flush=True)
+        comm.peer_destroy()
+        dist.destroy_process_group()
+        return
     # stage 2: RCCL captured inside ONE hipGraph
     os.environ['SEMSEG_DDP_GRAPH'] = '1'
     ts = TrainStep(sm, max_iters=1000, graph=True, bucket_bytes=8 << 20)
