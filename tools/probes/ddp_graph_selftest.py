@@ -58,7 +58,7 @@ def main():
     # stage 1: the default data-parallel launch mode (SegmentedStep: hipGraph segments, collectives between the replays)
     os.environ['SEMSEG_DDP_GRAPH'] = '0'
     ts0 = TrainStep(sm, max_iters=1000, graph=True, bucket_bytes=8 << 20)
-    for _ in range(5):
+    for _ in range(40):          # ~3 000 SyncBN exchanges and ~200 bucket all-reduces through the replayed segments
         loss, acc = ts0.step(feed)
     torch.cuda.synchronize()
     assert ts0.launch_mode() == 'segmented' and ts0.stats['replayed'] >= 2 and torch.isfinite(loss).item()
