@@ -3,7 +3,7 @@ run, or by hand under torchrun): a small model (ResNet18dilated + PPM_deepsup, 2
 goes through exactly the production code paths, in stages, and prints a marker per stage it passed:
   COMM_OK       the C ABI's own RCCL communicators came up and summed correctly (NativeDataParallel -> comm.init),
   PEER_OK       the one-node peer exchange of the SyncBN sums came up on every rank and summed correctly (comm.peer_init),
-  SEGMENTED_OK  the segmented hipGraph executor trained 5 steps, no exchange timed out, the replicas are bit-identical (they could
+  SEGMENTED_OK  the segmented hipGraph executor trained 40 steps, no exchange timed out, the replicas are bit-identical (they could
                 not be if any exchange or all-reduce were dropped or stale),
   GRAPH_OK      the whole step incl. the RCCL all-reduces replayed as ONE hipGraph with identical replicas -- only tried when the
                 peer exchange is NOT up (GRAPH_SKIPPED otherwise: the real run then stays segmented, see bench.py).
