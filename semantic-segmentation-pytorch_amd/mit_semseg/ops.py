@@ -80,7 +80,7 @@ def run_branches(fns, args):
     if not (BRANCH_STREAMS and len(fns) > 1 and torch.is_tensor(x0) and x0.is_cuda) or _sync_active() or _SEGMENTS is not None:
         return [f(a) for f, a in zip(fns, args)]
     if not torch.is_grad_enabled() and os.environ.get('SEMSEG_BRANCH_STREAMS', '1') != '2':
-        return [f(a) for f, a in zip(fns, args)]         # measured on the training step only (a forked hipGraph pays ~4 us per kernel)
+        return [f(a) for f, a in zip(fns, args)]         # measured on the training step only (a forked hipGraph is submitted node by node)
     main = torch.cuda.current_stream(x0.device)
     if main.cuda_stream in _BRANCH_TAG:                  # nested use: stay sequential on this branch's stream
         return [f(a) for f, a in zip(fns, args)]
