@@ -41,7 +41,7 @@ def _joint_case():
     return enc_sd, dec_sd, img, lab, masks
 
 
-def _worker(rank, world, port, out_dir, mode):
+def _worker(rank, world, port, out_dir, mode, unequal=False):
     peer = mode != 'gloo_allreduce'
     for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
         if p not in sys.path:
@@ -74,6 +74,8 @@ def _worker(rank, world, port, out_dir, mode):
         ts = TrainStep(sm, lr_encoder=LR, lr_decoder=LR, max_iters=10 ** 9, bucket_bytes=8 << 20)
         assert ts.buckets is not None and len(ts.buckets.buckets) > 1
         feed = {'img_data': img[sl].to(dev), 'seg_label': lab[sl].to(dev)}
+        if unequal and rank == 1:            # a different H x W on this rank (config 4: per-GPU batch shapes differ): 64 x 48 pixels
+            feed = {'img_data': img[sl][:, :, :, :48].contiguous().to(dev), 'seg_label': lab[sl][:, :, :6].contiguous().to(dev)}
         loss, acc = ts.step(dp.scatter(feed))
         mloss, macc = mean_over_ranks(loss, acc)
         torch.cuda.synchronize()
@@ -415,3 +417,19 @@ def test_peer_exchange_abi_two_contexts_one_process():
     finally:
         L.semseg_peer_destroy(lone)
         L.semseg_peer_destroy(ghost)
+
+
+def test_two_ranks_unequal_shapes_peer_equals_gloo():
+    """Per-GPU batches of different H x W (BASELINE configs[3], dataset.py:121-142): the ranks contribute different pixel counts to
+    every BN, so the count itself travels with the sums.  The in-kernel peer exchange (block 0 pushes the count, every block
+    gathers it) must train to exactly the replicas of the torch.distributed path, whose [sum, sum^2, n] protocol is pinned against
+    the oracle on CPU (tests/test_distributed_cpu.py::test_syncbn_statistics_protocol_unequal_shards)."""
+    runs = {}
+    for mode in ('peer_fused', 'gloo_allreduce'):
+        with tempfile.TemporaryDirectory() as out_dir:
+            mp.spawn(_worker, args=(2, _free_port(), out_dir, mode, True), nprocs=2, join=True)
+            runs[mode] = [torch.load(os.path.join(out_dir, 'rank%d.pt' % r), weights_only=False) for r in (0, 1)]
+    for k, v in runs['gloo_allreduce'][0]['sd'].items():
+        assert torch.equal(runs['peer_fused'][0]['sd'][k], v), ('peer_fused != gloo_allreduce', k)
+        assert torch.equal(runs['peer_fused'][1]['sd'][k], v), ('ranks differ', k)
+    assert runs['peer_fused'][0]['loss'].item() == runs['gloo_allreduce'][0]['loss'].item()
