@@ -204,6 +204,12 @@ int semseg_bn_finalize_mm(const double* stats, const float* zmm, int C, const fl
 int semseg_bn_apply_h2(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
                        int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
                        void* stream);
+/* semseg_bn_apply_h2 (relu != 0) + the ReLU decisions as a bitmask: gate[p * C/8 + c/8] bit (c % 8) = (y[p][c] > 0), P * C/8 bytes.
+ * semseg_bn_bwd_reduce_fused(_peer) and semseg_bn_bwd_apply_h2 take it in place of y when called with y = gate, y_ld = 0 (and no
+ * gate_scale): the backward of a BN with residual (resnet.py:84-92) then reads 1 bit instead of 4 bytes per element for the gate. */
+int semseg_bn_apply_h2_gate(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
+                            int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
+                            void* stream, unsigned char* gate);
 /* semseg_bn_bwd_reduce + gmax[c] = max_p |g[p,c]| */
 int semseg_bn_bwd_reduce_mm(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
                             const float* mean, const float* invstd, int relu, int P, int C,

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restric
                                                           int res_ld, float* __restrict__ y, uint16_t* __restrict__ planes,
                                                           size_t plane, int pitch, int* __restrict__ hdr, int P, int C,
                                                           int Cp, const uint32_t* __restrict__ blockbound, int nbound,
-                                                          float* __restrict__ absmax_out) {
+                                                          float* __restrict__ absmax_out, uint8_t* __restrict__ gate) {
     const int ex = h2_exponent_from(hdr, blockbound, nbound, absmax_out);
     const float sc2 = pow2i(ex);
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
@@ -683,6 +683,12 @@ __global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restric
             *reinterpret_cast<float4*>(y + p * C + c + 4 * h) = t;
             o[4 * h] = t.x; o[4 * h + 1] = t.y; o[4 * h + 2] = t.z; o[4 * h + 3] = t.w;
         }
+        if (RELU && gate) {                     // the ReLU decisions of these 8 channels, one bit each (y > 0): backward's gate
+            unsigned bits = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bits |= (o[e] > 0.f ? 1u : 0u) << e;
+            gate[p * (size_t)(C >> 3) + (c >> 3)] = (uint8_t)bits;
+        }
         f16x8 p0, p1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -697,9 +703,9 @@ __global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restric
     }
 }
 
-extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
-                                  int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
-                                  void* stream) {
+static int bn_apply_h2_impl(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
+                            int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
+                            void* stream, uint8_t* gate) {
     if (!z || !scale || !shift || !y || !y_planes || P <= 0 || C <= 0 || (C % 8) || !aligned16(z) || !aligned16(y) ||
         !aligned16(y_planes))
         return SEMSEG_EINVAL;
@@ -716,7 +722,7 @@ extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const floa
         if (blocks > target) blocks = target;
     }
     const int nbound = ceil_div(C, 16);
-#define LAUNCH(R, A) hipLaunchKernelGGL((bn_apply_h2_kernel<R, A>), dim3(blocks), dim3(256), 0, st, z, scale, shift, residual, res_ld, y, (uint16_t*)y_planes, plane, pitch, hdr, P, C, Cp, (const uint32_t*)blockbound, nbound, absmax_out)
+#define LAUNCH(R, A) hipLaunchKernelGGL((bn_apply_h2_kernel<R, A>), dim3(blocks), dim3(256), 0, st, z, scale, shift, residual, res_ld, y, (uint16_t*)y_planes, plane, pitch, hdr, P, C, Cp, (const uint32_t*)blockbound, nbound, absmax_out, gate)
     if (residual) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
     else          { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -724,9 +730,25 @@ extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const floa
     return 0;
 }
 
+extern "C" int semseg_bn_apply_h2(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
+                                  int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
+                                  void* stream) {
+    return bn_apply_h2_impl(z, scale, shift, residual, res_ld, relu, y, y_planes, P, C, blockbound, absmax_out, stream, nullptr);
+}
+
+// + the ReLU decisions as a bitmask (P x C/8 bytes, bit e of byte [p][c/8] = y[p][c + e] > 0): the backward kernels take it in place
+// of y (y_ld = 0), 1/32 of the bytes
+extern "C" int semseg_bn_apply_h2_gate(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
+                                       int relu, float* y, void* y_planes, int P, int C, const void* blockbound,
+                                       float* absmax_out, void* stream, unsigned char* gate) {
+    if (!gate || !relu) return SEMSEG_EINVAL;
+    return bn_apply_h2_impl(z, scale, shift, residual, res_ld, relu, y, y_planes, P, C, blockbound, absmax_out, stream, gate);
+}
+
 // ---- backward ----------------------------------------------------------------------------------
 // as bn_bwd_partial_kernel + per-channel max |g|:  gm[by][c]
-// GATE: 0 = no ReLU, 1 = ReLU gate recomputed from z (gscale/gshift), 2 = ReLU gate read from y
+// GATE: 0 = no ReLU, 1 = ReLU gate recomputed from z (gscale/gshift), 2 = ReLU gate read from y, 3 = from the forward's bitmask
+// (`y` then points to P x C/8 bytes, semseg_bn_apply_h2_gate)
 template <int GATE>
 __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __restrict__ dy, int dy_ld,
                                                                 const float* __restrict__ y, int y_ld,
@@ -746,7 +768,17 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
     if (ty < py && c < C) {
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        constexpr bool gate_z = GATE == 1, gate_y = GATE == 2;
+        constexpr bool gate_z = GATE == 1, gate_y = GATE == 2, gate_m = GATE == 3;
+        const uint8_t* mask = reinterpret_cast<const uint8_t*>(y) + (c >> 3);
+        const int mshift = c & 4, mld = C >> 3;
+        auto gate_of = [&](int p) {               // the 4 decisions of this thread's channels as a positive / zero float4
+            if (gate_y) return *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c);
+            if (gate_m) {
+                const unsigned b = (unsigned)mask[(size_t)p * mld] >> mshift;
+                return make_float4((float)(b & 1u), (float)(b >> 1 & 1u), (float)(b >> 2 & 1u), (float)(b >> 3 & 1u));
+            }
+            return f4zero();
+        };
         auto acc = [&](float4 g, const float4 v, const float4 yin) {
             if (GATE != 0) {
                 const float4 yy = gate_z ? relu_gate_from_z(v, gscale + c, gshift + c) : yin;
@@ -771,7 +803,7 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
             for (int u = 0; u < U; ++u) {
                 g[u] = *reinterpret_cast<const float4*>(dy + (size_t)(p + u * py) * dy_ld + c);
                 v[u] = *reinterpret_cast<const float4*>(z + (size_t)(p + u * py) * C + c);
-                yy[u] = gate_y ? *reinterpret_cast<const float4*>(y + (size_t)(p + u * py) * y_ld + c) : f4zero();
+                yy[u] = gate_of(p + u * py);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -779,7 +811,7 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
         }
         for (; p < row1; p += py)
             acc(*reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c), *reinterpret_cast<const float4*>(z + (size_t)p * C + c),
-                gate_y ? *reinterpret_cast<const float4*>(y + (size_t)p * y_ld + c) : f4zero());
+                gate_of(p));
     }
     if (ty < py) {
         double* r = red + ((size_t)ty * cx + tx) * 8;
@@ -982,10 +1014,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
             float4 v4 = f4zero();
             if (TRAIN || gate_z) v4 = *reinterpret_cast<const float4*>(z + p * C + c + 4 * h);
             v[4 * h] = v4.x; v[4 * h + 1] = v4.y; v[4 * h + 2] = v4.z; v[4 * h + 3] = v4.w;
-            if (RELU && !gate_z) {
+            if (RELU && !gate_z && y_ld) {
                 const float4 y4 = *reinterpret_cast<const float4*>(y + p * y_ld + c + 4 * h);
                 yy[4 * h] = y4.x; yy[4 * h + 1] = y4.y; yy[4 * h + 2] = y4.z; yy[4 * h + 3] = y4.w;
             }
+        }
+        if (RELU && !gate_z && !y_ld) {          // the forward's bitmask in place of y (semseg_bn_apply_h2_gate)
+            const unsigned b = reinterpret_cast<const uint8_t*>(y)[p * (size_t)(C >> 3) + (c >> 3)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) yy[e] = (float)(b >> e & 1u);
         }
         f16x8 p0, p1;
 #pragma unroll
@@ -1022,7 +1059,7 @@ extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y
         return SEMSEG_EINVAL;
     if (training && (!z || !mean || !sums || !stats_count)) return SEMSEG_EINVAL;
     if (relu && gate_scale && (!gate_shift || !z)) return SEMSEG_EINVAL;
-    if (relu && !gate_scale && (!y || (y_ld % 4) || y_ld < C)) return SEMSEG_EINVAL;
+    if (relu && !gate_scale && (!y || (y_ld != 0 && ((y_ld % 4) || y_ld < C)))) return SEMSEG_EINVAL;     // y_ld 0: bitmask
     hipStream_t st = (hipStream_t)stream;
     const int Cp = round_up32(C), pitch = split_pitch(C);
     const size_t plane = h2_plane_elems((size_t)P, C);
@@ -1338,7 +1375,7 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
         return SEMSEG_EINVAL;
     if (training && (!stats_count || !zmm)) return SEMSEG_EINVAL;
     if (relu && gate_scale && !gate_shift) return SEMSEG_EINVAL;
-    if (relu && !gate_scale && (!y || (y_ld % 4) || y_ld < C)) return SEMSEG_EINVAL;
+    if (relu && !gate_scale && (!y || (y_ld != 0 && ((y_ld % 4) || y_ld < C)) || (y_ld == 0 && (C % 8)))) return SEMSEG_EINVAL;
     const ColGeom g = col_geom(P, C);
     const size_t need = (size_t)g.gy * 2 * C * (sizeof(double) + sizeof(float));
     if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
@@ -1351,6 +1388,7 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
                        invstd, relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, gate_scale, gate_shift)
     if (!relu) LAUNCH_PARTIAL(0);
     else if (gate_scale) LAUNCH_PARTIAL(1);
+    else if (y_ld == 0) LAUNCH_PARTIAL(3);          // `y` is the forward's ReLU bitmask
     else LAUNCH_PARTIAL(2);
 #undef LAUNCH_PARTIAL
     SEMSEG_LAUNCH_CHECK();

@@ -62,6 +62,7 @@ SIGNATURES = {
     'semseg_bn_finalize_mm': (c_int, [vp, vp, c_int, vp, vp, vp, vp, vp, c_f, c_f, c_int, vp, vp, vp, vp, vp, vp, vp,
                                       c_int, vp]),
     'semseg_bn_apply_h2': (c_int, [vp, vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int, vp, vp, vp]),
+    'semseg_bn_apply_h2_gate': (c_int, [vp, vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int, vp, vp, vp, vp]),
     'semseg_bn_bwd_reduce_mm': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, vp, c_sz,
                                         vp]),
     'semseg_bn_bwd_bound': (c_int, [vp, vp, vp, vp, vp, vp, vp, c_int, c_int, vp, c_int, vp]),

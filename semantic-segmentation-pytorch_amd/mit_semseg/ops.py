@@ -751,6 +751,8 @@ _SEGMENTS = None
 PEER_FUSED = os.environ.get('SEMSEG_PEER_FUSED', '1') != '0'
 # BN outputs that are not written as planes (no ReLU): 0 = the four-launch unfused forward (A/B switch)
 BN_BOUND_FUSED = os.environ.get('SEMSEG_BN_BOUND_FUSED', '1') != '0'
+# BN + residual + ReLU: the forward leaves its ReLU decisions as a bitmask and backward reads that instead of y (0 = A/B switch)
+GATE_MASK = os.environ.get('SEMSEG_GATE_MASK', '1') != '0'
 
 
 def set_sync_bn_group(group, enabled=True):
@@ -974,6 +976,7 @@ class ConvBNActFn(Function):
         absmax = torch.empty((1,), device=dev, dtype=torch.float32) if bound_ok else None
         yp = torch.empty(L.semseg_split_h2_bytes(P, k), dtype=torch.uint8, device=dev) if (emit and bound_ok) else None
         y = empty_nhwc(n, k, oh, ow, dev)
+        gate = None
         sync = _sync_active()
         peer = _sync_peer(2 * k + 1) if sync else None
         if (not sync or peer is not None) and (yp is not None or (absmax is not None and BN_BOUND_FUSED)):
@@ -990,7 +993,12 @@ class ConvBNActFn(Function):
                 _native.check(L.semseg_bn_fwd_stats_fused_bound(*args, bound), 'bn_fwd_stats_fused_bound')
             else:
                 _native.check(L.semseg_bn_fwd_stats_fused(*args), 'bn_fwd_stats_fused')
-            if yp is not None:
+            if yp is not None and relu and residual is not None and GATE_MASK:
+                # backward's gate of a BN with residual is (y > 0): leave it as 1 bit per element instead of reading y twice
+                gate = torch.empty((P * (k // 8),), device=dev, dtype=torch.uint8)
+                _native.check(L.semseg_bn_apply_h2_gate(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y),
+                                                        _p(yp), P, k, _p(bb), _p(absmax), _st(), _p(gate)), 'bn_apply_h2_gate')
+            elif yp is not None:
                 _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), _p(yp),
                                                    P, k, _p(bb), _p(absmax), _st()), 'bn_apply_h2')
             else:
@@ -1010,8 +1018,8 @@ class ConvBNActFn(Function):
                 _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), k, P, k,
                                                 _st()), 'bn_apply')
         # the ReLU gate of a BN without residual is recomputed from z in backward: y need not be kept for it
-        keep_y = relu and residual is not None
-        ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v)
+        keep_y = relu and residual is not None and gate is None
+        ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate)
         ctx.geom = geom
         ctx.cfg = (bool(relu), residual is not None)
         box['planes'], box['absmax'] = yp, absmax
@@ -1026,7 +1034,7 @@ class ConvBNActFn(Function):
     def backward(ctx, dy, dx_other=None):
         L = _native.lib()
         sch = SCHEMES['h2']
-        xp, w, wtp, z, y, coef, gamma, stats, zmm, wino_v = ctx.saved_tensors
+        xp, w, wtp, z, y, coef, gamma, stats, zmm, wino_v, gate_bits = ctx.saved_tensors
         relu, has_res = ctx.cfg
         geom = ctx.geom
         n, h, wd, c, k, r, s, stride, pad, dil = geom
@@ -1046,9 +1054,10 @@ class ConvBNActFn(Function):
         gsc, gsh = (coef[2], coef[3]) if gate else (None, None)
         sync = _sync_active()
         peer = _sync_peer(2 * k + 1) if sync else None
+        y_arg, y_ld = (_p(gate_bits), 0) if gate_bits is not None else (_p(y), k)      # y_ld 0: the forward's ReLU bitmask
         if not sync or peer is not None:
             bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
-            args = (_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gsc), _p(gsh), int(relu), P, k, _p(count),
+            args = (_p(dy), dy_ld, y_arg, y_ld, _p(z), _p(coef[0]), _p(coef[1]), _p(gsc), _p(gsh), int(relu), P, k, _p(count),
                     _p(zmm), _p(gamma), 1, _p(sums), _p(dgamma), _p(dbeta), _p(bb), _p(ws), ws.numel(), _st())
             if peer is None:
                 _native.check(L.semseg_bn_bwd_reduce_fused(*args), 'bn_bwd_reduce_fused')
@@ -1061,13 +1070,14 @@ class ConvBNActFn(Function):
                 _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(None), 0, 1, _p(y), k, P, k, _st()),
                               'bn_apply')
                 gsc = gsh = None
+                y_arg, y_ld = _p(y), k
             _native.check(L.semseg_bn_bwd_reduce_mm(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), int(relu), P,
                                                     k, _p(sums), _p(gmax), _p(dgamma), _p(dbeta), _p(ws), ws.numel(),
                                                     _st()), 'bn_bwd_reduce_mm')
             _maybe_allreduce(sums)
             _native.check(L.semseg_bn_bwd_bound(_p(sums), _p(count), _p(gmax), _p(zmm), _p(coef[0]), _p(coef[1]), _p(gamma),
                                                 k, 1, _p(dzp), P, _st()), 'bn_bwd_bound')
-        _native.check(L.semseg_bn_bwd_apply_h2(_p(dy), dy_ld, _p(y), k, _p(z), _p(coef[0]), _p(coef[1]), _p(gamma),
+        _native.check(L.semseg_bn_bwd_apply_h2(_p(dy), dy_ld, y_arg, y_ld, _p(z), _p(coef[0]), _p(coef[1]), _p(gamma),
                                                _p(sums), _p(count), 1, int(relu), _p(dzp), _p(dres), P, k, _p(gsc), _p(gsh),
                                                _p(bb), _st()), 'bn_bwd_apply_h2')
         need_dw = ctx.needs_input_grad[1]

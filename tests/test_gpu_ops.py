@@ -411,6 +411,15 @@ def test_bn_h2_forward_kernels(n, c, h, w, relu, res):
                                                     ops._p(None), ops._p(None), ops._p(None), 0.1, 1e-5, int(relu), ops._p(rabs),
                                                     ops._p(coef_b[0]), ops._p(coef_b[1]), ops._p(coef_b[2]), ops._p(coef_b[3]),
                                                     ops._p(bb_b), ops._p(ws), ws.numel(), st, ops._p(absmax_b)), 'fwd_stats_fused_bound')
+    if relu and c % 8 == 0:
+        # ... and the ReLU decisions as a bitmask next to the same y / planes
+        y_g, yp_g = torch.empty_like(y_f), torch.full_like(yp_f, 0x5a)
+        gate_bits = torch.full((P * (c // 8),), 0xff, dtype=torch.uint8, device=d)
+        _native.check(L.semseg_bn_apply_h2_gate(ops._p(z), ops._p(coef_f[2]), ops._p(coef_f[3]), ops._p(r), c, 1, ops._p(y_g),
+                                                ops._p(yp_g), P, c, ops._p(bb), ops._p(None), st, ops._p(gate_bits)), 'apply_h2_gate')
+        torch.cuda.synchronize()
+        want = ((y_f > 0).view(P, c // 8, 8).to(torch.int32) << torch.arange(8, device=d, dtype=torch.int32)).sum(-1).to(torch.uint8)
+        assert torch.equal(y_g, y_f) and torch.equal(yp_g, yp_f) and torch.equal(gate_bits.view(P, c // 8), want)
     torch.cuda.synchronize()
     assert torch.equal(stats_b, stats_f) and torch.equal(coef_b, coef_f) and torch.equal(bb_b, bb)
     assert absmax_b.item() == absmax_f.item() == absmax.item()
@@ -500,6 +509,24 @@ def test_bn_h2_backward_kernels(n, c, h, w, relu, dres, training):
     _native.check(L.semseg_bn_bwd_apply_h2(ops._p(dy), c, ops._p(None if gate else y), c, ops._p(z), ops._p(mean), ops._p(invstd),
                                            ops._p(gamma), ops._p(sums_f), ops._p(count), int(training), int(relu), ops._p(dzp_f),
                                            ops._p(dres_f), P, c, ops._p(gsc), ops._p(gsh), ops._p(bb), st), 'apply_h2_fused')
+    if relu and not gate and c % 8 == 0:
+        # the forward's ReLU bitmask in place of y (y = mask, y_ld = 0; semseg_bn_apply_h2_gate's layout): identical results
+        bits = (y > 0).view(P, c // 8, 8).to(torch.int32)
+        mask = (bits << torch.arange(8, device=d, dtype=torch.int32)).sum(-1).to(torch.uint8).contiguous()
+        sums_m = torch.empty_like(sums_f)
+        dg_m, db_m, bb_m = torch.empty_like(dg_f), torch.empty_like(db_f), torch.empty_like(bb)
+        dzp_m = torch.full_like(dzp_f, 0x5a)
+        dres_m = torch.empty(P, c, device=d) if dres else None
+        _native.check(L.semseg_bn_bwd_reduce_fused(ops._p(dy), c, ops._p(mask), 0, ops._p(z), ops._p(mean), ops._p(invstd),
+                                                   ops._p(None), ops._p(None), 1, P, c, ops._p(count), ops._p(zmm), ops._p(gamma),
+                                                   int(training), ops._p(sums_m), ops._p(dg_m), ops._p(db_m), ops._p(bb_m), ops._p(ws),
+                                                   ws.numel(), st), 'reduce_fused_mask')
+        _native.check(L.semseg_bn_bwd_apply_h2(ops._p(dy), c, ops._p(mask), 0, ops._p(z), ops._p(mean), ops._p(invstd),
+                                               ops._p(gamma), ops._p(sums_m), ops._p(count), int(training), 1, ops._p(dzp_m),
+                                               ops._p(dres_m), P, c, ops._p(None), ops._p(None), ops._p(bb_m), st), 'apply_h2_mask')
+        torch.cuda.synchronize()
+        assert torch.equal(sums_m, sums_f) and torch.equal(dg_m, dg_f) and torch.equal(db_m, db_f) and torch.equal(bb_m, bb)
+        assert torch.equal(dzp_m, dzp_f) and (not dres or torch.equal(dres_m, dres_f))
     torch.cuda.synchronize()
     if gate:       # reference for the gated variant: the plain kernels on the y built from the same fmaf
         _native.check(L.semseg_bn_bwd_reduce(ops._p(dy), c, ops._p(y), c, ops._p(z), ops._p(mean), ops._p(invstd), 1, P, c,
