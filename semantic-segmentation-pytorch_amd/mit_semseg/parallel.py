@@ -223,10 +223,16 @@ class NativeDataParallel(nn.Module):
         # collectives through the C ABI's own RCCL communicator (csrc/comm.hip) when the group runs on RCCL: one ctypes call per
         # all-reduce instead of a c10d work object.  Collective + self-tested; any failure leaves torch.distributed in charge.
         from . import comm
-        self.native_comm = comm.init(group) if world_size(group) > 1 else False
-        # SyncBN payloads: the one-node peer exchange (csrc/peer.hip) -- one small kernel per exchange over xGMI peer stores,
-        # inside the step's hipGraph segments; RCCL keeps the gradient buckets.  Collective + self-tested as well.
-        self.peer_exchange = comm.peer_init(group) if (sync_bn and world_size(group) > 1) else False
+        self.native_comm = self.peer_exchange = False
+        if world_size(group) > 1:
+            import contextlib
+            dev = next(module.parameters()).device       # communicators and the inbox live on the module's device
+            with (torch.cuda.device(dev) if dev.type == 'cuda' else contextlib.nullcontext()):
+                self.native_comm = comm.init(group)
+                # SyncBN payloads: the one-node peer exchange (csrc/peer.hip) -- the sums cross xGMI inside the BN kernels (or in
+                # one small kernel), inside the step's hipGraph segments; RCCL keeps the gradient buckets.  Collective +
+                # self-tested as well.
+                self.peer_exchange = comm.peer_init(group) if sync_bn else False
 
     def scatter(self, batch):
         """This rank's element of the reference's per-GPU list (data_parallel.py:54-62).  A list must hold ONE dict (this
