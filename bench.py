@@ -421,7 +421,10 @@ def main():
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
+        from mit_semseg import comm
         dist.barrier()
+        comm.peer_check()
+        comm.peer_destroy()
         dist.destroy_process_group()
 
 

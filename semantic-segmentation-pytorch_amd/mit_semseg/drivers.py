@@ -165,6 +165,10 @@ def train_worker(rank, world, cfg, gpus, port):
     if rank == 0:
         print('Training Done!')
     if world > 1:
+        from . import comm
+        comm.peer_check()               # raises if a SyncBN exchange ever timed out
+        comm.peer_destroy()             # collective: nobody unmaps an inbox a peer may still write to
+        comm.destroy_all()
         dist.destroy_process_group()
 
 
