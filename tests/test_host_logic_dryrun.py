@@ -85,6 +85,11 @@ def test_train_step_host_logic(stub, cfg, mode, monkeypatch):
          ('semseg_bn_stats', 'semseg_bn_apply', 'semseg_bn_bwd_reduce', 'semseg_bn_bwd_apply')
     for must in conv + bn + ('semseg_log_softmax_fwd', 'semseg_nll_acc_fwd', 'semseg_nll_bwd', 'semseg_sgd_step'):
         assert must in names, must
+    if mode == 'h2' and arch_enc.startswith(('resnet', 'hrnet')):
+        # the last BN of every residual block leaves its ReLU decisions as a bitmask for backward (no y read there); BNs without
+        # ReLU (shortcut / fuse layers) take the three-launch forward whose finish kernel produces the |y| bound itself
+        assert 'semseg_bn_apply_h2_gate' in names
+        assert 'semseg_bn_fwd_stats_fused_bound' in names
     # second step exercises momentum buffers / grad re-allocation
     ts.step(feed)
 
