@@ -51,12 +51,13 @@ F32_CONV_LAST_HBM_BYTES = 1.78e9      # profiles/r1b_pmc_conv_last_fwd_wgrad.txt
 S3_CONV_LAST_HBM_BYTES = None
 
 
-# profiles/r3g_pmc_conv_last_dgrad_h2.txt (round 2; round 1: r2s_pmc_conv_last_dgrad_h2.txt, same kernel, same counters):
-# FETCH_SIZE 168157 KiB x 2 (the guide's gfx950 correction) + WRITE_SIZE 131072 KiB (the fp32 dx, no split-K); the algorithmic
+# profiles/r3ad_pmc_conv_last_dgrad_h2_tile14.txt (round 2, the 256x256 tile on 16 waves the tuner now picks; the 8-wave form in
+# r3g_pmc_conv_last_dgrad_h2.txt and round 1's r2s_pmc_conv_last_dgrad_h2.txt measured 168157 KiB, the same block tile):
+# FETCH_SIZE 168065 KiB x 2 (the guide's gfx950 correction) + WRITE_SIZE 131072 KiB (the fp32 dx, no split-K); the algorithmic
 # bytes of this launch are 226.5 MB (dy planes 16.8 MB + w planes 75.5 MB + 134.2 MB fp32 output).  FETCH_SIZE counts L2 -> fabric
 # requests: each of the 8 XCDs streams its own copy of the 16.8 MB dy planes (+134 MB), the rest is L2 capacity misses that the
 # 256 MB Infinity Cache absorbs before HBM -- an upper bound of the HBM traffic of an MFMA-bound kernel (0.8 ms x 8 TB/s = 6.4 GB)
-H2_CONV_LAST_HBM_BYTES = (2 * 168157 + 131072) * 1024
+H2_CONV_LAST_HBM_BYTES = (2 * 168065 + 131072) * 1024
 H2_HBM_BYTES = {1: H2_CONV_LAST_HBM_BYTES, 3: H2_CONV_LAST_HBM_BYTES}      # config -> measured traffic of its dominant launch
 H2_CONV_LAST_CLOCK_GHZ = 1.56     # SQ_WAVE_CYCLES x 4 / waves / duration of the same PMC pass: the MFMA-dense kernel runs
                                   # power-limited well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at
