@@ -187,16 +187,18 @@ def peer_init(group=None, max_doubles=PEER_MAX_DOUBLES, selftest=True):
         for n in (3, 257, max_doubles, 1025, 64, 2049, 5):       # 7 exchanges > 4 slots: reuse is exercised
             a = torch.full((n,), float(rank + 1), dtype=torch.float64, device=dev)
             a[0] = 1.0 / (rank + 1)                                # an order-sensitive sum: bit-identical on all ranks or not at all
-            ok = ok and L.semseg_peer_allreduce_sum_f64(handle, ctypes.c_void_p(a.data_ptr()), n, st) == 0
+            # every exchange is launched whatever the verdict so far: the other ranks are waiting for this rank's payload
+            rc = L.semseg_peer_allreduce_sum_f64(handle, ctypes.c_void_p(a.data_ptr()), n, st)
             torch.cuda.synchronize()
             first = 0.0
             for r in range(world):
                 first = first + 1.0 / (r + 1)
-            ok = ok and L.semseg_peer_status(handle) == 0 and bool((a[1:] == want).all()) and float(a[0].item()) == first
+            ok = ok and rc == 0 and L.semseg_peer_status(handle) == 0 and bool((a[1:] == want).all()) and float(a[0].item()) == first
         ok = _unanimous(ok, group)
-    if not ok:
+    if not ok:                       # the same verdict on every rank (_unanimous): everybody takes this branch together
+        torch.cuda.synchronize()
+        dist.barrier(group=group)    # nobody unmaps an inbox while a peer's self-test kernel may still store into it
         if handle:
-            dist.barrier(group=group)
             L.semseg_peer_destroy(handle)
         return False
     _PEERS[_key(group)] = dict(handle=handle, rank=rank, world=world, cap=max_doubles)
