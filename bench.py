@@ -45,22 +45,36 @@ CONFIGS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
-# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the guide's gfx950
-# correction + WRITE_SIZE); measured offline with tools/gpu_pmc.sh, summaries under profiles/ (None = not measured yet)
-F32_CONV_LAST_HBM_BYTES = 1.78e9      # profiles/r1b_pmc_conv_last_fwd_wgrad.txt: 873044 KB x 2 + 32768 KB
-S3_CONV_LAST_HBM_BYTES = None
+# HBM-side bytes and the clock under load of the dominant launch come from DATA: profiles/pmc_index.json lists the rocprofv3 PMC
+# passes (tools/gpu_pmc.sh; separate runs, FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE) keyed by (mode, pass,
+# geometry, tile, split).  The plan the tuner picks in THIS run selects the entry; no entry => traffic null and a warning.
+PMC_INDEX = os.path.join(ROOT, 'profiles', 'pmc_index.json')
 
 
-# profiles/r3ad_pmc_conv_last_dgrad_h2_tile14.txt (round 2, the 256x256 tile on 16 waves the tuner now picks; the 8-wave form in
-# r3g_pmc_conv_last_dgrad_h2.txt and round 1's r2s_pmc_conv_last_dgrad_h2.txt measured 168157 KiB, the same block tile):
-# FETCH_SIZE 168065 KiB x 2 (the guide's gfx950 correction) + WRITE_SIZE 131072 KiB (the fp32 dx, no split-K); the algorithmic
-# bytes of this launch are 226.5 MB (dy planes 16.8 MB + w planes 75.5 MB + 134.2 MB fp32 output).  FETCH_SIZE counts L2 -> fabric
-# requests: each of the 8 XCDs streams its own copy of the 16.8 MB dy planes (+134 MB), the rest is L2 capacity misses that the
-# 256 MB Infinity Cache absorbs before HBM -- an upper bound of the HBM traffic of an MFMA-bound kernel (0.8 ms x 8 TB/s = 6.4 GB)
-H2_CONV_LAST_HBM_BYTES = (2 * 168065 + 131072) * 1024
-H2_HBM_BYTES = {1: H2_CONV_LAST_HBM_BYTES, 3: H2_CONV_LAST_HBM_BYTES}      # config -> measured traffic of its dominant launch
-H2_CONV_LAST_CLOCK_GHZ = 1.56     # SQ_WAVE_CYCLES x 4 / waves / duration of the same PMC pass: the MFMA-dense kernel runs
-                                  # power-limited well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at
+def pmc_lookup(mode, pass_id, geom, plan):
+    try:
+        entries = json.load(open(PMC_INDEX))['entries']
+    except (OSError, ValueError, KeyError):
+        return None
+    if plan is None:
+        return None
+    for e in entries:
+        if e['mode'] == mode and e['pass'] == pass_id and list(e['geom']) == list(geom) and \
+                [e['tile'], e['split']] == list(plan[:2]):
+            return e
+    return None
+
+
+def algorithmic_bytes(pass_id, geom, mode):
+    """bytes one launch has to move at least once: the two operands as split planes (h2: 2 x fp16 = 4 B per element, s3: 6 B,
+    f32: 4 B) + the fp32 result"""
+    n, h, w, c, k, r, s, stride, pad, dil = geom
+    oh, ow = (h + 2 * pad - dil * (r - 1) - 1) // stride + 1, (w + 2 * pad - dil * (s - 1) - 1) // stride + 1
+    per = {'h2': 4, 's3': 6, 'f32': 4}[mode]
+    act_in, act_out = (n * oh * ow * k, n * h * w * c) if pass_id == 1 else (n * h * w * c, n * oh * ow * k)
+    return per * (act_in + c * r * s * k) + 4 * act_out
+
+
 DTYPE = {'h2': 'f32 (fp32 in/out/accumulate; products on the fp16 MFMA via a scaled 2-way fp16 split, 3 terms, 2^-22 per product)',
          's3': 'f32 (fp32 in/out/accumulate; products on the bf16 MFMA via an exact 3-way bf16 split, 6 terms)', 'f32': 'f32'}
 # MFMA products per fp32-accurate MAC block and the issued instruction, per split scheme
@@ -188,28 +202,36 @@ def roofline_entry(kt, gflop, cfg, cfg_id):
     pass_id, geom, layer = cfg['dominant']
     what_pass = 'data gradient' if pass_id == 1 else 'forward'
     plan = tuner.tuned_plans().get((ops.CONV_MODE, pass_id) + tuple(geom))
+    pmc = pmc_lookup(ops.CONV_MODE, pass_id, geom, plan)
+    if pmc is None:
+        print('[bench] no PMC pass in profiles/pmc_index.json for %s pass %d %s plan %s: roofline.traffic is null'
+              % (ops.CONV_MODE, pass_id, list(geom), list(plan[:2]) if plan else None), file=sys.stderr, flush=True)
+    traffic = (2 * pmc['fetch_kib'] + pmc['write_kib']) * 1024 if pmc else None
+    alg_bytes = algorithmic_bytes(pass_id, geom, ops.CONV_MODE)
     if ops.CONV_MODE in SPLIT_TERMS:
         # the kernel issues 16-bit MFMAs (dense peak 2.5 PF); each fp32-accurate MAC costs `terms` 16-bit MACs, so the
         # path's own ceiling is 2500/terms algorithmic TFLOP/s and its MFMA-pipe utilisation is terms*achieved/2500
         terms, inst, what = SPLIT_TERMS[ops.CONV_MODE]
-        traffic = H2_HBM_BYTES.get(cfg_id) if ops.CONV_MODE == 'h2' else S3_CONV_LAST_HBM_BYTES
-        has_pmc = ops.CONV_MODE == 'h2' and cfg_id in H2_HBM_BYTES
+        clock = pmc.get('clock_ghz') if pmc else None
         return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic,
                 'executed_16bit_mfma_tflops': round(terms * achieved, 1),
                 'mfma_pipe_utilisation': round(terms * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
                 'path_ceiling_tflops': round(PEAK_BF16_MFMA_TFLOPS / terms, 1),
+                'frac_of_path_ceiling': round(terms * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
                 'frac_of_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                'algorithmic_bytes': 226.5e6 if has_pmc else None,
-                'clock_ghz_under_load': H2_CONV_LAST_CLOCK_GHZ if has_pmc else None,
-                'mfma_pipe_utilisation_at_measured_clock': round(terms * achieved / (PEAK_BF16_MFMA_TFLOPS * H2_CONV_LAST_CLOCK_GHZ / 2.4), 4)
-                if has_pmc else None,
+                'algorithmic_bytes': alg_bytes,
+                'clock_ghz_under_load': clock,
+                'mfma_pipe_utilisation_at_measured_clock': round(terms * achieved / (PEAK_BF16_MFMA_TFLOPS * clock / 2.4), 4)
+                if clock else None,
+                'pmc_source': pmc.get('source') if pmc else None,
                 'plan_tile_split': list(plan[:2]) if plan else None,
                 'kernel': 'split-%s implicit-GEMM %s (%s per fp32-accurate MAC block, %s), %s (%.2f GFLOP/launch algorithmic, '
-                          '%.3f ms/launch, HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE from profiles/, bytes/launch)'
-                          % (ops.CONV_MODE, what_pass, what, inst, layer, gflop, kt * 1e3)}
+                          '%.3f ms/launch, HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE of the PMC pass named in pmc_source, '
+                          'bytes/launch)' % (ops.CONV_MODE, what_pass, what, inst, layer, gflop, kt * 1e3)}
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': F32_CONV_LAST_HBM_BYTES if cfg_id in (1, 3) else None,
+            'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'algorithmic_bytes': alg_bytes,
+            'pmc_source': pmc.get('source') if pmc else None,
             'kernel': 'exact-fp32 MFMA implicit-GEMM %s, %s (%.2f GFLOP/launch, %.3f ms/launch, HIP events)'
                       % (what_pass, layer, gflop, kt * 1e3)}
 
@@ -254,6 +276,7 @@ def ddp_graph_selftest(timeout_s=240):
     env.pop('TORCHELASTIC_USE_AGENT_STORE', None)       # rank 0 of the children opens its own store on the new port
     env.pop('SEMSEG_TUNE_CACHE', None)
     env['SEMSEG_TUNE'] = '0'                 # the library's heuristic launch plans: the child checks mechanisms, not speed
+    env.setdefault('SEMSEG_PEER', '1')       # the peer exchange is opt-in (comm.peer_enabled): the child is where it earns its place
     script = os.path.join(ROOT, 'tools', 'probes', 'ddp_graph_selftest.py')
     out, rc, why = '', None, 'not started'
     with tempfile.TemporaryFile() as log:
@@ -280,12 +303,91 @@ def ddp_graph_selftest(timeout_s=240):
 
 
 def collectives_used(world):
+    """which transport carried what, with the transports' own count of the ranks: `rccl_ranks` = ncclCommCount of the two native
+    communicators (C ABI semseg_comm_count), `peer_world` = ranks attached to the xGMI peer exchange"""
     if world == 1:
         return None
     from mit_semseg import comm
     buckets = 'C ABI RCCL communicator (semseg_comm_*)' if comm.active() else 'torch.distributed'
     syncbn = 'xGMI peer exchange kernel (semseg_peer_*)' if comm.peer_active() else buckets
-    return {'syncbn': syncbn, 'gradient_buckets': buckets}
+    import torch.distributed as dist
+    return {'syncbn': syncbn, 'gradient_buckets': buckets, 'rccl_ranks': comm.rccl_ranks(), 'peer_world': comm.peer_world(),
+            'torch_distributed_backend': dist.get_backend(), 'torch_distributed_world': dist.get_world_size()}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here -- `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` (what the
+    reference does with one command, train.py:184-190; drivers.launch does the same for train.py) -- and pass rank 0's JSON line
+    through.  Refuses (exit code 2, no JSON line) when the node has fewer GPUs than ranks, unless SEMSEG_BENCH_DEVICE names the
+    one GPU that all ranks are meant to share (functional check of the N > 1 path on a 1-GPU box, gloo transport)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    probe = os.environ.get('SEMSEG_BENCH_LAUNCH_PROBE') == '1'
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    env = dict(os.environ)
+    if not probe and have < n:
+        if 'SEMSEG_BENCH_DEVICE' not in env:
+            print('[bench] --gpus %d but this node has %d GPU(s): refusing to run (and to print a line with n_gpus != --gpus). '
+                  'SEMSEG_BENCH_DEVICE=<index> runs all ranks on ONE GPU over gloo as a functional check.' % (n, have),
+                  file=sys.stderr, flush=True)
+            return 2
+        env.setdefault('SEMSEG_DIST_BACKEND', 'gloo')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env['SEMSEG_BENCH_SELF_LAUNCHED'] = '1'
+    return subprocess.call(cmd, env=env)
+
+
+def launch_probe(args):
+    """SEMSEG_BENCH_LAUNCH_PROBE=1: every rank joins the process group (gloo), the ranks count themselves, rank 0 prints the line's
+    launch-related keys and everybody leaves -- the launch plumbing without a GPU (tests/test_distributed_cpu.py)."""
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        counted = int(t.item())
+    else:
+        counted = 1
+    if rank == 0:
+        print(json.dumps({'probe': True, 'n_gpus': world, 'ranks_counted': counted, 'gpus_arg': args.gpus,
+                          'self_launched': os.environ.get('SEMSEG_BENCH_SELF_LAUNCHED') == '1'}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def other_configs(skip, steps, warmup, budget_s=100):
+    """BASELINE configs[2..4] measured next to the headline (outside its timed region): one `bench.py --config N` leg each, in a
+    child process (own allocator pool, own launch plans), at most `budget_s` seconds per leg.  Returns {cfg: summary}."""
+    import subprocess
+    out = {}
+    for cid in sorted(CONFIGS):
+        if cid == skip:
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', str(cid), '--gpus', '1', '--steps', str(steps), '--warmup',
+               str(warmup), '--no-cpu-baseline', '--no-other-configs']
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
+            line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+            out[str(cid)] = {'workload': CONFIGS[cid]['yaml'], 'img_s': line['value'], 'ms_per_step': line['ms_per_step'],
+                             'launch': line['config']['launch'], 'step_conv_tflops': line['config']['step_conv_tflops_per_gpu'],
+                             'roofline_frac': line['roofline']['frac'], 'roofline_achieved_tflops': line['roofline']['achieved'],
+                             'final_loss': line['config']['final_loss'], 'steps': line['steps'],
+                             'leg_wall_s': round(time.perf_counter() - t0, 1)}
+        except Exception as e:                                    # never lose the headline to a side leg
+            out[str(cid)] = {'workload': CONFIGS[cid]['yaml'], 'img_s': None, 'error': repr(e)[:200],
+                             'leg_wall_s': round(time.perf_counter() - t0, 1)}
+    return out
 
 
 def main():
@@ -295,6 +397,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='N = 1, default config: skip the short legs of BASELINE configs[2..4] (config.other_configs)')
     ap.add_argument('--shapes', type=int, default=16,
                     help='config 3: number of distinct batch shapes of the stream that the run cycles through, all seen (and '
                          'captured) before the timed steps; 0 = the raw stream, cold path included')
@@ -302,6 +406,18 @@ def main():
                     help='index into BASELINE.json configs (default 1: the configuration the metric is quoted on)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+
+    # --gpus is the number of ranks of THIS job: with no launcher around us (WORLD_SIZE unset) start them here; under a
+    # launcher the two must agree -- a line whose n_gpus differs from --gpus is never printed
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if int(env_world or '1') != args.gpus:
+        print('[bench] --gpus %d but the launcher started WORLD_SIZE=%s rank(s): refusing to run' % (args.gpus, env_world),
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    if os.environ.get('SEMSEG_BENCH_LAUNCH_PROBE') == '1':
+        sys.exit(launch_probe(args))
 
     import __graft_entry__ as ge
     ge.build()
@@ -318,8 +434,6 @@ def main():
         selftest_ok = ddp_graph_selftest()
         if not selftest_ok['comm']:
             os.environ['SEMSEG_NATIVE_COMM'] = '0'      # before NativeDataParallel is built: torch.distributed carries the collectives
-        if not selftest_ok['peer']:
-            os.environ['SEMSEG_PEER'] = '0'
     rank, world, local = init_distributed()
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     if os.environ.get('SEMSEG_BENCH_DEVICE'):          # several ranks on one GPU (gloo): functional check of the N>1 path
@@ -332,8 +446,10 @@ def main():
         selftest_ok = dict(zip(STAGES, (bool(v) for v in flag.tolist())))
         if not selftest_ok['comm']:
             os.environ['SEMSEG_NATIVE_COMM'] = '0'
-        if not selftest_ok['peer']:
-            os.environ['SEMSEG_PEER'] = '0'
+        # the peer exchange (opt-in) is switched on only when EVERY rank's child trained the small model through it -- fused BN
+        # kernels exchanging inside hipGraph segments, bucket all-reduces on the side stream between them, bit-identical replicas
+        if os.environ.get('SEMSEG_PEER', '1') != '0':
+            os.environ['SEMSEG_PEER'] = '1' if (selftest_ok['peer'] and selftest_ok['segmented']) else '0'
         if not selftest_ok['segmented']:
             os.environ['SEMSEG_DDP_SEGMENTED'] = '0'
         # One hipGraph for the whole step needs the gradient buckets' side stream INSIDE the graph, and a graph with parallel
@@ -418,8 +534,22 @@ def main():
                        'final_loss': round(lossv, 5)},
             'roofline': roofline_entry(kt, kgflop, cfg, args.config),
         }
+        if world != args.gpus:                  # cannot happen past the checks at the top; never print a mislabelled line
+            raise SystemExit('[bench] world %d != --gpus %d' % (world, args.gpus))
+        cpu_thread, cpu_box = None, {}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg)
+            import threading
+            # the CPU leg (32 host threads, ~15 s) runs beside the GPU legs of the other configs (host-light): both are outside
+            # the timed region of every measurement they accompany
+            cpu_thread = threading.Thread(target=lambda: cpu_box.update(r=cpu_baseline(cfg)))
+            cpu_thread.start()
+        if world == 1 and args.config == 1 and not args.no_other_configs:
+            del step, sm, feeds                  # the legs run in child processes on the same GPU: hand the memory back first
+            torch.cuda.empty_cache()
+            out['config']['other_configs'] = other_configs(args.config, args.steps, args.warmup)
+        if cpu_thread is not None:
+            cpu_thread.join()
+            out['cpu_baseline'] = cpu_box.get('r')
         print(json.dumps(out), flush=True)
     if world > 1:
         from mit_semseg import comm

@@ -119,11 +119,6 @@ int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, floa
 int semseg_conv2d_dgrad_h2(const void* dys, const void* wts, float* dx, int dx_ld,
                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                            void* workspace, size_t workspace_bytes, void* stream);
-/* dx = addend + dgrad: `addend` ([N*H*W][addend_ld] fp32, NHWC) is the gradient another consumer of the same input
- * already produced (residual branch / downsample conv of a bottleneck, resnet.py:72-92); accumulated in the epilogue. */
-int semseg_conv2d_dgrad_acc_h2(const void* dys, const void* wts, const float* addend, int addend_ld, float* dx, int dx_ld,
-                               int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                               void* workspace, size_t workspace_bytes, void* stream);
 int semseg_conv2d_wgrad_h2(const void* xs, const void* dys, float* dw,
                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                            void* workspace, size_t workspace_bytes, void* stream);
@@ -464,6 +459,7 @@ int semseg_comm_available(void);                       /* 1 if an RCCL library c
 int semseg_comm_version(void);                         /* ncclGetVersion code, 0 if unavailable */
 int semseg_comm_unique_id(void* id128);                /* rank 0: 128-byte id to hand to the other ranks (host-side rendezvous) */
 int semseg_comm_init(int rank, int world, const void* id128, void** comm_out);     /* collective over all ranks */
+int semseg_comm_count(void* comm, int* count_out);    /* ncclCommCount: ranks RCCL reports for this communicator */
 int semseg_comm_allreduce_sum_f32(void* comm, float* buf, size_t count, void* stream);    /* in place: gradient buckets */
 int semseg_comm_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream);   /* in place: BN [sum, sum^2, n] */
 /* `n` payloads in one RCCL group (statistics of independent BN layers: PPM branches, HRNet branches) */

@@ -29,6 +29,7 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*GetVersion)(int*) = nullptr;
+    int (*CommCount)(ncclComm_t, int*) = nullptr;
     bool ok = false;
 };
 
@@ -56,6 +57,7 @@ void load_rccl() {
     BIND(GroupStart, "ncclGroupStart");
     BIND(GroupEnd, "ncclGroupEnd");
     BIND(GetVersion, "ncclGetVersion");
+    BIND(CommCount, "ncclCommCount");
 #undef BIND
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.GroupStart &&
                 g_rccl.GroupEnd;
@@ -103,6 +105,15 @@ extern "C" int semseg_comm_init(int rank, int world, const void* id128, void** c
     if (r->CommInitRank(&c, world, id, rank) != ncclSuccess || !c) return SEMSEG_ECOMM;
     *comm_out = new Comm{c, rank, world};
     return 0;
+}
+
+// the number of ranks RCCL itself reports for the communicator (ncclCommCount): the evidence bench.py prints for "these
+// collectives ran over N ranks of RCCL"
+extern "C" int semseg_comm_count(void* comm, int* count_out) {
+    const Rccl* r = rccl();
+    if (!r || !r->CommCount) return SEMSEG_ECOMM;
+    if (!comm || !count_out) return SEMSEG_EINVAL;
+    return r->CommCount(((Comm*)comm)->comm, count_out) == ncclSuccess ? 0 : SEMSEG_ECOMM;
 }
 
 template <int DTYPE>

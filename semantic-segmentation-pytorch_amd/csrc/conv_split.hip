@@ -338,8 +338,6 @@ struct SParams {
     const int* w_exp;
     uint32_t in_plane, w_plane;   // elements per plane (host checks the byte size < 2^31)
     const float* bias;
-    const float* addend;   // optional [M][addend_ld] fp32 added to the result (gradient accumulation in the dgrad epilogue)
-    int addend_ld;
     float* out;
     float* partial;
     int Cp, pitch, out_ld;   // Cp: channels padded to 32; pitch: row stride of the split planes (elements)
@@ -353,7 +351,6 @@ struct SParams {
     int batches;                                       // 0 / 1: plain; > 1: gridDim.z batches (splits must be 1)
     int batch_in_rows, batch_w_rows, batch_out_rows;   // batched GEMM (blockIdx.z = batch): row offsets per batch of the
                                                        // activation planes, of the weight planes (in units of T rows) and of `out`
-    int tap_major;           // k-tile order: 0 = channel chunk major, taps inner (default); 1 = tap major (SEMSEG_TAP_MAJOR=1)
 };
 
 // (chunk, tap) walk of the k loop, shared by both GEMM kernels.  Default order: channel chunk major, taps inner -- the T
@@ -363,8 +360,8 @@ struct KWalk {
     int cc, t, r, s;     // channel chunk, tap, tap row / column of the NEXT k-tile
     bool dirty;          // the tap changed since the last set_tap
     __device__ __forceinline__ void init(const SParams& p, int kt) {
-        if (p.tap_major) { t = kt / p.chunks; cc = kt - t * p.chunks; }
-        else             { cc = kt / p.T;     t = kt - cc * p.T; }
+        cc = kt / p.T;
+        t = kt - cc * p.T;
         r = t / p.S;
         s = t - r * p.S;
         dirty = true;
@@ -375,9 +372,7 @@ struct KWalk {
         if (++t == p.T) { t = 0; r = 0; s = 0; }
     }
     __device__ __forceinline__ void advance(const SParams& p) {
-        if (p.tap_major) {
-            if (++cc == p.chunks) { cc = 0; next_tap(p); }
-        } else if (p.T > 1) {
+        if (p.T > 1) {
             next_tap(p);
             if (t == 0) ++cc;
         } else {
@@ -436,7 +431,6 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
                 if constexpr (SCH::SCALED) v = (v * f1) * f2;
                 if (row < p.M) {
                     v += bvl;
-                    if (direct && p.addend) v += p.addend[(size_t)row * p.addend_ld + col];
                     dst[(size_t)row * dst_ld + col] = v;
                 }
             }
@@ -956,10 +950,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
 // out[m*out_ld + n] = bias[n] + sum_z partial[z][m*Cout + n]   (fixed order => deterministic)
 template <bool VEC>
 __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
-                                         const float* __restrict__ addend, int addend_ld, float* __restrict__ out, int out_ld,
+                                         float* __restrict__ out, int out_ld,
                                          int M, int Cout, int splits) {
     const size_t total = (size_t)M * Cout;
-    if (VEC) {          // Cout, out_ld, addend_ld multiples of 4 and 16-byte aligned bases (checked by the launcher)
+    if (VEC) {          // Cout, out_ld multiples of 4 and 16-byte aligned bases (checked by the launcher)
         const int qpr = Cout >> 2;
         const size_t quads = total >> 2;
         const float4* p4 = reinterpret_cast<const float4*>(partial);
@@ -970,7 +964,6 @@ __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, cons
             // thread and is latency-bound); the additions keep the order z = 0, 1, 2, ...
             float4 s = p4[i];
             const float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : f4zero();
-            const float4 a = addend ? *reinterpret_cast<const float4*>(addend + (size_t)m * addend_ld + n) : f4zero();
             for (int zz = 1; zz < splits; zz += 4) {
                 float4 v[4];
 #pragma unroll
@@ -981,7 +974,6 @@ __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, cons
                     if (zz + u < splits) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
             }
             if (bias) { s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
-            if (addend) { s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
             *reinterpret_cast<float4*>(out + (size_t)m * out_ld + n) = s;
         }
         return;
@@ -992,7 +984,6 @@ __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, cons
         float s = partial[i];
         for (int zz = 1; zz < splits; ++zz) s += partial[(size_t)zz * total + i];
         if (bias) s += bias[n];
-        if (addend) s += addend[(size_t)m * addend_ld + n];
         out[(size_t)m * out_ld + n] = s;
     }
 }
@@ -1097,8 +1088,6 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
     p.in_plane = (uint32_t)in_plane;
     p.w_plane = (uint32_t)w_plane;
     const SPlan pl = plan_gemm(SCH::ID, p.M, p.Cout, p.Cp, p.T, ov_tile, ov_split);
-    static const int tap_major = env_int("SEMSEG_TAP_MAJOR", 0);
-    p.tap_major = tap_major;
     p.chunks = pl.chunks;
     p.ktiles = pl.ktiles;
     p.kt_per_split = pl.kt_per_split;
@@ -1170,14 +1159,14 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
     if (pl.splits > 1) {
         const size_t total = (size_t)p.M * p.Cout;
         const bool vec = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && aligned16(p.out) && aligned16(p.partial) &&
-                         (!p.bias || aligned16(p.bias)) && (!p.addend || ((p.addend_ld % 4 == 0) && aligned16(p.addend)));
+                         (!p.bias || aligned16(p.bias));
         const int blocks = (int)min((size_t)2048, ceil_div_sz(vec ? total / 4 : total, 256));
         if (vec)
-            hipLaunchKernelGGL(split_gemm_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.addend,
-                               p.addend_ld, p.out, p.out_ld, p.M, p.Cout, pl.splits);
+            hipLaunchKernelGGL(split_gemm_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.out, p.out_ld,
+                               p.M, p.Cout, pl.splits);
         else
-            hipLaunchKernelGGL(split_gemm_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.addend,
-                               p.addend_ld, p.out, p.out_ld, p.M, p.Cout, pl.splits);
+            hipLaunchKernelGGL(split_gemm_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.out, p.out_ld,
+                               p.M, p.Cout, pl.splits);
         SEMSEG_LAUNCH_CHECK();
     }
     return 0;
@@ -1220,15 +1209,13 @@ static int conv_fwd(const void* xs, const void* ws, const float* bias, float* y,
 template <class SCH>
 static int conv_dgrad(const void* dys, const void* wts, float* dx, int dx_ld,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                      void* workspace, size_t workspace_bytes, void* stream, const float* addend = nullptr, int addend_ld = 0) {
+                      void* workspace, size_t workspace_bytes, void* stream) {
     if (!dys || !wts || !dx || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0 || dx_ld < C) return SEMSEG_EINVAL;
-    if (addend && addend_ld < C) return SEMSEG_EINVAL;
     if (!aligned16(dys) || !aligned16(wts)) return SEMSEG_EINVAL;
     const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
     if (OH <= 0 || OW <= 0) return SEMSEG_EINVAL;
     SParams p = {};
     p.in = (const uint16_t*)dys; p.wgt = (const uint16_t*)wts; p.bias = nullptr; p.out = dx;
-    p.addend = addend; p.addend_ld = addend_ld;
     p.Cp = round_up32(K); p.pitch = split_pitch(K); p.out_ld = dx_ld;
     p.Hin = OH; p.Win = OW;
     p.Hout = H; p.Wout = W; p.Cout = C;
@@ -1272,7 +1259,7 @@ extern "C" int semseg_winograd_gemm_h2(const void* v_planes, const void* u_plane
     if (!v_planes || !u_planes || !Mout || tiles <= 0 || C <= 0 || K <= 0 || !aligned16(v_planes) || !aligned16(u_planes))
         return SEMSEG_EINVAL;
     SParams p = {};
-    p.in = (const uint16_t*)v_planes; p.wgt = (const uint16_t*)u_planes; p.bias = nullptr; p.addend = nullptr; p.out = Mout;
+    p.in = (const uint16_t*)v_planes; p.wgt = (const uint16_t*)u_planes; p.bias = nullptr; p.out = Mout;
     p.Cp = round_up32(C); p.pitch = split_pitch(C); p.out_ld = K;
     p.Hin = 1; p.Win = tiles; p.Hout = 1; p.Wout = tiles; p.Cout = K;
     p.M = tiles;
@@ -1285,7 +1272,6 @@ extern "C" int semseg_winograd_gemm_h2(const void* v_planes, const void* u_plane
         return SEMSEG_EINVAL;
     p.in_plane = (uint32_t)in_plane;
     p.w_plane = (uint32_t)w_plane;
-    p.tap_major = 0;
     p.chunks = p.Cp / 32;
     p.ktiles = p.chunks;
     p.kt_per_split = p.ktiles;
@@ -1308,15 +1294,6 @@ extern "C" int semseg_winograd_gemm_h2(const void* v_planes, const void* u_plane
         case 14: return launch_dma<SchH2, 256, 256, 4, 4, 12>(p, st);
         default: return SEMSEG_EINVAL;
     }
-}
-
-// dx = addend + dgrad(dys, wts): the gradient another consumer of the same input has already produced is accumulated in the
-// epilogue (no separate add pass); addend may alias dx only element for element (it is read before the write)
-extern "C" int semseg_conv2d_dgrad_acc_h2(const void* dys, const void* wts, const float* addend, int addend_ld, float* dx,
-                                          int dx_ld, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                                          int dil, void* workspace, size_t workspace_bytes, void* stream) {
-    return conv_dgrad<SchH2>(dys, wts, dx, dx_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream,
-                             addend, addend_ld);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1874,9 +1851,7 @@ static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_spl
         if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
         const long tiles = (long)ceil_div(K, kWTiles[t][0]) * ceil_div(C, kWTiles[t][1]) * T;
-        // SEMSEG_WGRAD_MAX_SPLIT (default 64): the M = 131 072 stem layers still walk 73 serial k-tiles per block at 56
-        // splits; raising the cap is the queued experiment of DESIGN section 8 (the tuner then tries 96 ... 256)
-        static const int max_split = max(1, env_int("SEMSEG_WGRAD_MAX_SPLIT", 64));
+        const int max_split = 64;      // a cap of 256 measured nothing better (profiles/r3i-m_ab_tile_forms.txt)
         for (int sp = 1; sp <= max_split; ++sp) {
             if (force_split > 0 && sp != min(force_split, mtiles)) continue;
             if (force_split <= 0 && sp > 1 && mtiles / sp < 8) break;
@@ -2041,15 +2016,13 @@ extern "C" int semseg_winograd_wgrad_gemm_h2(const void* v_planes, const void* d
     p.x_exp = h2_exp_ptr(v_planes, (size_t)16 * tiles, C);
     p.dy_exp = h2_exp_ptr(dm_planes, (size_t)16 * tiles, K);
     p.batches = 16; p.batch_rows = tiles;
-    static const int force_split = env_int("SEMSEG_WINO_WSPLIT", 0);
     const bool big = K >= 256 && C >= 256;
     const int BM = big ? 256 : 128, BN = big ? 256 : 128;
     p.tiles_k = ceil_div(K, BM); p.tiles_c = ceil_div(C, BN);
     const int mtiles = ceil_div(tiles, 32);
     // enough blocks for two waves of the chip; splits over the tiles only when the 16 batches do not provide them
-    int splits = force_split > 0 ? force_split : 1;
-    if (force_split <= 0)
-        while (splits < 8 && (long)p.tiles_k * p.tiles_c * 16 * splits < 384 && mtiles / (splits * 2) >= 8) splits *= 2;
+    int splits = 1;
+    while (splits < 8 && (long)p.tiles_k * p.tiles_c * 16 * splits < 384 && mtiles / (splits * 2) >= 8) splits *= 2;
     p.m_per_split = ceil_div(mtiles, splits) * 32;
     p.splits = ceil_div(tiles, p.m_per_split);
     const size_t slab = (size_t)16 * K * C;
@@ -2057,9 +2030,7 @@ extern "C" int semseg_winograd_wgrad_gemm_h2(const void* v_planes, const void* d
         if (!workspace || workspace_bytes < (size_t)p.splits * slab * sizeof(float)) return SEMSEG_EWORKSPACE;
         p.partial = (float*)workspace;
     }
-    static const int w16 = env_int("SEMSEG_WINO_W16", 0);          // 16-wave form of the 256x256 tile
-    const int rc = big ? (w16 ? launch_wgrad_dma<SchH2, 256, 256, 4, 4, 12>(p, st) : launch_wgrad_dma<SchH2, 256, 256, 2, 4, 2>(p, st))
-                       : launch_wgrad_dma<SchH2, 128, 128, 2, 2, 2>(p, st);
+    const int rc = big ? launch_wgrad_dma<SchH2, 256, 256, 2, 4, 2>(p, st) : launch_wgrad_dma<SchH2, 128, 128, 2, 2, 2>(p, st);
     if (rc) return rc;
     if (p.splits > 1) {
         const int blocks = (int)min((size_t)2048, ceil_div_sz(slab / 4, 256));

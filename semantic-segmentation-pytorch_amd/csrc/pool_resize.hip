@@ -421,37 +421,6 @@ struct MultiPool {
     int nscale, ncols;
 };
 
-__global__ __launch_bounds__(256) void multipool_rowsum_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ rowsum,
-                                                               MultiPool mp, int N, int H, int W, int C) {
-    const int qpr = C / 4;
-    const size_t total = (size_t)N * H * qpr;
-    GRID_STRIDE(i, total) {
-        const size_t row = i / qpr;                 // n * H + h
-        const int c = (int)(i - row * qpr) * 4;
-        float4 acc[MP_MAXCOLS];
-#pragma unroll
-        for (int k = 0; k < MP_MAXCOLS; ++k) acc[k] = f4zero();
-        const float* src = x + row * W * (size_t)x_ld + c;
-        for (int w = 0; w < W; ++w) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)w * x_ld);
-#pragma unroll
-            for (int k = 0; k < MP_MAXCOLS; ++k) {
-                // slot k belongs to scale sc, column bin j: static unrolled slots, dynamic membership test
-                int sc = 0;
-#pragma unroll
-                for (int t = 1; t < MP_MAXSCALES; ++t) sc += (t < mp.nscale && k >= mp.col0[t]) ? 1 : 0;
-                const int j = k - mp.col0[sc];
-                const bool in = (k < mp.ncols) && (w >= bin_start(j, W, mp.s[sc])) && (w < bin_end(j, W, mp.s[sc]));
-                if (in) { acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w; }
-            }
-        }
-        float* dst = rowsum + row * (size_t)mp.ncols * C + c;
-#pragma unroll
-        for (int k = 0; k < MP_MAXCOLS; ++k)
-            if (k < mp.ncols) *reinterpret_cast<float4*>(dst + (size_t)k * C) = acc[k];
-    }
-}
-
 __global__ __launch_bounds__(256) void multipool_finish_kernel(const float* __restrict__ rowsum, MultiPool mp, int N, int H, int W,
                                                                int C, int bins_total) {
     const int qpr = C / 4;
@@ -520,10 +489,10 @@ __global__ __launch_bounds__(256) void multipool_bwd_kernel(MultiPool mp, float*
     }
 }
 
-// ---- second generation of the two streaming passes.  The kernels above are ALU-bound, not HBM-bound: the bin bounds are
-// integer divisions by run-time values, evaluated per (pixel, slot) in the forward row walk and per (pixel, channel quad)
-// in the backward pass (rocprof r2s: 123 us / 111 us for a 2x64x64x2048 map whose 67 MB stream in ~15 us).  Here the bounds
-// are computed once per thread (forward: 16 slots before the row walk; backward: per pixel, reused for every channel quad
+// ---- the two streaming passes.  A first generation evaluated the bin bounds -- integer divisions by run-time values -- per
+// (pixel, slot) in the forward row walk and per (pixel, channel quad) in the backward pass and was ALU-bound (rocprof r2s:
+// 123 us / 111 us for a 2x64x64x2048 map whose 67 MB stream in ~15 us; multipool_bwd_kernel above is what is left of it, for
+// maps with fewer than two pixels per bin).  Here the bounds are computed once per thread (forward: 16 slots before the row walk; backward: per pixel, reused for every channel quad
 // of the thread) and the forward walk keeps 8 row loads in flight.  Same summation order, bit-identical results.
 __global__ __launch_bounds__(256) void multipool_rowsum2_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ rowsum,
                                                                 MultiPool mp, int N, int H, int W, int C) {
@@ -632,11 +601,6 @@ __global__ __launch_bounds__(256) void multipool_bwd2_kernel(MultiPool mp, float
     }
 }
 
-static bool multipool_v2() {
-    static const bool on = [] { const char* v = getenv("SEMSEG_MULTIPOOL_V1"); return !(v && *v == '1'); }();
-    return on;
-}
-
 static int multipool_setup(MultiPool& mp, void* const* ys_host, const int* sizes_host, int nscale) {
     if (!ys_host || !sizes_host || nscale <= 0 || nscale > MP_MAXSCALES) return SEMSEG_EINVAL;
     mp.nscale = nscale;
@@ -669,12 +633,8 @@ extern "C" int semseg_adaptive_avgpool_multi_fwd(const float* x, int x_ld, int N
     if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* rowsum = (float*)workspace;
-    if (multipool_v2())
-        hipLaunchKernelGGL(multipool_rowsum2_kernel, dim3(stream_blocks((size_t)N * H * (C / 4))), dim3(256), 0, st, x, x_ld, rowsum,
-                           mp, N, H, W, C);
-    else
-        hipLaunchKernelGGL(multipool_rowsum_kernel, dim3(stream_blocks((size_t)N * H * (C / 4))), dim3(256), 0, st, x, x_ld, rowsum,
-                           mp, N, H, W, C);
+    hipLaunchKernelGGL(multipool_rowsum2_kernel, dim3(stream_blocks((size_t)N * H * (C / 4))), dim3(256), 0, st, x, x_ld, rowsum,
+                       mp, N, H, W, C);
     SEMSEG_LAUNCH_CHECK();
     int bins = 0;
     for (int i = 0; i < nscale; ++i) bins += sizes_host[i] * sizes_host[i];
@@ -692,7 +652,7 @@ extern "C" int semseg_adaptive_avgpool_multi_bwd(void* const* dys_host, const in
     if (rc) return rc;
     bool two_bins = (size_t)N * H * W < ((size_t)1 << 31);
     for (int i = 0; i < nscale; ++i) two_bins = two_bins && H >= 2 * sizes_host[i] && W >= 2 * sizes_host[i];
-    if (multipool_v2() && two_bins) {
+    if (two_bins) {
         size_t blocks = ceil_div_sz((size_t)N * H * W, 4);
         if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(multipool_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mp, dx, dx_ld, N, H, W, C);

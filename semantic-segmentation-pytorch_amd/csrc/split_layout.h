@@ -12,15 +12,10 @@ static inline int round_up32(int c) { return (c + 31) & ~31; }
 
 // Row pitch (16-bit elements) of a split plane.  A power-of-two pitch of >= 2 KB walks the gathered rows of an operand
 // tile (128 rows x 64 B) over a fraction of the L2 channels only, so such pitches are skewed by 256 B.
-// SEMSEG_S3_PITCH_PAD overrides the skew (elements; tools/conv_bench.py).
+// (conv_last fwd 83 -> 104 TFLOP/s in the pad sweep of round 1)
 inline int split_pitch(int C) {
-    static int pad = -1;
-    if (pad < 0) {
-        const char* v = getenv("SEMSEG_S3_PITCH_PAD");
-        pad = (v && *v) ? atoi(v) : 128;
-    }
     const int Cp = round_up32(C);
-    return ((Cp * 2) % 2048 == 0) ? Cp + pad : Cp;
+    return ((Cp * 2) % 2048 == 0) ? Cp + 128 : Cp;
 }
 
 // The planes are followed by SPLIT_ZERO_TAIL_BYTES of zeros: the LDS-DMA conv kernel points the lanes of padded /

@@ -46,7 +46,6 @@ SIGNATURES = {
     'semseg_conv2d_h2_workspace_bytes': (c_sz, [c_int] * 10),
     'semseg_conv2d_fwd_h2': (c_int, [vp, vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
     'semseg_conv2d_dgrad_h2': (c_int, [vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
-    'semseg_conv2d_dgrad_acc_h2': (c_int, [vp, vp, vp, c_int, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
     'semseg_conv2d_wgrad_h2': (c_int, [vp, vp, vp] + [c_int] * 10 + [vp, c_sz, vp]),
     'semseg_conv2d_h2_set_plan': (c_int, [c_int] * 13),
     'semseg_bias_grad': (c_int, [vp, c_int, vp, c_int, c_int, vp, c_sz, vp]),
@@ -135,6 +134,7 @@ SIGNATURES = {
     'semseg_comm_version': (c_int, []),
     'semseg_comm_unique_id': (c_int, [vp]),
     'semseg_comm_init': (c_int, [c_int, c_int, vp, ctypes.POINTER(vp)]),
+    'semseg_comm_count': (c_int, [vp, ctypes.POINTER(c_int)]),
     'semseg_comm_allreduce_sum_f32': (c_int, [vp, vp, c_sz, vp]),
     'semseg_comm_allreduce_sum_f64': (c_int, [vp, vp, c_sz, vp]),
     'semseg_comm_allreduce_sum_f64_multi': (c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(c_sz), c_int, vp]),

@@ -43,8 +43,9 @@ def active(group=None):
 
 def init(group=None, selftest=True):
     """Bring up one RCCL communicator for the ranks of `group` (torch.distributed must be initialised with the nccl backend:
-    one process per GPU, current device set).  Collective.  Every rank learns whether ALL ranks succeeded; on any failure the
-    communicator is torn down everywhere and False is returned (torch.distributed then carries the collectives)."""
+    one process per GPU, current device set).  Collective.  The ranks vote after EVERY stage (id broadcast, communicator init, self-test) and leave
+    together on the first failure -- no rank is left alone inside a blocking ncclCommInitRank; on any failure the communicators
+    built so far are torn down everywhere and False is returned (torch.distributed then carries the collectives)."""
     import torch.distributed as dist
     if not enabled() or not (dist.is_available() and dist.is_initialized()):
         return False
@@ -57,6 +58,14 @@ def init(group=None, selftest=True):
     dev = torch.device('cuda', torch.cuda.current_device())
     handles = {}
     ok = bool(L.semseg_comm_available())
+
+    def agree(flag):
+        # every stage ends with a vote: a rank that failed must not leave the others inside the next collective (ncclCommInitRank
+        # of the second channel blocks until ALL ranks call it), so everybody learns the verdict and leaves the loop together
+        f = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+        return int(f.item()) == 1
+
     for ch in CHANNELS:
         idbuf = (ctypes.c_ubyte * 128)()
         have = ok
@@ -69,15 +78,23 @@ def init(group=None, selftest=True):
             t[128] = 1 if have else 0
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         host = t.cpu()
+        # stage 1: does every rank have the library and rank 0's id?  (vote BEFORE the blocking communicator init)
+        ok = agree(ok and int(host[128]) == 1)
+        if not ok:
+            break
         handle = ctypes.c_void_p()
-        if int(host[128]) == 1 and ok:
-            ids = (ctypes.c_ubyte * 128)(*host[:128].tolist())
-            ok = L.semseg_comm_init(rank, world, ids, ctypes.byref(handle)) == 0
-        else:
-            ok = False
+        ids = (ctypes.c_ubyte * 128)(*host[:128].tolist())
+        ok = L.semseg_comm_init(rank, world, ids, ctypes.byref(handle)) == 0
         if handle:
             handles[ch] = handle
-        if ok and selftest:
+        # stage 2: the communicator is up on every rank (and RCCL counts the ranks we expect)
+        if ok:
+            cnt = ctypes.c_int(0)
+            ok = L.semseg_comm_count(handle, ctypes.byref(cnt)) != 0 or cnt.value == world    # old RCCL without CommCount: skip
+        ok = agree(ok)
+        if not ok:
+            break
+        if selftest:
             # every rank contributes rank+1: the sum must be world (world+1) / 2 in both payload types
             a = torch.full((257,), float(rank + 1), dtype=torch.float64, device=dev)
             b = torch.full((1031,), float(rank + 1), dtype=torch.float32, device=dev)
@@ -87,14 +104,35 @@ def init(group=None, selftest=True):
             torch.cuda.synchronize()
             want = world * (world + 1) / 2.0
             ok = ok and bool((a == want).all()) and bool((b == want).all())
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) != 1:
+            # stage 3: the known-sum self-test
+            ok = agree(ok)
+            if not ok:
+                break
+    if not ok:
         for h in handles.values():
             L.semseg_comm_destroy(h)
         return False
     _COMMS[_key(group)] = dict(rank=rank, world=world, **handles)
     return True
+
+
+def rccl_ranks(group=None):
+    """{channel: ncclCommCount of its communicator} -- what RCCL itself says about the world the collectives run over (None when
+    the native communicators are not up)"""
+    rec = _COMMS.get(_key(group))
+    if rec is None:
+        return None
+    out = {}
+    for ch in CHANNELS:
+        cnt = ctypes.c_int(0)
+        rc = _native.lib().semseg_comm_count(rec[ch], ctypes.byref(cnt))
+        out[ch] = cnt.value if rc == 0 else None
+    return out
+
+
+def peer_world(group=None):
+    rec = _PEERS.get(_key(group))
+    return rec['world'] if rec is not None else None
 
 
 def allreduce_sum(buf, group=None, channel='sync'):
@@ -127,8 +165,12 @@ PEER_MAX_DOUBLES = 2 * 4096 + 1          # [sum, sum^2, n] of a 4096-channel BN
 
 
 def peer_enabled():
-    """SEMSEG_PEER=0 (read when the exchange would be built): SyncBN payloads stay with RCCL / torch.distributed"""
-    return os.environ.get('SEMSEG_PEER', '1') != '0'
+    """SEMSEG_PEER=1 (read when the exchange would be built) turns the peer exchange on; the default leaves the SyncBN payloads
+    with RCCL / torch.distributed.  Opt-in because no run on more than one GPU has exercised it yet (IPC-mapped inboxes across
+    devices, xGMI store ordering): bench.py switches it on for its real run only after a child process per rank has trained a
+    small model through it (fused BN kernels exchanging inside hipGraph segments, bucket all-reduces beside them, bit-identical
+    replicas) -- tools/probes/ddp_graph_selftest.py; `train.py` users run that script once on their node and export SEMSEG_PEER=1."""
+    return os.environ.get('SEMSEG_PEER', '0') == '1'
 
 
 def peer_active(group=None):

@@ -172,6 +172,13 @@ def train_worker(rank, world, cfg, gpus, port):
         dist.destroy_process_group()
 
 
+def rank_devices(rank, world, device):
+    """the `gpus` argument of a worker started by torchrun: workers read only their own entry (gpus[rank])"""
+    devs = [None] * world
+    devs[rank] = device
+    return devs
+
+
 def launch(worker, cfg, gpus, *extra):
     """run `worker(rank, world, cfg, gpus, port, *extra)` as one process per entry of `gpus` -- unless torchrun already did"""
     import torch.multiprocessing as mp
@@ -179,10 +186,15 @@ def launch(worker, cfg, gpus, *extra):
         import torch.distributed as dist
         rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
         local = int(os.environ.get('LOCAL_RANK', rank))
-        torch.cuda.set_device(local)
+        # this rank's device is chosen by its LOCAL rank: the `--gpus` list names the devices of ONE node (entry LOCAL_RANK when
+        # it lists one device per local rank, else device LOCAL_RANK itself), never indexed by the global rank -- on the second
+        # node of a multi-node launch RANK runs past the local device count
+        nlocal = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+        device = gpus[local] if len(gpus) == nlocal else local
+        torch.cuda.set_device(device)
         if not dist.is_initialized():
             dist.init_process_group('nccl', rank=rank, world_size=world)
-        return worker(rank, world, cfg, list(range(world)) if len(gpus) != world else gpus, 0, *extra)
+        return worker(rank, world, cfg, rank_devices(rank, world, device), 0, *extra)
     if len(gpus) == 1:
         return worker(0, 1, cfg, gpus, 0, *extra)
     import socket

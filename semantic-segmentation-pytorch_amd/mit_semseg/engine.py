@@ -218,9 +218,7 @@ class TrainStep:
         loss, acc = self.sm(feed)
         if self.buckets is not None:
             self.buckets.prepare()            # hooks launch each bucket's all-reduce as backward completes it
-        ops.side_wgrad_begin(loss.device)     # weight gradients run on a second stream, off backward's critical path
         loss.backward()
-        ops.side_wgrad_join()
         scale = 1.0
         if self.buckets is not None:
             self.buckets.finish()

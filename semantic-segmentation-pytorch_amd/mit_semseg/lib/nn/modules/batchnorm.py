@@ -21,14 +21,20 @@ __all__ = ['SynchronizedBatchNorm1d', 'SynchronizedBatchNorm2d', 'SynchronizedBa
 class _SynchronizedBatchNorm(nn.Module):
     def __init__(self, num_features, eps=1e-5, momentum=0.001, affine=True):
         super().__init__()
-        if not affine:
-            raise NotImplementedError('affine=False is not used by any mit_semseg model')
         self.num_features = num_features
         self.eps = eps
         self.momentum = momentum
         self.affine = affine
-        self.weight = nn.Parameter(torch.ones(num_features))
-        self.bias = nn.Parameter(torch.zeros(num_features))
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            # batchnorm.py:79-83 `affine=False`: y = (x - mean) * inv_std.  As in torch's _BatchNorm the module then has NO
+            # weight / bias entries (state-dict parity); the kernels get a constant gamma = 1 / beta = 0 that needs no gradient
+            self.register_parameter('weight', None)
+            self.register_parameter('bias', None)
+            self.register_buffer('_unit_gamma', torch.ones(num_features), persistent=False)
+            self.register_buffer('_zero_beta', torch.zeros(num_features), persistent=False)
         self.register_buffer('running_mean', torch.zeros(num_features))
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
@@ -67,10 +73,34 @@ class _SynchronizedBatchNorm(nn.Module):
     def forward(self, input, residual=None, relu=False):
         """y = BN(input); the fused form y = relu(BN(input) + residual) is what the blocks call."""
         x, shape = self._as4d(input)
-        y = ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                               residual=residual, training=self.training, momentum=self.momentum,
-                               eps=self.eps, relu=relu, num_batches_tracked=self.num_batches_tracked)
+        gamma, beta = (self.weight, self.bias) if self.affine else (self._unit_gamma, self._zero_beta)
+        c = x.shape[1]
+        if c % 4:
+            y = self._forward_odd_channels(x, gamma, beta, residual, relu)
+        else:
+            y = ops.batch_norm_act(x, gamma, beta, self.running_mean, self.running_var,
+                                   residual=residual, training=self.training, momentum=self.momentum,
+                                   eps=self.eps, relu=relu, num_batches_tracked=self.num_batches_tracked)
         return y if shape is None else y.reshape(shape)
+
+    def _forward_odd_channels(self, x, gamma, beta, residual, relu):
+        """channel counts that are not a multiple of 4 (no mit_semseg model has one; the reference's own unit tests use 10,
+        tests/test_sync_batchnorm.py:66-107): the kernels move 4 channels per lane, so the tensors are padded with constant
+        channels (torch glue, never on the hot path), normalised, and cut back; the running statistics of the real channels
+        are copied back from the padded buffers."""
+        c = x.shape[1]
+        pad = 4 - c % 4
+        fill = lambda t, v: torch.cat([t, torch.full((pad,), v, device=t.device, dtype=t.dtype)])      # noqa: E731
+        widen = lambda t: torch.nn.functional.pad(t, (0, 0, 0, 0, 0, pad))                             # noqa: E731
+        rm, rv = fill(self.running_mean, 0.0), fill(self.running_var, 1.0)
+        y = ops.batch_norm_act(widen(x), fill(gamma, 1.0), fill(beta, 0.0), rm, rv,
+                               residual=widen(residual) if residual is not None else None, training=self.training,
+                               momentum=self.momentum, eps=self.eps, relu=relu, num_batches_tracked=self.num_batches_tracked)
+        if self.training:
+            with torch.no_grad():
+                self.running_mean.copy_(rm[:c])
+                self.running_var.copy_(rv[:c])
+        return y[:, :c]
 
     def extra_repr(self):
         return '{num_features}, eps={eps}, momentum={momentum}, affine={affine}'.format(**self.__dict__)

@@ -124,23 +124,23 @@ def conv_bn_relu6(conv, bn, x):
 def conv_bn(conv, bn, x, residual=None, relu=False, passthrough=False):
     """bn(conv(x), residual=..., relu=...) -- the conv -> BN [-> +residual] [-> ReLU] unit every block of the reference
     is made of (resnet.py:72-92, models.py:160-167, hrnet.py:45-61) -- dispatched as ONE fused autograd node when the
-    h2 path can run it (ops.conv_bn_act), else as the two modules.  passthrough=True returns (y, x'), x' being x routed
-    through the node (see ops.conv_bn_act): the blocks hand x' to their shortcut so that its gradient is accumulated in
-    this conv's data-gradient kernel."""
-    if passthrough and not ops.PASSTHROUGH and torch.is_grad_enabled() and x.requires_grad:
-        # x has two consumers (this conv and the block's shortcut): fork it so that their two gradients are added by the native
-        # add kernel instead of autograd's torch-side accumulation; the planes this conv splits serve the shortcut's conv too
-        xa, xb = ops.fork(x)
-        y = conv_bn(conv, bn, xa, residual=residual, relu=relu)
-        ops.share_planes(xa, xb)
-        return y, xb
-    if conv.bias is None and x.dim() == 4 and type(conv) is Conv2d and isinstance(bn, SynchronizedBatchNorm2d):
+    h2 path can run it (ops.conv_bn_act), else as the two modules.  passthrough=True returns (y, x'): x has a second consumer
+    (the block's shortcut) and x' is the alias to hand to it."""
+    if passthrough:
+        if torch.is_grad_enabled() and x.requires_grad:
+            # fork x so that the two gradients are added by the native add kernel instead of autograd's torch-side
+            # accumulation; the planes this conv splits serve the shortcut's conv too
+            xa, xb = ops.fork(x)
+            y = conv_bn(conv, bn, xa, residual=residual, relu=relu)
+            ops.share_planes(xa, xb)
+            return y, xb
+        return conv_bn(conv, bn, x, residual=residual, relu=relu), x
+    if conv.bias is None and x.dim() == 4 and type(conv) is Conv2d and isinstance(bn, SynchronizedBatchNorm2d) and bn.affine:
         return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                bn.num_batches_tracked, residual=residual, stride=conv.stride[0],
                                padding=conv.padding[0], dilation=conv.dilation[0], training=bn.training,
-                               momentum=bn.momentum, eps=bn.eps, relu=relu, passthrough=passthrough)
-    y = bn(conv(x), residual=residual, relu=relu)
-    return (y, x) if passthrough else y
+                               momentum=bn.momentum, eps=bn.eps, relu=relu)
+    return bn(conv(x), residual=residual, relu=relu)
 
 
 class ReLU(nn.Module):

@@ -295,9 +295,6 @@ class C1DeepSup(nn.Module):
         return ops.log_softmax(x), ops.log_softmax(d)
 
 
-PPM_STREAMS = os.environ.get('SEMSEG_PPM_STREAMS', '0') == '1'
-
-
 class PPM(nn.Module):
     """models.py:389-434: pyramid pooling (1,2,3,6) -> concat -> 3x3 conv head."""
 
@@ -313,8 +310,6 @@ class PPM(nn.Module):
         conv5, c5 = ops.fork(conv5)                  # two consumers: the pyramid pooling and the concat
         pooled = ops.adaptive_avg_pool_multi(c5, [b._modules['0'].output_size for b in self.ppm])
         fns = [lambda p, b=b: ops.interpolate_bilinear(b.after_pool(p), size) for b in self.ppm]
-        if PPM_STREAMS:       # measured: 14.1 -> 17.3 ms/step (a forked hipGraph dispatches slower); A/B switch only
-            return ops.concat([conv5] + ops.run_branches(fns, list(pooled)))
         return ops.concat([conv5] + [f(p) for f, p in zip(fns, pooled)])
 
     def forward(self, conv_out, segSize=None):

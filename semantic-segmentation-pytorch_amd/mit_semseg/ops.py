@@ -141,8 +141,8 @@ def _crosses_to(t, stream):
 
 
 def workspace(nbytes, device, tag=''):
-    """`tag`: kernels running concurrently on different streams need disjoint scratch (tag 'side': the weight-gradient
-    stream).  A buffer that is outgrown stays allocated (`_WS_RETIRED`): a hipGraph captured earlier (TrainStep, one
+    """`tag`: kernels running concurrently on different streams need disjoint scratch (the branch streams of run_branches
+    get their own).  A buffer that is outgrown stays allocated (`_WS_RETIRED`): a hipGraph captured earlier (TrainStep, one
     InferenceGraph per shape) has its address baked into split-K / BN-partial launches, and handing the block back to the
     caching allocator would let a replay scribble over whatever tensor gets it next.  Growth is geometric (x1.5), so the
     retired blocks add up to at most twice the live one."""
@@ -315,12 +315,6 @@ class Conv2dFn(Function):
 FUSE = os.environ.get('SEMSEG_FUSE', '1') != '0'
 
 
-# SEMSEG_PASSTHROUGH=1: block shortcuts hang off conv1's fused node and their gradient is accumulated in its dgrad epilogue.
-# Measured (one box, interleaved A/B, gpurun r1x): 17.15 ms with vs 17.04 ms without -- the strided 4-byte addend reads in
-# the MFMA epilogue cost more than the 16 vectorised add launches they replace, so the default is off.
-PASSTHROUGH = os.environ.get('SEMSEG_PASSTHROUGH', '0') == '1'
-
-
 def attach_planes(t, buf, scheme, rows, ch):
     """Remember the split planes of activation `t` on the tensor object: the next conv that consumes this very object
     (unchanged: same version counter, same storage) reads them instead of splitting again."""
@@ -386,7 +380,6 @@ WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '1024'))
 # the weight gradient of the same layers in the Winograd domain (dU[f] = dM[f]^T V[f], V kept from the forward pass):
 # in-box A/B (gpurun wg1) 16.50 -> 16.02 ms per step.  SEMSEG_WINOGRAD_WGRAD=0 disables.
 WINOGRAD_WGRAD = os.environ.get('SEMSEG_WINOGRAD_WGRAD', '1') != '0'
-WINOGRAD_EVAL = os.environ.get('SEMSEG_WINOGRAD_EVAL', '0') == '1'
 
 
 def _wino_eligible(k, c, r, s):
@@ -521,81 +514,29 @@ class Conv2dSplitFn(Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
-# ---- weight gradients on a side stream ---------------------------------------------------------------------------
-# dw is consumed only by the optimiser, so the wgrad kernels need not sit on backward's critical path: between
-# side_wgrad_begin() and side_wgrad_join() (TrainStep brackets loss.backward() with them) every wgrad launch goes to a
-# second HIP stream that forks from the main stream once the planes of dy exist.  The main stream carries the
-# dependent chain (BN backward -> dgrad -> BN backward ...), much of it small kernels that leave most of the 256 CUs idle;
-# the wgrad GEMMs fill those CUs.  Under hipGraph capture the fork/join become parallel branches of the graph.
-# Operand buffers are kept alive in `pending` until the join (the caching allocator must not hand them to a later
-# main-stream allocation while the side stream still reads them).  Opt-in (SEMSEG_SIDE_WGRAD=1): on MI355X the overlap
-# did not pay (profiles/r1g: hipGraph replay 18.8 ms with the fork vs 17.9 ms without; the contended kernels slow each other
-# down by about what the overlap saves).
-_SIDE = {'on': False, 'stream': None, 'pending': []}
-SIDE_WGRAD = os.environ.get('SEMSEG_SIDE_WGRAD', '0') == '1'
-
-
-def side_wgrad_begin(device):
-    if not SIDE_WGRAD or device.type != 'cuda':
-        return
-    if _SIDE['stream'] is None or _SIDE['stream'].device != device:
-        _SIDE['stream'] = torch.cuda.Stream(device=device)
-    _SIDE['on'] = True
-
-
-def side_wgrad_sync():
-    """Make the current stream wait for the weight gradients launched so far (before anything reads .grad)."""
-    if _SIDE['on'] and _SIDE['stream'] is not None:
-        torch.cuda.current_stream().wait_stream(_SIDE['stream'])
-
-
-def side_wgrad_join():
-    side_wgrad_sync()
-    _SIDE['pending'].clear()
-    _SIDE['on'] = False
-
-
-def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, addend=None):
-    """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys).
-    `addend` (h2): a gradient w.r.t. the same input that is already known; it is accumulated in the dgrad epilogue."""
+def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
+    """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys)."""
     n, h, wd, c, k, r, s, stride, pad, dil = geom
     dev = w.device
     dx = dw = None
     if need_dw:
-        side = _SIDE['stream'] if _SIDE['on'] else None
-        tag = 'side' if side is not None else ''
+        dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
 
-        def run_w():
-            dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
-
-            def launch_w():
-                ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev, tag)
-                _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
-                              'conv2d_wgrad_' + scheme)
-            tuner.ensure(scheme, 2, geom, launch_w)
-            launch_w()
-            return dwb.permute(0, 3, 1, 2)
-        if side is None:
-            dw = run_w()
-        else:
-            side.wait_stream(torch.cuda.current_stream())       # fork: dys / xs are complete on the main stream
-            with torch.cuda.stream(side):
-                dw = run_w()
-            _SIDE['pending'].append((xs, dys))
+        def launch_w():
+            ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
+            _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
+                          'conv2d_wgrad_' + scheme)
+        tuner.ensure(scheme, 2, geom, launch_w)
+        launch_w()
+        dw = dwb.permute(0, 3, 1, 2)
     if need_dx:
         wts = wtp if wtp is not None else _weight_crsk_planes(L, sch, w, dev)
         dx = empty_nhwc(n, c, h, wd, dev)
 
-        add, add_ld = as_nhwc(addend) if addend is not None else (None, 0)
-
         def launch_d():
             ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
-            if add is None:
-                _native.check(sch.fn(L, 'dgrad')(_p(dys), _p(wts), _p(dx), c, *geom, _p(ws), ws.numel(), _st()),
-                              'conv2d_dgrad_' + scheme)
-            else:
-                _native.check(L.semseg_conv2d_dgrad_acc_h2(_p(dys), _p(wts), _p(add), add_ld, _p(dx), c, *geom, _p(ws),
-                                                           ws.numel(), _st()), 'conv2d_dgrad_acc_h2')
+            _native.check(sch.fn(L, 'dgrad')(_p(dys), _p(wts), _p(dx), c, *geom, _p(ws), ws.numel(), _st()),
+                          'conv2d_dgrad_' + scheme)
         tuner.ensure(scheme, 1, geom, launch_d)
         launch_d()
     return dx, dw
@@ -713,32 +654,9 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     if CONV_MODE == 'f32':
         return Conv2dFn.apply(x, weight, bias, int(stride), int(padding), int(dilation))
     _require_cuda(x)
-    if WINOGRAD_EVAL and not torch.is_grad_enabled() and bias is None and int(stride) == 1 and int(padding) == int(dilation) \
-            and _wino_eligible(*weight.shape):
-        # evaluation-mode forward of the >= 1024-channel 3x3 convs (conv_last of the PPM heads, models.py:456,519): Winograd
-        # F(2x2, 3x3) as in training; the |x| bound the input transform scales by comes from an absmax pass over x since the
-        # eval-mode BN kernels carry none.  Opt-in (SEMSEG_WINOGRAD_EVAL=1): at the single-image batches of eval.py / test.py it
-        # measures the same 3.19 ms per 512x512 image as the direct convolution (profiles/r3g_bench_infer_*.jsonl)
-        weight_planes(weight, 'h2')                     # builds the planes of this parameter state (incl. the Winograd ones)
-        u = weight_wino(weight)
-        if u is not None:
-            return _winograd_eval(x, weight, u, int(dilation))
     xp = input_planes(x, CONV_MODE)
     wp, wtp = weight_planes(weight, CONV_MODE)
     return Conv2dSplitFn.apply(x, weight, bias, xp, wp, wtp, int(stride), int(padding), int(dilation), CONV_MODE)
-
-
-def _winograd_eval(x, weight, u_planes, dil):
-    L = _native.lib()
-    x, x_ld = as_nhwc(x.detach())
-    n, c, h, wd = x.shape
-    k = int(weight.shape[0])
-    bound = torch.empty((1,), device=x.device, dtype=torch.float32)
-    ws = workspace(4096, x.device)
-    _native.check(L.semseg_absmax(_p(x), x_ld, n * h * wd, c, _p(bound), _p(ws), ws.numel(), _st()), 'absmax')
-    z = empty_nhwc(n, k, h, wd, x.device)
-    _winograd_fwd(L, x, (bound,), u_planes, z, (n, h, wd, c, k, 3, 3, 1, dil, dil))
-    return z
 
 
 # ------------------------------------------------------------------------------------------------
@@ -749,10 +667,6 @@ _SYNC_GROUP = {'group': None, 'enabled': False, 'force': os.environ.get('SEMSEG_
 # the next segment begins -- at replay the collectives are issued eagerly between the segment launches
 _SEGMENTS = None
 PEER_FUSED = os.environ.get('SEMSEG_PEER_FUSED', '1') != '0'
-# BN outputs that are not written as planes (no ReLU): 0 = the four-launch unfused forward (A/B switch)
-BN_BOUND_FUSED = os.environ.get('SEMSEG_BN_BOUND_FUSED', '1') != '0'
-# BN + residual + ReLU: the forward leaves its ReLU decisions as a bitmask and backward reads that instead of y (0 = A/B switch)
-GATE_MASK = os.environ.get('SEMSEG_GATE_MASK', '1') != '0'
 
 
 def set_sync_bn_group(group, enabled=True):
@@ -932,7 +846,7 @@ class ConvBNActFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg, box):
-        stride, pad, dil, momentum, eps, relu, emit, passthrough = cfg
+        stride, pad, dil, momentum, eps, relu, emit = cfg
         L = _native.lib()
         sch = SCHEMES['h2']
         w = krsc(weight.detach())
@@ -979,7 +893,7 @@ class ConvBNActFn(Function):
         gate = None
         sync = _sync_active()
         peer = _sync_peer(2 * k + 1) if sync else None
-        if (not sync or peer is not None) and (yp is not None or (absmax is not None and BN_BOUND_FUSED)):
+        if (not sync or peer is not None) and (yp is not None or absmax is not None):
             # one rank: finish + finalize in one kernel; the apply kernel derives the exponent from the per-block bounds.
             # SyncBN over the peer exchange: the same kernel exchanges its sums with the other ranks on the way (csrc/peer_dev.h)
             bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
@@ -993,7 +907,7 @@ class ConvBNActFn(Function):
                 _native.check(L.semseg_bn_fwd_stats_fused_bound(*args, bound), 'bn_fwd_stats_fused_bound')
             else:
                 _native.check(L.semseg_bn_fwd_stats_fused(*args), 'bn_fwd_stats_fused')
-            if yp is not None and relu and residual is not None and GATE_MASK:
+            if yp is not None and relu and residual is not None:
                 # backward's gate of a BN with residual is (y > 0): leave it as 1 bit per element instead of reading y twice
                 gate = torch.empty((P * (k // 8),), device=dev, dtype=torch.uint8)
                 _native.check(L.semseg_bn_apply_h2_gate(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y),
@@ -1023,15 +937,11 @@ class ConvBNActFn(Function):
         ctx.geom = geom
         ctx.cfg = (bool(relu), residual is not None)
         box['planes'], box['absmax'] = yp, absmax
-        if passthrough:
-            # the input travels on as a second output: its other consumers (residual add, downsample conv) hang off THIS
-            # node, their gradient arrives here as `dx_other` and is accumulated in the dgrad epilogue (no add pass)
-            return y, x
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy, dx_other=None):
+    def backward(ctx, dy):
         L = _native.lib()
         sch = SCHEMES['h2']
         xp, w, wtp, z, y, coef, gamma, stats, zmm, wino_v, gate_bits = ctx.saved_tensors
@@ -1085,7 +995,7 @@ class ConvBNActFn(Function):
         if wino_v is not None and need_dw:
             dw_wino = _winograd_wgrad(L, wino_v, dzp, geom)
             need_dw = False
-        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, ctx.needs_input_grad[0], need_dw, addend=dx_other)
+        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, ctx.needs_input_grad[0], need_dw)
         if dw_wino is not None:
             dw = dw_wino
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
@@ -1093,22 +1003,16 @@ class ConvBNActFn(Function):
 
 
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, residual=None, stride=1,
-                padding=0, dilation=1, training=False, momentum=0.1, eps=1e-5, relu=False, passthrough=False):
+                padding=0, dilation=1, training=False, momentum=0.1, eps=1e-5, relu=False):
     """act(BN(conv(x)) + residual) for a bias-free conv.  Training on the h2 path with K % 8 == 0 runs the fused node
-    (ConvBNActFn); everything else composes conv2d + batch_norm_act.
-    passthrough=True returns (y, x'): x' is x routed through the node -- a block that feeds x' (instead of x) to its
-    other consumers (residual add / downsample conv, resnet.py:72-92) gets their gradient accumulated inside this conv's
-    data-gradient kernel instead of a separate add pass."""
+    (ConvBNActFn); everything else composes conv2d + batch_norm_act."""
     if not (FUSE and CONV_MODE == 'h2' and training and weight.shape[0] % 8 == 0):
         z = conv2d(x, weight, None, stride, padding, dilation)
-        y = batch_norm_act(z, gamma, beta, running_mean, running_var, residual=residual, training=training,
-                           momentum=momentum, eps=eps, relu=relu, num_batches_tracked=num_batches_tracked)
-        return (y, x) if passthrough else y
+        return batch_norm_act(z, gamma, beta, running_mean, running_var, residual=residual, training=training,
+                              momentum=momentum, eps=eps, relu=relu, num_batches_tracked=num_batches_tracked)
     _require_cuda(x)
     wp, wtp = weight_planes(weight, 'h2')
-    want_pair = bool(passthrough)
-    passthrough = want_pair and PASSTHROUGH and x.requires_grad and torch.is_grad_enabled()
-    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu), passthrough)
+    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu))
     box = {}
     kk, cc, rr, ss = weight.shape
     if int(stride) == 1 and int(padding) == int(dilation) and _wino_eligible(kk, cc, rr, ss):
@@ -1121,21 +1025,14 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
         xp = planes_of(x, 'h2', n * h * w, c)        # Winograd forward and weight gradient work on V: x needs no planes
     else:
         xp = input_planes(x, 'h2')
-    out = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean, running_var,
-                            num_batches_tracked, cfg, box)
-    y, xr = out if passthrough else (out, x)
+    y = ConvBNActFn.apply(x, weight, gamma, beta, residual, xp, wp, wtp, absmax_of(residual), running_mean, running_var,
+                          num_batches_tracked, cfg, box)
     yp, absmax = box['planes'], box['absmax']
     if yp is not None:
         attach_planes(y, yp, 'h2', y.shape[0] * y.shape[2] * y.shape[3], y.shape[1])
     if absmax is not None:
         attach_absmax(y, absmax)
-    if xr is not x:                        # same storage, new tensor object: carry the plane / bound records over
-        if xp is not None:
-            attach_planes(xr, xp, 'h2', n * h * w, c)
-        bound = bounds_of(x)
-        if bound is not None:
-            attach_absmax(xr, bound)
-    return (y, xr) if want_pair else y
+    return y
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1211,6 +1108,10 @@ class ForkFn(Function):
 
     @staticmethod
     def forward(ctx, x):
+        # without this autograd hands backward a full-size ZERO tensor for an alias nobody differentiated through (Resnet.forward
+        # forks every stage output when return_feature_maps is set; the PPM / C1 heads use one or two of them), and the branch
+        # below would never be taken: a fill plus an add launch per unused alias and step
+        ctx.set_materialize_grads(False)
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
@@ -1417,6 +1318,7 @@ class MultiAdaptiveAvgPoolFn(Function):
     @staticmethod
     def forward(ctx, x, sizes):
         L = _native.lib()
+        ctx.set_materialize_grads(False)              # backward builds the zero gradient of an unused scale itself (it is tiny)
         x, ld = as_nhwc(x.detach())
         n, c, h, w = x.shape
         ns = len(sizes)
@@ -1458,8 +1360,7 @@ def adaptive_avg_pool_multi(x, sizes):
     """[adaptive_avg_pool(x, s) for s in sizes] -- fused when the sizes are square ints, at most 4 scales and 16 column
     bins in total (PPM: 1 + 2 + 3 + 6); anything else pools scale by scale."""
     sizes = list(sizes)
-    if (os.environ.get('SEMSEG_MULTIPOOL', '1') != '0' and len(sizes) <= 4 and all(isinstance(s, int) and s > 0 for s in sizes) and sum(sizes) <= 16 and x.shape[1] % 4 == 0
-            and len(sizes) > 1):
+    if 1 < len(sizes) <= 4 and all(isinstance(s, int) and s > 0 for s in sizes) and sum(sizes) <= 16 and x.shape[1] % 4 == 0:
         return list(MultiAdaptiveAvgPoolFn.apply(x, tuple(sizes)))
     return [adaptive_avg_pool(x, s) for s in sizes]
 

@@ -128,7 +128,6 @@ class GradientBuckets:
         """copy p.grad into the bucket slices (physical order), re-point p.grad at the slice.  One multi-tensor copy per
         bucket (torch._foreach_copy_) instead of one copy launch per parameter -- the data-parallel step launches eagerly and
         is host-bound, and a ResNet-50 has 161 parameters -- and the slice views are built once per gradient layout."""
-        ops.side_wgrad_sync()                 # weight gradients may still be in flight on the wgrad stream
         views = b.setdefault('views', {})
         dsts, srcs, moved = [], [], []
         for p, off, n in b['items']:

@@ -64,10 +64,7 @@ def _save_cache():
         json.dump({','.join(map(str, k)): list(v) for k, v in _done.items()}, f)
     os.replace(tmp, CACHE)
 _SPLITS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64)
-# weight gradient only: more split candidates when the library's cap is raised (SEMSEG_WGRAD_MAX_SPLIT, csrc/conv_split.hip
-# plan_wgrad) -- off by default
-_WGRAD_MAX_SPLIT = int(os.environ.get('SEMSEG_WGRAD_MAX_SPLIT', '64'))
-_WSPLITS = _SPLITS + tuple(s for s in (96, 128, 192, 256) if s <= _WGRAD_MAX_SPLIT)
+_WSPLITS = _SPLITS
 # fwd/dgrad tile ids per scheme (csrc/conv_split.hip): 0..2 register staged, 3 = 256x128 LDS-DMA, h2 only: 4 = 256x128
 # 3-slot ring, 5 = 256x256, 6..10 their software-pipelined / 128x128 forms, 11..13 = 4-wave forms (256x256, 256x128 2- and 3-slot),
 # 14 = 256x256 on 16 waves, 15..17 = 64x64 / 128x64 on the LDS-DMA ring (4 waves).  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).

@@ -299,3 +299,43 @@ def test_gradient_buckets_small_tail():
         for p, o, n in b['items']:
             assert o == off and n == p.numel()
             off += n
+
+
+def _bench_cmd(*args, **env):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + list(args), env=e, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (train.py:184-190 drives all GPUs from one
+    command) and the line says n_gpus 2; SEMSEG_BENCH_LAUNCH_PROBE=1 stops every rank after the rendezvous (no GPU here)."""
+    import json
+    r = _bench_cmd('--gpus', '2', '--steps', '1', '--warmup', '0', SEMSEG_BENCH_LAUNCH_PROBE='1')
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['ranks_counted'] == 2 and line['gpus_arg'] == 2 and line['self_launched'] is True
+
+
+def test_bench_refuses_a_mislabelled_world():
+    """a launcher that started a different number of ranks than --gpus says, or a node with fewer GPUs than --gpus: no JSON
+    line, exit code 2 (never a line whose n_gpus differs from --gpus)"""
+    r = _bench_cmd('--gpus', '8', SEMSEG_BENCH_LAUNCH_PROBE='1', WORLD_SIZE='1', RANK='0')
+    assert r.returncode == 2 and 'refusing' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    r = _bench_cmd('--gpus', '8')                    # this container has no GPU: 8 ranks cannot each have one
+    assert r.returncode == 2 and 'refusing' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_bench_roofline_constants_come_from_the_pmc_index():
+    """roofline.traffic / clock are looked up in profiles/pmc_index.json by the plan the tuner picked; an unknown plan gives None"""
+    import bench
+    geom = (2, 64, 64, 4096, 512, 3, 3, 1, 1, 1)
+    e = bench.pmc_lookup('h2', 1, geom, (14, 1))
+    assert e is not None and os.path.exists(os.path.join(bench.ROOT, e['source'])) and e['fetch_kib'] > 0
+    assert bench.pmc_lookup('h2', 1, geom, (3, 2)) is None and bench.pmc_lookup('h2', 1, geom, None) is None
+    # dy planes 16.8 MB + weight planes 75.5 MB + fp32 dx 134.2 MB
+    assert abs(bench.algorithmic_bytes(1, geom, 'h2') - 226.5e6) < 0.1e6

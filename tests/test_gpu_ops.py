@@ -132,6 +132,41 @@ def test_batch_norm_act(shape, training, relu, res):
     assert rel_err(rmg, rmr) < 1e-5 and rel_err(rvg, rvr) < 1e-5
 
 
+@pytest.mark.parametrize('kind,shape,affine,training', [
+    ('1d', (16, 10), True, True), ('1d', (16, 10), True, False),          # testSyncBatchNormNormalTrain / NormalEval
+    ('1d', (16, 10), False, True), ('1d', (16, 10), False, False),        # testSyncBatchNormSyncTrain / SyncEval: affine=False
+    ('2d', (16, 10, 16, 16), True, True),                                 # testSyncBatchNorm2DSyncTrain
+    ('2d', (4, 12, 8, 8), False, True),
+])
+def test_sync_batchnorm_modules_like_the_reference_unit_tests(kind, shape, affine, training):
+    """the cases of the reference's own SyncBN tests (lib/nn/modules/tests/test_sync_batchnorm.py:44-107): output, input
+    gradient and running statistics against nn.BatchNorm with the same arguments, 10 features (not a multiple of the kernels'
+    4-channel lanes), affine=False included (batchnorm.py:39-48,79-83)"""
+    import torch.nn as nn
+    from mit_semseg.lib.nn import SynchronizedBatchNorm1d, SynchronizedBatchNorm2d
+    c = shape[1]
+    ref = (nn.BatchNorm1d if kind == '1d' else nn.BatchNorm2d)(c, eps=1e-5, momentum=0.001, affine=affine).double()
+    mine = (SynchronizedBatchNorm1d if kind == '1d' else SynchronizedBatchNorm2d)(c, eps=1e-5, momentum=0.001, affine=affine)
+    assert ('weight' in mine.state_dict()) == affine and ('bias' in mine.state_dict()) == affine
+    mine.to(dev())
+    ref.train(training)
+    mine.train(training)
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(shape, generator=g)
+    xr = x.double().requires_grad_(True)
+    xg = x.to(dev()).requires_grad_(True)
+    yr = ref(xr)
+    yr.sum().backward()
+    y = mine(xg)
+    y.sum().backward()
+    torch.cuda.synchronize()
+    assert y.shape == yr.shape
+    assert (y.cpu().double() - yr).abs().max().item() < 1e-5
+    assert (xg.grad.cpu().double() - xr.grad).abs().max().item() < 1e-5
+    assert (mine.running_mean.cpu().double() - ref.running_mean).abs().max().item() < 1e-6
+    assert (mine.running_var.cpu().double() - ref.running_var).abs().max().item() < 1e-6
+
+
 def test_batch_norm_train_single_value_raises():
     from mit_semseg import ops
     x = torch.randn(1, 8, 1, 1, device=dev())
@@ -662,43 +697,6 @@ def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
     assert rel_err(got, ref) < (REL * 4 if pass_id == 2 else REL), (pass_id, tile, split, rel_err(got, ref))
 
 
-@pytest.mark.parametrize('case', [(2, 64, 24, 24, 128, 3, 1, 1, 1), (2, 256, 17, 19, 64, 1, 2, 0, 1), (2, 512, 16, 16, 256, 3, 1, 2, 2)], ids=str)
-def test_conv_bn_passthrough_accumulates_shortcut_gradient(case, monkeypatch):
-    """ops.conv_bn_act(passthrough=True): the gradient of the block shortcut (x' = x routed through the node) is added
-    inside the data-gradient kernel -- same x.grad as letting autograd add the two branches"""
-    from mit_semseg import ops
-    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
-    monkeypatch.setattr(ops, 'PASSTHROUGH', True)          # opt-in feature (SEMSEG_PASSTHROUGH=1)
-    n, c, h, w, k, ks, stride, pad, dil = case
-    g = torch.Generator().manual_seed(hash(case) & 0xffff)
-    x = torch.randn(n, c, h, w, generator=g)
-    wt = torch.randn(k, c, ks, ks, generator=g) / (c * ks * ks) ** 0.5
-    gam, bet = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g) * 0.1
-    oh = (h + 2 * pad - dil * (ks - 1) - 1) // stride + 1
-    ow = (w + 2 * pad - dil * (ks - 1) - 1) // stride + 1
-    gy, gx = torch.randn(n, k, oh, ow, generator=g), torch.randn(n, c, h, w, generator=g)
-
-    def run(passthrough):
-        xg = cl(x).requires_grad_(True)
-        wg = torch.nn.Parameter(cl(wt))
-        gg, bg = torch.nn.Parameter(gam.to(dev())), torch.nn.Parameter(bet.to(dev()))
-        bufs = (torch.zeros(k, device=dev()), torch.ones(k, device=dev()), torch.zeros((), dtype=torch.long, device=dev()))
-        out = ops.conv_bn_act(xg, wg, gg, bg, *bufs, stride=stride, padding=pad, dilation=dil, training=True, relu=True,
-                              passthrough=passthrough)
-        y, xr = out if passthrough else (out, xg)
-        if passthrough:
-            assert xr is not xg and xr.data_ptr() == xg.data_ptr()
-            assert ops.planes_of(xr, 'h2', n * h * w, c) is not None          # the planes travel with x'
-        ((y * cl(gy)).sum() + (xr * cl(gx)).sum()).backward()
-        torch.cuda.synchronize()
-        return y.detach(), xg.grad, wg.grad
-
-    y0, dx0, dw0 = run(False)
-    y1, dx1, dw1 = run(True)
-    assert torch.equal(y0, y1) and torch.equal(dw0, dw1)
-    torch.testing.assert_close(dx1, dx0, rtol=1e-6, atol=1e-6)
-
-
 def test_inference_weight_planes_follow_sgd_updates(monkeypatch):
     """no_grad forwards build the weight planes once and keep them; the fused SGD kernel (which updates parameters behind
     torch's version counter) must invalidate them"""
@@ -886,25 +884,3 @@ def test_absmax_scalar(rows, c, ld):
     assert out.item() != out.item()
 
 
-def test_eval_mode_winograd_forward_matches_direct(monkeypatch):
-    """conv2d under no_grad for a >= 1024-channel 3x3 conv goes through the Winograd path (absmax bound + transforms + batched GEMM)
-    and agrees with the direct h2 convolution and with float64"""
-    from mit_semseg import ops
-    from mit_semseg.models.layers import Conv2d
-    d = torch.device('cuda:0')
-    torch.manual_seed(0)
-    conv = Conv2d(1024, 256, 3, padding=2, dilation=2, bias=False).to(d)
-    x = torch.randn(1, 1024, 24, 40, device=d).contiguous(memory_format=torch.channels_last)
-    calls = []
-    orig = ops._winograd_eval
-    monkeypatch.setattr(ops, '_winograd_eval', lambda *a: (calls.append(1), orig(*a))[1])
-    monkeypatch.setattr(ops, 'WINOGRAD_EVAL', True)                   # opt-in path (SEMSEG_WINOGRAD_EVAL=1)
-    with torch.no_grad():
-        y = conv(x)
-        monkeypatch.setattr(ops, 'WINOGRAD', False)
-        y_direct = conv(x)
-    assert len(calls) == 1
-    ref = F.conv2d(x.double().cpu(), conv.weight.detach().double().cpu(), None, 1, 2, 2)
-    scale = ref.abs().max().item()
-    assert (y.cpu().double() - ref).abs().max().item() < 2e-5 * scale
-    assert (y_direct.cpu().double() - ref).abs().max().item() < 2e-5 * scale

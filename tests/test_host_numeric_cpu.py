@@ -169,3 +169,34 @@ def test_resnext_golden_with_direct_grouped_kernels_emulated(monkeypatch, tmp_pa
     finally:
         torch.set_num_threads(prev)
     assert len(calls) == 33
+
+
+@pytest.mark.parametrize('kind,shape,affine,training', [
+    ('1d', (16, 10), True, True), ('1d', (16, 10), False, True), ('1d', (16, 10), False, False),
+    ('2d', (16, 10, 16, 16), True, True), ('2d', (4, 12, 8, 8), False, True)])
+def test_sync_batchnorm_module_affine_false_and_odd_channels(kind, shape, affine, training, monkeypatch):
+    """host logic of _SynchronizedBatchNorm (reference batchnorm.py:39-48,79-83 and its unit tests' 10-feature cases): no weight /
+    bias entries with affine=False, channel padding for counts the 4-channel lanes do not divide, running statistics copied
+    back -- on the CPU twin; the kernels' side is tests/test_gpu_ops.py::test_sync_batchnorm_modules_like_the_reference_unit_tests"""
+    import torch.nn as nn
+    cpu_twin.install(monkeypatch)
+    from mit_semseg.lib.nn import SynchronizedBatchNorm1d, SynchronizedBatchNorm2d
+    c = shape[1]
+    ref = (nn.BatchNorm1d if kind == '1d' else nn.BatchNorm2d)(c, eps=1e-5, momentum=0.001, affine=affine)
+    mine = (SynchronizedBatchNorm1d if kind == '1d' else SynchronizedBatchNorm2d)(c, eps=1e-5, momentum=0.001, affine=affine)
+    keys = set(mine.state_dict())
+    assert ('weight' in keys) == affine and ('bias' in keys) == affine and '_unit_gamma' not in keys
+    assert {'running_mean', 'running_var', 'num_batches_tracked', '_tmp_running_mean', '_tmp_running_var', '_running_iter'} <= keys
+    ref.train(training)
+    mine.train(training)
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(7))
+    xr, xm = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yr, ym = ref(xr), mine(xm)
+    (yr * yr).sum().backward()
+    (ym * ym).sum().backward()
+    assert ym.shape == yr.shape
+    torch.testing.assert_close(ym, yr, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(xm.grad, xr.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(mine.running_mean, ref.running_mean, atol=1e-7, rtol=1e-6)
+    torch.testing.assert_close(mine.running_var, ref.running_var, atol=1e-7, rtol=1e-6)
+    assert int(mine.num_batches_tracked) == int(training)
