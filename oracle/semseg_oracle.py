@@ -80,14 +80,50 @@ def _residual_tail_gammas(manifest):
     return keys
 
 
-def synth_state_dict(manifest, seed=0):
-    """manifest: {key: shape}.  Returns {key: tensor}."""
+def synth_heavy_conv(key, shape, seed=0, channel_scales=True):
+    """Conv weight with the statistics of a TRAINED net instead of a fresh init: heavy-tailed elements (a log-normal factor per
+    element, sigma 1.5: the largest entries of a tensor are > 1e3 x its median magnitude) and output channels whose scales span
+    2.5 decades (10^u, u ~ U[-1.5, 1]: the pre-BN activations of different channels then have variances from 1e-3 to 1e2 -- what
+    the BN running_var of a trained checkpoint looks like; `channel_scales=False` for convs that no BN follows -- the classifiers
+    -- so that the logits stay O(1)).  Overall second moment per channel = He-normal x its channel scale."""
+    g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * seed + 104729) & 0x7FFFFFFF)
+    shape = tuple(shape)
+    fan_in = shape[1] * shape[2] * shape[3]
+    sigma = 1.5
+    w = torch.randn(shape, generator=g) * torch.exp(sigma * torch.randn(shape, generator=g)) * math.exp(-sigma * sigma)
+    ch = 10.0 ** (torch.rand(shape[0], generator=g) * 2.5 - 1.5)
+    if not channel_scales:
+        ch = torch.ones(shape[0])
+    return w * math.sqrt(2.0 / fan_in) * ch.view(-1, 1, 1, 1)
+
+
+def synth_state_dict(manifest, seed=0, style='he'):
+    """manifest: {key: shape}.  Returns {key: tensor}.  style 'he': fresh-init statistics (synth_tensor); 'heavy': conv weights
+    of synth_heavy_conv (BN running statistics then have to be calibrated, tests/golden/make_golden.py::calibrate_bn)."""
     tails = _residual_tail_gammas(manifest)
     sd = {}
     for k, s in sorted(manifest.items()):
-        t = synth_tensor(k, s, seed)
+        if style == 'heavy' and len(s) == 4:
+            # a conv WITH a bias is one no BN follows (the 1x1 classifiers, models.py:366,459,462,540)
+            t = synth_heavy_conv(k, s, seed, channel_scales=(k[:-len('weight')] + 'bias') not in manifest)
+        else:
+            t = synth_tensor(k, s, seed)
         sd[k] = t * 0.3 if k in tails else t
     return sd
+
+
+def golden_state_dicts(g):
+    """(encoder, decoder) state dicts of a golden case (tests/golden/*.pt): the seeded synthetic weights of the case's style,
+    with the BN running statistics the generator calibrated on the reference (stored in the fixture) where the case has them"""
+    m = g['meta']
+    style = m.get('weights_style', 'he')
+    enc = synth_state_dict(g['manifest_enc'], m['seed'], style)
+    dec = synth_state_dict(g['manifest_dec'], m['seed'] + 1, style)
+    for sd, key in ((enc, 'bn_running_enc'), (dec, 'bn_running_dec')):
+        for k, v in (g.get(key) or {}).items():
+            assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
+            sd[k] = v.clone()
+    return enc, dec
 
 
 def synth_batch(n, h, w, seg_rate, num_class=150, seed=304):

@@ -1206,6 +1206,27 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
     }
 }
 
+// Co-residency guard of the kernels that exchange with their peers while they run (csrc/peer_dev.h): block b of a rank spins
+// until block b of every other rank has pushed, so a rank must be able to hold its whole exchanging grid on the device at once
+// -- then no block ever waits for one that could not be dispatched, whatever order the hardware dispatches blocks in.  (With
+// in-order dispatch the lowest unfinished block index is resident on every rank and progress follows anyway; this guard removes
+// the reliance on that.)  ceil(C/16) blocks of 256 threads against CUs x resident blocks per CU: 256 blocks for the widest BN
+// of the path (4096 channels) against >= 2048 on an MI355X.
+template <class K>
+static bool exchange_grid_fits(K kernel, int blocks) {
+    static int capacity = -1;                    // per kernel instantiation
+    if (capacity < 0) {
+        int dev = 0, cus = 0, per = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        capacity = cus * per;
+    }
+    return blocks <= capacity;
+}
+
 static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var,
                                    int64_t* num_batches_tracked, float momentum, float eps, int relu,
@@ -1227,6 +1248,7 @@ static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, 
     hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
                        g.rows_per_block, partial, mm, absmax_out);
     SEMSEG_LAUNCH_CHECK();
+    if (peer && !exchange_grid_fits(bn_fwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;
     if (peer)
         hipLaunchKernelGGL(bn_fwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
                            (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
@@ -1392,6 +1414,7 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
     else LAUNCH_PARTIAL(2);
 #undef LAUNCH_PARTIAL
     SEMSEG_LAUNCH_CHECK();
+    if (peer && !exchange_grid_fits(bn_bwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;
     if (peer)
         hipLaunchKernelGGL(bn_bwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
                            (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,

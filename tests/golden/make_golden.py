@@ -129,13 +129,40 @@ def group_weight(module):
     return [dict(params=decay), dict(params=no_decay, weight_decay=.0)]
 
 
+def calibrate_bn(enc, dec, h, w, seed, n=8):
+    """'heavy' weights: give every BN the running statistics a TRAINED net would carry -- the statistics of its own input -- by
+    one training-mode forward of the unmodified reference modules over a calibration batch with momentum 1 (running <- batch
+    statistic; running_var then spans ~1e-3 ... 1e2 like the per-channel scales of the weights).  Returns the calibrated
+    buffers {key: tensor} of encoder and decoder (they travel in the fixture: they are not a function of the seed alone)."""
+    bns = [m for mod in (enc, dec) for m in mod.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+    saved = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    enc.train(); dec.train()
+    img = torch.randn(n, 3, h, w, generator=torch.Generator().manual_seed(90001 + seed))
+    with torch.no_grad():
+        dec(enc(img, return_feature_maps=True))
+    for m, mom in zip(bns, saved):
+        m.momentum = mom
+        m.num_batches_tracked.zero_()
+    pick = lambda mod: {k: v.clone() for k, v in mod.state_dict().items()                 # noqa: E731
+                        if k.rsplit('.', 1)[-1] in ('running_mean', 'running_var')}
+    return pick(enc), pick(dec)
+
+
 def run_case(name, arch_enc, arch_dec, fc_dim, n, h, w, seg_rate, training, deep_sup_scale,
-             step=False, seg_size=None, seed=0, grads_full=False, dtype=torch.float32, variant=None):
+             step=False, seg_size=None, seed=0, grads_full=False, dtype=torch.float32, variant=None, weights_style='he',
+             bn_running=None):
     torch.manual_seed(304)
     enc, dec = build_reference(arch_enc, arch_dec, fc_dim, use_softmax=seg_size is not None)
     man_e, man_d = manifest_of(enc), manifest_of(dec)
-    enc.load_state_dict(O.synth_state_dict(man_e, seed))
-    dec.load_state_dict(O.synth_state_dict(man_d, seed + 1))
+    enc.load_state_dict(O.synth_state_dict(man_e, seed, weights_style))
+    dec.load_state_dict(O.synth_state_dict(man_d, seed + 1, weights_style))
+    if weights_style == 'heavy':
+        if bn_running is None:
+            bn_running = calibrate_bn(enc, dec, h, w, seed)
+        enc.load_state_dict(bn_running[0], strict=False)
+        dec.load_state_dict(bn_running[1], strict=False)
     if dtype != torch.float32:
         enc, dec = enc.to(dtype), dec.to(dtype)
     masks = {}
@@ -177,9 +204,11 @@ def run_case(name, arch_enc, arch_dec, fc_dim, n, h, w, seg_rate, training, deep
             {k: v.clone() for k, v in dec.state_dict().items() if v.is_floating_point()}))
     meta = dict(name=name, arch_encoder=arch_enc, arch_decoder=arch_dec, fc_dim=fc_dim, n=n, h=h, w=w,
                 seg_rate=seg_rate, training=training, deep_sup_scale=deep_sup_scale, step=step,
-                seg_size=seg_size, seed=seed, lr=0.02, torch=torch.__version__)
+                seg_size=seg_size, seed=seed, lr=0.02, torch=torch.__version__, weights_style=weights_style)
     out = {'meta': meta, 'manifest_enc': man_e, 'manifest_dec': man_d,
            'dropout': {k: v.clone() for k, v in masks.items()}}
+    if bn_running is not None:
+        out['bn_running_enc'], out['bn_running_dec'] = bn_running
     if seg_size is not None:
         with torch.no_grad():
             out['prob'] = sm(feed, segSize=tuple(seg_size)).clone()
@@ -213,7 +242,8 @@ def run_case(name, arch_enc, arch_dec, fc_dim, n, h, w, seg_rate, training, deep
         out['after_enc'] = {k: summarize(v) for k, v in enc.state_dict().items() if v.is_floating_point()}
         out['after_dec'] = {k: summarize(v) for k, v in dec.state_dict().items() if v.is_floating_point()}
         aux = dict(name=name, arch_enc=arch_enc, arch_dec=arch_dec, fc_dim=fc_dim, n=n, h=h, w=w, seg_rate=seg_rate,
-                   training=training, deep_sup_scale=deep_sup_scale, step=True, seed=seed)
+                   training=training, deep_sup_scale=deep_sup_scale, step=True, seed=seed, weights_style=weights_style,
+                   bn_running=bn_running)
         r64 = run_case(dtype=torch.float64, **aux)
         out['loss64'] = r64['loss'].item()
         runs = [dict(grads=(dict(enc_grads), dict(dec_grads)),
@@ -255,6 +285,13 @@ CASES = [
          n=2, h=192, w=192, seg_rate=8, training=True, deep_sup_scale=0.4, step=True, seed=2, grads_full=True),
     dict(name='resnext101_c1_512_train', arch_enc='resnext101', arch_dec='c1', fc_dim=2048,
          n=4, h=512, w=512, seg_rate=32, training=True, deep_sup_scale=None, step=True, seed=3),
+    # weights and BN statistics of a TRAINED net instead of a fresh init (O.synth_heavy_conv + calibrate_bn): heavy-tailed conv
+    # weights (max / median > 1e3), per-channel scales over 2.5 decades, running_var from ~1e-3 to ~1e2 consistent with the
+    # activations.  Eval mode consumes the running statistics; the training case starts its EMA from them.
+    dict(name='r50d_ppmds_64_trainedlike_eval', arch_enc='resnet50dilated', arch_dec='ppm_deepsup', fc_dim=2048,
+         n=2, h=64, w=64, seg_rate=8, training=False, deep_sup_scale=0.4, seed=4, weights_style='heavy'),
+    dict(name='r18d_ppmds_64_trainedlike_train', arch_enc='resnet18dilated', arch_dec='ppm_deepsup', fc_dim=512,
+         n=2, h=64, w=64, seg_rate=8, training=True, deep_sup_scale=0.4, step=True, seed=5, weights_style='heavy'),
 ]
 
 

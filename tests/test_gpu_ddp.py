@@ -433,3 +433,17 @@ def test_two_ranks_unequal_shapes_peer_equals_gloo():
         assert torch.equal(runs['peer_fused'][0]['sd'][k], v), ('peer_fused != gloo_allreduce', k)
         assert torch.equal(runs['peer_fused'][1]['sd'][k], v), ('ranks differ', k)
     assert runs['peer_fused'][0]['loss'].item() == runs['gloo_allreduce'][0]['loss'].item()
+
+
+def test_peer_exchange_world8_in_one_process():
+    """The peer exchange at its full world of 8 ranks on the ONE test GPU: eight contexts in a child process, eight streams on
+    eight hardware queues (GPU_MAX_HW_QUEUES=16) -- rank-ordered sums over more exchanges than slots and lanes, the fused BN
+    kernels on eight unequal shards against the unfused path, a missing rank -> NaN + status (tests/peer_world8_worker.py)."""
+    import subprocess
+    env = dict(os.environ, GPU_MAX_HW_QUEUES='16')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'peer_world8_worker.py')], env=env, capture_output=True,
+                       text=True, timeout=300)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    for marker in ('WORLD8_EXCHANGE_OK', 'WORLD8_FUSED_BN_OK', 'WORLD8_TIMEOUT_OK'):
+        assert marker in r.stdout, marker

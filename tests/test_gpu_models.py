@@ -20,8 +20,7 @@ LOGP_ATOL = 1e-3
 def build_native(g, dev, use_softmax=False):
     from mit_semseg.models import ModelBuilder, SegmentationModule
     m = g['meta']
-    enc_sd = O.synth_state_dict(g['manifest_enc'], m['seed'])
-    dec_sd = O.synth_state_dict(g['manifest_dec'], m['seed'] + 1)
+    enc_sd, dec_sd = O.golden_state_dicts(g)
     with tempfile.TemporaryDirectory() as d:
         pe, pd = os.path.join(d, 'e.pth'), os.path.join(d, 'd.pth')
         torch.save(enc_sd, pe)
@@ -115,7 +114,7 @@ def _native_grads(g, dev):
 
 
 @pytest.mark.parametrize('name', ['r18d_ppmds_64_train', 'r50d_ppmds_64_train', 'r50_upernet_128_train', 'hrnetv2_c1_64_train',
-                                  'mnv2d_c1ds_64_train', 'mnv2d_c1ds_192_train'])
+                                  'mnv2d_c1ds_64_train', 'mnv2d_c1ds_192_train', 'r18d_ppmds_64_trainedlike_train'])
 def test_native_gradients_vs_reference_anchor(name, monkeypatch):
     """EVERY parameter gradient of one backward against the float64 anchor of the unmodified reference
     (tests/golden/make_golden.py::anchor): elementwise on small tensors and on a seeded 1024-element sample of large ones --
@@ -272,3 +271,38 @@ def test_hrnet_branch_streams_equal_one_stream(monkeypatch):
         assert res[key][1] == base[1], (key, res[key][1], base[1])
         for k, v in base[0].items():
             assert torch.equal(res[key][0][k], v), (key, k)
+
+
+# every environment switch of the product that survives in the code base, with the golden case(s) that exercise what it changes:
+# the parity suite must hold on BOTH sides of each switch (they are read at import time, hence one child process per switch)
+SWITCH_CASES = [
+    ('SEMSEG_CONV=s3', 'r18d_ppmds_64_train'),               # 3-way bf16 split family end to end
+    ('SEMSEG_CONV=f32', 'r18d_ppmds_64_train'),              # exact-fp32 MFMA family end to end
+    ('SEMSEG_FUSE=0', 'r50d_ppmds_64_train'),                # no plane hand-over, unfused conv / BN nodes
+    ('SEMSEG_WINOGRAD=0', 'r50d_ppmds_64_train'),            # conv_last (4096 channels) through the direct kernels
+    ('SEMSEG_WINOGRAD_WGRAD=0', 'r50d_ppmds_64_train'),
+    ('SEMSEG_WINOGRAD_MIN_C=256', 'r50d_ppmds_64_train'),    # Winograd for every eligible 3x3 conv of the net
+    ('SEMSEG_TUNE=0', 'r50d_ppmds_64_train'),                # the library's heuristic launch plans
+    ('SEMSEG_TUNE_BUCKETS=0', 'r18d_ppmds_64_train'),
+    ('SEMSEG_FORCE_SYNC_PATH=1', 'r18d_ppmds_64_train'),     # the unfused SyncBN kernel sequence on one rank
+    ('SEMSEG_BRANCH_STREAMS=0', 'hrnetv2_c1_64_train'),
+    ('SEMSEG_DEPTHWISE_DIRECT=0', 'mnv2d_c1ds_64_train'),
+    ('SEMSEG_GROUPED_DIRECT=0', 'resnext101_upernet_128_eval'),
+]
+
+
+@pytest.mark.parametrize('switch,case', SWITCH_CASES, ids=[s for s, _ in SWITCH_CASES])
+def test_env_switch_keeps_model_parity(switch, case):
+    """the golden tests of `case` (forward bounds, post-step state and, where stored, every gradient against the float64
+    anchors) in a child process with `switch` set"""
+    import subprocess
+    import sys
+    if os.environ.get('SEMSEG_SWITCH_CHILD'):
+        pytest.skip('already inside a switch child')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    k, v = switch.split('=')
+    env = dict(os.environ, SEMSEG_SWITCH_CHILD='1', **{k: v})
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_models.py'), '-q', '-x', '-m', 'gpu',
+                        '-k', '%s and not switch' % case], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0 and ' passed' in tail, '%s: %s\n%s' % (switch, tail, r.stderr[-1500:])

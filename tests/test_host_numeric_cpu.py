@@ -18,8 +18,7 @@ from oracle import semseg_oracle as O
 def _build(g, use_softmax):
     from mit_semseg.models import ModelBuilder, SegmentationModule
     m = g['meta']
-    enc_sd = O.synth_state_dict(g['manifest_enc'], m['seed'])
-    dec_sd = O.synth_state_dict(g['manifest_dec'], m['seed'] + 1)
+    enc_sd, dec_sd = O.golden_state_dicts(g)
     with tempfile.TemporaryDirectory() as d:
         pe, pd = os.path.join(d, 'e.pth'), os.path.join(d, 'd.pth')
         torch.save(enc_sd, pe)

@@ -70,6 +70,25 @@ def anchor_ratio(got, rec, what):
     return ratio
 
 
+def is_head_tensor(key, p, num_class=150):
+    """decoder parameters with NO ReLU gate between them and the loss: the 1x1 classifier convs (models.py:456-465 conv_last[4] /
+    conv_last_deepsup of the PPM heads, :540 conv_last[1] of UPerNet, :366 conv_last of C1 / C1DeepSup) -- recognised by their
+    num_class output channels.  Their gradient is dlogits^T x activations, a smooth function of the forward pass, so it must
+    agree ELEMENTWISE at roundoff level; the band statistics below exist for the ill-conditioned rest."""
+    return key.startswith('conv_last') and ((p.dim() == 4 and p.shape[0] == num_class and tuple(p.shape[2:]) == (1, 1)) or
+                                            (p.dim() == 1 and p.numel() == num_class and key.endswith('.bias')))
+
+
+def scale_error(got, rec):
+    """max |got - ref64| / max|ref64| on the full tensor or its seeded sample"""
+    f = got.detach().double().cpu().flatten()
+    if 'full' in rec:
+        ref, g = rec['full'].double().flatten(), f
+    else:
+        ref, g = rec['sample'].double(), f[sample_index(rec['numel'])]
+    return (g - ref).abs().max().item() / (rec['absmax'] + 1e-30)
+
+
 # Acceptance over ALL tensors of a case.  The deviation of a correct fp32 implementation from the band is heavy-tailed: a ReLU
 # gate that resolves the other way (pre-activation ~1e-7) moves a handful of tensors by several bands while the bulk sits well
 # inside one band.  So: the typical tensor must be inside the band itself, 95 % within 4 bands, none beyond 16.
@@ -90,8 +109,7 @@ def oracle_run(g, with_step=None):
     """Run the oracle on the golden case's recipe.  Returns (result dict, enc_sd, dec_sd, grads)."""
     m = g['meta']
     step = m['step'] if with_step is None else with_step
-    enc = O.clone_sd(O.synth_state_dict(g['manifest_enc'], m['seed']), requires_grad=step)
-    dec = O.clone_sd(O.synth_state_dict(g['manifest_dec'], m['seed'] + 1), requires_grad=step)
+    enc, dec = (O.clone_sd(sd, requires_grad=step) for sd in O.golden_state_dicts(g))
     img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=304 + m['seed'])
     if m['seg_size'] is not None:
         with torch.no_grad():
