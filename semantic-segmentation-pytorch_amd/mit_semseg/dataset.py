@@ -311,9 +311,11 @@ class TrainDataset:
                     self.batch_record_list[k] = []
                     return batch_records
 
-    def decode(self, index):
-        """host half of __getitem__ (record selection, random draws, PIL decode): what a prefetch thread runs"""
-        from PIL import Image
+    def plan(self, index):
+        """the SEQUENTIAL part of __getitem__ (dataset.py:153-160): record selection and every numpy random draw, in the
+        reference's order (shuffle seeded by the first index, short-side size, one flip per sample) -- no file is touched, so a
+        planner thread can run ahead while a pool decodes the files of earlier batches in parallel.  Returns (records, flips,
+        short size)."""
         if not self.if_shuffled:
             np.random.seed(index)
             np.random.shuffle(self.list_sample)
@@ -323,16 +325,24 @@ class TrainDataset:
             this_short_size = np.random.choice(self.imgSizes)
         else:
             this_short_size = self.imgSizes
-        images, segms, flips = [], [], []
-        for rec in batch_records:
-            img = Image.open(os.path.join(self.root_dataset, rec['fpath_img'])).convert('RGB')
-            segm = Image.open(os.path.join(self.root_dataset, rec['fpath_segm']))
-            assert segm.mode == 'L'
-            assert img.size == segm.size
-            flips.append(bool(np.random.choice([0, 1])) if self.random_flip else False)
-            images.append(torch.from_numpy(np.array(img)))
-            segms.append(torch.from_numpy(np.array(segm)))
-        return images, segms, flips, this_short_size
+        flips = [bool(np.random.choice([0, 1])) if self.random_flip else False for _ in batch_records]
+        return batch_records, flips, this_short_size
+
+    def load_record(self, rec):
+        """decode the image / annotation pair of one record (dataset.py:162-169) into uint8 tensors: independent of every other
+        record, and Pillow releases the GIL while it decodes -- the unit of work of the decode pool"""
+        from PIL import Image
+        img = Image.open(os.path.join(self.root_dataset, rec['fpath_img'])).convert('RGB')
+        segm = Image.open(os.path.join(self.root_dataset, rec['fpath_segm']))
+        assert segm.mode == 'L'
+        assert img.size == segm.size
+        return torch.from_numpy(np.array(img)), torch.from_numpy(np.array(segm))
+
+    def decode(self, index):
+        """host half of __getitem__ (plan + file decode) in one call"""
+        batch_records, flips, this_short_size = self.plan(index)
+        pairs = [self.load_record(rec) for rec in batch_records]
+        return [p[0] for p in pairs], [p[1] for p in pairs], flips, this_short_size
 
     def assemble(self, decoded):
         """device half: resize / flip / normalise / label down-sampling / padding in HIP kernels"""

@@ -64,21 +64,29 @@ def checkpoint_paths(cfg, which):
 
 
 class _Prefetcher:
-    """decodes the next batches on a host thread while the GPU trains (the reference spends 16 DataLoader workers on decode +
-    resize, train.py:163-177; here only the file decode is host work, the resize runs on the device)"""
+    """Host side of the input pipeline while the GPU trains.  The reference spends TRAIN.workers = 16 DataLoader processes on
+    decode + resize + normalise (train.py:163-177); here only the file decode is host work (the rest runs on the device,
+    csrc/input_pipeline.hip), and it is spread over a POOL of threads: a planner thread walks the dataset's sequential part (record
+    grouping and numpy draws, `TrainDataset.plan`) and hands every record's decode to the pool (`TrainDataset.load_record`;
+    Pillow releases the GIL inside its decoders, so the threads scale over the host cores); batches leave in plan order, `depth`
+    of them in flight.  tools/input_pipeline_bench.py measures decode + assembly against the step rate."""
 
-    def __init__(self, dataset, first_index, depth=4):
+    def __init__(self, dataset, first_index, depth=8, workers=16):
+        from concurrent.futures import ThreadPoolExecutor
         self.q = queue.Queue(maxsize=depth)
         self.dataset = dataset
         self.index = first_index
         self.error = None
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix='semseg-decode')
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
     def _run(self):
         try:
             while True:
-                self.q.put(self.dataset.decode(self.index))
+                records, flips, short = self.dataset.plan(self.index)
+                futures = [self.pool.submit(self.dataset.load_record, rec) for rec in records]
+                self.q.put((futures, flips, short))           # blocks while `depth` batches are waiting: bounds the decoded memory
                 self.index += 1
         except BaseException as e:                    # surfaces in the training loop
             self.error = e
@@ -88,7 +96,12 @@ class _Prefetcher:
         item = self.q.get()
         if item is None:
             raise self.error
-        return self.dataset.assemble(item)
+        futures, flips, short = item
+        pairs = [f.result() for f in futures]         # a decode error surfaces here
+        return self.dataset.assemble(([p[0] for p in pairs], [p[1] for p in pairs], flips, short))
+
+    def __iter__(self):
+        return self
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -147,7 +160,7 @@ def train_worker(rank, world, cfg, gpus, port):
         NativeDataParallel(sm, device_ids=gpus)            # SyncBN statistics + (TrainStep) gradient all-reduce over RCCL
     dataset = TrainDataset(cfg.DATASET.root_dataset, cfg.DATASET.list_train, cfg.DATASET,
                            batch_per_gpu=cfg.TRAIN.batch_size_per_gpu, device=dev)
-    iterator = _Prefetcher(dataset, first_index=rank)      # first index seeds this rank's shuffle (dataset.py:112-116)
+    iterator = _Prefetcher(dataset, first_index=rank, workers=cfg.TRAIN.workers)    # first index seeds this rank's shuffle (dataset.py:112-116)
     if rank == 0:
         print('1 Epoch = {} iters'.format(cfg.TRAIN.epoch_iters))
     max_iters = cfg.TRAIN.epoch_iters * cfg.TRAIN.num_epoch

@@ -10,7 +10,8 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.util import golden_cases, load_golden, anchor_ratio, check_anchor_ratios, HEURISTIC_PLAN_GOLDEN
+from tests.util import (golden_cases, load_golden, anchor_ratios, check_anchor_ratios, is_head_tensor, scale_error,
+                        HEAD_SCALE_ERR, HEURISTIC_PLAN_GOLDEN)
 from oracle import semseg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -93,14 +94,14 @@ def test_native_matches_reference_golden(name, monkeypatch):
     # TrainStep has stepped already: compare the post-step state (weights, BN running stats) -- it pins grads, weight decay,
     # momentum and lr -- against the reference's float64 anchor with the reference's own fp32 deviation as the yardstick
     # (tests/util.anchor_ratio / check_anchor_ratios)
-    ratios = []
+    items = []
     for mod, want, side in ((sm.encoder, g['anchor_after_enc'], 'enc.'), (sm.decoder, g['anchor_after_dec'], 'dec.')):
         sd = mod.state_dict()
         for k in want:
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue
-            ratios.append((anchor_ratio(sd[k], want[k], 'after-step ' + k), side + k))
-    print(check_anchor_ratios(ratios, name + ' after-step state'))
+            items.append((side + k, sd[k], want[k]))
+    print(check_anchor_ratios(anchor_ratios(items), name + ' after-step state'))
 
 
 def _native_grads(g, dev):
@@ -129,11 +130,18 @@ def test_native_gradients_vs_reference_anchor(name, monkeypatch):
         monkeypatch.setattr(tuner, 'ENABLED', False)
     g = load_golden(name)
     sm = _native_grads(g, torch.device('cuda:0'))
-    ratios = []
+    items, heads = [], []
     for mod, want, side in ((sm.encoder, g['anchor_grads_enc'], 'enc.'), (sm.decoder, g['anchor_grads_dec'], 'dec.')):
         for k, p in mod.named_parameters():
-            ratios.append((anchor_ratio(p.grad, want[k], 'grad ' + k), side + k))
-    print(check_anchor_ratios(ratios, name + ' gradients'))
+            items.append((side + k, p.grad, want[k]))
+            if side == 'dec.' and is_head_tensor(k, p):
+                heads.append((scale_error(p.grad, want[k]), side + k))
+    print(check_anchor_ratios(anchor_ratios(items), name + ' gradients'))
+    # the classifier convs: no ReLU gate between them and the loss, so their gradients agree elementwise at roundoff level
+    # (measured 2e-6 ... 1.2e-5 of the tensor's scale on every case, h2 and exact-fp32 alike)
+    assert heads, 'no classifier tensors found'
+    print('%s classifier gradients: max |err| / scale %.2e (%s)' % ((name,) + max(heads)))
+    assert max(heads)[0] <= HEAD_SCALE_ERR, heads
 
 
 FULL_SIZE = {

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from tests import cpu_twin
-from tests.util import golden_cases, load_golden, check_summary, anchor_ratio, check_anchor_ratios, HEAVY_GOLDEN
+from tests.util import golden_cases, load_golden, check_summary, anchor_ratios, check_anchor_ratios, HEAVY_GOLDEN
 from oracle import semseg_oracle as O
 
 
@@ -81,14 +81,14 @@ def _run_case(name, step_tol=(1e-4, 1e-3)):
     # yardstick: the reference's own fp32 reproducibility band per tensor (tests/util.anchor_ratio) -- the twin composes the
     # same torch kernels in a slightly different order (fused residual adds), which an ill-conditioned net (MobileNetV2 on
     # seeded weights) amplifies beyond any fixed tolerance
-    ratios = []
-    for mod, want in ((sm.encoder, g['anchor_after_enc']), (sm.decoder, g['anchor_after_dec'])):
+    items = []
+    for mod, want, side in ((sm.encoder, g['anchor_after_enc'], 'enc.'), (sm.decoder, g['anchor_after_dec'], 'dec.')):
         sd = mod.state_dict()
         for k in want:
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue
-            ratios.append((anchor_ratio(sd[k].detach().contiguous(), want[k], 'after-step ' + k), k))
-    print(check_anchor_ratios(ratios, name))
+            items.append((side + k, sd[k].detach().contiguous(), want[k]))
+    print(check_anchor_ratios(anchor_ratios(items), name))
 
 
 def test_mobilenet_golden_with_direct_depthwise_kernels_emulated(monkeypatch, tmp_path):

@@ -167,6 +167,44 @@ def test_product_dataset_mirror_draws_like_the_reference(emulated_kernels, monke
     assert np.array_equal(feed['seg_label'].numpy(), want['seg_label'])
 
 
+def test_decode_pool_yields_the_sequential_batches(emulated_kernels, monkeypatch, tmp_path):
+    """drivers._Prefetcher with a pool of decode threads (the replacement of the reference's 16 DataLoader workers,
+    train.py:163-177): batch k of the pooled iterator is exactly dataset[first + k] of a second, sequentially read dataset with
+    the same numpy seed -- the planner thread makes the random draws in the reference's order whatever order the pool finishes
+    the file decodes in."""
+    Image = pytest.importorskip('PIL.Image')
+    import types
+    from mit_semseg import _native
+    from mit_semseg import dataset as D
+    from mit_semseg.drivers import _Prefetcher
+    lib = _HostKernels(_native.lib(), emulated_kernels, _native.SIGNATURES)
+    monkeypatch.setattr(_native, 'lib', lambda: lib)
+    monkeypatch.setattr(D, '_require_cuda', lambda *a: None)
+    monkeypatch.setattr(D, '_st', lambda: ctypes.c_void_p(0))
+    rng = np.random.default_rng(11)
+    recs = []
+    for k in range(9):
+        h, w = int(rng.integers(30, 60)), int(rng.integers(30, 60))
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(str(tmp_path / ('i%d.png' % k)))
+        Image.fromarray(rng.integers(0, 151, (h, w), dtype=np.uint8), mode='L').save(str(tmp_path / ('s%d.png' % k)))
+        recs.append({'fpath_img': 'i%d.png' % k, 'fpath_segm': 's%d.png' % k, 'width': w, 'height': h})
+    opt = types.SimpleNamespace(imgSizes=(32, 40, 48), imgMaxSize=80, padding_constant=8, segm_downsampling_rate=8)
+    seq = D.TrainDataset(str(tmp_path), [dict(r) for r in recs], opt, batch_per_gpu=2, device='cpu')
+    want = [seq[3 + k] for k in range(7)]                  # sequential reads: seeds numpy with the first index, then draws on
+    pooled = D.TrainDataset(str(tmp_path), [dict(r) for r in recs], opt, batch_per_gpu=2, device='cpu')
+    it = _Prefetcher(pooled, first_index=3, depth=3, workers=4)
+    # the planner thread re-seeds numpy with the first index and runs ahead by `depth` batches; the sequential read is complete
+    got = [next(it) for _ in range(7)]
+    for a, b in zip(got, want):
+        assert np.array_equal(a['img_data'].numpy(), b['img_data'].numpy())
+        assert np.array_equal(a['seg_label'].numpy(), b['seg_label'].numpy())
+    # a decode error surfaces in the consumer instead of killing a pool thread silently
+    os.remove(str(tmp_path / 'i0.png'))
+    with pytest.raises(Exception):
+        for _ in range(20):
+            next(it)
+
+
 def val_golden():
     g = np.load(GOLDEN)
     p = [int(v) for v in g['val_params']]

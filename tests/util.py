@@ -45,16 +45,25 @@ def sample_index(numel, k=1024):
     return torch.randint(0, numel, (k,), generator=torch.Generator().manual_seed(numel % (2 ** 31)))
 
 
-def anchor_ratio(got, rec, what):
+def anchor_ratio(got, rec, what, rel_band=0.0):
     """`got` against the float64 ANCHOR record of the reference (make_golden.anchor): how far the native result is from the
     exact (float64) result of the reference's arithmetic, in units of the reference's OWN fp32 reproducibility band (the
     largest deviation from float64 over five executions of the unmodified reference, see anchor()):
 
-        ratio = max|got - ref64| / (band_max + floor)           elementwise, on the full tensor or its seeded sample
+        ratio = max|got - ref64| / (band + floor)               elementwise, on the full tensor or its seeded sample
         (full tensors also: ||got - ref64||_2 / (band_l2 + floor sqrt(n)); the larger of the two is returned)
+        band  = max(band of THIS tensor, rel_band x max|ref64|)
 
-    floor = fp32 representation of the anchor itself (1e-6 of max|ref64|).  A ratio around 1 means "as reproducible as the
-    reference is against itself"; a kernel bug gives ratios of 1e2...1e4."""
+    floor = fp32 representation of the anchor itself (1e-6 of max|ref64|).  `rel_band` (case_rel_band): the band of the TYPICAL
+    tensor of the case relative to its scale.  Why a tensor's own band is not enough (tools/probes/anchor_control.py,
+    profiles/r4_anchor_control_h2_vs_f32.txt): what moves a gradient between two correct fp32 executions is mostly ReLU gates
+    with a ~1e-7 pre-activation resolving the other way -- a DISCRETE event.  Five executions sample it poorly: a tensor in
+    which no gate happened to flip among the five gets a band of pure roundoff (3e-4 of its scale for `layer4.2.bn2.bias` of
+    r50d_ppmds_64_train against 7.5e-3 for the median tensor of the same net), and the first flip in a sixth execution -- another
+    launch plan of this library, or its exact-fp32 kernels -- lands 30 ... 5000 "bands" out while being as close to the anchor
+    as every other tensor is, relative to scale.  So no tensor is held to a tighter relative band than the typical tensor of
+    its case.  A ratio around 1 means "as reproducible as the reference is against itself"; a kernel bug moves a tensor by O(1)
+    of its scale = 1e2 ... 1e3 typical bands."""
     f = got.detach().double().cpu().flatten()
     assert f.numel() == rec['numel'], (what, f.numel(), rec['numel'])
     assert torch.isfinite(f).all(), what + ': non-finite values'
@@ -64,10 +73,23 @@ def anchor_ratio(got, rec, what):
     else:
         ref, g = rec['sample'].double(), f[sample_index(rec['numel'])]
     d = (g - ref).abs()
-    ratio = d.max().item() / (rec['err_max'] + floor)
+    ratio = d.max().item() / (max(rec['err_max'], rel_band * rec['absmax']) + floor)
     if 'full' in rec:
-        ratio = max(ratio, d.norm().item() / (rec['err_l2'] + floor * rec['numel'] ** 0.5))
+        ratio = max(ratio, d.norm().item() / (max(rec['err_l2'], rel_band * ref.norm().item()) + floor * rec['numel'] ** 0.5))
     return ratio
+
+
+def case_rel_band(records):
+    """median over the anchor records of a case of (fp32 band of the reference) / (scale of the tensor)"""
+    v = sorted(r['err_max'] / r['absmax'] for r in records if r['absmax'] > 0)
+    return v[len(v) // 2] if v else 0.0
+
+
+def anchor_ratios(items):
+    """items: [(name, tensor, anchor record)] of ONE case -> [(ratio, name)] with the case-wide relative band as the lower limit
+    of every tensor's band (anchor_ratio)"""
+    rel = case_rel_band([rec for _, _, rec in items])
+    return [(anchor_ratio(t, rec, name, rel), name) for name, t, rec in items]
 
 
 def is_head_tensor(key, p, num_class=150):
@@ -91,8 +113,14 @@ def scale_error(got, rec):
 
 # Acceptance over ALL tensors of a case.  The deviation of a correct fp32 implementation from the band is heavy-tailed: a ReLU
 # gate that resolves the other way (pre-activation ~1e-7) moves a handful of tensors by several bands while the bulk sits well
-# inside one band.  So: the typical tensor must be inside the band itself, 95 % within 4 bands, none beyond 16.
+# inside one band.  So: the typical tensor must be inside the band itself, 95 % within 4 bands, none beyond ANCHOR_MAX.
+# The control (tools/probes/anchor_control.py: the same measurement on the default h2 path and on the exact-fp32 MFMA kernels,
+# profiles/r4_anchor_control_h2_vs_f32.txt) shows the two paths in the same range -- the 2^-22 products of h2 are not what
+# decides these ratios -- and, with the case-wide relative band as the lower limit (anchor_ratio), a worst tensor of <= 6 on
+# either path; ANCHOR_MAX leaves a factor over that for launch plans not seen yet.
 ANCHOR_MEDIAN, ANCHOR_P95, ANCHOR_MAX = 1.0, 4.0, 16.0
+# tensors with no ReLU gate between them and the loss (is_head_tensor): elementwise, relative to the tensor's scale
+HEAD_SCALE_ERR = 1e-4
 
 
 def check_anchor_ratios(ratios, what):

@@ -39,14 +39,17 @@ def worker():
             tuner.ENABLED = False
         g = util.load_golden(name)
         sm = _native_grads(g, dev)
-        ratios, heads = [], []
+        items, heads = [], []
         for mod, want, side in ((sm.encoder, g['anchor_grads_enc'], 'enc.'), (sm.decoder, g['anchor_grads_dec'], 'dec.')):
             for k, p in mod.named_parameters():
-                ratios.append((util.anchor_ratio(p.grad, want[k], k), side + k))
+                items.append((side + k, p.grad, want[k]))
                 if side == 'dec.' and util.is_head_tensor(k, p):
                     heads.append((util.scale_error(p.grad, want[k]), side + k))
-        med, p95, mx, worst, n = summarize(ratios)
-        rows.append(dict(case=name, what='gradients', n=n, median=med, p95=p95, max=mx, worst=worst,
+        med, p95, mx, worst, n = summarize(util.anchor_ratios(items))
+        raw = max(util.anchor_ratio(t, rec, k) for k, t, rec in items)          # without the case-wide lower limit of the band
+        worst_scale = max(util.scale_error(t, rec) for k, t, rec in items)
+        rows.append(dict(case=name, what='gradients', n=n, median=med, p95=p95, max=mx, worst=worst, raw_max=raw,
+                         rel_band=util.case_rel_band([rec for _, _, rec in items]), worst_scale_err=worst_scale,
                          head_rel_err_max=max(h[0] for h in heads) if heads else None))
         # post-step state of the same case through TrainStep
         from mit_semseg.engine import TrainStep
@@ -56,15 +59,18 @@ def worker():
         ts = TrainStep(sm, lr_encoder=m['lr'], lr_decoder=m['lr'], max_iters=10 ** 9)
         ts.step({'img_data': img.to(dev), 'seg_label': lab.to(dev)})
         torch.cuda.synchronize()
-        ratios = []
+        items = []
         for mod, want, side in ((sm.encoder, g['anchor_after_enc'], 'enc.'), (sm.decoder, g['anchor_after_dec'], 'dec.')):
             sd = mod.state_dict()
             for k in want:
                 if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                     continue
-                ratios.append((util.anchor_ratio(sd[k], want[k], k), side + k))
-        med, p95, mx, worst, n = summarize(ratios)
-        rows.append(dict(case=name, what='after-step', n=n, median=med, p95=p95, max=mx, worst=worst, head_rel_err_max=None))
+                items.append((side + k, sd[k], want[k]))
+        med, p95, mx, worst, n = summarize(util.anchor_ratios(items))
+        raw = max(util.anchor_ratio(t, rec, k) for k, t, rec in items)
+        rows.append(dict(case=name, what='after-step', n=n, median=med, p95=p95, max=mx, worst=worst, raw_max=raw,
+                         rel_band=util.case_rel_band([rec for _, _, rec in items]),
+                         worst_scale_err=max(util.scale_error(t, rec) for k, t, rec in items), head_rel_err_max=None))
         tuner.ENABLED = True
     print('ANCHOR_TABLE ' + json.dumps({'mode': ops.CONV_MODE, 'rows': rows}), flush=True)
 
@@ -83,14 +89,17 @@ def main():
             print('mode %s failed:\n%s\n%s' % (mode, r.stdout[-1500:], r.stderr[-3000:]))
             continue
         tables[mode] = json.loads(line[-1][len('ANCHOR_TABLE '):])['rows']
-    lines = ['deviation from the float64 anchor of the unmodified reference, in units of the reference\'s own fp32 band',
-             '%-26s %-11s %5s | %-24s | %-24s | worst tensor (h2 / f32)' % ('case', 'what', 'n', 'h2: median p95 max', 'f32: median p95 max')]
+    lines = ['deviation from the float64 anchor of the unmodified reference, in units of the reference\'s own fp32 band (no tensor held',
+             'to a tighter relative band than the median tensor of its case, tests/util.anchor_ratio; `raw` = without that lower limit;',
+             '`scale` = largest |err| / max|ref| over the tensors of the case)',
+             '%-31s %-10s %5s %8s | %-40s | %-40s | worst tensor (h2 / f32)' % ('case', 'what', 'n', 'relband', 'h2: median p95 max (raw max) scale',
+                                                                            'f32: median p95 max (raw max) scale')]
+    fmt = lambda r: '%5.2f %5.2f %6.2f (%8.2f) %.1e' % (r['median'], r['p95'], r['max'], r['raw_max'], r['worst_scale_err'])   # noqa: E731
     for i, row in enumerate(tables.get('h2', [])):
         f = tables['f32'][i] if 'f32' in tables else None
-        fs = '%6.2f %6.2f %7.2f' % (f['median'], f['p95'], f['max']) if f else 'n/a'
-        lines.append('%-26s %-11s %5d | %6.2f %6.2f %7.2f     | %-24s | %s / %s%s' % (
-            row['case'], row['what'], row['n'], row['median'], row['p95'], row['max'], fs, row['worst'], f['worst'] if f else '',
-            ('   head |err|/scale: h2 %.1e f32 %.1e' % (row['head_rel_err_max'], f['head_rel_err_max']))
+        lines.append('%-31s %-10s %5d %8.1e | %-40s | %-40s | %s / %s%s' % (
+            row['case'], row['what'], row['n'], row['rel_band'], fmt(row), fmt(f) if f else 'n/a', row['worst'], f['worst'] if f else '',
+            ('   classifier |err|/scale: h2 %.1e f32 %.1e' % (row['head_rel_err_max'], f['head_rel_err_max']))
             if (row['head_rel_err_max'] is not None and f) else ''))
     text = '\n'.join(lines)
     print(text)
