@@ -116,6 +116,17 @@ size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R
 int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* semseg_conv2d_fwd_h2 (no bias) that ALSO gathers the BatchNorm statistics of its result in the GEMM epilogue -- the conv -> BN
+ * pairs of resnet.py:72-92 / models.py:160-167 without the statistics sweep over the conv output: every wave writes the fp64
+ * column sums / sums of squares and fp32 column min / max of its sub-tile as one partial row into stats_ws
+ * (semseg_conv2d_fwd_stats_bytes(K) bytes), zeroes *bound_word, and *parts_out (host) = the number of partial rows, to be
+ * handed to semseg_bn_fwd_finish_fused.  *parts_out == 0: the launch plan of this geometry splits the reduction (or has more
+ * than 512 wave rows) and nothing was gathered -- run semseg_bn_fwd_stats_fused on y instead. */
+size_t semseg_conv2d_fwd_stats_bytes(int K);
+int semseg_conv2d_fwd_stats_h2(const void* xs, const void* ws, float* y, int y_ld,
+                               int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                               void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
+                               float* bound_word, int* parts_out, void* stream);
 int semseg_conv2d_dgrad_h2(const void* dys, const void* wts, float* dx, int dx_ld,
                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                            void* workspace, size_t workspace_bytes, void* stream);
@@ -255,6 +266,14 @@ int semseg_bn_fwd_stats_fused_peer(const float* z, int P, int C, double* stats, 
                                    float momentum, float eps, int relu, const float* res_absmax,
                                    float* mean, float* invstd, float* scale, float* shift, void* blockbound,
                                    void* workspace, size_t workspace_bytes, void* stream, void* peer, float* absmax_out /* nullable */);
+/* the finish half of semseg_bn_fwd_stats_fused[_bound|_peer] alone, on the partial sums the convolution's epilogue gathered
+ * (semseg_conv2d_fwd_stats_h2: `parts` rows in `partials`, which also zeroed *absmax_out's word): mean / invstd / scale /
+ * shift, running statistics, per-block bounds -- no pass over the conv output.  peer / absmax_out: NULL or as above. */
+int semseg_bn_fwd_finish_fused(const void* partials, size_t partials_bytes, int parts, int P, int C, double* stats, float* zmm,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, float momentum, float eps, int relu, const float* res_absmax,
+                               float* mean, float* invstd, float* scale, float* shift, void* blockbound, void* stream,
+                               void* peer /* nullable */, float* absmax_out /* nullable */);
 int semseg_bn_bwd_reduce_fused_peer(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
                                     const float* mean, const float* invstd, const float* gate_scale, const float* gate_shift,
                                     int relu, int P, int C, const double* stats_count, const float* zmm, const float* gamma,

@@ -1227,27 +1227,33 @@ static bool exchange_grid_fits(K kernel, int blocks) {
     return blocks <= capacity;
 }
 
+// `pre_parts` > 0: the partial sums exist already -- `workspace` holds pre_parts rows of [2C] fp64 sums followed by pre_parts rows
+// of [2C] fp32 min / max, written by the convolution's epilogue (semseg_conv2d_fwd_stats_h2, which also zeroed the bound word)
+// -- and only the finish kernel is launched; else the statistics sweep over z runs first.
 static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, float* zmm, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var,
                                    int64_t* num_batches_tracked, float momentum, float eps, int relu,
                                    const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
                                    void* blockbound, void* workspace, size_t workspace_bytes, void* stream, void* peer,
-                                   float* absmax_out) {
+                                   float* absmax_out, int pre_parts = 0) {
     semseg_peer::PeerArgs pa = {};
     if (peer && (!semseg_peer::peer_args(peer, &pa) || 2 * C + 1 > pa.cap)) return SEMSEG_EINVAL;
-    if (!z || !stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || !blockbound || P <= 0 || C <= 0 ||
-        (C % 4) || !aligned16(z))
+    if ((!z && pre_parts <= 0) || !stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || !blockbound ||
+        P <= 0 || C <= 0 || (C % 4) || (z && !aligned16(z)))
         return SEMSEG_EINVAL;
-    const ColGeom g = col_geom(P, C);
+    ColGeom g = col_geom(P, C);
+    if (pre_parts > 0) g.gy = pre_parts;
     const size_t need = (size_t)g.gy * 2 * C * (sizeof(double) + sizeof(float));
     if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     double* partial = (double*)workspace;
     float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
-    const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
-    hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
-                       g.rows_per_block, partial, mm, absmax_out);
-    SEMSEG_LAUNCH_CHECK();
+    if (pre_parts <= 0) {
+        const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
+        hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
+                           g.rows_per_block, partial, mm, absmax_out);
+        SEMSEG_LAUNCH_CHECK();
+    }
     if (peer && !exchange_grid_fits(bn_fwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;
     if (peer)
         hipLaunchKernelGGL(bn_fwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
@@ -1296,6 +1302,19 @@ extern "C" int semseg_bn_fwd_stats_fused_peer(const float* z, int P, int C, doub
     return bn_fwd_stats_fused_impl(z, P, C, stats, zmm, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                                    relu, res_absmax, mean, invstd, scale, shift, blockbound, workspace, workspace_bytes, stream,
                                    peer, absmax_out);
+}
+
+// the finish half alone, on partial sums that the convolution's epilogue left in `partials` (semseg_conv2d_fwd_stats_h2: `parts`
+// rows); `peer` / `absmax_out` optional as in the entry points above
+extern "C" int semseg_bn_fwd_finish_fused(const void* partials, size_t partials_bytes, int parts, int P, int C, double* stats,
+                                          float* zmm, const float* gamma, const float* beta, float* running_mean,
+                                          float* running_var, int64_t* num_batches_tracked, float momentum, float eps, int relu,
+                                          const float* res_absmax, float* mean, float* invstd, float* scale, float* shift,
+                                          void* blockbound, void* stream, void* peer, float* absmax_out) {
+    if (parts <= 0 || !partials) return SEMSEG_EINVAL;
+    return bn_fwd_stats_fused_impl(nullptr, P, C, stats, zmm, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
+                                   eps, relu, res_absmax, mean, invstd, scale, shift, blockbound, const_cast<void*>(partials),
+                                   partials_bytes, stream, peer, absmax_out, parts);
 }
 
 // PEER: as bn_fwd_finish_fused_kernel -- [sum g, sum g xhat] summed over the ranks inside the kernel; dgamma / dbeta stay the

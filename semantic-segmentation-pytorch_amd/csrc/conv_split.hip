@@ -351,6 +351,13 @@ struct SParams {
     int batches;                                       // 0 / 1: plain; > 1: gridDim.z batches (splits must be 1)
     int batch_in_rows, batch_w_rows, batch_out_rows;   // batched GEMM (blockIdx.z = batch): row offsets per batch of the
                                                        // activation planes, of the weight planes (in units of T rows) and of `out`
+    // BN statistics of the result gathered in the epilogue (forward convs that a BatchNorm follows, splits == 1 only): every
+    // WAVE writes the column sums / sums of squares (fp64) and column minima / maxima (fp32) of its WM x WN sub-tile as partial
+    // row  (first row of the sub-tile) / WM  of  st_sum[parts][2 Cout] / st_mm[parts][2 Cout] -- the layout the BN finish kernels
+    // reduce (csrc/bn.hip), so the separate statistics sweep over the result (one launch, one read of it) is not needed
+    double* st_sum;
+    float* st_mm;
+    float* st_zero;          // the |y| bound word the finish kernel max-reduces into with atomics: zeroed here
 };
 
 // (chunk, tap) walk of the k loop, shared by both GEMM kernels.  Default order: channel chunk major, taps inner -- the T
@@ -417,11 +424,15 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
     descale_factors<SCH>(p.in_exp, p.w_exp, f1, f2);
     const int col_l = lane & 31;
     const int row_l = 4 * (lane >> 5);
+    const bool stats = direct && p.st_sum != nullptr;            // uniform
+    if (stats && p.st_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.st_zero[0] = 0.f;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int col = col0 + j * 32 + col_l;
-        if (col >= p.Cout) continue;
+        if (col >= p.Cout) continue;       // lane ^ 32 holds the same column: both halves of a column take the same branch
         const float bvl = (direct && p.bias) ? p.bias[col] : 0.f;
+        double su = 0.0, sq = 0.0;
+        float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -432,7 +443,26 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
                 if (row < p.M) {
                     v += bvl;
                     dst[(size_t)row * dst_ld + col] = v;
+                    if (stats) {               // of the value as stored: what the BN that follows normalises
+                        const double d = (double)v;
+                        su += d;
+                        sq = fma(d, d, sq);
+                        mn = fminf(mn, v);
+                        mx = fmaxf(mx, v);
+                    }
                 }
+            }
+        }
+        if (stats) {
+            // the other 16 rows of every 32-row fragment live in lane ^ 32; fixed order (low half + high half): deterministic
+            const double su2 = __shfl_xor(su, 32), sq2 = __shfl_xor(sq, 32);
+            const float mn2 = __shfl_xor(mn, 32), mx2 = __shfl_xor(mx, 32);
+            if (lane < 32) {
+                const size_t at = (size_t)(row0 / (FM * 32)) * 2 * p.Cout + col;
+                p.st_sum[at] = su + su2;
+                p.st_sum[at + p.Cout] = sq + sq2;
+                p.st_mm[at] = fminf(mn, mn2);
+                p.st_mm[at + p.Cout] = fmaxf(mx, mx2);
             }
         }
     }
@@ -1002,6 +1032,17 @@ static const int kTiles[19][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {
                                    {256, 128}, {256, 256}, {128, 128}, {256, 128}, {256, 256}, {256, 128}, {256, 128},
                                    {256, 256}, {64, 64}, {128, 64}, {64, 64}, {128, 128}};
 
+// rows of the wave sub-tile (BM / waves along M) per tile id: the epilogue statistics write one partial row per wave row
+static const int kWaveM[19] = {64, 64, 32, 64, 64, 128, 32, 64, 128, 32, 64, 128, 128, 128, 64, 32, 64, 32, 64};
+constexpr int kMaxEpilogueParts = 512;      // beyond that (the 256 x 256 maps of the stem) the separate statistics sweep is cheaper to finish
+
+struct EpilogueStats {      // optional request of run_gemm's caller
+    void* buf;              // room for parts x 2 Cout x (double + float)
+    size_t bytes;
+    float* zero_word;
+    int parts;              // out: partial rows written; 0 = not gathered (split-K plan, too many parts, buffer too small)
+};
+
 // Launch plan: same wave-quantisation model as plan_igemm (conv_igemm.hip) -- tile x split-K candidates, cost =
 // waves * (k-tiles per block * tile cost + fixed) + split-K slab traffic.  The LDS-DMA tiles (3..5) are chosen by the
 // tuner / overrides only.  Tuning overrides for tools/conv_bench.py: SEMSEG_S3_TILE=0..5, SEMSEG_S3_SPLITK=n
@@ -1080,7 +1121,7 @@ static int launch_dma(const SParams& p, hipStream_t st) {
 
 template <class SCH>
 static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* workspace, size_t workspace_bytes,
-                    hipStream_t st) {
+                    hipStream_t st, EpilogueStats* es = nullptr) {
     const size_t in_plane = in_rows * p.pitch, w_plane = (size_t)p.Cout * p.T * p.pitch;
     if (2 * SCH::NP * in_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
         2 * SCH::NP * w_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31))
@@ -1099,6 +1140,18 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
         const size_t need = (size_t)pl.splits * p.M * p.Cout * sizeof(float);
         if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
         p.partial = (float*)workspace;
+    }
+    p.st_sum = nullptr; p.st_mm = nullptr; p.st_zero = nullptr;
+    if (es) {
+        es->parts = 0;
+        const int parts = pl.tiles_m * (pl.BM / kWaveM[pl.tile]);
+        const size_t need = (size_t)parts * 2 * p.Cout * (sizeof(double) + sizeof(float));
+        if (pl.splits == 1 && p.batches <= 1 && parts <= kMaxEpilogueParts && es->buf && es->bytes >= need && aligned16(es->buf)) {
+            p.st_sum = (double*)es->buf;
+            p.st_mm = reinterpret_cast<float*>(p.st_sum + (size_t)parts * 2 * p.Cout);
+            p.st_zero = es->zero_word;
+            es->parts = parts;
+        }
     }
     int rc = SEMSEG_EINVAL;
     switch (pl.tile) {
@@ -1184,7 +1237,7 @@ static inline int out_dim(int in, int k, int stride, int pad, int dil) {
 template <class SCH>
 static int conv_fwd(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+                    void* workspace, size_t workspace_bytes, void* stream, EpilogueStats* es = nullptr) {
     if (!xs || !ws || !y || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0 || y_ld < K) return SEMSEG_EINVAL;
     if (!aligned16(xs) || !aligned16(ws)) return SEMSEG_EINVAL;
     const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
@@ -1203,7 +1256,7 @@ static int conv_fwd(const void* xs, const void* ws, const float* bias, float* y,
     }
     int ov_tile = -1, ov_split = 0;
     lookup_plan(SCH::ID, 0, N, H, W, C, K, R, S, stride, pad, dil, &ov_tile, &ov_split);
-    return run_gemm<SCH>(p, (size_t)N * H * W, ov_tile, ov_split, workspace, workspace_bytes, (hipStream_t)stream);
+    return run_gemm<SCH>(p, (size_t)N * H * W, ov_tile, ov_split, workspace, workspace_bytes, (hipStream_t)stream, es);
 }
 
 template <class SCH>
@@ -1240,6 +1293,23 @@ extern "C" int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float*
                                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     return conv_fwd<SchH2>(xs, ws, bias, y, y_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
+}
+// forward conv + the BN statistics of its result gathered in the GEMM epilogue (EpilogueStats): *parts_out = number of partial
+// rows written to stats_ws (layout of semseg_bn_fwd_finish_fused), 0 = the launch plan of this geometry does not allow it
+// (split-K, or more than kMaxEpilogueParts wave rows) and the caller runs the separate statistics sweep instead
+extern "C" size_t semseg_conv2d_fwd_stats_bytes(int K) {
+    return (size_t)kMaxEpilogueParts * 2 * (K > 0 ? K : 0) * (sizeof(double) + sizeof(float));
+}
+extern "C" int semseg_conv2d_fwd_stats_h2(const void* xs, const void* ws, float* y, int y_ld,
+                                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                          void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
+                                          float* bound_word, int* parts_out, void* stream) {
+    if (!parts_out) return SEMSEG_EINVAL;
+    EpilogueStats es = {stats_ws, stats_ws_bytes, bound_word, 0};
+    const int rc = conv_fwd<SchH2>(xs, ws, nullptr, y, y_ld, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes,
+                                   stream, &es);
+    *parts_out = rc ? 0 : es.parts;
+    return rc;
 }
 extern "C" int semseg_conv2d_dgrad_s3(const void* dys, const void* wts, float* dx, int dx_ld,
                                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

@@ -45,6 +45,8 @@ SIGNATURES = {
     'semseg_absmax': (c_int, [vp, c_int, c_int, c_int, vp, vp, c_sz, vp]),
     'semseg_conv2d_h2_workspace_bytes': (c_sz, [c_int] * 10),
     'semseg_conv2d_fwd_h2': (c_int, [vp, vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
+    'semseg_conv2d_fwd_stats_bytes': (c_sz, [c_int]),
+    'semseg_conv2d_fwd_stats_h2': (c_int, [vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp, c_sz, vp, ctypes.POINTER(c_int), vp]),
     'semseg_conv2d_dgrad_h2': (c_int, [vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
     'semseg_conv2d_wgrad_h2': (c_int, [vp, vp, vp] + [c_int] * 10 + [vp, c_sz, vp]),
     'semseg_conv2d_h2_set_plan': (c_int, [c_int] * 13),
@@ -75,6 +77,8 @@ SIGNATURES = {
                                                vp, vp, c_sz, vp] + [vp, vp]),
     'semseg_bn_fwd_stats_fused_bound': (c_int, [vp, c_int, c_int, vp, vp, vp, vp, vp, vp, vp, c_f, c_f, c_int, vp, vp, vp, vp, vp,
                                                 vp, vp, c_sz, vp] + [vp]),
+    'semseg_bn_fwd_finish_fused': (c_int, [vp, c_sz, c_int, c_int, c_int, vp, vp, vp, vp, vp, vp, vp, c_f, c_f, c_int, vp, vp, vp, vp, vp,
+                                          vp, vp, vp, vp]),
     'semseg_bn_bwd_reduce_fused_peer': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, c_int,
                                            vp, vp, vp, vp, vp, c_sz, vp] + [vp]),
     'semseg_weights_prepare_h2': (c_int, [ctypes.POINTER(WPrepTensor), c_int, vp]),

@@ -377,6 +377,9 @@ def absmax_of(t):
 # SEMSEG_WINOGRAD=0 disables.
 WINOGRAD = os.environ.get('SEMSEG_WINOGRAD', '1') != '0'
 WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '1024'))
+# the BN statistics of a conv -> BN pair gathered in the conv's GEMM epilogue instead of by a sweep over its output (ConvBNActFn);
+# SEMSEG_EPILOGUE_STATS=0: the separate statistics kernel (A/B switch, tests/test_gpu_models.py SWITCH_CASES)
+EPILOGUE_STATS = os.environ.get('SEMSEG_EPILOGUE_STATS', '1') != '0'
 # the weight gradient of the same layers in the Winograd domain (dU[f] = dM[f]^T V[f], V kept from the forward pass):
 # in-box A/B (gpurun wg1) 16.50 -> 16.02 ms per step.  SEMSEG_WINOGRAD_WGRAD=0 disables.
 WINOGRAD_WGRAD = os.environ.get('SEMSEG_WINOGRAD_WGRAD', '1') != '0'
@@ -870,43 +873,67 @@ class ConvBNActFn(Function):
             wino_v = _winograd_fwd(L, x.detach(), box['x_bounds'], wino, z, geom)
             if not (WINOGRAD_WGRAD and ctx.needs_input_grad[1]):
                 wino_v = None
-        else:
-            wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
-
-            def launch():
-                ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
-                _native.check(sch.fn(L, 'fwd')(_p(xp), _p(wsp), _p(None), _p(z), k, *geom, _p(ws), ws.numel(), _st()),
-                              'conv2d_fwd_h2')
-            tuner.ensure('h2', 0, geom, launch)
-            launch()
-        stats = torch.empty((2 * k + 1,), device=dev, dtype=torch.float64)
-        zmm = torch.empty((2 * k,), device=dev, dtype=torch.float32)
-        ws = workspace(L.semseg_bn_mm_workspace_bytes(P, k), dev)
-        coef = torch.empty((4, k), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
         res, res_ld = (None, 0)
         if residual is not None:
             res, res_ld = as_nhwc(residual.detach())
         bound_ok = residual is None or res_absmax is not None
         absmax = torch.empty((1,), device=dev, dtype=torch.float32) if bound_ok else None
         yp = torch.empty(L.semseg_split_h2_bytes(P, k), dtype=torch.uint8, device=dev) if (emit and bound_ok) else None
-        y = empty_nhwc(n, k, oh, ow, dev)
-        gate = None
         sync = _sync_active()
         peer = _sync_peer(2 * k + 1) if sync else None
-        if (not sync or peer is not None) and (yp is not None or absmax is not None):
+        fused_stats = (not sync or peer is not None) and (yp is not None or absmax is not None)
+        bound = None if yp is not None else absmax            # no planes: the bound of |y| comes from the finish kernel itself
+        parts = ctypes.c_int(0)
+        stats_ws = None
+        if wino is None:
+            wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
+            if fused_stats and EPILOGUE_STATS:
+                # the BN statistics of z are gathered in the GEMM epilogue (one partial row per wave row; csrc/conv_split.hip
+                # gemm_epilogue) when the launch plan of this geometry does not split the reduction: no sweep over z for them
+                conv_bytes = (sch.fn(L, 'workspace_bytes')(*geom) + 255) & ~255
+                stats_bytes = L.semseg_conv2d_fwd_stats_bytes(k)
+
+                def launch():
+                    ws = workspace(conv_bytes + stats_bytes, dev)
+                    base = ws.data_ptr()
+                    _native.check(L.semseg_conv2d_fwd_stats_h2(_p(xp), _p(wsp), _p(z), k, *geom, vp(base), conv_bytes,
+                                                               vp(base + conv_bytes), stats_bytes, _p(bound), ctypes.byref(parts),
+                                                               _st()), 'conv2d_fwd_stats_h2')
+                    return ws
+                tuner.ensure('h2', 0, geom, launch)
+                stats_ws = launch()
+            else:
+                def launch():
+                    ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
+                    _native.check(sch.fn(L, 'fwd')(_p(xp), _p(wsp), _p(None), _p(z), k, *geom, _p(ws), ws.numel(), _st()),
+                                  'conv2d_fwd_h2')
+                tuner.ensure('h2', 0, geom, launch)
+                launch()
+        stats = torch.empty((2 * k + 1,), device=dev, dtype=torch.float64)
+        zmm = torch.empty((2 * k,), device=dev, dtype=torch.float32)
+        ws = workspace(L.semseg_bn_mm_workspace_bytes(P, k), dev)
+        coef = torch.empty((4, k), device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
+        y = empty_nhwc(n, k, oh, ow, dev)
+        gate = None
+        if fused_stats:
             # one rank: finish + finalize in one kernel; the apply kernel derives the exponent from the per-block bounds.
             # SyncBN over the peer exchange: the same kernel exchanges its sums with the other ranks on the way (csrc/peer_dev.h)
             bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
-            args = (_p(z), P, k, _p(stats), _p(zmm), _p(g), _p(b), _p(running_mean), _p(running_var), _p(nbt), float(momentum),
-                    float(eps), int(relu), _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(bb), _p(ws),
-                    ws.numel(), _st())
-            bound = None if yp is not None else _p(absmax)       # no planes: the bound of |y| comes from the finish kernel itself
-            if peer is not None:
-                _native.check(L.semseg_bn_fwd_stats_fused_peer(*args, peer, bound), 'bn_fwd_stats_fused_peer')
-            elif bound is not None:
-                _native.check(L.semseg_bn_fwd_stats_fused_bound(*args, bound), 'bn_fwd_stats_fused_bound')
+            tail = (_p(g), _p(b), _p(running_mean), _p(running_var), _p(nbt), float(momentum), float(eps), int(relu),
+                    _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(bb))
+            if parts.value > 0:
+                off = (sch.fn(L, 'workspace_bytes')(*geom) + 255) & ~255
+                _native.check(L.semseg_bn_fwd_finish_fused(vp(stats_ws.data_ptr() + off), stats_ws.numel() - off, parts.value, P, k,
+                                                           _p(stats), _p(zmm), *tail, _st(), peer, _p(bound)),
+                              'bn_fwd_finish_fused')
             else:
-                _native.check(L.semseg_bn_fwd_stats_fused(*args), 'bn_fwd_stats_fused')
+                args = (_p(z), P, k, _p(stats), _p(zmm)) + tail + (_p(ws), ws.numel(), _st())
+                if peer is not None:
+                    _native.check(L.semseg_bn_fwd_stats_fused_peer(*args, peer, _p(bound)), 'bn_fwd_stats_fused_peer')
+                elif bound is not None:
+                    _native.check(L.semseg_bn_fwd_stats_fused_bound(*args, _p(bound)), 'bn_fwd_stats_fused_bound')
+                else:
+                    _native.check(L.semseg_bn_fwd_stats_fused(*args), 'bn_fwd_stats_fused')
             if yp is not None and relu and residual is not None:
                 # backward's gate of a BN with residual is (y > 0): leave it as 1 bit per element instead of reading y twice
                 gate = torch.empty((P * (k // 8),), device=dev, dtype=torch.uint8)

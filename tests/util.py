@@ -116,9 +116,11 @@ def scale_error(got, rec):
 # inside one band.  So: the typical tensor must be inside the band itself, 95 % within 4 bands, none beyond ANCHOR_MAX.
 # The control (tools/probes/anchor_control.py: the same measurement on the default h2 path and on the exact-fp32 MFMA kernels,
 # profiles/r4_anchor_control_h2_vs_f32.txt) shows the two paths in the same range -- the 2^-22 products of h2 are not what
-# decides these ratios -- and, with the case-wide relative band as the lower limit (anchor_ratio), a worst tensor of <= 6 on
-# either path; ANCHOR_MAX leaves a factor over that for launch plans not seen yet.
-ANCHOR_MEDIAN, ANCHOR_P95, ANCHOR_MAX = 1.0, 4.0, 16.0
+# decides these ratios (h2: medians 0.00-0.71, p95 <= 1.39, worst tensor 7.1 over 14 case x kind rows; exact fp32: medians up to
+# 3.7, worst 326 on HRNetV2, whose plain BN kernels sum fp32 strips) -- the limits below were 1 / 4 / 16 before the control and
+# the case-wide lower limit of the band (anchor_ratio); they leave a factor of ~1.7 over the worst h2 value for launch plans
+# not seen yet.
+ANCHOR_MEDIAN, ANCHOR_P95, ANCHOR_MAX = 1.0, 3.0, 12.0
 # tensors with no ReLU gate between them and the loss (is_head_tensor): elementwise, relative to the tensor's scale
 HEAD_SCALE_ERR = 1e-4
 
