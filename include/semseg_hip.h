@@ -101,6 +101,8 @@ int semseg_conv2d_s3_set_plan(int pass, int N, int H, int W, int C, int K, int R
  * (per-product error ~2^-21: below the fp32 accumulation noise of any reduction >= 27 terms; csrc/conv_split.hip).
  * Split layout: fp16 [2][rows][pitch] (pitch as for s3) + 256 B of zeros + a 4352-byte header (int32 e, partial maxima);
  * size = semseg_split_h2_bytes; 16-byte aligned.
+ * semseg_conv2d_h2_set_plan pass 3 pins the tile (0, 6..10 or 14; split 1) of the batched Winograd forward GEMM, keyed
+ * (N = tiles, H = W = 1, C, K, 3, 3, 1, 1, 1).
  * Tile ids for semseg_conv2d_h2_set_plan -- fwd/dgrad (pass 0/1): 0..3 as s3, 4 = 256x128 LDS-DMA 3-slot ring, 5 = 256x256
  * LDS-DMA, 6 = 128x128 LDS-DMA (two blocks per CU), 7/8/9 = 3/5/6 with software-pipelined fragment reads (one barrier
  * per k-tile), 10 = the ring 4 with the same pipeline; wgrad (pass 2): 0 = 128x128, 1 = 64x64 register staged, 2 = 128x128,
@@ -195,6 +197,9 @@ size_t semseg_bn_mm_workspace_bytes(int P, int C);
 /* semseg_bn_stats + zmm[0..C) = min_p z[p,c], zmm[C..2C) = max_p z[p,c] (fp32; local to this rank) */
 int semseg_bn_stats_mm(const float* z, int P, int C, double* stats, float* zmm, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* the sweep half of semseg_bn_stats_mm alone (partial sums into `workspace`, semseg_bn_mm_workspace_bytes; no other output):
+ * the cost a split-K launch plan adds to a conv -> BN pair, timed by the launch-plan tuner */
+int semseg_bn_stats_mm_partial(const float* z, int P, int C, void* workspace, size_t workspace_bytes, void* stream);
 /* semseg_bn_finalize + absmax_out[0] = an upper bound of max |act(BN(z) + residual)| given |residual| <= res_absmax[0]
  * (device scalars; res_absmax NULL = no residual; absmax_out may be NULL) and, if y_planes != NULL, the exponent word
  * of that h2 split buffer (P rows x C channels) derived from the bound. */

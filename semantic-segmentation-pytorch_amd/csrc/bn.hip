@@ -549,6 +549,23 @@ extern "C" int semseg_bn_stats_mm(const float* z, int P, int C, double* stats, f
     return 0;
 }
 
+// the sweep half of semseg_bn_stats_mm / semseg_bn_fwd_stats_fused alone: partial sums into `workspace`, nothing else touched.
+// What a launch plan that splits the conv's reduction costs on top of the conv (the epilogue cannot gather statistics from
+// split-K slabs): mit_semseg.tuner times conv + this for such candidates against conv-with-epilogue-statistics for the others.
+extern "C" int semseg_bn_stats_mm_partial(const float* z, int P, int C, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!z || P <= 0 || C <= 0 || (C % 4) || !aligned16(z)) return SEMSEG_EINVAL;
+    const ColGeom g = col_geom(P, C);
+    const size_t need = (size_t)g.gy * 2 * C * (sizeof(double) + sizeof(float));
+    if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
+    double* partial = (double*)workspace;
+    float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
+    const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
+    hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, (hipStream_t)stream, z, P, C, g.cx, g.py,
+                       g.rows_per_block, partial, mm, (float*)nullptr);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 // bn_finalize_kernel + the bound of |y| and the exponent of y's h2 planes.  One block (C <= a few thousand).
 //   y = act(fmaf(z, scale, shift) (+ res)): fmaf and the fp32 add are monotone, so per channel the extremes of the BN
 //   part are attained at zmin / zmax EXACTLY as bn_apply computes them, and |res| <= res_absmax.

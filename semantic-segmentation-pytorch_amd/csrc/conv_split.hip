@@ -105,7 +105,11 @@ static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
-    if (pass < 0 || pass > 2 || tile > max_tile(sch, pass) || split > 64) return SEMSEG_EINVAL;
+    // pass 3: the batched GEMM of the Winograd forward (semseg_winograd_gemm_h2), keyed (tiles, 1, 1, C, K, 3, 3, 1, 1, 1); no split
+    if (pass < 0 || pass > 3 || tile > max_tile(sch, pass == 3 ? 0 : pass) || split > 64) return SEMSEG_EINVAL;
+    if (pass == 3 && tile >= 0 && (sch != SchH2::ID || split != 1 || !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 ||
+                                                                       tile == 10 || tile == 14)))
+        return SEMSEG_EINVAL;
     std::lock_guard<std::mutex> lk(g_plans_mu);
     const SKey key{sch, pass, N, H, W, C, K, R, S, stride, pad, dil};
     if (tile < 0 || split < 1) g_plans.erase(key);
@@ -1348,8 +1352,9 @@ extern "C" int semseg_winograd_gemm_h2(const void* v_planes, const void* u_plane
     p.splits = 1;
     p.partial = nullptr;
     p.batches = 16; p.batch_in_rows = tiles; p.batch_w_rows = K; p.batch_out_rows = tiles;
-    static const int force = env_int("SEMSEG_WINO_TILE", -1);
-    const int tile = force >= 0 ? force : ((tiles >= 1024 && K >= 256) ? 8 : 9);
+    int ov_tile = -1, ov_split = 0;
+    lookup_plan(SchH2::ID, 3, tiles, 1, 1, C, K, 3, 3, 1, 1, 1, &ov_tile, &ov_split);
+    const int tile = ov_tile >= 0 ? ov_tile : ((tiles >= 1024 && K >= 256) ? 8 : 9);
     const int BM = kTiles[tile][0], BN = kTiles[tile][1];
     p.tiles_m = ceil_div(tiles, BM);
     p.tiles_n = ceil_div(K, BN);

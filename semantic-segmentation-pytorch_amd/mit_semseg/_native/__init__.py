@@ -60,6 +60,7 @@ SIGNATURES = {
     'semseg_bn_bwd_apply': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int, vp]),
     'semseg_bn_mm_workspace_bytes': (c_sz, [c_int, c_int]),
     'semseg_bn_stats_mm': (c_int, [vp, c_int, c_int, vp, vp, vp, c_sz, vp]),
+    'semseg_bn_stats_mm_partial': (c_int, [vp, c_int, c_int, vp, c_sz, vp]),
     'semseg_bn_finalize_mm': (c_int, [vp, vp, c_int, vp, vp, vp, vp, vp, c_f, c_f, c_int, vp, vp, vp, vp, vp, vp, vp,
                                       c_int, vp]),
     'semseg_bn_apply_h2': (c_int, [vp, vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int, vp, vp, vp]),

@@ -890,16 +890,22 @@ class ConvBNActFn(Function):
             if fused_stats and EPILOGUE_STATS:
                 # the BN statistics of z are gathered in the GEMM epilogue (one partial row per wave row; csrc/conv_split.hip
                 # gemm_epilogue) when the launch plan of this geometry does not split the reduction: no sweep over z for them
-                conv_bytes = (sch.fn(L, 'workspace_bytes')(*geom) + 255) & ~255
                 stats_bytes = L.semseg_conv2d_fwd_stats_bytes(k)
 
                 def launch():
+                    # the split-K need follows the plan in force (the tuner pins one candidate after the other around this call):
+                    # sized per launch, and the partials' place is remembered from the launch that counts -- the last one
+                    conv_bytes = (sch.fn(L, 'workspace_bytes')(*geom) + 255) & ~255
                     ws = workspace(conv_bytes + stats_bytes, dev)
                     base = ws.data_ptr()
                     _native.check(L.semseg_conv2d_fwd_stats_h2(_p(xp), _p(wsp), _p(z), k, *geom, vp(base), conv_bytes,
                                                                vp(base + conv_bytes), stats_bytes, _p(bound), ctypes.byref(parts),
                                                                _st()), 'conv2d_fwd_stats_h2')
-                    return ws
+                    if parts.value == 0 and tuner.timing():
+                        # a candidate that splits the reduction pays the statistics sweep on top: part of what the tuner compares
+                        _native.check(L.semseg_bn_stats_mm_partial(_p(z), P, k, vp(base + conv_bytes), stats_bytes, _st()),
+                                      'bn_stats_mm_partial')
+                    return base + conv_bytes
                 tuner.ensure('h2', 0, geom, launch)
                 stats_ws = launch()
             else:
@@ -922,8 +928,7 @@ class ConvBNActFn(Function):
             tail = (_p(g), _p(b), _p(running_mean), _p(running_var), _p(nbt), float(momentum), float(eps), int(relu),
                     _p(res_absmax), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(bb))
             if parts.value > 0:
-                off = (sch.fn(L, 'workspace_bytes')(*geom) + 255) & ~255
-                _native.check(L.semseg_bn_fwd_finish_fused(vp(stats_ws.data_ptr() + off), stats_ws.numel() - off, parts.value, P, k,
+                _native.check(L.semseg_bn_fwd_finish_fused(vp(stats_ws), L.semseg_conv2d_fwd_stats_bytes(k), parts.value, P, k,
                                                            _p(stats), _p(zmm), *tail, _st(), peer, _p(bound)),
                               'bn_fwd_finish_fused')
             else:

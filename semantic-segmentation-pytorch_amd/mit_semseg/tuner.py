@@ -106,6 +106,15 @@ def tuned_plans():
     return dict(_done)
 
 
+_TIMING = [False]
+
+
+def timing():
+    """True while ensure() is timing candidates: a launch closure may then add the follow-up work that only SOME plans need
+    (ops.ConvBNActFn: the statistics sweep of a split-K plan) so that the candidates are compared on what they really cost"""
+    return _TIMING[0]
+
+
 def ensure(scheme, pass_id, geom, launch):
     """scheme = 'h2' | 's3'; geom = (N,H,W,C,K,R,S,stride,pad,dil); launch() issues the conv of this pass on the
     current stream."""
@@ -142,6 +151,7 @@ def ensure(scheme, pass_id, geom, launch):
     stats['timed'] += 1
     best = None
     ranked = []                                     # (ms, tile, split) of every candidate that ran
+    _TIMING[0] = True
     try:
         launch()                                    # heuristic plan first (also warms caches / sizes the workspace)
         base = _time(launch, 2)
@@ -180,6 +190,7 @@ def ensure(scheme, pass_id, geom, launch):
             ms, tile, split = min(finals)
             best = (tile, split, ms)
     finally:
+        _TIMING[0] = False
         if best is None or best[0] < 0:
             set_plan(pass_id, *geom, -1, 0)
         else:

@@ -270,6 +270,12 @@ CASES = [
          n=1, h=72, w=104, seg_rate=8, training=False, deep_sup_scale=0.4),
     dict(name='hrnetv2_c1_64_train', arch_enc='hrnetv2', arch_dec='c1', fc_dim=720,
          n=2, h=64, w=64, seg_rate=4, training=True, deep_sup_scale=None, step=True),
+    # the same step at 128 x 128: at 64 x 64 the coarsest HRNet branch is a 2 x 2 map -- its BNs normalise over 8 values -- and
+    # the gradients of that case sit on a knife edge (profiles/r4_anchor_control_h2_vs_f32.txt: the exact-fp32 kernels land 4
+    # bands from the anchor in the MEDIAN tensor, the h2 kernels 0.00 or 4 bands depending on the launch plans of the run);
+    # the gradient / post-step acceptance of HRNetV2 is therefore taken on this case (32 values per channel at the coarsest level)
+    dict(name='hrnetv2_c1_128_train', arch_enc='hrnetv2', arch_dec='c1', fc_dim=720,
+         n=2, h=128, w=128, seg_rate=4, training=True, deep_sup_scale=None, step=True, seed=6),
     dict(name='r18d_ppm_infer_64x80', arch_enc='resnet18dilated', arch_dec='ppm', fc_dim=512,
          n=1, h=64, w=80, seg_rate=8, training=False, deep_sup_scale=None, seg_size=[35, 45]),
     dict(name='r50_upernet_infer_64', arch_enc='resnet50', arch_dec='upernet', fc_dim=2048,

@@ -697,6 +697,80 @@ def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
     assert rel_err(got, ref) < (REL * 4 if pass_id == 2 else REL), (pass_id, tile, split, rel_err(got, ref))
 
 
+@pytest.mark.parametrize('case', PLAN_CASES + [(2, 64, 40, 40, 64, 3, 1, 1, 1), (2, 1024, 8, 8, 48, 1, 1, 0, 1)], ids=str)
+@pytest.mark.parametrize('tile', list(range(19)))
+def test_conv_epilogue_statistics_match_the_sweep(case, tile):
+    """semseg_conv2d_fwd_stats_h2 (BN statistics of the conv result gathered per wave row in the GEMM epilogue) +
+    semseg_bn_fwd_finish_fused against the statistics sweep over the same result (semseg_bn_fwd_stats_fused), for EVERY tile
+    form of the forward kernels under a pinned plan: same z (the conv itself is unchanged), bit-identical min / max, fp64 sums
+    equal up to their summation order, identical BN coefficients up to one rounding of the mean; a split-K plan reports 0
+    partial rows and gathers nothing."""
+    import ctypes
+    from mit_semseg import ops, _native
+    L = _native.lib()
+    vp = ctypes.c_void_p
+    P_ = lambda t: vp(t.data_ptr())              # noqa: E731
+    n, c, h, w, k, ks, stride, pad, dil = case
+    geom = (n, h, w, c, k, ks, ks, stride, pad, dil)
+    oh, ow = ops.conv_out_size(h, ks, stride, pad, dil), ops.conv_out_size(w, ks, stride, pad, dil)
+    M = n * oh * ow
+    g = torch.Generator().manual_seed(tile + 31 * k)
+    x = (torch.randn(n, h, w, c, generator=g) * 1.7 + 0.3).to(dev())
+    wt = (torch.randn(k, ks, ks, c, generator=g) / (c * ks * ks) ** 0.5).to(dev())
+    xp = ops.SCHEMES['h2'].split(x, n * h * w, c, c)
+    wp = ops.SCHEMES['h2'].split(wt, k * ks * ks, c, c)
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    gamma, beta = (torch.rand(k, generator=g) + 0.5).to(dev()), torch.randn(k, generator=g).to(dev())
+
+    def outputs():
+        return dict(stats=torch.zeros(2 * k + 1, dtype=torch.float64, device=dev()), zmm=torch.zeros(2 * k, device=dev()),
+                    rm=torch.zeros(k, device=dev()), rv=torch.ones(k, device=dev()), nbt=torch.zeros((), dtype=torch.int64, device=dev()),
+                    coef=torch.zeros(4, k, device=dev()), bb=torch.zeros((k + 15) // 16, dtype=torch.int32, device=dev()),
+                    bound=torch.full((1,), 123.0, device=dev()))
+
+    def tail(o):
+        return (P_(gamma), P_(beta), P_(o['rm']), P_(o['rv']), P_(o['nbt']), 0.1, 1e-5, 1, vp(0), P_(o['coef'][0]), P_(o['coef'][1]),
+                P_(o['coef'][2]), P_(o['coef'][3]), P_(o['bb']))
+    for split in (1, 2):
+        _native.check(L.semseg_conv2d_h2_set_plan(0, *geom, tile, split), 'set_plan')
+        try:
+            conv_ws = torch.empty(max(256, L.semseg_conv2d_h2_workspace_bytes(*geom)), dtype=torch.uint8, device=dev())
+            stats_ws = torch.empty(L.semseg_conv2d_fwd_stats_bytes(k), dtype=torch.uint8, device=dev())
+            z = torch.empty(M, k, device=dev())
+            a, b = outputs(), outputs()
+            parts = ctypes.c_int(-1)
+            _native.check(L.semseg_conv2d_fwd_stats_h2(P_(xp), P_(wp), P_(z), k, *geom, P_(conv_ws), conv_ws.numel(), P_(stats_ws),
+                                                       stats_ws.numel(), P_(a['bound']), ctypes.byref(parts), st), 'conv_stats')
+            z2 = torch.empty(M, k, device=dev())
+            _native.check(L.semseg_conv2d_fwd_h2(P_(xp), P_(wp), vp(0), P_(z2), k, *geom, P_(conv_ws), conv_ws.numel(), st), 'conv')
+            torch.cuda.synchronize()
+            assert torch.equal(z, z2)
+            bn_ws = torch.empty(L.semseg_bn_mm_workspace_bytes(M, k), dtype=torch.uint8, device=dev())
+            _native.check(L.semseg_bn_fwd_stats_fused_bound(P_(z), M, k, P_(b['stats']), P_(b['zmm']), *tail(b), P_(bn_ws),
+                                                            bn_ws.numel(), st, P_(b['bound'])), 'sweep')
+            torch.cuda.synchronize()
+            if split > 1 and L.semseg_conv2d_h2_workspace_bytes(*geom) > 0:
+                assert parts.value == 0                # split-K slabs: nothing gathered, the caller sweeps
+                continue
+            if parts.value == 0:
+                continue                               # more wave rows than the epilogue form serves
+            assert float(a['bound'].item()) == 0.0     # the epilogue zeroed the bound word for the finish kernel's atomics
+            _native.check(L.semseg_bn_fwd_finish_fused(P_(stats_ws), stats_ws.numel(), parts.value, M, k, P_(a['stats']), P_(a['zmm']),
+                                                       *tail(a), st, vp(0), P_(a['bound'])), 'finish')
+            torch.cuda.synchronize()
+            assert torch.equal(a['zmm'], b['zmm'])
+            ref = b['stats'].cpu()
+            assert float(a['stats'][2 * k].item()) == float(M)
+            err = (a['stats'].cpu() - ref).abs() / ref.abs().clamp_min(1e-300)
+            assert err[:2 * k].max().item() < 1e-12, err.max().item()
+            torch.testing.assert_close(a['coef'], b['coef'], rtol=2e-6, atol=1e-7)
+            torch.testing.assert_close(a['rv'], b['rv'], rtol=1e-6, atol=1e-8)
+            assert abs(float(a['bound'].item()) - float(b['bound'].item())) <= 1e-5 * abs(float(b['bound'].item()))
+            assert int(a['nbt'].item()) == 1
+        finally:
+            L.semseg_conv2d_h2_set_plan(0, *geom, -1, 0)
+
+
 def test_inference_weight_planes_follow_sgd_updates(monkeypatch):
     """no_grad forwards build the weight planes once and keep them; the fused SGD kernel (which updates parameters behind
     torch's version counter) must invalidate them"""

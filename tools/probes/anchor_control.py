@@ -17,7 +17,7 @@ for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-GRAD_CASES = ['r18d_ppmds_64_train', 'r50d_ppmds_64_train', 'r50_upernet_128_train', 'hrnetv2_c1_64_train',
+GRAD_CASES = ['r18d_ppmds_64_train', 'r50d_ppmds_64_train', 'r50_upernet_128_train', 'hrnetv2_c1_64_train', 'hrnetv2_c1_128_train',
               'mnv2d_c1ds_64_train', 'mnv2d_c1ds_192_train', 'r18d_ppmds_64_trainedlike_train']
 
 
