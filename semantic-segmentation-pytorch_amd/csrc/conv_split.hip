@@ -356,9 +356,9 @@ struct SParams {
     int batch_in_rows, batch_w_rows, batch_out_rows;   // batched GEMM (blockIdx.z = batch): row offsets per batch of the
                                                        // activation planes, of the weight planes (in units of T rows) and of `out`
     // BN statistics of the result gathered in the epilogue (forward convs that a BatchNorm follows, splits == 1 only): every
-    // WAVE writes the column sums / sums of squares (fp64) and column minima / maxima (fp32) of its WM x WN sub-tile as partial
-    // row  (first row of the sub-tile) / WM  of  st_sum[parts][2 Cout] / st_mm[parts][2 Cout] -- the layout the BN finish kernels
-    // reduce (csrc/bn.hip), so the separate statistics sweep over the result (one launch, one read of it) is not needed
+    // BLOCK writes the column sums / sums of squares (fp64) and column minima / maxima (fp32) of its BM x BN tile as partial row
+    // tm of  st_sum[tiles_m][2 Cout] / st_mm[tiles_m][2 Cout] -- the layout the BN finish kernels reduce (csrc/bn.hip), so the
+    // separate statistics sweep over the result (one launch, one read of it) is not needed
     double* st_sum;
     float* st_mm;
     float* st_zero;          // the |y| bound word the finish kernel max-reduces into with atomics: zeroed here
@@ -411,9 +411,14 @@ __device__ __forceinline__ void descale_factors(const int* ea, const int* eb, fl
 // all 64 banks exactly once, and a ds_write_b128 lane group (8 lanes = 2 whole rows) covers 128 contiguous bytes.
 __device__ __forceinline__ int s_slot(int row, int q) { return row * 4 + (q ^ ((row >> 2) & 3)); }
 
-// epilogue shared by both GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-template <class SCH, int FM, int FN>
-__device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM][FN], int row0, int col0, int z, int lane) {
+// epilogue shared by both GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+// `tm` = row-tile index of the block, `wm` / `wcol` = the wave's row position in the block (0 .. WGM-1) and first column inside
+// the block tile, `smem` = the block's LDS (the operand tiles are dead by now): when the launch gathers BN statistics
+// (p.st_sum), the WGM waves that share a column range combine their column sums / minima / maxima through LDS in wave order,
+// so that ONE partial row per block row tile reaches memory (tiles_m rows for the BN finish kernel instead of tiles_m x WGM).
+template <class SCH, int FM, int FN, int WGM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM][FN], int row0, int col0, int z, int lane, int tm,
+                                              int wm, int wcol, void* smem) {
     float* dst;
     int dst_ld;
     const bool direct = p.splits == 1;
@@ -428,15 +433,16 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
     descale_factors<SCH>(p.in_exp, p.w_exp, f1, f2);
     const int col_l = lane & 31;
     const int row_l = 4 * (lane >> 5);
-    const bool stats = direct && p.st_sum != nullptr;            // uniform
+    const bool stats = direct && p.st_sum != nullptr;            // uniform over the block
     if (stats && p.st_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.st_zero[0] = 0.f;
+    double su[FN], sq[FN];
+    float mn[FN], mx[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
+        su[j] = 0.0; sq[j] = 0.0; mn[j] = INFINITY; mx[j] = -INFINITY;
         const int col = col0 + j * 32 + col_l;
-        if (col >= p.Cout) continue;       // lane ^ 32 holds the same column: both halves of a column take the same branch
+        if (col >= p.Cout) continue;
         const float bvl = (direct && p.bias) ? p.bias[col] : 0.f;
-        double su = 0.0, sq = 0.0;
-        float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -449,26 +455,63 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
                     dst[(size_t)row * dst_ld + col] = v;
                     if (stats) {               // of the value as stored: what the BN that follows normalises
                         const double d = (double)v;
-                        su += d;
-                        sq = fma(d, d, sq);
-                        mn = fminf(mn, v);
-                        mx = fmaxf(mx, v);
+                        su[j] += d;
+                        sq[j] = fma(d, d, sq[j]);
+                        mn[j] = fminf(mn[j], v);
+                        mx[j] = fmaxf(mx[j], v);
                     }
                 }
             }
         }
-        if (stats) {
-            // the other 16 rows of every 32-row fragment live in lane ^ 32; fixed order (low half + high half): deterministic
-            const double su2 = __shfl_xor(su, 32), sq2 = __shfl_xor(sq, 32);
-            const float mn2 = __shfl_xor(mn, 32), mx2 = __shfl_xor(mx, 32);
-            if (lane < 32) {
-                const size_t at = (size_t)(row0 / (FM * 32)) * 2 * p.Cout + col;
-                p.st_sum[at] = su + su2;
-                p.st_sum[at + p.Cout] = sq + sq2;
-                p.st_mm[at] = fminf(mn, mn2);
-                p.st_mm[at + p.Cout] = fmaxf(mx, mx2);
+    }
+    if (!stats) return;
+    // the other 16 rows of every 32-row fragment live in lane ^ 32; fixed order (low half + high half): deterministic
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        su[j] += __shfl_xor(su[j], 32);
+        sq[j] += __shfl_xor(sq[j], 32);
+        mn[j] = fminf(mn[j], __shfl_xor(mn[j], 32));
+        mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32));
+    }
+    if constexpr (WGM > 1) {
+        double* sd = reinterpret_cast<double*>(smem);                       // [WGM][BN][2]
+        float* sf = reinterpret_cast<float*>(sd + (size_t)WGM * BN * 2);    // [WGM][BN][2]
+        __syncthreads();                       // every wave has left the k loop: the operand tiles in LDS are dead
+        if (lane < 32) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int c = wcol + j * 32 + col_l;
+                sd[((size_t)wm * BN + c) * 2] = su[j];
+                sd[((size_t)wm * BN + c) * 2 + 1] = sq[j];
+                sf[((size_t)wm * BN + c) * 2] = mn[j];
+                sf[((size_t)wm * BN + c) * 2 + 1] = mx[j];
             }
         }
+        __syncthreads();
+        if (wm != 0 || lane >= 32) return;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int c = wcol + j * 32 + col_l;
+#pragma unroll
+            for (int w = 1; w < WGM; ++w) {    // wave order: deterministic
+                su[j] += sd[((size_t)w * BN + c) * 2];
+                sq[j] += sd[((size_t)w * BN + c) * 2 + 1];
+                mn[j] = fminf(mn[j], sf[((size_t)w * BN + c) * 2]);
+                mx[j] = fmaxf(mx[j], sf[((size_t)w * BN + c) * 2 + 1]);
+            }
+        }
+    } else if (lane >= 32) {
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = col0 + j * 32 + col_l;
+        if (col >= p.Cout) continue;
+        const size_t at = (size_t)tm * 2 * p.Cout + col;
+        p.st_sum[at] = su[j];
+        p.st_sum[at + p.Cout] = sq[j];
+        p.st_mm[at] = mn[j];
+        p.st_mm[at + p.Cout] = mx[j];
     }
 }
 
@@ -678,7 +721,7 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
     }
     if (kt_begin < kt_end) compute_tile();
     S_MFMA_DRAIN();
-    gemm_epilogue<SCH, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane);
+    gemm_epilogue<SCH, FM, FN, 2, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, tm, wm, wn * WN, smem4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -978,7 +1021,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
-    gemm_epilogue<SCH, FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane);
+    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, tm, wm, wn * WN, smem);
 }
 
 // out[m*out_ld + n] = bias[n] + sum_z partial[z][m*Cout + n]   (fixed order => deterministic)
@@ -1036,9 +1079,8 @@ static const int kTiles[19][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {
                                    {256, 128}, {256, 256}, {128, 128}, {256, 128}, {256, 256}, {256, 128}, {256, 128},
                                    {256, 256}, {64, 64}, {128, 64}, {64, 64}, {128, 128}};
 
-// rows of the wave sub-tile (BM / waves along M) per tile id: the epilogue statistics write one partial row per wave row
-static const int kWaveM[19] = {64, 64, 32, 64, 64, 128, 32, 64, 128, 32, 64, 128, 128, 128, 64, 32, 64, 32, 64};
-constexpr int kMaxEpilogueParts = 512;      // beyond that (the 256 x 256 maps of the stem) the separate statistics sweep is cheaper to finish
+constexpr int kMaxEpilogueParts = 512;      // partial rows (= block row tiles) the BN finish kernel is asked to reduce; beyond
+                                            // that (the 256 x 256 maps of the stem on small tiles) the separate sweep is cheaper
 
 struct EpilogueStats {      // optional request of run_gemm's caller
     void* buf;              // room for parts x 2 Cout x (double + float)
@@ -1148,7 +1190,7 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
     p.st_sum = nullptr; p.st_mm = nullptr; p.st_zero = nullptr;
     if (es) {
         es->parts = 0;
-        const int parts = pl.tiles_m * (pl.BM / kWaveM[pl.tile]);
+        const int parts = pl.tiles_m;          // one partial row per block row tile (the waves combine through LDS)
         const size_t need = (size_t)parts * 2 * p.Cout * (sizeof(double) + sizeof(float));
         if (pl.splits == 1 && p.batches <= 1 && parts <= kMaxEpilogueParts && es->buf && es->bytes >= need && aligned16(es->buf)) {
             p.st_sum = (double*)es->buf;

@@ -371,12 +371,16 @@ def absmax_of(t):
     return b[0] if (b is not None and len(b) == 1) else None
 
 
-# Winograd F(2x2, 3x3) for the forward pass of 3x3 stride-1 convs with at least this many input channels (csrc/winograd.hip).
-# Measured per layer (gpurun r2n, R50dilated+PPM, 2x64x64 maps): 4096 ch 0.55 vs 0.79 ms direct, 1024 ch ~0.14 vs 0.23 ms,
-# 512 ch break-even, 256 ch 63 vs 50 us (the transforms are HBM-bound passes: V is 4x the input) -> threshold 1024.
-# SEMSEG_WINOGRAD=0 disables.
+# Winograd F(2x2, 3x3) for the forward pass (and weight gradient) of 3x3 stride-1 convs with at least this many input channels
+# (csrc/winograd.hip).  Measured per layer on 2 x 64 x 64 maps (profiles/r4_winograd_midsize_probe.txt: every piece timed alone,
+# the batched GEMM on its tuned tile form): 4096 ch 0.55 vs 0.79 ms direct, 1024 ch 136 vs 210 us, 512 ch (layer4's dilated 3x3
+# convs) 88 + 7 (statistics sweep) vs 123 us, 256 ch 41 + 7 vs 48 us (break-even: the transforms are HBM-bound passes, V is 4x the
+# input) -> threshold 512.  Round 2 had it at 1024: the GEMM then ran on the 8-wave 256 x 256 tile (66 us at 512 channels
+# against 56 us on the 16-wave form the tuner now pins as plan pass 3).  SEMSEG_WINOGRAD=0 disables.
 WINOGRAD = os.environ.get('SEMSEG_WINOGRAD', '1') != '0'
-WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '1024'))
+WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '512'))
+# the 3-channel first conv of a backbone through the dedicated kernels of csrc/stem.hip (0 = the implicit GEMM on padded planes)
+STEM_DIRECT = os.environ.get('SEMSEG_STEM_DIRECT', '1') != '0'
 # the BN statistics of a conv -> BN pair gathered in the conv's GEMM epilogue instead of by a sweep over its output (ConvBNActFn);
 # SEMSEG_EPILOGUE_STATS=0: the separate statistics kernel (A/B switch, tests/test_gpu_models.py SWITCH_CASES)
 EPILOGUE_STATS = os.environ.get('SEMSEG_EPILOGUE_STATS', '1') != '0'
@@ -814,7 +818,11 @@ def _winograd_fwd(L, x, bounds, u_planes, z, geom):
     nb = len(bounds)
     bp = (vp * nb)(*[b.data_ptr() for b in bounds])
     _native.check(L.semseg_winograd_input_h2(_p(x), x_ld, bp, nb, _p(v), n, h, wd, c, dil, _st()), 'winograd_input_h2')
-    _native.check(L.semseg_winograd_gemm_h2(_p(v), _p(u_planes), _p(m), tiles, c, k, _st()), 'winograd_gemm_h2')
+
+    def gemm():
+        _native.check(L.semseg_winograd_gemm_h2(_p(v), _p(u_planes), _p(m), tiles, c, k, _st()), 'winograd_gemm_h2')
+    tuner.ensure_winograd_gemm(tiles, c, k, gemm)
+    gemm()
     _native.check(L.semseg_winograd_output(_p(m), _p(z), k, n, h, wd, k, dil, _st()), 'winograd_output')
     return v
 
@@ -849,7 +857,7 @@ class ConvBNActFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg, box):
-        stride, pad, dil, momentum, eps, relu, emit = cfg
+        stride, pad, dil, momentum, eps, relu, emit, stem = cfg
         L = _native.lib()
         sch = SCHEMES['h2']
         w = krsc(weight.detach())
@@ -885,7 +893,13 @@ class ConvBNActFn(Function):
         bound = None if yp is not None else absmax            # no planes: the bound of |y| comes from the finish kernel itself
         parts = ctypes.c_int(0)
         stats_ws = None
-        if wino is None:
+        x_img = None
+        if stem:
+            # the 3-channel image conv: dedicated streaming kernel on the fp32 image (csrc/stem.hip), no planes of the image
+            x_img, x_img_ld = as_nhwc(x.detach())
+            _native.check(L.semseg_stem_conv3x3_fwd(_p(x_img), x_img_ld, _p(w), _p(z), k, n, h, wd, c, k, stride, pad, dil, _st()),
+                          'stem_conv3x3_fwd')
+        elif wino is None:
             wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
             if fused_stats and EPILOGUE_STATS:
                 # the BN statistics of z are gathered in the GEMM epilogue (one partial row per wave row; csrc/conv_split.hip
@@ -965,8 +979,9 @@ class ConvBNActFn(Function):
                                                 _st()), 'bn_apply')
         # the ReLU gate of a BN without residual is recomputed from z in backward: y need not be kept for it
         keep_y = relu and residual is not None and gate is None
-        ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate)
+        ctx.save_for_backward(xp if x_img is None else x_img, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate)
         ctx.geom = geom
+        ctx.stem = x_img is not None
         ctx.cfg = (bool(relu), residual is not None)
         box['planes'], box['absmax'] = yp, absmax
         return y
@@ -1024,6 +1039,18 @@ class ConvBNActFn(Function):
                                                _p(bb), _st()), 'bn_bwd_apply_h2')
         need_dw = ctx.needs_input_grad[1]
         dw_wino = None
+        if ctx.stem:
+            # xp is the fp32 image here; the image needs no gradient (conv_bn_act takes this path only then)
+            dw = None
+            if need_dw:
+                x_img, x_img_ld = as_nhwc(xp)
+                dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
+                wsb = workspace(L.semseg_stem_conv3x3_wgrad_workspace_bytes(n, h, wd, c, k, stride, pad, dil), dev)
+                _native.check(L.semseg_stem_conv3x3_wgrad_h2(_p(x_img), x_img_ld, _p(dzp), _p(dwb), n, h, wd, c, k, stride, pad, dil,
+                                                             _p(wsb), wsb.numel(), _st()), 'stem_conv3x3_wgrad_h2')
+                dw = dwb.permute(0, 3, 1, 2)
+            return (None, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
+                    None, None, None, None, None, None, None, None, None)
         if wino_v is not None and need_dw:
             dw_wino = _winograd_wgrad(L, wino_v, dzp, geom)
             need_dw = False
@@ -1044,16 +1071,21 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
                               momentum=momentum, eps=eps, relu=relu, num_batches_tracked=num_batches_tracked)
     _require_cuda(x)
     wp, wtp = weight_planes(weight, 'h2')
-    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu))
-    box = {}
     kk, cc, rr, ss = weight.shape
+    # the first conv of a backbone (3-channel image): csrc/stem.hip instead of a 32-channel-padded implicit GEMM
+    stem = STEM_DIRECT and rr == 3 and ss == 3 and not x.requires_grad and x.is_cuda and \
+        bool(_native.lib().semseg_stem_conv3x3_supported(int(cc), int(kk)))
+    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu), stem)
+    box = {}
     if int(stride) == 1 and int(padding) == int(dilation) and _wino_eligible(kk, cc, rr, ss):
         xb = bounds_of(x)
         if xb is not None and len(xb) <= 8:
             box['wino'] = weight_wino(weight)            # None until prepare_conv_weights has run for this weight state
             box['x_bounds'] = xb
     n, c, h, w = x.shape
-    if box.get('wino') is not None and (WINOGRAD_WGRAD or not weight.requires_grad):
+    if stem:
+        xp = None
+    elif box.get('wino') is not None and (WINOGRAD_WGRAD or not weight.requires_grad):
         xp = planes_of(x, 'h2', n * h * w, c)        # Winograd forward and weight gradient work on V: x needs no planes
     else:
         xp = input_planes(x, 'h2')

@@ -115,6 +115,50 @@ def timing():
     return _TIMING[0]
 
 
+WINO_TILES = (6, 7, 8, 9, 10, 14)       # tile forms the batched Winograd forward GEMM can run on (csrc/conv_split.hip, plan pass 3)
+
+
+def ensure_winograd_gemm(tiles, c, k, launch):
+    """launch plan of the batched GEMM of the Winograd forward (semseg_winograd_gemm_h2): the tile form is pinned per
+    (tiles, C, K) as plan pass 3, timed once on the real buffers like the direct convolutions (the library's own rule -- the
+    8-wave 256 x 256 tile -- is 15-20 % behind the 16-wave form on the 512- and 1024-channel layers,
+    profiles/r4_winograd_midsize_probe.txt)"""
+    geom = (int(tiles), 1, 1, int(c), int(k), 3, 3, 1, 1, 1)
+    key = ('h2', 3) + geom
+    if ENABLED and not _cache_loaded:
+        _load_cache()
+    if not ENABLED or key in _done:
+        return
+    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return
+    L = _native.lib()
+    set_plan = _set_plan(L, 'h2')
+    stats['timed'] += 1
+    best = None
+    _TIMING[0] = True
+    try:
+        launch()
+        best = (-1, 0, _time(launch, 2))
+        for tile in WINO_TILES:
+            if set_plan(3, *geom, tile, 1) != 0:
+                continue
+            try:
+                launch()
+                ms = _time(launch, 3)
+            except RuntimeError:
+                continue
+            if ms < best[2]:
+                best = (tile, 1, ms)
+    finally:
+        _TIMING[0] = False
+        if best is None or best[0] < 0:
+            set_plan(3, *geom, -1, 0)
+        else:
+            set_plan(3, *geom, best[0], 1)
+    _done[key] = best
+    _save_cache()
+
+
 def ensure(scheme, pass_id, geom, launch):
     """scheme = 'h2' | 's3'; geom = (N,H,W,C,K,R,S,stride,pad,dil); launch() issues the conv of this pass on the
     current stream."""

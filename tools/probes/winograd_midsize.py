@@ -92,7 +92,7 @@ def main():
         print('%-34s %9.1f | %8.1f %8.1f %8.1f | %s   plan %s parts %d | direct %.0f TF, wino gemm alone %.0f TF-alg, '
               'fully fused best case (gemm + extra 8 B/elem of V + out - sweep) %.1f us' % (
                   name, t_direct, t_in, t_out, t_sweep, ' '.join('%d:%.1f' % kv for kv in sorted(gemms.items())),
-                  list(plan[:2]) if plan else None, parts.value, gf / t_direct * 1e-3 * 1e3, gf / best * 1e-3 * 1e3,
+                  list(plan[:2]) if plan else None, parts.value, gf / t_direct * 1e3, gf / best * 1e3,
                   best + 0.5 * t_in + t_out - t_sweep), flush=True)
 
 
