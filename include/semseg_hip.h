@@ -379,6 +379,8 @@ typedef struct {
     const float* w; void* krsc; void* crsk; int K, T, C;
     void* wino;   /* optional, T == 9 only: Winograd-transformed weights U = G g G^T as h2 planes, rows 16*K (f, k), channels C:
                      semseg_split_h2_bytes(16*K, C) bytes; NULL = not wanted */
+    void* wino_t; /* optional, T == 9 only: the transformed weights of the DATA GRADIENT (taps flipped, C and K swapped), rows 16*C
+                     (f, c), channels K: semseg_split_h2_bytes(16*C, K) bytes; NULL = not wanted */
 } semseg_wprep_tensor;
 int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host, int n, void* stream);
 
@@ -404,6 +406,11 @@ int semseg_label_metrics(const int64_t* pred, const int64_t* label, int P, int C
 int semseg_winograd_tiles(int N, int H, int W, int dil);
 int semseg_winograd_input_h2(const float* x, int x_ld, const float* const* bounds_host, int nbounds, void* v_planes,
                              int N, int H, int W, int C, int dil, void* stream);
+/* the input transform with the source given as h2 planes ([N*H*W] rows x C channels; exponent of V = exponent of the source - 2):
+ * the DATA GRADIENT of the same layers in the Winograd domain is  input_planes(dz) -> gemm(V, U' = field `wino_t` of
+ * semseg_weights_prepare_h2, tiles, C = filters, K = input channels) -> output(dx): the 3x3 stride-1 convolution of dz with the
+ * flipped, transposed weights */
+int semseg_winograd_input_planes_h2(const void* src_planes, void* v_planes, int N, int H, int W, int C, int dil, void* stream);
 int semseg_winograd_gemm_h2(const void* v_planes, const void* u_planes, float* M, int tiles, int C, int K, void* stream);
 int semseg_winograd_output(const float* M, float* z, int z_ld, int N, int H, int W, int K, int dil, void* stream);
 /* Weight gradient of the same layers in the Winograd domain (the autograd of nn.Conv2d.weight at those call sites):

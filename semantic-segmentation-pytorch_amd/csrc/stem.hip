@@ -7,7 +7,8 @@
 //             image at all), weights tap-major in LDS;
 //   wgrad   : dw[k][tap][c] = sum_p dy[p][k] x[p @ tap][c], dy read from the h2 planes the BN backward kernel wrote (dz has no
 //             fp32 copy); one block = a run of pixels, thread = one k x one of 4 pixel lanes, the C x 9 input values of a pixel
-//             broadcast from LDS; fp32 partial sums over <= 64 pixels, fp64 across lanes / blocks in a fixed order.
+//             read by all k-threads from the same addresses (broadcast); fp32 partial sums over <= 64 pixels, fp64 across lanes
+//             / blocks in a fixed order.
 // Arithmetic is exact fp32 FMA (tighter than the h2 products).  No data gradient: the image needs none.
 #include "common.h"
 #include "split_layout.h"
@@ -66,47 +67,50 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     }
 }
 
-// partial[block][k][9*C] (double): sums over the block's pixels, in the scaled domain of the dy planes
+// partial[block][k][9*C] (double): sums over the block's pixels, in the scaled domain of the dy planes.
+// thread = (k, one of 4 pixel lanes); a lane walks its own pixels (p0 + lane, += 4): the 9 x C input values of a pixel are read by
+// the 64 k-threads of the wave from the SAME addresses (one broadcast transaction per load, L1-resident image rows), dy[p][k] is
+// coalesced over k.  No barrier and no LDS inside the loop (a first version staged the inputs through LDS with two barriers per
+// four pixels and was 2x slower than the padded implicit GEMM it replaces).
 constexpr int WG_LANES = 4;                       // pixel lanes per block (threads = K x lanes, K <= 64)
+template <int C>
 __global__ __launch_bounds__(256) void stem_wgrad_partial_kernel(const float* __restrict__ x, int x_ld,
                                                                  const uint16_t* __restrict__ dyp, size_t dy_plane, int dy_pitch,
                                                                  double* __restrict__ partial, StemGeom g, int px_per_block) {
-    __shared__ float xs[WG_LANES][STEM_TAPS * STEM_MAX_C];
     __shared__ double red[WG_LANES][64];
+    constexpr int KT = STEM_TAPS * C;
     const int k = threadIdx.x % g.K, lane = threadIdx.x / g.K;       // blockDim.x == K * WG_LANES
-    const int KT = STEM_TAPS * g.C;
     const int p0 = blockIdx.x * px_per_block;
     const int p1 = min(g.M, p0 + px_per_block);
-    float acc[STEM_TAPS * STEM_MAX_C];
+    float acc[KT];
 #pragma unroll
-    for (int i = 0; i < STEM_TAPS * STEM_MAX_C; ++i) acc[i] = 0.f;
-    for (int base = p0; base < p1; base += WG_LANES) {
-        __syncthreads();                          // the previous round's reads of xs are done
-        for (int q = threadIdx.x; q < WG_LANES * KT; q += blockDim.x) {
-            const int l = q / KT, tc = q - l * KT;
-            const int p = base + l;
-            float v = 0.f;
-            if (p < p1) {
-                int n, oh, ow;
-                stem_pixel(g, p, n, oh, ow);
-                const int t = tc / g.C, c = tc - t * g.C;
-                const int r = t / 3, s = t - r * 3;
-                const int ih = oh * g.stride - g.pad + r * g.dil, iw = ow * g.stride - g.pad + s * g.dil;
-                if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) v = x[((size_t)(n * g.H + ih) * g.W + iw) * x_ld + c];
+    for (int i = 0; i < KT; ++i) acc[i] = 0.f;
+    const _Float16* d0 = reinterpret_cast<const _Float16*>(dyp);
+    const _Float16* d1 = reinterpret_cast<const _Float16*>(dyp + dy_plane);
+    for (int p = p0 + lane; p < p1; p += WG_LANES) {
+        int n, oh, ow;
+        stem_pixel(g, p, n, oh, ow);
+        const size_t o = (size_t)p * dy_pitch + k;
+        const float d = (float)d0[o] + (float)d1[o];
+        const float* img = x + (size_t)n * g.H * g.W * x_ld;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * g.stride - g.pad + r * g.dil;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int iw = ow * g.stride - g.pad + s * g.dil;
+                const bool ok = ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+                const float* xp = img + ((size_t)(ok ? ih : 0) * g.W + (ok ? iw : 0)) * x_ld;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float xv = ok ? xp[c] : 0.f;
+                    acc[(r * 3 + s) * C + c] = fmaf(d, xv, acc[(r * 3 + s) * C + c]);
+                }
             }
-            xs[l][tc] = v;
-        }
-        __syncthreads();
-        const int p = base + lane;
-        if (p < p1) {
-            const size_t o = (size_t)p * dy_pitch + k;
-            const float d = (float)reinterpret_cast<const _Float16*>(dyp)[o] + (float)reinterpret_cast<const _Float16*>(dyp + dy_plane)[o];
-#pragma unroll
-            for (int i = 0; i < STEM_TAPS * STEM_MAX_C; ++i)
-                if (i < KT) acc[i] = fmaf(d, xs[lane][i], acc[i]);
         }
     }
     // lanes -> one row per (k, tap-channel) in fp64, fixed order
+#pragma unroll
     for (int i = 0; i < KT; ++i) {
         __syncthreads();
         red[lane][k] = (double)acc[i];
@@ -156,7 +160,7 @@ extern "C" int semseg_stem_conv3x3_fwd(const float* x, int x_ld, const float* w,
     if (!x || !w || !y || x_ld < C || y_ld < K || (y_ld % 4) || !aligned16(y) || !stem_geom(g, N, H, W, C, K, stride, pad, dil))
         return SEMSEG_EINVAL;
     size_t blocks = ceil_div_sz((size_t)g.M * (K / 4), 256);
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 2048) blocks = 2048;           // the block's copy of the weights in LDS is loaded once per block: keep blocks long-lived
     const size_t smem = (size_t)STEM_TAPS * C * K * sizeof(float);
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, x, x_ld, w, y, y_ld, g);
     SEMSEG_LAUNCH_CHECK();
@@ -179,8 +183,16 @@ extern "C" int semseg_stem_conv3x3_wgrad_h2(const float* x, int x_ld, const void
     if (!workspace || workspace_bytes < (size_t)nb * total * sizeof(double)) return SEMSEG_EWORKSPACE;
     const int px = ceil_div(g.M, nb);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(stem_wgrad_partial_kernel, dim3(nb), dim3(K * WG_LANES), 0, st, x, x_ld, (const uint16_t*)dys,
-                       h2_plane_elems((size_t)g.M, K), split_pitch(K), (double*)workspace, g, px);
+#define STEM_WG(CC)                                                                                                        \
+    hipLaunchKernelGGL(stem_wgrad_partial_kernel<CC>, dim3(nb), dim3(K * WG_LANES), 0, st, x, x_ld, (const uint16_t*)dys, \
+                       h2_plane_elems((size_t)g.M, K), split_pitch(K), (double*)workspace, g, px)
+    switch (C) {
+        case 1: STEM_WG(1); break;
+        case 2: STEM_WG(2); break;
+        case 3: STEM_WG(3); break;
+        default: STEM_WG(4); break;
+    }
+#undef STEM_WG
     SEMSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const double*)workspace, nb, total, h2_exp_ptr(dys, (size_t)g.M, K), dw);
     SEMSEG_LAUNCH_CHECK();

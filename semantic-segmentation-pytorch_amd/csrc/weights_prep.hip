@@ -9,7 +9,7 @@
 #include "common.h"
 #include "split_layout.h"
 
-constexpr int WPREP_MAX_TENSORS = 48;      // 48 x 56 B of descriptors stay below the 4 KiB kernel-argument limit
+constexpr int WPREP_MAX_TENSORS = 48;      // 48 x 72 B of descriptors stay below the 4 KiB kernel-argument limit
 constexpr int WPREP_CHUNKS = 256;          // absmax partial blocks per tensor (<= H2_MAX_PARTIALS)
 
 struct WPrepTensor {
@@ -20,6 +20,8 @@ struct WPrepTensor {
     int tile_base;         // first flat tile id of this tensor
     uint16_t* wino;        // optional (T == 9): h2 split buffer of the Winograd-transformed weights, rows 16*K, channels C
     int wino_base;         // first flat block id of this tensor in wprep_wino_kernel
+    uint16_t* wino_t;      // optional (T == 9): the same for the DATA GRADIENT (flipped taps, roles of C and K swapped): rows 16*C, channels K
+    int wino_t_base;       // first flat block id of this tensor in wprep_wino_t_kernel
 };
 struct WPrepBatch {
     WPrepTensor t[WPREP_MAX_TENSORS];
@@ -212,6 +214,85 @@ __global__ __launch_bounds__(256) void wprep_wino_kernel(const WPrepBatch b, int
     }
 }
 
+// U' = G g' G^T for the data gradient in the Winograd domain: dx = conv(dz, g') with g'[c][r][s][k] = g[k][2-r][2-s][c] (the
+// flipped taps, channels and filters swapped) is a 3x3 stride-1 convolution of the same geometry, so it runs through the same
+// input transform / batched GEMM / output transform as the forward.  Read from the CRSK planes this launch sequence has just
+// written (rows (c, tap), k contiguous: coalesced; p0 + p1 is the weight to 22 bits, the precision the direct data gradient
+// multiplies with), transformed in the scaled domain with a factor 1/4 (|U'| <= 2.25 max|g|: stays inside fp16), exponent = e - 2.
+// One thread = 4 filters k of one channel c.
+__global__ __launch_bounds__(256) void wprep_wino_t_kernel(const WPrepBatch b, int pitch_pad) {
+    int ti = -1;
+    for (int i = 0; i < b.n; ++i)
+        if (b.t[i].wino_t && (int)blockIdx.x >= b.t[i].wino_t_base) ti = i;     // block-uniform; bases ascend
+    if (ti < 0) return;
+    const WPrepTensor t = b.t[ti];
+    const int K = t.K, C = t.C;
+    const int Kp = (K + 31) & ~31;
+    const int pitch_k = ((Kp * 2) % 2048 == 0) ? Kp + pitch_pad : Kp;
+    const size_t plane_crsk = (size_t)C * 9 * pitch_k;
+    const size_t plane = (size_t)16 * C * pitch_k;
+    const unsigned char* ctail = reinterpret_cast<const unsigned char*>(t.crsk) + (size_t)H2_NP * plane_crsk * 2;
+    const int ex = *reinterpret_cast<const int*>(ctail + SPLIT_ZERO_TAIL_BYTES);
+    if ((int)blockIdx.x == t.wino_t_base) {
+        unsigned char* tail = reinterpret_cast<unsigned char*>(t.wino_t) + (size_t)H2_NP * plane * 2;
+        if (threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16) reinterpret_cast<uint4*>(tail)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) *reinterpret_cast<int*>(tail + SPLIT_ZERO_TAIL_BYTES) = ex - 2;
+    }
+    const int G4 = Kp >> 2;
+    const size_t item = (size_t)((int)blockIdx.x - t.wino_t_base) * 256 + threadIdx.x;
+    if (item >= (size_t)C * G4) return;
+    const int c = (int)(item / G4);
+    const int k = (int)(item - (size_t)c * G4) << 2;
+    float g[3][3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const size_t o = ((size_t)c * 9 + (8 - (r * 3 + q))) * pitch_k + k;         // flipped tap
+            const f16x4 p0 = *reinterpret_cast<const f16x4*>(t.crsk + o);
+            const f16x4 p1 = *reinterpret_cast<const f16x4*>(t.crsk + plane_crsk + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[r][q][e] = (k + e < K) ? ((float)p0[e] + (float)p1[e]) * 0.25f : 0.f;
+        }
+    float a[4][3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g0 = g[0][q][e], g1 = g[1][q][e], g2 = g[2][q][e];
+            a[0][q][e] = g0;
+            a[1][q][e] = 0.5f * (g0 + g1 + g2);
+            a[2][q][e] = 0.5f * (g0 - g1 + g2);
+            a[3][q][e] = g2;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float u[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = a[i][0][e], a1 = a[i][1][e], a2 = a[i][2][e];
+            u[0][e] = a0;
+            u[1][e] = 0.5f * (a0 + a1 + a2);
+            u[2][e] = 0.5f * (a0 - a1 + a2);
+            u[3][e] = a2;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f16x4 p0, p1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 hi, lo;
+                h2_split_of(u[j][e], hi, lo);
+                p0[e] = hi;
+                p1[e] = lo;
+            }
+            const size_t off = ((size_t)(i * 4 + j) * C + c) * pitch_k + k;
+            *reinterpret_cast<f16x4*>(t.wino_t + off) = p0;
+            *reinterpret_cast<f16x4*>(t.wino_t + plane + off) = p1;
+        }
+    }
+}
+
 extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host, int n, void* stream) {
     if (!tensors_host || n < 0) return SEMSEG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -219,7 +300,7 @@ extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host
     for (int base = 0; base < n; base += WPREP_MAX_TENSORS) {
         WPrepBatch b;
         b.n = min(WPREP_MAX_TENSORS, n - base);
-        int tiles = 0, wino_blocks = 0;
+        int tiles = 0, wino_blocks = 0, wino_t_blocks = 0;
         for (int i = 0; i < b.n; ++i) {
             const semseg_wprep_tensor& s = tensors_host[base + i];
             if (!s.w || !s.krsc || !s.crsk || s.K <= 0 || s.T <= 0 || s.C <= 0) return SEMSEG_EINVAL;
@@ -239,6 +320,13 @@ extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host
                 b.t[i].wino = (uint16_t*)s.wino;
                 wino_blocks += (int)ceil_div_sz((size_t)s.K * (round_up32(s.C) / 4), 256);
             }
+            b.t[i].wino_t = nullptr;
+            b.t[i].wino_t_base = wino_t_blocks;
+            if (s.wino_t) {
+                if (s.T != 9 || !aligned16(s.wino_t)) return SEMSEG_EINVAL;
+                b.t[i].wino_t = (uint16_t*)s.wino_t;
+                wino_t_blocks += (int)ceil_div_sz((size_t)s.C * (round_up32(s.K) / 4), 256);
+            }
         }
         if (b.n == 0) break;
         hipLaunchKernelGGL(wprep_absmax_kernel, dim3(WPREP_CHUNKS, b.n), dim3(256), 0, st, b, pitch_pad);
@@ -247,6 +335,10 @@ extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host
         SEMSEG_LAUNCH_CHECK();
         if (wino_blocks > 0) {
             hipLaunchKernelGGL(wprep_wino_kernel, dim3(wino_blocks), dim3(256), 0, st, b, pitch_pad);
+            SEMSEG_LAUNCH_CHECK();
+        }
+        if (wino_t_blocks > 0) {            // after wprep_split_kernel: reads the CRSK planes it wrote
+            hipLaunchKernelGGL(wprep_wino_t_kernel, dim3(wino_t_blocks), dim3(256), 0, st, b, pitch_pad);
             SEMSEG_LAUNCH_CHECK();
         }
     }

@@ -147,6 +147,100 @@ extern "C" int semseg_winograd_input_h2(const float* x, int x_ld, const float* c
     return 0;
 }
 
+// The same input transform with the SOURCE given as h2 planes (the data gradient in the Winograd domain: its input is dz, which
+// the BN backward kernel writes as planes only).  p0 + p1 is the value to 22 bits in the scaled domain of the planes;
+// |B^T d B| <= 4 max|d|, so the transform is formed with a factor 1/4 in that domain (exact in fp32) and the exponent of V is
+// the exponent of the source minus 2 -- no bound, no rescaling.
+__global__ __launch_bounds__(256) void wino_input_planes_kernel(const uint16_t* __restrict__ src, size_t src_plane, int src_pitch,
+                                                                const int* __restrict__ src_hdr, uint16_t* __restrict__ planes,
+                                                                size_t plane, int pitch, int* __restrict__ hdr, WinoGeom g, int Cp) {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16) reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) hdr[0] = src_hdr[0] - 2;
+    }
+    const int G4 = Cp >> 2;
+    const size_t total = (size_t)g.tiles * G4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx / G4);
+        const int c = (int)(idx - (size_t)t * G4) << 2;
+        int n, ph, pw, ty, tx;
+        wino_tile(g, t, n, ph, pw, ty, tx);
+        float4 d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int qh = 2 * ty - 1 + a;
+            const int h = qh * g.dil + ph;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int qw = 2 * tx - 1 + bb;
+                const int w = qw * g.dil + pw;
+                const bool ok = (c < g.C) && (qh >= 0) && (qw >= 0) && (h < g.H) && (w < g.W);
+                float4 v = f4zero();
+                if (ok) {
+                    const size_t off = ((size_t)(n * g.H + h) * g.W + w) * src_pitch + c;
+                    const f16x4 p0 = *reinterpret_cast<const f16x4*>(src + off);
+                    const f16x4 p1 = *reinterpret_cast<const f16x4*>(src + src_plane + off);
+                    v = make_float4(((float)p0[0] + (float)p1[0]) * 0.25f, ((float)p0[1] + (float)p1[1]) * 0.25f,
+                                    ((float)p0[2] + (float)p1[2]) * 0.25f, ((float)p0[3] + (float)p1[3]) * 0.25f);
+                }
+                d[a][bb] = v;
+            }
+        }
+        float4 v[4][4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float4 d0 = d[0][bb], d1 = d[1][bb], d2 = d[2][bb], d3 = d[3][bb];
+            v[0][bb] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+            v[1][bb] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+            v[2][bb] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+            v[3][bb] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 t0 = v[a][0], t1 = v[a][1], t2 = v[a][2], t3 = v[a][3];
+            const float4 o[4] = {make_float4(t0.x - t2.x, t0.y - t2.y, t0.z - t2.z, t0.w - t2.w),
+                                 make_float4(t1.x + t2.x, t1.y + t2.y, t1.z + t2.z, t1.w + t2.w),
+                                 make_float4(t2.x - t1.x, t2.y - t1.y, t2.z - t1.z, t2.w - t1.w),
+                                 make_float4(t1.x - t3.x, t1.y - t3.y, t1.z - t3.z, t1.w - t3.w)};
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const float e[4] = {o[bb].x, o[bb].y, o[bb].z, o[bb].w};
+                f16x4 p0, p1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    _Float16 hi, lo;
+                    h2_split_of(e[q], hi, lo);
+                    p0[q] = hi;
+                    p1[q] = lo;
+                }
+                const size_t off = ((size_t)(a * 4 + bb) * g.tiles + t) * pitch + c;
+                *reinterpret_cast<f16x4*>(planes + off) = p0;
+                *reinterpret_cast<f16x4*>(planes + plane + off) = p1;
+            }
+        }
+    }
+}
+
+// src_planes: h2 planes of a [N*H*W rows] x [C channels] tensor (e.g. dz of a conv whose data gradient runs in the Winograd domain)
+extern "C" int semseg_winograd_input_planes_h2(const void* src_planes, void* v_planes, int N, int H, int W, int C, int dil,
+                                               void* stream) {
+    if (!src_planes || !v_planes || N <= 0 || H <= 0 || W <= 0 || C <= 0 || dil <= 0 || !aligned16(src_planes) || !aligned16(v_planes))
+        return SEMSEG_EINVAL;
+    const WinoGeom g = wino_geom(N, H, W, C, 1, dil);
+    const size_t P = (size_t)N * H * W, rows = (size_t)16 * g.tiles;
+    const int Cp = round_up32(C), pitch = split_pitch(C);
+    const size_t src_plane = h2_plane_elems(P, C), plane = h2_plane_elems(rows, C);
+    if ((size_t)2 * H2_NP * plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31)) return SEMSEG_EINVAL;
+    const int* src_hdr = h2_exp_ptr(src_planes, P, C);
+    int* hdr = const_cast<int*>(h2_exp_ptr(v_planes, rows, C));
+    size_t blocks = ceil_div_sz((size_t)g.tiles * (Cp / 4), 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(wino_input_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src_planes,
+                       src_plane, pitch, src_hdr, (uint16_t*)v_planes, plane, pitch, hdr, g, Cp);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 // one thread = 4 output channels of one tile: 16 float4 loads of M, 2x2 outputs
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, float* __restrict__ z, int z_ld, WinoGeom g) {
     const int K4 = g.K >> 2;

@@ -22,7 +22,7 @@ class SgdTensor(ctypes.Structure):
 
 
 class WPrepTensor(ctypes.Structure):
-    _fields_ = [('w', vp), ('krsc', vp), ('crsk', vp), ('K', c_int), ('T', c_int), ('C', c_int), ('wino', vp)]
+    _fields_ = [('w', vp), ('krsc', vp), ('crsk', vp), ('K', c_int), ('T', c_int), ('C', c_int), ('wino', vp), ('wino_t', vp)]
 
 
 # name -> (restype, argtypes); mirrors include/semseg_hip.h one to one
@@ -117,6 +117,7 @@ SIGNATURES = {
     'semseg_label_metrics': (c_int, [vp, vp, c_int, c_int, vp, vp]),
     'semseg_winograd_tiles': (c_int, [c_int, c_int, c_int, c_int]),
     'semseg_winograd_input_h2': (c_int, [vp, c_int, ctypes.POINTER(vp), c_int, vp, c_int, c_int, c_int, c_int, c_int, vp]),
+    'semseg_winograd_input_planes_h2': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
     'semseg_winograd_gemm_h2': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
     'semseg_winograd_output': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'semseg_winograd_dm_h2': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),

@@ -387,6 +387,18 @@ EPILOGUE_STATS = os.environ.get('SEMSEG_EPILOGUE_STATS', '1') != '0'
 # the weight gradient of the same layers in the Winograd domain (dU[f] = dM[f]^T V[f], V kept from the forward pass):
 # in-box A/B (gpurun wg1) 16.50 -> 16.02 ms per step.  SEMSEG_WINOGRAD_WGRAD=0 disables.
 WINOGRAD_WGRAD = os.environ.get('SEMSEG_WINOGRAD_WGRAD', '1') != '0'
+# ... from this many input channels on: the batched weight-gradient GEMM has only K x C / 256^2 x 16 output tiles, 64 for a
+# 512 -> 512 layer, and splitting the 2048-tile reduction 8 ways to fill the chip costs a 134 MB slab reduce -- measured no gain
+# over the direct weight gradient there (gpurun r4g), so the 512-channel layers run Winograd forward + direct weight gradient
+WINOGRAD_WGRAD_MIN_C = 1024
+# the data gradient of the same layers in the Winograd domain: dx = conv3x3(dz, flipped + transposed weights) through the same
+# input transform (from the planes of dz) / batched GEMM / output transform; U' = G g' G^T comes from the weight preparation.
+# conv_last of the PPM head (4096 <- 512 @ 64 x 64): ~0.6 vs 0.79 ms for the direct kernel.  SEMSEG_WINOGRAD_DGRAD=0 disables.
+WINOGRAD_DGRAD = os.environ.get('SEMSEG_WINOGRAD_DGRAD', '1') != '0'
+
+
+def _wino_dgrad_eligible(k):
+    return WINOGRAD_DGRAD and k >= 256           # the reduction of the data-gradient GEMM runs over the filters
 
 
 def _wino_eligible(k, c, r, s):
@@ -415,9 +427,11 @@ def prepare_conv_weights(weights):
             cb = torch.empty(L.semseg_split_h2_bytes(c * r * s, k), dtype=torch.uint8, device=w.device)
             ub = torch.empty(L.semseg_split_h2_bytes(16 * k, c), dtype=torch.uint8, device=w.device) \
                 if _wino_eligible(k, c, r, s) else None
-            rec = (weakref.ref(w), w._version, w.data_ptr(), kb, cb, ub)
+            utb = torch.empty(L.semseg_split_h2_bytes(16 * c, k), dtype=torch.uint8, device=w.device) \
+                if (_wino_eligible(k, c, r, s) and _wino_dgrad_eligible(k)) else None
+            rec = (weakref.ref(w), w._version, w.data_ptr(), kb, cb, ub, utb)
         else:
-            rec = (rec[0], w._version, rec[2], rec[3], rec[4], rec[5])
+            rec = (rec[0], w._version, rec[2], rec[3], rec[4], rec[5], rec[6])
         _WPLANES[id(w)] = rec
         todo.append((w, rec))
     if not todo:
@@ -428,6 +442,7 @@ def prepare_conv_weights(weights):
         arr[i].w, arr[i].krsc, arr[i].crsk = w.data_ptr(), rec[3].data_ptr(), rec[4].data_ptr()
         arr[i].K, arr[i].T, arr[i].C = k, r * s, c
         arr[i].wino = rec[5].data_ptr() if rec[5] is not None else None
+        arr[i].wino_t = rec[6].data_ptr() if rec[6] is not None else None
     _native.check(L.semseg_weights_prepare_h2(arr, len(todo), _st()), 'weights_prepare_h2')
     return len(todo)
 
@@ -437,6 +452,15 @@ def weight_wino(w):
     rec = _WPLANES.get(id(w)) if FUSE else None
     if rec is not None and rec[0]() is w and rec[1] == w._version and rec[2] == w.data_ptr():
         return rec[5]
+    return None
+
+
+def weight_wino_t(w):
+    """planes of the Winograd-transformed weights of the DATA GRADIENT (U', rows (f, c), channels k) for this exact parameter
+    state, else None"""
+    rec = _WPLANES.get(id(w)) if FUSE else None
+    if rec is not None and rec[0]() is w and rec[1] == w._version and rec[2] == w.data_ptr():
+        return rec[6]
     return None
 
 
@@ -844,6 +868,26 @@ def _winograd_wgrad(L, v, dzp, geom):
     return dwb.permute(0, 3, 1, 2)
 
 
+def _winograd_dgrad(L, dzp, ut_planes, geom):
+    """dx of a 3x3 stride-1 pad == dil convolution in the Winograd domain, from the h2 planes of dz: the convolution of dz (k
+    channels) with the flipped, transposed weights (U' planes, csrc/weights_prep.hip) -- input transform from planes, the batched
+    GEMM of the forward with the roles of c and k swapped, output transform into dx"""
+    n, h, wd, c, k, r, s, stride, pad, dil = geom
+    dev = dzp.device
+    tiles = L.semseg_winograd_tiles(n, h, wd, dil)
+    v = torch.empty(L.semseg_split_h2_bytes(16 * tiles, k), dtype=torch.uint8, device=dev)
+    m = torch.empty((16 * tiles, c), dtype=torch.float32, device=dev)
+    dx = empty_nhwc(n, c, h, wd, dev)
+    _native.check(L.semseg_winograd_input_planes_h2(_p(dzp), _p(v), n, h, wd, k, dil, _st()), 'winograd_input_planes_h2')
+
+    def gemm():
+        _native.check(L.semseg_winograd_gemm_h2(_p(v), _p(ut_planes), _p(m), tiles, k, c, _st()), 'winograd_gemm_h2')
+    tuner.ensure_winograd_gemm(tiles, k, c, gemm)
+    gemm()
+    _native.check(L.semseg_winograd_output(_p(m), _p(dx), c, n, h, wd, c, dil, _st()), 'winograd_output')
+    return dx
+
+
 class ConvBNActFn(Function):
     """y = act(BN_train(conv(x)) [+ residual]) as ONE autograd node on the h2 path (resnet.py:72-92 blocks,
     models.py:160-167 conv3x3_bn_relu, hrnet.py).  Versus Conv2dSplitFn + BatchNormActFn:
@@ -857,6 +901,7 @@ class ConvBNActFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg, box):
+        wut = box.get('wino_t')             # U' planes of the Winograd data gradient (None: direct kernel)
         stride, pad, dil, momentum, eps, relu, emit, stem = cfg
         L = _native.lib()
         sch = SCHEMES['h2']
@@ -879,7 +924,7 @@ class ConvBNActFn(Function):
         wino_v = None
         if wino is not None:
             wino_v = _winograd_fwd(L, x.detach(), box['x_bounds'], wino, z, geom)
-            if not (WINOGRAD_WGRAD and ctx.needs_input_grad[1]):
+            if not (WINOGRAD_WGRAD and c >= WINOGRAD_WGRAD_MIN_C and ctx.needs_input_grad[1]):
                 wino_v = None
         res, res_ld = (None, 0)
         if residual is not None:
@@ -979,7 +1024,7 @@ class ConvBNActFn(Function):
                                                 _st()), 'bn_apply')
         # the ReLU gate of a BN without residual is recomputed from z in backward: y need not be kept for it
         keep_y = relu and residual is not None and gate is None
-        ctx.save_for_backward(xp if x_img is None else x_img, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate)
+        ctx.save_for_backward(xp if x_img is None else x_img, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate, wut)
         ctx.geom = geom
         ctx.stem = x_img is not None
         ctx.cfg = (bool(relu), residual is not None)
@@ -991,7 +1036,7 @@ class ConvBNActFn(Function):
     def backward(ctx, dy):
         L = _native.lib()
         sch = SCHEMES['h2']
-        xp, w, wtp, z, y, coef, gamma, stats, zmm, wino_v, gate_bits = ctx.saved_tensors
+        xp, w, wtp, z, y, coef, gamma, stats, zmm, wino_v, gate_bits, wut = ctx.saved_tensors
         relu, has_res = ctx.cfg
         geom = ctx.geom
         n, h, wd, c, k, r, s, stride, pad, dil = geom
@@ -1054,9 +1099,16 @@ class ConvBNActFn(Function):
         if wino_v is not None and need_dw:
             dw_wino = _winograd_wgrad(L, wino_v, dzp, geom)
             need_dw = False
-        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, ctx.needs_input_grad[0], need_dw)
+        need_dx = ctx.needs_input_grad[0]
+        dx_wino = None
+        if wut is not None and need_dx:
+            dx_wino = _winograd_dgrad(L, dzp, wut, geom)
+            need_dx = False
+        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, need_dx, need_dw)
         if dw_wino is not None:
             dw = dw_wino
+        if dx_wino is not None:
+            dx = dx_wino
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
                 None, None, None, None, None, None, None, None, None)
 
@@ -1082,10 +1134,12 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
         if xb is not None and len(xb) <= 8:
             box['wino'] = weight_wino(weight)            # None until prepare_conv_weights has run for this weight state
             box['x_bounds'] = xb
+        if x.requires_grad and _wino_dgrad_eligible(kk):
+            box['wino_t'] = weight_wino_t(weight)        # the data gradient in the Winograd domain needs no bound: dz comes as planes
     n, c, h, w = x.shape
     if stem:
         xp = None
-    elif box.get('wino') is not None and (WINOGRAD_WGRAD or not weight.requires_grad):
+    elif box.get('wino') is not None and ((WINOGRAD_WGRAD and c >= WINOGRAD_WGRAD_MIN_C) or not weight.requires_grad):
         xp = planes_of(x, 'h2', n * h * w, c)        # Winograd forward and weight gradient work on V: x needs no planes
     else:
         xp = input_planes(x, 'h2')
@@ -1637,4 +1691,4 @@ def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum
     for p in params:
         rec = _WPLANES.get(id(p))
         if rec is not None:
-            _WPLANES[id(p)] = (rec[0], -1, rec[2], rec[3], rec[4], rec[5])
+            _WPLANES[id(p)] = (rec[0], -1, rec[2], rec[3], rec[4], rec[5], rec[6])

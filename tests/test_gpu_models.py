@@ -289,6 +289,7 @@ SWITCH_CASES = [
     ('SEMSEG_FUSE=0', 'r50d_ppmds_64_train'),                # no plane hand-over, unfused conv / BN nodes
     ('SEMSEG_WINOGRAD=0', 'r50d_ppmds_64_train'),            # conv_last (4096 channels) through the direct kernels
     ('SEMSEG_WINOGRAD_WGRAD=0', 'r50d_ppmds_64_train'),
+    ('SEMSEG_WINOGRAD_DGRAD=0', 'r50d_ppmds_64_train'),      # conv_last / deepsup / layer4 data gradients through the direct kernels
     ('SEMSEG_WINOGRAD_MIN_C=256', 'r50d_ppmds_64_train'),    # Winograd for every eligible 3x3 conv of the net
     ('SEMSEG_WINOGRAD_MIN_C=1024', 'r50d_ppmds_64_train'),   # round 2's threshold: layer4's 512-channel convs direct
     ('SEMSEG_TUNE=0', 'r50d_ppmds_64_train'),                # the library's heuristic launch plans

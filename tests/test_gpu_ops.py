@@ -910,6 +910,42 @@ def test_winograd_wgrad(n, c, h, w, k, dil, monkeypatch):
     assert rel_err(dw, ref) < REL * 4, rel_err(dw, ref)
 
 
+@pytest.mark.parametrize('n,c,h,w,k,dil', [(2, 256, 16, 16, 256, 1), (1, 128, 24, 24, 512, 4), (2, 64, 17, 19, 256, 2),
+                                           (1, 36, 7, 9, 320, 1), (2, 1024, 8, 8, 512, 1), (2, 4096, 16, 16, 512, 1)], ids=str)
+def test_winograd_dgrad(n, c, h, w, k, dil, monkeypatch):
+    """data gradient in the Winograd domain (input transform from the h2 planes of dz, the forward's batched GEMM on U' = the
+    transformed flipped / transposed weights of the weight preparation, output transform into dx) against a float64 data gradient
+    and against the direct h2 data-gradient kernel (same error class)"""
+    from mit_semseg import ops, _native
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    monkeypatch.setattr(ops, 'WINOGRAD', True)
+    monkeypatch.setattr(ops, 'WINOGRAD_DGRAD', True)
+    monkeypatch.setattr(ops, 'WINOGRAD_MIN_C', 32)
+    L = _native.lib()
+    g = torch.Generator().manual_seed(n * 1000 + c + dil + 11)
+    wt = torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    wt.view(-1)[::991] *= 25.0
+    dz = torch.randn(n, k, h, w, generator=g) * 1e-3
+    dz.view(-1)[::1013] *= 20.0
+    ref = torch.nn.grad.conv2d_input((n, c, h, w), wt.double(), dz.double(), stride=1, padding=dil, dilation=dil)
+    geom = (n, h, w, c, k, 3, 3, 1, dil, dil)
+    wp = torch.nn.Parameter(cl(wt))
+    ops.prepare_conv_weights([wp])
+    ut = ops.weight_wino_t(wp)
+    assert ut is not None
+    dzp = ops.SCHEMES['h2'].split(cl(dz).permute(0, 2, 3, 1), n * h * w, k, k)
+    dx = ops._winograd_dgrad(L, dzp, ut, geom)
+    torch.cuda.synchronize()
+    assert dx.shape == ref.shape
+    e_wino = rel_err(dx, ref)
+    _, wtp = ops.weight_planes(wp, 'h2')
+    dx_direct, _ = ops._split_conv_grads(L, ops.SCHEMES['h2'], 'h2', geom, None, dzp, wp.detach(), wtp, True, False)
+    torch.cuda.synchronize()
+    e_direct = rel_err(dx_direct, ref)
+    print('winograd dgrad %s: rel err %.2e (direct kernel %.2e)' % ((n, c, h, w, k, dil), e_wino, e_direct))
+    assert e_wino < REL * 4, (e_wino, e_direct)
+
+
 def test_conv_bn_act_winograd_wgrad_matches_direct(monkeypatch):
     """the fused node with SEMSEG_WINOGRAD_WGRAD: same weight gradient as the direct wgrad kernels and as float64"""
     from mit_semseg import ops
