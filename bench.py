@@ -141,11 +141,24 @@ def variable_feeds(dev, rank, cfg, count, distinct=0):
     return shapes, pool
 
 
+def dominant_is_winograd(cfg):
+    """the dominant launch of the step is the data gradient of the widest 3x3 conv of the head; since round 3 that pass runs in the
+    Winograd domain when the layer is eligible (ops.WINOGRAD_DGRAD: 3x3, stride 1, pad == dil, C >= WINOGRAD_MIN_C, K >= 256)"""
+    from mit_semseg import ops
+    pass_id, geom, _ = cfg['dominant']
+    n, h, w, c, k, r, s, stride, pad, dil = geom
+    return (pass_id == 1 and ops.CONV_MODE == 'h2' and ops.FUSE and ops.WINOGRAD_DGRAD and stride == 1 and pad == dil and
+            ops._wino_eligible(k, c, r, s) and ops._wino_dgrad_eligible(k))
+
+
 def time_dominant_kernel(dev, cfg, iters=10):
-    """HIP-event timing of the dominant kernel of the step (CONFIGS[..]['dominant']; for configs[1] the implicit-GEMM DATA
-    GRADIENT of decoder.conv_last.0, 3x3 4096->512 @64x64, N=2: 309.24 GFLOP, 12.6 % of the step's FLOPs) through the C ABI on
-    pre-split operands, i.e. ONLY the conv entry point (igemm_dma_kernel<SchH2,...> on the default h2 path, tuned plan) on the
-    stream it is launched on (torch's current stream).  Returns (seconds per launch, GFLOP per launch)."""
+    """HIP-event timing of the dominant kernel of the step (CONFIGS[..]['dominant']; for configs[1] the DATA GRADIENT of
+    decoder.conv_last.0, 3x3 4096->512 @64x64, N=2: 309.24 GFLOP, 12.6 % of the step's FLOPs) through the C ABI on pre-split
+    operands, on the stream it is launched on (torch's current stream).  Returns (seconds per pass, GFLOP per pass, extras).
+    Direct form: ONE launch (igemm_dma_kernel<SchH2,...>, tuned plan).  Winograd form (dominant_is_winograd): the pass is three
+    launches -- input transform from the planes of dy, the batched GEMM over the 16 frequencies (the dominant launch), output
+    transform -- and the time returned is that of ALL THREE (the algorithmic FLOPs of the layer are what the three produce
+    together); the GEMM launch alone is timed as well (extras)."""
     import ctypes
     from mit_semseg import ops, _native, tuner
     L = _native.lib()
@@ -155,6 +168,33 @@ def time_dominant_kernel(dev, cfg, iters=10):
     gflop = 2.0 * n * h * w * c * k * r * s * 1e-9
     st = lambda: vp(torch.cuda.current_stream().cuda_stream)   # noqa: E731
     P = lambda t: vp(t.data_ptr())                              # noqa: E731
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+    if dominant_is_winograd(cfg):
+        wparam = torch.nn.Parameter((torch.randn(k, r, s, c, device=dev) * 0.01).permute(0, 3, 1, 2))      # KRSC memory
+        ops.prepare_conv_weights([wparam])
+        ut = ops.weight_wino_t(wparam)
+        dy = torch.randn(n, h, w, k, device=dev) * 1e-3
+        dyp = ops.SCHEMES['h2'].split(dy, n * h * w, k, k)
+        t_pass = timed(lambda: ops._winograd_dgrad(L, dyp, ut, geom))
+        tiles = L.semseg_winograd_tiles(n, h, w, dil)
+        v = torch.empty(L.semseg_split_h2_bytes(16 * tiles, k), dtype=torch.uint8, device=dev)
+        m = torch.empty((16 * tiles, c), dtype=torch.float32, device=dev)
+        _native.check(L.semseg_winograd_input_planes_h2(P(dyp), P(v), n, h, w, k, dil, st()), 'winograd_input_planes_h2')
+        t_gemm = timed(lambda: _native.check(L.semseg_winograd_gemm_h2(P(v), P(ut), P(m), tiles, k, c, st()), 'winograd_gemm_h2'))
+        plan = tuner.tuned_plans().get(('h2', 3, tiles, 1, 1, k, c, 3, 3, 1, 1, 1))
+        return t_pass, gflop, {'form': 'winograd', 'gemm_s': t_gemm, 'gemm_tile': plan[0] if plan else None,
+                               'executed_gflop': 3 * 16 * 2.0 * tiles * k * c * 1e-9}
     if pass_id == 1:
         a = torch.randn(n, h, w, k, device=dev) * 1e-3                 # dy
         wt = torch.randn(c, r, s, k, device=dev) * 0.01                # CRSK
@@ -183,29 +223,23 @@ def time_dominant_kernel(dev, cfg, iters=10):
                 _native.check(L.semseg_conv2d_dgrad(P(a), k, P(wt), P(out), c, *geom, P(ws), ws.numel(), st()), 'dgrad')
             else:
                 _native.check(L.semseg_conv2d_fwd(P(a), c, P(wt), vp(0), P(out), k, *geom, P(ws), ws.numel(), st()), 'fwd')
-    for _ in range(2):
-        launch()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        launch()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3, gflop
+    return timed(launch), gflop, {'form': 'direct'}
 
 
-def roofline_entry(kt, gflop, cfg, cfg_id):
-    """bound = MFMA.  `achieved` is ALGORITHMIC conv TFLOP/s (2*MACs of the layer / kernel time)."""
+def roofline_entry(kt, gflop, cfg, cfg_id, extras=None):
+    """bound = MFMA.  `achieved` is ALGORITHMIC conv TFLOP/s (2*MACs of the layer / time of the pass)."""
     from mit_semseg import ops, tuner
+    extras = extras or {'form': 'direct'}
     achieved = gflop / kt * 1e-3
     pass_id, geom, layer = cfg['dominant']
     what_pass = 'data gradient' if pass_id == 1 else 'forward'
-    plan = tuner.tuned_plans().get((ops.CONV_MODE, pass_id) + tuple(geom))
-    pmc = pmc_lookup(ops.CONV_MODE, pass_id, geom, plan)
+    wino = extras.get('form') == 'winograd'
+    plan = None if wino else tuner.tuned_plans().get((ops.CONV_MODE, pass_id) + tuple(geom))
+    pmc = None if wino else pmc_lookup(ops.CONV_MODE, pass_id, geom, plan)
     if pmc is None:
-        print('[bench] no PMC pass in profiles/pmc_index.json for %s pass %d %s plan %s: roofline.traffic is null'
-              % (ops.CONV_MODE, pass_id, list(geom), list(plan[:2]) if plan else None), file=sys.stderr, flush=True)
+        print('[bench] no PMC pass in profiles/pmc_index.json for the %s form of %s pass %d %s plan %s: roofline.traffic is null'
+              % (extras.get('form'), ops.CONV_MODE, pass_id, list(geom), list(plan[:2]) if plan else extras.get('gemm_tile')),
+              file=sys.stderr, flush=True)
     traffic = (2 * pmc['fetch_kib'] + pmc['write_kib']) * 1024 if pmc else None
     alg_bytes = algorithmic_bytes(pass_id, geom, ops.CONV_MODE)
     if ops.CONV_MODE in SPLIT_TERMS:
@@ -213,22 +247,34 @@ def roofline_entry(kt, gflop, cfg, cfg_id):
         # path's own ceiling is 2500/terms algorithmic TFLOP/s and its MFMA-pipe utilisation is terms*achieved/2500
         terms, inst, what = SPLIT_TERMS[ops.CONV_MODE]
         clock = pmc.get('clock_ghz') if pmc else None
+        if wino:
+            # Winograd F(2x2,3x3): the GEMM launch executes 16/36 of the direct MACs (x `terms` products each)
+            executed = extras['executed_gflop'] / extras['gemm_s'] * 1e-3
+            kernel = ('Winograd-domain %s of %s: input transform from the h2 planes of dy + ONE batched igemm_dma_kernel launch over '
+                      'the 16 frequencies (%s, tile id %s; the dominant launch: %.3f ms, %.1f executed 16-bit TFLOP/s) + output '
+                      'transform; achieved = the layer\'s %.2f algorithmic GFLOP / the %.3f ms of all three launches, HIP events'
+                      % (what_pass, layer, inst, extras.get('gemm_tile'), extras['gemm_s'] * 1e3, executed, gflop, kt * 1e3))
+        else:
+            executed = terms * achieved
+            kernel = ('split-%s implicit-GEMM %s (%s per fp32-accurate MAC block, %s), %s (%.2f GFLOP/launch algorithmic, '
+                      '%.3f ms/launch, HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE of the PMC pass named in pmc_source, '
+                      'bytes/launch)' % (ops.CONV_MODE, what_pass, what, inst, layer, gflop, kt * 1e3))
         return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), 'traffic': traffic,
-                'executed_16bit_mfma_tflops': round(terms * achieved, 1),
-                'mfma_pipe_utilisation': round(terms * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
-                'path_ceiling_tflops': round(PEAK_BF16_MFMA_TFLOPS / terms, 1),
-                'frac_of_path_ceiling': round(terms * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
+                'form': extras.get('form'),
+                'executed_16bit_mfma_tflops': round(executed, 1),
+                'mfma_pipe_utilisation': round(executed / PEAK_BF16_MFMA_TFLOPS, 4),
+                'path_ceiling_tflops': round(PEAK_BF16_MFMA_TFLOPS / terms * (2.25 if wino else 1.0), 1),
+                'frac_of_path_ceiling': round(achieved / (PEAK_BF16_MFMA_TFLOPS / terms * (2.25 if wino else 1.0)), 4),
                 'frac_of_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                 'algorithmic_bytes': alg_bytes,
                 'clock_ghz_under_load': clock,
-                'mfma_pipe_utilisation_at_measured_clock': round(terms * achieved / (PEAK_BF16_MFMA_TFLOPS * clock / 2.4), 4)
+                'mfma_pipe_utilisation_at_measured_clock': round(executed / (PEAK_BF16_MFMA_TFLOPS * clock / 2.4), 4)
                 if clock else None,
                 'pmc_source': pmc.get('source') if pmc else None,
-                'plan_tile_split': list(plan[:2]) if plan else None,
-                'kernel': 'split-%s implicit-GEMM %s (%s per fp32-accurate MAC block, %s), %s (%.2f GFLOP/launch algorithmic, '
-                          '%.3f ms/launch, HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE of the PMC pass named in pmc_source, '
-                          'bytes/launch)' % (ops.CONV_MODE, what_pass, what, inst, layer, gflop, kt * 1e3)}
+                'plan_tile_split': list(plan[:2]) if plan else ([extras.get('gemm_tile'), 1] if wino else None),
+                'dominant_launch_ms': round((extras['gemm_s'] if wino else kt) * 1e3, 4),
+                'kernel': kernel}
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic, 'algorithmic_bytes': alg_bytes,
             'pmc_source': pmc.get('source') if pmc else None,
@@ -507,7 +553,14 @@ def main():
     px = [h * w for h, w in shapes[args.warmup:]]
     gflop_img = cfg['gflop'] * (sum(px) / len(px)) / (512.0 * 512.0)
     if rank == 0:
-        kt, kgflop = time_dominant_kernel(dev, cfg)
+        try:
+            kt, kgflop, kextras = time_dominant_kernel(dev, cfg)
+        except Exception as e:                     # never lose the line to the roofline leg: fall back to the direct kernel
+            print('[bench] timing the dominant pass in its Winograd form failed (%r): timing the direct kernel instead' % (e,),
+                  file=sys.stderr, flush=True)
+            from mit_semseg import ops as _ops
+            _ops.WINOGRAD_DGRAD = False
+            kt, kgflop, kextras = time_dominant_kernel(dev, cfg)
         per_gpu = value / world
         out = {
             'metric': 'train images/sec (whole job) @%s bs2/GPU' % ('multi-scale variable-size' if cfg.get('variable') else '512x512'), 'value': round(value, 3), 'unit': 'images/sec',
@@ -535,7 +588,7 @@ def main():
                        'step_conv_tflops_per_gpu': round(per_gpu * gflop_img * 1e-3, 2),
                        'train_gflop_per_image': round(gflop_img, 1),
                        'final_loss': round(lossv, 5)},
-            'roofline': roofline_entry(kt, kgflop, cfg, args.config),
+            'roofline': roofline_entry(kt, kgflop, cfg, args.config, kextras),
         }
         if world != args.gpus:                  # cannot happen past the checks at the top; never print a mislabelled line
             raise SystemExit('[bench] world %d != --gpus %d' % (world, args.gpus))

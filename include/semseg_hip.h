@@ -118,16 +118,6 @@ size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R
 int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                          void* workspace, size_t workspace_bytes, void* stream);
-/* ---- the first convolution of a backbone (resnet.py:100, hrnet.py:278, mobilenet.py: 3x3 on the 3-channel image) ----
- * Dedicated streaming kernels for C <= 4 input channels, K <= 64 (K % 4 == 0) output channels: the forward reads the fp32 NHWC
- * image directly (exact fp32 FMAs, no split planes of the image), the weight gradient reads dy as the h2 planes the BN backward
- * kernel wrote and the image; there is no data gradient (the image needs none).  w / dw: [K][3][3][C] fp32 (KRSC). */
-int semseg_stem_conv3x3_supported(int C, int K);
-int semseg_stem_conv3x3_fwd(const float* x, int x_ld, const float* w, float* y, int y_ld, int N, int H, int W, int C, int K,
-                            int stride, int pad, int dil, void* stream);
-size_t semseg_stem_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int C, int K, int stride, int pad, int dil);
-int semseg_stem_conv3x3_wgrad_h2(const float* x, int x_ld, const void* dys, float* dw, int N, int H, int W, int C, int K,
-                                 int stride, int pad, int dil, void* workspace, size_t workspace_bytes, void* stream);
 /* semseg_conv2d_fwd_h2 (no bias) that ALSO gathers the BatchNorm statistics of its result in the GEMM epilogue -- the conv -> BN
  * pairs of resnet.py:72-92 / models.py:160-167 without the statistics sweep over the conv output: every wave writes the fp64
  * column sums / sums of squares and fp32 column min / max of its sub-tile as one partial row into stats_ws

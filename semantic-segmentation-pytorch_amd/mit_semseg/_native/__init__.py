@@ -45,10 +45,6 @@ SIGNATURES = {
     'semseg_absmax': (c_int, [vp, c_int, c_int, c_int, vp, vp, c_sz, vp]),
     'semseg_conv2d_h2_workspace_bytes': (c_sz, [c_int] * 10),
     'semseg_conv2d_fwd_h2': (c_int, [vp, vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
-    'semseg_stem_conv3x3_supported': (c_int, [c_int, c_int]),
-    'semseg_stem_conv3x3_fwd': (c_int, [vp, c_int, vp, vp, c_int] + [c_int] * 8 + [vp]),
-    'semseg_stem_conv3x3_wgrad_workspace_bytes': (c_sz, [c_int] * 8),
-    'semseg_stem_conv3x3_wgrad_h2': (c_int, [vp, c_int, vp, vp] + [c_int] * 8 + [vp, c_sz, vp]),
     'semseg_conv2d_fwd_stats_bytes': (c_sz, [c_int]),
     'semseg_conv2d_fwd_stats_h2': (c_int, [vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp, c_sz, vp, ctypes.POINTER(c_int), vp]),
     'semseg_conv2d_dgrad_h2': (c_int, [vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),

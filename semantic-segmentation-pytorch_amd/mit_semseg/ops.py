@@ -379,8 +379,6 @@ def absmax_of(t):
 # against 56 us on the 16-wave form the tuner now pins as plan pass 3).  SEMSEG_WINOGRAD=0 disables.
 WINOGRAD = os.environ.get('SEMSEG_WINOGRAD', '1') != '0'
 WINOGRAD_MIN_C = int(os.environ.get('SEMSEG_WINOGRAD_MIN_C', '512'))
-# the 3-channel first conv of a backbone through the dedicated kernels of csrc/stem.hip (0 = the implicit GEMM on padded planes)
-STEM_DIRECT = os.environ.get('SEMSEG_STEM_DIRECT', '1') != '0'
 # the BN statistics of a conv -> BN pair gathered in the conv's GEMM epilogue instead of by a sweep over its output (ConvBNActFn);
 # SEMSEG_EPILOGUE_STATS=0: the separate statistics kernel (A/B switch, tests/test_gpu_models.py SWITCH_CASES)
 EPILOGUE_STATS = os.environ.get('SEMSEG_EPILOGUE_STATS', '1') != '0'
@@ -902,7 +900,7 @@ class ConvBNActFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg, box):
         wut = box.get('wino_t')             # U' planes of the Winograd data gradient (None: direct kernel)
-        stride, pad, dil, momentum, eps, relu, emit, stem = cfg
+        stride, pad, dil, momentum, eps, relu, emit = cfg
         L = _native.lib()
         sch = SCHEMES['h2']
         w = krsc(weight.detach())
@@ -938,13 +936,7 @@ class ConvBNActFn(Function):
         bound = None if yp is not None else absmax            # no planes: the bound of |y| comes from the finish kernel itself
         parts = ctypes.c_int(0)
         stats_ws = None
-        x_img = None
-        if stem:
-            # the 3-channel image conv: dedicated streaming kernel on the fp32 image (csrc/stem.hip), no planes of the image
-            x_img, x_img_ld = as_nhwc(x.detach())
-            _native.check(L.semseg_stem_conv3x3_fwd(_p(x_img), x_img_ld, _p(w), _p(z), k, n, h, wd, c, k, stride, pad, dil, _st()),
-                          'stem_conv3x3_fwd')
-        elif wino is None:
+        if wino is None:
             wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
             if fused_stats and EPILOGUE_STATS:
                 # the BN statistics of z are gathered in the GEMM epilogue (one partial row per wave row; csrc/conv_split.hip
@@ -1024,9 +1016,8 @@ class ConvBNActFn(Function):
                                                 _st()), 'bn_apply')
         # the ReLU gate of a BN without residual is recomputed from z in backward: y need not be kept for it
         keep_y = relu and residual is not None and gate is None
-        ctx.save_for_backward(xp if x_img is None else x_img, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate, wut)
+        ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate, wut)
         ctx.geom = geom
-        ctx.stem = x_img is not None
         ctx.cfg = (bool(relu), residual is not None)
         box['planes'], box['absmax'] = yp, absmax
         return y
@@ -1084,18 +1075,6 @@ class ConvBNActFn(Function):
                                                _p(bb), _st()), 'bn_bwd_apply_h2')
         need_dw = ctx.needs_input_grad[1]
         dw_wino = None
-        if ctx.stem:
-            # xp is the fp32 image here; the image needs no gradient (conv_bn_act takes this path only then)
-            dw = None
-            if need_dw:
-                x_img, x_img_ld = as_nhwc(xp)
-                dwb = torch.empty((k, r, s, c), device=dev, dtype=torch.float32)
-                wsb = workspace(L.semseg_stem_conv3x3_wgrad_workspace_bytes(n, h, wd, c, k, stride, pad, dil), dev)
-                _native.check(L.semseg_stem_conv3x3_wgrad_h2(_p(x_img), x_img_ld, _p(dzp), _p(dwb), n, h, wd, c, k, stride, pad, dil,
-                                                             _p(wsb), wsb.numel(), _st()), 'stem_conv3x3_wgrad_h2')
-                dw = dwb.permute(0, 3, 1, 2)
-            return (None, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None, dres,
-                    None, None, None, None, None, None, None, None, None)
         if wino_v is not None and need_dw:
             dw_wino = _winograd_wgrad(L, wino_v, dzp, geom)
             need_dw = False
@@ -1124,10 +1103,7 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
     _require_cuda(x)
     wp, wtp = weight_planes(weight, 'h2')
     kk, cc, rr, ss = weight.shape
-    # the first conv of a backbone (3-channel image): csrc/stem.hip instead of a 32-channel-padded implicit GEMM
-    stem = STEM_DIRECT and rr == 3 and ss == 3 and not x.requires_grad and x.is_cuda and \
-        bool(_native.lib().semseg_stem_conv3x3_supported(int(cc), int(kk)))
-    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu), stem)
+    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu))
     box = {}
     if int(stride) == 1 and int(padding) == int(dilation) and _wino_eligible(kk, cc, rr, ss):
         xb = bounds_of(x)
@@ -1137,9 +1113,7 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
         if x.requires_grad and _wino_dgrad_eligible(kk):
             box['wino_t'] = weight_wino_t(weight)        # the data gradient in the Winograd domain needs no bound: dz comes as planes
     n, c, h, w = x.shape
-    if stem:
-        xp = None
-    elif box.get('wino') is not None and ((WINOGRAD_WGRAD and c >= WINOGRAD_WGRAD_MIN_C) or not weight.requires_grad):
+    if box.get('wino') is not None and ((WINOGRAD_WGRAD and c >= WINOGRAD_WGRAD_MIN_C) or not weight.requires_grad):
         xp = planes_of(x, 'h2', n * h * w, c)        # Winograd forward and weight gradient work on V: x needs no planes
     else:
         xp = input_planes(x, 'h2')

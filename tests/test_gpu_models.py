@@ -294,7 +294,6 @@ SWITCH_CASES = [
     ('SEMSEG_WINOGRAD_MIN_C=1024', 'r50d_ppmds_64_train'),   # round 2's threshold: layer4's 512-channel convs direct
     ('SEMSEG_TUNE=0', 'r50d_ppmds_64_train'),                # the library's heuristic launch plans
     ('SEMSEG_EPILOGUE_STATS=0', 'r50d_ppmds_64_train'),
-    ('SEMSEG_STEM_DIRECT=0', 'r18d_ppmds_64_train'),          # the image conv through the implicit GEMM on padded planes
       # BN statistics by the separate sweep instead of the conv epilogue
     ('SEMSEG_TUNE_BUCKETS=0', 'r18d_ppmds_64_train'),
     ('SEMSEG_FORCE_SYNC_PATH=1', 'r18d_ppmds_64_train'),     # the unfused SyncBN kernel sequence on one rank

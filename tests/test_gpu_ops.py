@@ -771,42 +771,6 @@ def test_conv_epilogue_statistics_match_the_sweep(case, tile):
             L.semseg_conv2d_h2_set_plan(0, *geom, -1, 0)
 
 
-@pytest.mark.parametrize('n,c,h,w,k,stride,pad,dil', [(2, 3, 64, 64, 64, 2, 1, 1), (1, 3, 37, 53, 64, 2, 1, 1), (2, 3, 40, 24, 32, 2, 1, 1),
-                                                      (1, 4, 19, 21, 16, 1, 2, 2), (2, 3, 512, 512, 64, 2, 1, 1)], ids=str)
-def test_stem_conv_kernels_vs_float64(n, c, h, w, k, stride, pad, dil):
-    """csrc/stem.hip (the first conv of every backbone, resnet.py:100 / hrnet.py:278 / mobilenet.py: 3x3 on the 3-channel image):
-    forward from the fp32 image and weight gradient from the h2 planes of dy, against torch's float64 convolution"""
-    import ctypes
-    from mit_semseg import ops, _native
-    L = _native.lib()
-    vp = ctypes.c_void_p
-    assert L.semseg_stem_conv3x3_supported(c, k) == 1 and L.semseg_stem_conv3x3_supported(8, 64) == 0
-    g = torch.Generator().manual_seed(h * 7 + k)
-    x = torch.randn(n, c, h, w, generator=g)
-    wt = torch.randn(k, c, 3, 3, generator=g) * 0.2
-    xr, wr = x.double(), wt.double().requires_grad_(True)
-    yr = F.conv2d(xr, wr, None, stride, pad, dil)
-    gy = torch.randn(yr.shape, generator=g) * 1e-3
-    yr.backward(gy.double())
-    oh, ow = yr.shape[2:]
-    xg = x.permute(0, 2, 3, 1).contiguous().to(dev())                   # NHWC, ld = c
-    wg = wt.permute(0, 2, 3, 1).contiguous().to(dev())                  # KRSC
-    y = torch.empty(n, oh, ow, k, device=dev())
-    st = vp(torch.cuda.current_stream().cuda_stream)
-    _native.check(L.semseg_stem_conv3x3_fwd(vp(xg.data_ptr()), c, vp(wg.data_ptr()), vp(y.data_ptr()), k, n, h, w, c, k, stride, pad, dil,
-                                            st), 'stem fwd')
-    torch.cuda.synchronize()
-    assert rel_err(y.permute(0, 3, 1, 2), yr) < 2e-6
-    dy = gy.permute(0, 2, 3, 1).contiguous().to(dev())
-    dyp = ops.SCHEMES['h2'].split(dy, n * oh * ow, k, k)
-    dw = torch.empty(k, 3, 3, c, device=dev())
-    ws = torch.empty(max(256, L.semseg_stem_conv3x3_wgrad_workspace_bytes(n, h, w, c, k, stride, pad, dil)), dtype=torch.uint8, device=dev())
-    _native.check(L.semseg_stem_conv3x3_wgrad_h2(vp(xg.data_ptr()), c, vp(dyp.data_ptr()), vp(dw.data_ptr()), n, h, w, c, k, stride, pad,
-                                                 dil, vp(ws.data_ptr()), ws.numel(), st), 'stem wgrad')
-    torch.cuda.synchronize()
-    assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2e-6          # dy carries 22 bits through its planes; fp64 across pixels
-
-
 def test_inference_weight_planes_follow_sgd_updates(monkeypatch):
     """no_grad forwards build the weight planes once and keep them; the fused SGD kernel (which updates parameters behind
     torch's version counter) must invalidate them"""
