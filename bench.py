@@ -51,15 +51,15 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_32x32x16
 PMC_INDEX = os.path.join(ROOT, 'profiles', 'pmc_index.json')
 
 
-def pmc_lookup(mode, pass_id, geom, plan):
+def pmc_lookup(mode, pass_id, geom, plan, form='direct'):
     try:
         entries = json.load(open(PMC_INDEX))['entries']
     except (OSError, ValueError, KeyError):
         return None
-    if plan is None:
+    if plan is None or plan[0] is None:
         return None
     for e in entries:
-        if e['mode'] == mode and e['pass'] == pass_id and list(e['geom']) == list(geom) and \
+        if e['mode'] == mode and e['pass'] == pass_id and list(e['geom']) == list(geom) and e.get('form', 'direct') == form and \
                 [e['tile'], e['split']] == list(plan[:2]):
             return e
     return None
@@ -234,11 +234,11 @@ def roofline_entry(kt, gflop, cfg, cfg_id, extras=None):
     pass_id, geom, layer = cfg['dominant']
     what_pass = 'data gradient' if pass_id == 1 else 'forward'
     wino = extras.get('form') == 'winograd'
-    plan = None if wino else tuner.tuned_plans().get((ops.CONV_MODE, pass_id) + tuple(geom))
-    pmc = None if wino else pmc_lookup(ops.CONV_MODE, pass_id, geom, plan)
+    plan = (extras.get('gemm_tile'), 1) if wino else tuner.tuned_plans().get((ops.CONV_MODE, pass_id) + tuple(geom))
+    pmc = pmc_lookup(ops.CONV_MODE, pass_id, geom, plan, 'winograd' if wino else 'direct')
     if pmc is None:
         print('[bench] no PMC pass in profiles/pmc_index.json for the %s form of %s pass %d %s plan %s: roofline.traffic is null'
-              % (extras.get('form'), ops.CONV_MODE, pass_id, list(geom), list(plan[:2]) if plan else extras.get('gemm_tile')),
+              % (extras.get('form'), ops.CONV_MODE, pass_id, list(geom), list(plan[:2]) if plan else None),
               file=sys.stderr, flush=True)
     traffic = (2 * pmc['fetch_kib'] + pmc['write_kib']) * 1024 if pmc else None
     alg_bytes = algorithmic_bytes(pass_id, geom, ops.CONV_MODE)
@@ -252,7 +252,9 @@ def roofline_entry(kt, gflop, cfg, cfg_id, extras=None):
             executed = extras['executed_gflop'] / extras['gemm_s'] * 1e-3
             kernel = ('Winograd-domain %s of %s: input transform from the h2 planes of dy + ONE batched igemm_dma_kernel launch over '
                       'the 16 frequencies (%s, tile id %s; the dominant launch: %.3f ms, %.1f executed 16-bit TFLOP/s) + output '
-                      'transform; achieved = the layer\'s %.2f algorithmic GFLOP / the %.3f ms of all three launches, HIP events'
+                      'transform; achieved = the layer\'s %.2f algorithmic GFLOP / the %.3f ms of all three launches, HIP events; '
+                      'traffic = FETCH_SIZE*2+WRITE_SIZE summed over the three launches (PMC pass named in pmc_source): the fp32 '
+                      'intermediate of the 16 frequencies is written and read back'
                       % (what_pass, layer, inst, extras.get('gemm_tile'), extras['gemm_s'] * 1e3, executed, gflop, kt * 1e3))
         else:
             executed = terms * achieved
@@ -272,7 +274,7 @@ def roofline_entry(kt, gflop, cfg, cfg_id, extras=None):
                 'mfma_pipe_utilisation_at_measured_clock': round(executed / (PEAK_BF16_MFMA_TFLOPS * clock / 2.4), 4)
                 if clock else None,
                 'pmc_source': pmc.get('source') if pmc else None,
-                'plan_tile_split': list(plan[:2]) if plan else ([extras.get('gemm_tile'), 1] if wino else None),
+                'plan_tile_split': list(plan[:2]) if plan else None,
                 'dominant_launch_ms': round((extras['gemm_s'] if wino else kt) * 1e3, 4),
                 'kernel': kernel}
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

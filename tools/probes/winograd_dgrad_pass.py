@@ -1,0 +1,41 @@
+"""The dominant pass of the configs[1] step since round 3 -- the Winograd-domain data gradient of decoder.conv_last.0 (3x3, 4096 <- 512
+@ 64 x 64, N = 2) -- launched `--iters` times through the C ABI, for rocprofv3 (kernel trace / PMC passes, tools/gpu_pmc_wino.sh):
+input transform from the planes of dy, the batched GEMM on its tuned tile, output transform."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--tile', type=int, default=14)
+    args = ap.parse_args()
+    from mit_semseg import ops, _native
+    L = _native.lib()
+    dev = torch.device('cuda:0')
+    n, h, w, c, k, dil = 2, 64, 64, 4096, 512, 1
+    geom = (n, h, w, c, k, 3, 3, 1, dil, dil)
+    wparam = torch.nn.Parameter((torch.randn(k, 3, 3, c, device=dev) * 0.01).permute(0, 3, 1, 2))
+    ops.prepare_conv_weights([wparam])
+    ut = ops.weight_wino_t(wparam)
+    dy = torch.randn(n, h, w, k, device=dev) * 1e-3
+    dyp = ops.SCHEMES['h2'].split(dy, n * h * w, k, k)
+    tiles = L.semseg_winograd_tiles(n, h, w, dil)
+    from mit_semseg import tuner
+    tuner.ENABLED = False
+    _native.check(L.semseg_conv2d_h2_set_plan(3, tiles, 1, 1, k, c, 3, 3, 1, 1, 1, args.tile, 1), 'set_plan')
+    for _ in range(args.iters):
+        ops._winograd_dgrad(L, dyp, ut, geom)
+    torch.cuda.synchronize()
+    print('done: %d passes, tiles %d, gemm tile %d' % (args.iters, tiles, args.tile))
+
+
+if __name__ == '__main__':
+    main()
