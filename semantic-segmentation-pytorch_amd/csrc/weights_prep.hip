@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void wprep_wino_t_kernel(const WPrepBatch b, i
 extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host, int n, void* stream) {
     if (!tensors_host || n < 0) return SEMSEG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int pitch_pad = split_pitch(1024) - 1024;      // the skew in effect (SEMSEG_S3_PITCH_PAD)
+    const int pitch_pad = split_pitch(1024) - 1024;      // the skew split_layout.h applies to power-of-two pitches
     for (int base = 0; base < n; base += WPREP_MAX_TENSORS) {
         WPrepBatch b;
         b.n = min(WPREP_MAX_TENSORS, n - base);
