@@ -110,6 +110,12 @@ int semseg_conv2d_s3_set_plan(int pass, int N, int H, int W, int C, int K, int R
  * fp32 summation order differs); tests/test_gpu_ops.py::test_h2_conv_every_tile_pinned runs each one. */
 size_t semseg_split_h2_bytes(int rows, int C);
 int semseg_split_h2(const float* x, int x_ld, void* xs, int rows, int C, void* stream);
+/* semseg_split_h2 when an upper bound of max|x| is known as `nbounds` (<= 8) DEVICE scalars (max of them is used): one launch,
+ * no absmax pass over x.  semseg_bound_sum: out[0] = the sum of such scalars (rounded up) -- the bound of a sum of tensors
+ * (hrnet.py:231-248) from the bounds of its terms. */
+int semseg_split_h2_bounds(const float* x, int x_ld, void* xs, int rows, int C, const float* const* bounds_host, int nbounds,
+                           void* stream);
+int semseg_bound_sum(const float* const* bounds_host, int nbounds, float* out, void* stream);
 /* out[0] = max |x| over the fp32 window [rows][0..C) with row stride x_ld (a NaN anywhere gives NaN); workspace >= 4 KiB.
  * The bound the Winograd input transform needs when no producer kernel carried one (evaluation-mode forward). */
 int semseg_absmax(const float* x, int x_ld, int rows, int C, float* out, void* workspace, size_t workspace_bytes,

@@ -305,6 +305,109 @@ extern "C" int semseg_split_h2(const float* x, int x_ld, void* xs, int rows, int
     return 0;
 }
 
+// The same split when an UPPER BOUND of max|x| is already known as device scalars (BN outputs of the fused chain carry one;
+// max over the inputs of a concat / pooling window): the exponent comes from the bound(s) -- any upper bound will do, h2_exponent
+// -- and the absmax pass over x is not needed: one launch instead of two.
+struct SplitBounds {
+    const float* p[8];
+    int n;
+};
+template <bool VEC>
+__global__ __launch_bounds__(256) void split_h2_bounds_kernel(const float* __restrict__ x, int x_ld, uint16_t* __restrict__ out,
+                                                              int rows, int C, int Cp, int pitch, size_t plane, SplitBounds b,
+                                                              int* __restrict__ hdr) {
+    float bound = 0.f;
+    bool bad = false;
+    for (int i = 0; i < b.n; ++i) {
+        const float v = b.p[i][0];
+        bad = bad || !(v == v);
+        bound = fmaxf(bound, v);
+    }
+    const int ex = h2_exponent(bad ? 0x7fc00000u : __float_as_uint(bound));
+    const float sc = pow2i(ex);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16) reinterpret_cast<uint4*>(out + 2 * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) hdr[0] = ex;
+    }
+    const int G = Cp >> 3;
+    const size_t total = (size_t)rows * G;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int row = (int)(idx / G);
+        const int c = (int)(idx - (size_t)row * G) << 3;
+        float v[8];
+        const float* src = x + (size_t)row * x_ld + c;
+        if (VEC && c + 8 <= C) {
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 bb = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bb.x; v[5] = bb.y; v[6] = bb.z; v[7] = bb.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (c + e < C) ? src[e] : 0.f;
+        }
+        f16x8 p0, p1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 h0, h1;
+            h2_split_of(v[e] * sc, h0, h1);
+            p0[e] = h0;
+            p1[e] = h1;
+        }
+        const size_t o = (size_t)row * pitch + c;
+        *reinterpret_cast<f16x8*>(out + o) = p0;
+        *reinterpret_cast<f16x8*>(out + plane + o) = p1;
+    }
+}
+
+extern "C" int semseg_split_h2_bounds(const float* x, int x_ld, void* xs, int rows, int C, const float* const* bounds_host,
+                                      int nbounds, void* stream) {
+    if (!x || !xs || rows <= 0 || C <= 0 || x_ld < C || !bounds_host || nbounds <= 0 || nbounds > 8) return SEMSEG_EINVAL;
+    SplitBounds b;
+    b.n = nbounds;
+    for (int i = 0; i < 8; ++i) b.p[i] = i < nbounds ? bounds_host[i] : nullptr;
+    for (int i = 0; i < nbounds; ++i)
+        if (!b.p[i]) return SEMSEG_EINVAL;
+    const int Cp = round_up32(C), pitch = split_pitch(C);
+    const size_t plane = (size_t)rows * pitch;
+    int* hdr = const_cast<int*>(h2_exp_ptr(xs, (size_t)rows, C));
+    const bool vec = (x_ld % 4 == 0) && aligned16(x);
+    const size_t total = (size_t)rows * (Cp >> 3);
+    const int blocks = (int)min((size_t)16384, ceil_div_sz(total, 256));
+    if (vec)
+        hipLaunchKernelGGL(split_h2_bounds_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs, rows,
+                           C, Cp, pitch, plane, b, hdr);
+    else
+        hipLaunchKernelGGL(split_h2_bounds_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs,
+                           rows, C, Cp, pitch, plane, b, hdr);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[0] = sum of `n` (<= 8) non-negative device scalars: the bound of |a + b + ...| from the bounds of the terms (the exchange
+// sums of hrnet.py:231-248, whose result feeds the residual branch of the next module's blocks: without a bound of it the BN
+// kernels of those blocks cannot bound their own outputs and every conv of the branch falls back to absmax + split passes)
+__global__ void bound_sum_kernel(SplitBounds b, float* __restrict__ out) {
+    float s = 0.f;
+    bool bad = false;
+    for (int i = 0; i < b.n; ++i) {
+        const float v = b.p[i][0];
+        bad = bad || !(v == v);
+        s += v;
+    }
+    out[0] = bad ? __uint_as_float(0x7fc00000u) : s * 1.0000005f;      // rounded up: stays an upper bound of the exact sum
+}
+
+extern "C" int semseg_bound_sum(const float* const* bounds_host, int nbounds, float* out, void* stream) {
+    if (!bounds_host || !out || nbounds <= 0 || nbounds > 8) return SEMSEG_EINVAL;
+    SplitBounds b;
+    b.n = nbounds;
+    for (int i = 0; i < 8; ++i) b.p[i] = i < nbounds ? bounds_host[i] : nullptr;
+    for (int i = 0; i < nbounds; ++i)
+        if (!b.p[i]) return SEMSEG_EINVAL;
+    hipLaunchKernelGGL(bound_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, b, out);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 // max |x| of an fp32 [rows][x_ld] window as ONE device scalar (the bound the Winograd input transform scales by when no producer
 // kernel left one: the evaluation-mode forward, where BN applies running statistics and carries no min / max)
 __global__ __launch_bounds__(256) void absmax_finish_kernel(const uint32_t* __restrict__ partial, int npartial,

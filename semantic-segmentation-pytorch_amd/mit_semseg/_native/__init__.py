@@ -42,6 +42,8 @@ SIGNATURES = {
     'semseg_conv2d_s3_set_plan': (c_int, [c_int] * 13),
     'semseg_split_h2_bytes': (c_sz, [c_int, c_int]),
     'semseg_split_h2': (c_int, [vp, c_int, vp, c_int, c_int, vp]),
+    'semseg_split_h2_bounds': (c_int, [vp, c_int, vp, c_int, c_int, ctypes.POINTER(vp), c_int, vp]),
+    'semseg_bound_sum': (c_int, [ctypes.POINTER(vp), c_int, vp, vp]),
     'semseg_absmax': (c_int, [vp, c_int, c_int, c_int, vp, vp, c_sz, vp]),
     'semseg_conv2d_h2_workspace_bytes': (c_sz, [c_int] * 10),
     'semseg_conv2d_fwd_h2': (c_int, [vp, vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),

@@ -131,15 +131,21 @@ class HighResolutionModule(nn.Module):
         for i in range(len(self.fuse_layers)):
             # same left-to-right summation order as hrnet.py:232-248
             y = x[0] if i == 0 else self.fuse_layers[i][0](x[0])
+            bounds = [ops.absmax_of(y)]                     # |sum| <= sum of the terms' bounds (up-sampling is a convex combination)
             last = self.num_branches - 1
             for j in range(1, self.num_branches):
                 relu = j == last                            # the final ReLU (hrnet.py:248) rides on the last add
-                if j == i:
-                    y = ops.add_act(y, x[j], relu=relu)
-                elif j > i:
-                    y = ops.interpolate_bilinear(self.fuse_layers[i][j](x[j]), x[i].shape[2:], base=y, relu=relu)
+                t = x[j] if j == i else self.fuse_layers[i][j](x[j])
+                bounds.append(ops.absmax_of(t))
+                if j > i:
+                    y = ops.interpolate_bilinear(t, x[i].shape[2:], base=y, relu=relu)
                 else:
-                    y = ops.add_act(y, self.fuse_layers[i][j](x[j]), relu=relu)
+                    y = ops.add_act(y, t, relu=relu)
+            if all(b is not None for b in bounds):
+                # the exchange output feeds the residual branch of the next module's blocks: with a bound of it their BN kernels
+                # can bound (and emit the split planes of) their own outputs -- without, every conv of the next branch pays an
+                # absmax + split pass over its input (115 such pairs per HRNetV2 step before round 3)
+                ops.attach_absmax(y, ops.bound_sum(bounds))
             fused.append(y)
         return fused
 

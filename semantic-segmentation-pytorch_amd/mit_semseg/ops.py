@@ -343,10 +343,32 @@ def input_planes(x, scheme):
     xp = planes_of(x, scheme, n * h * w, c)
     if xp is None:
         xn, ld = as_nhwc(x.detach())
-        xp = SCHEMES[scheme].split(xn, n * h * w, c, ld)
+        bounds = bounds_of(x) if scheme == 'h2' else None
+        if bounds is not None and len(bounds) <= 8:
+            # an upper bound of max|x| travels with the tensor (BN outputs, pooling / concat / sums of them): the exponent comes
+            # from it and the absmax pass over x is skipped -- one launch instead of two (h2_exponent accepts any upper bound)
+            L = _native.lib()
+            xp = torch.empty(L.semseg_split_h2_bytes(n * h * w, c), dtype=torch.uint8, device=xn.device)
+            bp = (vp * len(bounds))(*[b.data_ptr() for b in bounds])
+            _native.check(L.semseg_split_h2_bounds(_p(xn), ld, _p(xp), n * h * w, c, bp, len(bounds), _st()), 'split_h2_bounds')
+        else:
+            xp = SCHEMES[scheme].split(xn, n * h * w, c, ld)
         if FUSE:
             attach_planes(x, xp, scheme, n * h * w, c)
     return xp
+
+
+def bound_sum(bounds):
+    """one device scalar >= sum of the given bound scalars: the bound of |t1 + t2 + ...| from bounds of the terms"""
+    bounds = list(bounds)
+    if len(bounds) == 1:
+        return bounds[0]
+    if not 1 <= len(bounds) <= 8:
+        raise ValueError('bound_sum takes 1 ... 8 bound scalars')
+    out = torch.empty((1,), device=bounds[0].device, dtype=torch.float32)
+    bp = (vp * len(bounds))(*[b.data_ptr() for b in bounds])
+    _native.check(_native.lib().semseg_bound_sum(bp, len(bounds), _p(out), _st()), 'bound_sum')
+    return out
 
 
 def attach_absmax(t, bounds):

@@ -344,6 +344,44 @@ def _h2_decode(buf, rows, ch):
     return val.cpu(), e, raw, tail
 
 
+@pytest.mark.parametrize('rows,c,ld', [(4096, 96, 96), (300, 150, 160), (77, 24, 40), (8192, 512, 512)], ids=str)
+def test_split_h2_with_known_bounds_and_bound_sum(rows, c, ld):
+    """semseg_split_h2_bounds: with the exact max|x| as the bound the planes are those of semseg_split_h2 bit for bit; with bounds
+    that are loose by 3x (two of them, the larger counts) the planes still reconstruct x to 2^-21 of the bound; semseg_bound_sum
+    gives a scalar >= the sum of its terms"""
+    import ctypes
+    from mit_semseg import ops, _native
+    L = _native.lib()
+    vp = ctypes.c_void_p
+    g = torch.Generator().manual_seed(rows + c)
+    x = (torch.randn(rows, ld, generator=g) * 3.0).to(dev())
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    ref = ops.SCHEMES['h2'].split(x, rows, c, ld)
+    exact = x[:, :c].abs().max().reshape(1)
+
+    def split(bounds):
+        out = torch.empty(L.semseg_split_h2_bytes(rows, c), dtype=torch.uint8, device=dev())
+        bp = (vp * len(bounds))(*[b.data_ptr() for b in bounds])
+        _native.check(L.semseg_split_h2_bounds(vp(x.data_ptr()), ld, vp(out.data_ptr()), rows, c, bp, len(bounds), st), 'split_bounds')
+        torch.cuda.synchronize()
+        return out
+    got = split([exact])
+    v0, e0, raw0, tail0 = _h2_decode(ref, rows, c)
+    v1, e1, raw1, tail1 = _h2_decode(got, rows, c)
+    assert e0 == e1 and torch.equal(raw0, raw1) and int(tail1.max()) == 0
+    loose = split([exact * 0.5, exact * 3.0])
+    v2, e2, _, _ = _h2_decode(loose, rows, c)
+    assert e2 in (e0 - 1, e0 - 2)
+    err = (v2 - x[:, :c].double().cpu()).abs().max().item()
+    assert err <= 2.0 ** -21 * 3.0 * float(exact.item()), err
+    terms = [torch.rand(1, generator=g).to(dev()) * 10 ** k for k in range(4)]
+    s_out = ops.bound_sum(terms)
+    torch.cuda.synchronize()
+    want = sum(float(t.item()) for t in terms)
+    assert want <= float(s_out.item()) <= want * (1 + 1e-5)
+    assert ops.bound_sum(terms[:1]) is terms[0]
+
+
 @pytest.mark.parametrize('k,c,r', [(64, 3, 3), (64, 64, 3), (150, 512, 1), (512, 1024, 3), (48, 48, 3), (180, 720, 3),
                                    (2048, 1024, 1), (96, 48, 3), (512, 4096, 3)], ids=str)
 def test_weights_prepare_h2_matches_split(k, c, r):
