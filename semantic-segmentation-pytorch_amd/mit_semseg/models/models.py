@@ -363,7 +363,12 @@ class UPerNet(nn.Module):
         fpn_feature_list = [f]
         for i in reversed(range(len(conv_out) - 1)):
             lateral = self.fpn_in[i](conv_out[i])
+            bounds = (ops.absmax_of(lateral), ops.absmax_of(f))
             f = ops.interpolate_bilinear(f, lateral.shape[2:], base=lateral)     # top-down: lateral + up(f)
+            if bounds[0] is not None and bounds[1] is not None:
+                # |lateral + up(f)| <= bound(lateral) + bound(f): the 3x3 conv that follows then needs no absmax pass over the sum
+                # (and may take the Winograd forward, which scales its input transform by a bound)
+                ops.attach_absmax(f, ops.bound_sum(bounds))
             fpn_feature_list.append(self.fpn_out[i](f))
         fpn_feature_list.reverse()                                               # [P2 - P5]
         out_size = fpn_feature_list[0].shape[2:]
