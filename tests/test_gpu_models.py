@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.util import (golden_cases, load_golden, anchor_ratios, check_anchor_ratios, is_head_tensor, scale_error,
+from tests.util import (golden_cases, load_golden, anchor_ratios, check_anchor_ratios, is_head_tensor, scale_error, post_step_bands,
                         HEAD_SCALE_ERR, HEURISTIC_PLAN_GOLDEN, KNIFE_EDGE_GOLDEN)
 from oracle import semseg_oracle as O
 
@@ -101,7 +101,7 @@ def test_native_matches_reference_golden(name, monkeypatch):
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue
             items.append((side + k, sd[k], want[k]))
-    print(check_anchor_ratios(anchor_ratios(items), name + ' after-step state'))
+    print(check_anchor_ratios(anchor_ratios(items, post_step_bands(g, m['lr'])), name + ' after-step state'))
 
 
 def _native_grads(g, dev):

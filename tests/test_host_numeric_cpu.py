@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from tests import cpu_twin
-from tests.util import golden_cases, load_golden, check_summary, anchor_ratios, check_anchor_ratios, HEAVY_GOLDEN
+from tests.util import golden_cases, load_golden, check_summary, anchor_ratios, check_anchor_ratios, post_step_bands, HEAVY_GOLDEN
 from oracle import semseg_oracle as O
 
 
@@ -88,7 +88,7 @@ def _run_case(name, step_tol=(1e-4, 1e-3)):
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue
             items.append((side + k, sd[k].detach().contiguous(), want[k]))
-    print(check_anchor_ratios(anchor_ratios(items), name))
+    print(check_anchor_ratios(anchor_ratios(items, post_step_bands(g, g['meta']['lr'])), name))
 
 
 def test_mobilenet_golden_with_direct_depthwise_kernels_emulated(monkeypatch, tmp_path):

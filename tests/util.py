@@ -54,14 +54,14 @@ def sample_index(numel, k=1024):
     return torch.randint(0, numel, (k,), generator=torch.Generator().manual_seed(numel % (2 ** 31)))
 
 
-def anchor_ratio(got, rec, what, rel_band=0.0):
+def anchor_ratio(got, rec, what, rel_band=0.0, abs_band=0.0):
     """`got` against the float64 ANCHOR record of the reference (make_golden.anchor): how far the native result is from the
     exact (float64) result of the reference's arithmetic, in units of the reference's OWN fp32 reproducibility band (the
     largest deviation from float64 over five executions of the unmodified reference, see anchor()):
 
         ratio = max|got - ref64| / (band + floor)               elementwise, on the full tensor or its seeded sample
         (full tensors also: ||got - ref64||_2 / (band_l2 + floor sqrt(n)); the larger of the two is returned)
-        band  = max(band of THIS tensor, rel_band x max|ref64|)
+        band  = max(band of THIS tensor, rel_band x max|ref64|, abs_band)
 
     floor = fp32 representation of the anchor itself (1e-6 of max|ref64|).  `rel_band` (case_rel_band): the band of the TYPICAL
     tensor of the case relative to its scale.  Why a tensor's own band is not enough (tools/probes/anchor_control.py,
@@ -82,9 +82,10 @@ def anchor_ratio(got, rec, what, rel_band=0.0):
     else:
         ref, g = rec['sample'].double(), f[sample_index(rec['numel'])]
     d = (g - ref).abs()
-    ratio = d.max().item() / (max(rec['err_max'], rel_band * rec['absmax']) + floor)
+    ratio = d.max().item() / (max(rec['err_max'], rel_band * rec['absmax'], abs_band) + floor)
     if 'full' in rec:
-        ratio = max(ratio, d.norm().item() / (max(rec['err_l2'], rel_band * ref.norm().item()) + floor * rec['numel'] ** 0.5))
+        ratio = max(ratio, d.norm().item() / (max(rec['err_l2'], rel_band * ref.norm().item(), abs_band * rec['numel'] ** 0.5) +
+                                              floor * rec['numel'] ** 0.5))
     return ratio
 
 
@@ -94,11 +95,30 @@ def case_rel_band(records):
     return v[len(v) // 2] if v else 0.0
 
 
-def anchor_ratios(items):
+def anchor_ratios(items, abs_bands=None):
     """items: [(name, tensor, anchor record)] of ONE case -> [(ratio, name)] with the case-wide relative band as the lower limit
-    of every tensor's band (anchor_ratio)"""
+    of every tensor's band (anchor_ratio); abs_bands: {name: absolute lower limit} (post_step_bands)"""
     rel = case_rel_band([rec for _, _, rec in items])
-    return [(anchor_ratio(t, rec, name, rel), name) for name, t, rec in items]
+    abs_bands = abs_bands or {}
+    return [(anchor_ratio(t, rec, name, rel, abs_bands.get(name, 0.0)), name) for name, t, rec in items]
+
+
+def post_step_bands(g, lr):
+    """{parameter name ('enc.' / 'dec.' + key): lr x (band of its GRADIENT)} for the post-step state of golden `g`.  A parameter
+    after the first SGD step is w - lr (grad + wd w): its deviation from the anchor is lr times the deviation of its gradient, so it
+    inherits the gradient's yardstick -- the gradient's band with the case-wide relative band of the gradients as the lower limit
+    (anchor_ratio).  The reference's own post-step band of a tensor is again a sample of five executions: r18d_ppmds_64_train's
+    `layer4.1.bn2.bias` sits 0.02 gradient bands from the anchor and 17 of its own post-step bands (gpurun r4w), both the same
+    deviation."""
+    out = {}
+    for side in ('enc', 'dec'):
+        recs = g.get('anchor_grads_' + side)
+        if not recs:
+            continue
+        rel = case_rel_band(list(g['anchor_grads_enc'].values()) + list(g['anchor_grads_dec'].values()))
+        for k, rec in recs.items():
+            out[side + '.' + k] = lr * max(rec['err_max'], rel * rec['absmax'])
+    return out
 
 
 def is_head_tensor(key, p, num_class=150):

@@ -66,7 +66,7 @@ def worker():
                 if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                     continue
                 items.append((side + k, sd[k], want[k]))
-        med, p95, mx, worst, n = summarize(util.anchor_ratios(items))
+        med, p95, mx, worst, n = summarize(util.anchor_ratios(items, util.post_step_bands(g, m['lr'])))
         raw = max(util.anchor_ratio(t, rec, k) for k, t, rec in items)
         rows.append(dict(case=name, what='after-step', n=n, median=med, p95=p95, max=mx, worst=worst, raw_max=raw,
                          rel_band=util.case_rel_band([rec for _, _, rec in items]),
