@@ -128,14 +128,18 @@ class HighResolutionModule(nn.Module):
         # the branch streams too makes hipStreamEndCapture crash on this ROCm (gpurun r3x; eager launches are fine): they stay
         # on the current stream.
         fused = []
-        for i in range(len(self.fuse_layers)):
+        rows = len(self.fuse_layers)
+        # every branch output feeds every row of the exchange: `rows` consumers.  ops.fork hands each row its own alias, so the
+        # gradients of the rows are summed by the native add kernel in one fixed order instead of autograd's own accumulation
+        xs = [ops.fork(t, rows) for t in x]
+        for i in range(rows):
             # same left-to-right summation order as hrnet.py:232-248
-            y = x[0] if i == 0 else self.fuse_layers[i][0](x[0])
+            y = xs[0][i] if i == 0 else self.fuse_layers[i][0](xs[0][i])
             bounds = [ops.absmax_of(y)]                     # |sum| <= sum of the terms' bounds (up-sampling is a convex combination)
             last = self.num_branches - 1
             for j in range(1, self.num_branches):
                 relu = j == last                            # the final ReLU (hrnet.py:248) rides on the last add
-                t = x[j] if j == i else self.fuse_layers[i][j](x[j])
+                t = xs[j][i] if j == i else self.fuse_layers[i][j](xs[j][i])
                 bounds.append(ops.absmax_of(t))
                 if j > i:
                     y = ops.interpolate_bilinear(t, x[i].shape[2:], base=y, relu=relu)
