@@ -1,11 +1,12 @@
 #!/bin/bash
 # PMC passes (separate runs, as MI355X_MICROARCH.md prescribes) on the Winograd-domain data gradient of conv_last (the dominant pass of
 # the configs[1] step):   gpurun --timeout 900 -- 'bash tools/gpu_pmc_wino.sh <tag>'
-TAG=${1:-pmcw}; ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
+TAG=${1:-pmcw}; EXTRA="${2:-}"; ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 python __graft_entry__.py > $OUT/build.log 2>&1
 cd /tmp
-CMD="python $ROOT/tools/probes/winograd_dgrad_pass.py --iters 5"
+CMD="python $ROOT/tools/probes/winograd_dgrad_pass.py --iters 5 ${EXTRA//,/ }"     # e.g. --mode,fwd,--geom,2:64:64:512:512:4 (":" -> ",")
+CMD=${CMD//:/,}
 run() { n=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o $n -- $CMD > $OUT/$n.log 2>&1
   echo "pmc pass $n rc=$?"; }

@@ -16,12 +16,31 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--tile', type=int, default=14)
+    ap.add_argument('--geom', default='2,64,64,4096,512,1', help='n,h,w,c,k,dil of the 3x3 stride-1 conv (default: conv_last)')
+    ap.add_argument('--mode', default='dgrad', choices=('dgrad', 'fwd'))
     args = ap.parse_args()
     from mit_semseg import ops, _native
     L = _native.lib()
     dev = torch.device('cuda:0')
-    n, h, w, c, k, dil = 2, 64, 64, 4096, 512, 1
+    n, h, w, c, k, dil = (int(v) for v in args.geom.split(','))
     geom = (n, h, w, c, k, 3, 3, 1, dil, dil)
+    if args.mode == 'fwd':
+        # the forward of the same layer family (e.g. layer4's dilated 512 -> 512 convs: --geom 2,64,64,512,512,4): input transform
+        # of x, batched GEMM on the pinned tile, output transform
+        from mit_semseg import tuner
+        tuner.ENABLED = False
+        wparam = torch.nn.Parameter((torch.randn(k, 3, 3, c, device=dev) * 0.01).permute(0, 3, 1, 2))
+        ops.prepare_conv_weights([wparam])
+        x = torch.randn(n, c, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        bound = x.abs().max().reshape(1)
+        z = ops.empty_nhwc(n, k, h, w, dev)
+        tiles = L.semseg_winograd_tiles(n, h, w, dil)
+        _native.check(L.semseg_conv2d_h2_set_plan(3, tiles, 1, 1, c, k, 3, 3, 1, 1, 1, args.tile, 1), 'set_plan')
+        for _ in range(args.iters):
+            ops._winograd_fwd(L, x, (bound,), ops.weight_wino(wparam), z, geom)
+        torch.cuda.synchronize()
+        print('done: %d forward passes, tiles %d, gemm tile %d' % (args.iters, tiles, args.tile))
+        return
     wparam = torch.nn.Parameter((torch.randn(k, 3, 3, c, device=dev) * 0.01).permute(0, 3, 1, 2))
     ops.prepare_conv_weights([wparam])
     ut = ops.weight_wino_t(wparam)
