@@ -298,6 +298,14 @@ CASES = [
          n=2, h=64, w=64, seg_rate=8, training=False, deep_sup_scale=0.4, seed=4, weights_style='heavy'),
     dict(name='r18d_ppmds_64_trainedlike_train', arch_enc='resnet18dilated', arch_dec='ppm_deepsup', fc_dim=512,
          n=2, h=64, w=64, seg_rate=8, training=True, deep_sup_scale=0.4, step=True, seed=5, weights_style='heavy'),
+    # the arch strings of ModelBuilder no other case builds: the undilated resnet18 / resnet101 encoders (stride 32) and the
+    # 256-wide UPerNet (`upernet_lite`); UPerNet's fpn_inplanes are fixed at (256 ... 2048) in build_decoder, so it only pairs
+    # with the bottleneck encoders; the deep-supervision heads read layer3 at the resolution of layer4, so they only pair with the
+    # dilated encoders
+    dict(name='r101_upernetlite_128_train', arch_enc='resnet101', arch_dec='upernet_lite', fc_dim=2048,
+         n=2, h=128, w=128, seg_rate=4, training=True, deep_sup_scale=None, step=True, seed=7),
+    dict(name='r18_c1_128_train', arch_enc='resnet18', arch_dec='c1', fc_dim=512,
+         n=2, h=128, w=128, seg_rate=32, training=True, deep_sup_scale=None, step=True, seed=8),
 ]
 
 

@@ -115,7 +115,8 @@ def _native_grads(g, dev):
 
 
 @pytest.mark.parametrize('name', ['r18d_ppmds_64_train', 'r50d_ppmds_64_train', 'r50_upernet_128_train', 'hrnetv2_c1_128_train',
-                                  'mnv2d_c1ds_64_train', 'mnv2d_c1ds_192_train', 'r18d_ppmds_64_trainedlike_train'])
+                                  'mnv2d_c1ds_64_train', 'mnv2d_c1ds_192_train', 'r18d_ppmds_64_trainedlike_train',
+                                  'r101_upernetlite_128_train', 'r18_c1_128_train'])
 def test_native_gradients_vs_reference_anchor(name, monkeypatch):
     """EVERY parameter gradient of one backward against the float64 anchor of the unmodified reference
     (tests/golden/make_golden.py::anchor): elementwise on small tensors and on a seeded 1024-element sample of large ones --
