@@ -456,7 +456,8 @@ struct SParams {
     int chunks, ktiles, kt_per_split;
     int tiles_m, tiles_n, splits;
     int batches;                                       // 0 / 1: plain; > 1: gridDim.z batches (splits must be 1)
-    int batch_in_rows, batch_w_rows, batch_out_rows;   // batched GEMM (blockIdx.z = batch): row offsets per batch of the
+    int tn_fast;                                        // block order inside an XCD: column tiles fastest (run_gemm)
+    int batch_in_rows, batch_w_rows, batch_out_rows;   // batched GEMM (one batch per grid z): row offsets per batch of the
                                                        // activation planes, of the weight planes (in units of T rows) and of `out`
     // BN statistics of the result gathered in the epilogue (forward convs that a BatchNorm follows, splits == 1 only): every
     // BLOCK writes the column sums / sums of squares (fp64) and column minima / maxima (fp32) of its BM x BN tile as partial row
@@ -515,18 +516,18 @@ __device__ __forceinline__ void descale_factors(const int* ea, const int* eb, fl
 __device__ __forceinline__ int s_slot(int row, int q) { return row * 4 + (q ^ ((row >> 2) & 3)); }
 
 // epilogue shared by both GEMM kernels.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-// `tm` = row-tile index of the block, `wm` / `wcol` = the wave's row position in the block (0 .. WGM-1) and first column inside
+// `bz` = batch of a batched GEMM, `tm` = row-tile index of the block, `wm` / `wcol` = the wave's row position in the block (0 .. WGM-1) and first column inside
 // the block tile, `smem` = the block's LDS (the operand tiles are dead by now): when the launch gathers BN statistics
 // (p.st_sum), the WGM waves that share a column range combine their column sums / minima / maxima through LDS in wave order,
 // so that ONE partial row per block row tile reaches memory (tiles_m rows for the BN finish kernel instead of tiles_m x WGM).
 template <class SCH, int FM, int FN, int WGM, int BN>
-__device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM][FN], int row0, int col0, int z, int lane, int tm,
-                                              int wm, int wcol, void* smem) {
+__device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM][FN], int row0, int col0, int z, int bz, int lane,
+                                              int tm, int wm, int wcol, void* smem) {
     float* dst;
     int dst_ld;
     const bool direct = p.splits == 1;
     if (direct) {
-        dst = p.out + (size_t)blockIdx.z * p.batch_out_rows * p.out_ld;
+        dst = p.out + (size_t)bz * p.batch_out_rows * p.out_ld;
         dst_ld = p.out_ld;
     } else {
         dst = p.partial + (size_t)z * p.M * p.Cout;
@@ -637,13 +638,25 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // block -> (tm, tn, z): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
-    // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows)
-    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, p.tiles_m * p.tiles_n * p.splits);
-    const int tm = lid % p.tiles_m;
-    const int tnz = lid / p.tiles_m;
-    const int tn = tnz % p.tiles_n;
-    const int z = tnz / p.tiles_n;
+    // block -> (tm, tn, z, batch): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
+    // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows); the
+    // batches of a batched GEMM (Winograd positions) are dealt to the XCDs WHOLE, so both operands of a batch stay in one L2
+    const int per_batch = p.tiles_m * p.tiles_n * p.splits;
+    const int lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), per_batch * gridDim.z);
+    const int bz = lin / per_batch;
+    const int lid = lin - bz * per_batch;
+    int tm, tn, z;
+    if (p.tn_fast) {          // all column tiles of a row tile side by side: the pixel rows are fetched once (run_gemm)
+        tn = lid % p.tiles_n;
+        const int tmz = lid / p.tiles_n;
+        tm = tmz % p.tiles_m;
+        z = tmz / p.tiles_m;
+    } else {
+        tm = lid % p.tiles_m;
+        const int tnz = lid / p.tiles_m;
+        tn = tnz % p.tiles_n;
+        z = tnz / p.tiles_n;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
@@ -663,7 +676,7 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
             const int ow = rem - oh * p.Wout;
             a_ih0[i] = oh * p.a + p.off;
             a_iw0[i] = ow * p.a + p.off;
-            a_base[i] = n * p.Hin * p.Win + (int)blockIdx.z * p.batch_in_rows;
+            a_base[i] = n * p.Hin * p.Win + bz * p.batch_in_rows;
         } else {
             a_ih0[i] = -(1 << 28);
             a_iw0[i] = -(1 << 28);
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
     for (int i = 0; i < BPASS; ++i) {
         const int n = n0 + lrow + i * RPP;
         const bool ok = n < p.Cout;
-        b_off[i] = ok ? (uint32_t)(n + (int)blockIdx.z * p.batch_w_rows) * w_row + 8u * q : 0u;
+        b_off[i] = ok ? (uint32_t)(n + bz * p.batch_w_rows) * w_row + 8u * q : 0u;
         b_ok |= (ok ? 1u : 0u) << i;
     }
     KWalk kw;
@@ -824,7 +837,7 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
     }
     if (kt_begin < kt_end) compute_tile();
     S_MFMA_DRAIN();
-    gemm_epilogue<SCH, FM, FN, 2, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, tm, wm, wn * WN, smem4);
+    gemm_epilogue<SCH, FM, FN, 2, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -874,13 +887,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
 
-    // block -> (tm, tn, z): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
-    // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows)
-    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, p.tiles_m * p.tiles_n * p.splits);
-    const int tm = lid % p.tiles_m;
-    const int tnz = lid / p.tiles_m;
-    const int tn = tnz % p.tiles_n;
-    const int z = tnz / p.tiles_n;
+    // block -> (tm, tn, z, batch): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
+    // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows); the
+    // batches of a batched GEMM (Winograd positions) are dealt to the XCDs WHOLE, so both operands of a batch stay in one L2
+    const int per_batch = p.tiles_m * p.tiles_n * p.splits;
+    const int lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), per_batch * gridDim.z);
+    const int bz = lin / per_batch;
+    const int lid = lin - bz * per_batch;
+    int tm, tn, z;
+    if (p.tn_fast) {          // all column tiles of a row tile side by side: the pixel rows are fetched once (run_gemm)
+        tn = lid % p.tiles_n;
+        const int tmz = lid / p.tiles_n;
+        tm = tmz % p.tiles_m;
+        z = tmz / p.tiles_m;
+    } else {
+        tm = lid % p.tiles_m;
+        const int tnz = lid / p.tiles_m;
+        tn = tnz % p.tiles_n;
+        z = tnz / p.tiles_n;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
@@ -907,7 +932,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
             const int ow = rem - oh * p.Wout;
             a_ih0[i] = oh * p.a + p.off;
             a_iw0[i] = ow * p.a + p.off;
-            a_base[i] = n * p.Hin * p.Win + (int)blockIdx.z * p.batch_in_rows;
+            a_base[i] = n * p.Hin * p.Win + bz * p.batch_in_rows;
         } else {
             a_ih0[i] = -(1 << 28);
             a_iw0[i] = -(1 << 28);
@@ -924,7 +949,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     for (int i = 0; i < BG; ++i) {
         const int n = n0 + (wave + NW * i) * 16 + lrow;
         const bool ok = n < p.Cout;
-        b_src[i] = ok ? (uint32_t)(n + (int)blockIdx.z * p.batch_w_rows) * w_row_b + 16u * q : b_zero;
+        b_src[i] = ok ? (uint32_t)(n + bz * p.batch_w_rows) * w_row_b + 16u * q : b_zero;
         b_msk[i] = ok ? 0xffffffffu : 0u;
     }
     uint32_t a_src[AG], a_msk[AG];
@@ -1124,7 +1149,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
-    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, lane, tm, wm, wn * WN, smem);
+    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
 }
 
 // out[m*out_ld + n] = bias[n] + sum_z partial[z][m*Cout + n]   (fixed order => deterministic)
@@ -1290,6 +1315,13 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
         if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
         p.partial = (float*)workspace;
     }
+    // Block order inside an XCD.  Row tiles fastest (default): the blocks of an XCD share one weight slice and the halo rows of
+    // neighbouring pixel tiles, and every pixel row is fetched by as many XCDs as there are column tiles.  For a 1x1 convolution
+    // the weights are the small operand (C x K against M x C) and there is no halo: column tiles fastest fetches the pixel rows
+    // ONCE and streams the whole weight matrix through every L2 instead (profiles/r4_pmc_step_traffic_cfg1.txt: layer3's
+    // 1024 -> 256 conv fetched its input 3.9 times, the 256 -> 1024 one 7.2 times).
+    static const int order_env = [] { const char* e = getenv("SEMSEG_IGEMM_ORDER"); return e ? atoi(e) : -1; }();   // tools only
+    p.tn_fast = order_env >= 0 ? (order_env != 0) : (p.T == 1 && p.batches <= 1 && pl.tiles_n > 1);
     p.st_sum = nullptr; p.st_mm = nullptr; p.st_zero = nullptr;
     if (es) {
         es->parts = 0;
@@ -1626,14 +1658,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
+    // block -> (tile, z): the hardware deals the blocks of a launch to the XCDs in the order x + gridDim.x * y, so the remap
+    // runs over (tile, split) TOGETHER: an XCD receives whole row chunks z, and the tiles of a chunk -- the taps / channel
+    // blocks that read the same rows of x and dy -- meet in ONE L2 (a remap of x alone assumes gridDim.x % 8 == 0 and still
+    // deals every chunk to all eight XCDs: profiles/r4_pmc_step_traffic_cfg1.txt, 9 x 56 blocks fetched 9x their operands)
     const int ntiles = p.tiles_k * p.tiles_c * p.T;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, ntiles * gridDim.y);
+    const int tile = lin % ntiles;
     const int t = tile % p.T;
     const int tc = (tile / p.T) % p.tiles_c;
     const int tk = tile / (p.T * p.tiles_c);
     const int k0 = tk * BM, c0 = tc * BN;
     const int r = t / p.S, s = t - r * p.S;
-    const int z = blockIdx.y;
+    const int z = lin / ntiles;
     const int m_begin = z * p.m_per_split;
     const int m_end = min(p.M, m_begin + p.m_per_split);
 
@@ -1811,14 +1848,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
 
+    // block -> (tile, z): the hardware deals the blocks of a launch to the XCDs in the order x + gridDim.x * y, so the remap
+    // runs over (tile, split) TOGETHER: an XCD receives whole row chunks z, and the tiles of a chunk -- the taps / channel
+    // blocks that read the same rows of x and dy -- meet in ONE L2 (a remap of x alone assumes gridDim.x % 8 == 0 and still
+    // deals every chunk to all eight XCDs: profiles/r4_pmc_step_traffic_cfg1.txt, 9 x 56 blocks fetched 9x their operands)
     const int ntiles = p.tiles_k * p.tiles_c * p.T;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, ntiles * gridDim.y);
+    const int tile = lin % ntiles;
     const int t = tile % p.T;
     const int tc = (tile / p.T) % p.tiles_c;
     const int tk = tile / (p.T * p.tiles_c);
     const int k0 = tk * BM, c0 = tc * BN;
     const int r = t / p.S, s = t - r * p.S;
-    const int z = blockIdx.y;
+    const int z = lin / ntiles;
     const int m_begin = z * p.m_per_split;
     const int m_end = min(p.M, m_begin + p.m_per_split);
     const int nk = (m_end - m_begin + 31) >> 5;

@@ -1,0 +1,59 @@
+"""Sequence of C-ABI calls of ONE training step with their integer arguments (CPU only: the ABI is replaced by a stub that records and
+computes nothing, as tests/test_host_logic_dryrun.py does).  Lines up with the dispatch order of a kernel trace of the eager step
+(tools/probes/step_traffic.py), so a launch in a PMC table can be given its geometry.   python tools/abi_call_trace.py [--config 1]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import torch  # noqa: E402
+
+
+class Recorder:
+    def __init__(self, signatures):
+        self.calls = []
+        for name, (res, args) in signatures.items():
+            setattr(self, name, self._make(name, res))
+
+    def _make(self, name, res):
+        def fn(*args):
+            ints = [a if isinstance(a, int) else getattr(a, 'value', None) for a in args]
+            self.calls.append((name, [v for v in ints if isinstance(v, int) and 0 <= v < (1 << 24)]))
+            return 1 << 20 if res is ctypes.c_size_t else 0
+        return fn
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', type=int, default=1)
+    ap.add_argument('--grep', default='conv2d,winograd')
+    args = ap.parse_args()
+    from mit_semseg import _native, ops, tuner
+    rec = Recorder(_native.SIGNATURES)
+    _native.lib = lambda: rec
+    ops._require_cuda = lambda *a: None
+    ops._st = lambda: ctypes.c_void_p(0)
+    ops._WS = {}
+    tuner.ENABLED = False
+    import bench
+    from mit_semseg.engine import TrainStep
+    cfg = bench.CONFIGS[args.config]
+    sm = bench.build_model(torch.device('cpu'), cfg)
+    feed = bench.synth_feed(torch.device('cpu'), 0, cfg)
+    step = TrainStep(sm, lr_encoder=0.02, lr_decoder=0.02, max_iters=10 ** 5, graph=False)
+    step.step(feed)
+    rec.calls.clear()
+    step.step(feed)
+    keys = [k for k in args.grep.split(',') if k]
+    for name, ints in rec.calls:
+        if not keys or any(k in name for k in keys):
+            print('%-36s %s' % (name.replace('semseg_', ''), ' '.join(str(v) for v in ints)))
+
+
+if __name__ == '__main__':
+    main()

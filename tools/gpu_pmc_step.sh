@@ -1,0 +1,17 @@
+#!/bin/bash
+# HBM traffic of one whole training step by kernel (two PMC passes, separate runs as MI355X_MICROARCH.md prescribes):
+#   gpurun --timeout 600 -- 'bash tools/gpu_pmc_step.sh <tag> [config] [step_ms]'
+TAG=${1:-pmcstep}; CFG=${2:-1}; STEP_MS=${3:-}; ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+cp profiles/r4z_tuned_plans_h2.json /tmp/plans_step.json; export SEMSEG_TUNE_CACHE=/tmp/plans_step.json
+cd /tmp
+CMD="python $ROOT/tools/probes/step_traffic.py --config $CFG --steps 3"
+run() { n=$1; shift
+  timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o $n -- $CMD > $OUT/$n.log 2>&1
+  echo "pmc pass $n rc=$?"; tail -1 $OUT/$n.log | cut -c1-200; }
+run fetch FETCH_SIZE
+grep -q "eager steps" $OUT/fetch.log || { echo "first pass did not finish"; tail -5 $OUT/fetch.log; exit 1; }
+run write WRITE_SIZE
+cd $ROOT
+python tools/pmc_step_summary.py $OUT $STEP_MS > $OUT/summary.txt 2>&1; head -60 $OUT/summary.txt
+find $OUT -name '*.csv' -size +2M -delete
