@@ -1,0 +1,59 @@
+"""The profiling helpers that turn rocprofv3 counter files into the tables under profiles/ (CPU only, synthetic input)."""
+import csv
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_pass(root, sub, counter, names, value_of):
+    d = os.path.join(root, sub, 'box')
+    os.makedirs(d)
+    with open(os.path.join(d, sub + '_counter_collection.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Dispatch_Id', 'Kernel_Name', 'Counter_Name', 'Counter_Value'])
+        for i, name in enumerate(names, 1):
+            for xcd in range(8):                       # one row per XCD, as rocprofv3 writes them
+                w.writerow([i, name, counter, value_of(name) / 8.0])
+
+
+def test_pmc_step_summary_finds_the_last_step_and_doubles_fetch(tmp_path):
+    """three identical eager steps after some initialisation, a few read-back dispatches after the last one: the summary counts ONE
+    step, doubles FETCH_SIZE (gfx950 correction of the guide) and leaves WRITE_SIZE as it is"""
+    step = ['void igemm_dma_kernel<SchH2, 64, 64, 2, 2, 12>(SParams)'] * 30 + ['bn_apply_h2_kernel<true, true>(float const*, int)'] * 25 \
+        + ['sgd_kernel(SgdBatch, float const*, float, float)'] * 7 + ['wprep_split_kernel(WPrepBatch, int)'] * 2
+    names = ['__amd_rocclr_copyBuffer'] * 11 + ['wprep_split_kernel(WPrepBatch, int)'] * 2 + step * 3 + ['__amd_rocclr_copyBuffer'] * 2
+    kib = {'void igemm': 1000.0, 'bn_apply_h': 500.0, 'sgd_kernel': 100.0, 'wprep_spli': 10.0, '__amd_rocc': 1.0}
+    _write_pass(str(tmp_path), 'fetch', 'FETCH_SIZE', names, lambda n: kib[n[:10]])
+    _write_pass(str(tmp_path), 'write', 'WRITE_SIZE', names, lambda n: kib[n[:10]] / 2)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_step_summary.py'), str(tmp_path), '10.0'],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert 'fetch pass: %d dispatches, %d per step' % (len(names), len(step)) in out
+    rows = {l.split()[0]: l.split() for l in out.splitlines() if l and l.split()[0] in ('igemm_dma_kernel<SchH2,', 'TOTAL')}
+    total = rows['TOTAL']
+    read_mb = (30 * 1000 + 25 * 500 + 7 * 100 + 2 * 10) * 2 * 1024 / 1e6
+    write_mb = (30 * 1000 + 25 * 500 + 7 * 100 + 2 * 10) / 2 * 1024 / 1e6
+    assert int(total[1]) == len(step)
+    assert abs(float(total[2]) - read_mb) < 0.06 and abs(float(total[3]) - write_mb) < 0.06
+    assert 'TB/s average over the step' in out
+
+
+def test_abi_call_trace_lists_every_convolution_of_the_step():
+    """tools/abi_call_trace.py: the C-ABI call sequence of one configs[1] training step on the recording stub -- 63 forward convs
+    (five of them in the Winograd domain), as many data gradients minus the stem's, every weight gradient; the geometry columns are what the PMC tables are labelled with"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'abi_call_trace.py'), '--config', '1', '--grep', 'conv2d_fwd,conv2d_dgrad,conv2d_wgrad,winograd_gemm,winograd_wgrad_gemm'],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l.split() for l in r.stdout.splitlines() if l.strip()]
+    count = lambda name: sum(1 for l in lines if l[0] == name)        # noqa: E731
+    fwd = count('conv2d_fwd_stats_h2') + count('conv2d_fwd_h2')
+    wino_gemm, wino_wgrad = count('winograd_gemm_h2'), count('winograd_wgrad_gemm_h2')
+    convs = (3 + 16 * 3 + 4) + (4 + 1 + 1) + (1 + 1)     # deep-stem ResNet-50 (stem, 16 bottlenecks, 4 downsamples), PPM + conv_last + classifier, deepsup
+    assert fwd + wino_gemm // 2 == convs, (fwd, wino_gemm)           # a Winograd layer runs its GEMM in the forward and in the data gradient
+    assert count('conv2d_dgrad_h2') + wino_gemm // 2 == convs - 1    # no data gradient into the image
+    assert count('conv2d_wgrad_h2') + wino_wgrad == convs
+    stem = [l for l in lines if l[0] == 'conv2d_fwd_stats_h2'][0]
+    assert stem[2:] == ['2', '512', '512', '3', '64', '3', '3', '2', '1', '1']
