@@ -56,4 +56,4 @@ def test_abi_call_trace_lists_every_convolution_of_the_step():
     assert count('conv2d_dgrad_h2') + wino_gemm // 2 == convs - 1    # no data gradient into the image
     assert count('conv2d_wgrad_h2') + wino_wgrad == convs
     stem = [l for l in lines if l[0] == 'conv2d_fwd_stats_h2'][0]
-    assert stem[2:] == ['2', '512', '512', '3', '64', '3', '3', '2', '1', '1']
+    assert stem[2:12] == ['2', '512', '512', '3', '64', '3', '3', '2', '1', '1']           # after y_ld: N H W C K R S stride pad dil
