@@ -306,6 +306,11 @@ CASES = [
          n=2, h=128, w=128, seg_rate=4, training=True, deep_sup_scale=None, step=True, seed=7),
     dict(name='r18_c1_128_train', arch_enc='resnet18', arch_dec='c1', fc_dim=512,
          n=2, h=128, w=128, seg_rate=32, training=True, deep_sup_scale=None, step=True, seed=8),
+    # the inference branch (use_softmax: resize to segSize + softmax) of the C1 heads, which the PPM / UPerNet inference cases do not build
+    dict(name='hrnetv2_c1_infer_64x96', arch_enc='hrnetv2', arch_dec='c1', fc_dim=720,
+         n=1, h=64, w=96, seg_rate=4, training=False, deep_sup_scale=None, seg_size=[50, 75], seed=9),
+    dict(name='mnv2d_c1ds_infer_64x80', arch_enc='mobilenetv2dilated', arch_dec='c1_deepsup', fc_dim=320,
+         n=1, h=64, w=80, seg_rate=8, training=False, deep_sup_scale=None, seg_size=[37, 45], seed=10),
 ]
 
 

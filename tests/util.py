@@ -11,7 +11,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 # golden cases whose ~150 convolution geometries (dense forms of grouped convs, 101-layer backbones) no other test uses: they
 # run on the library's heuristic launch plans instead of timing every tile x split candidate
 HEURISTIC_PLAN_GOLDEN = ('mnv2d_c1ds_64_train', 'mnv2d_c1ds_192_train', 'resnext101_upernet_128_eval', 'resnext101_c1_512_train',
-                         'r101_upernetlite_128_train', 'r18_c1_128_train')
+                         'r101_upernetlite_128_train', 'r18_c1_128_train', 'hrnetv2_c1_infer_64x96', 'mnv2d_c1ds_infer_64x80')
 # 4 x 512 x 512 through ResNeXt-101 (every BN sees >= 1024 values per channel): a training step of it takes the CPU minutes, so
 # the CPU-side tests run its forward only; the GPU test runs the whole step against the stored results of the reference
 HEAVY_GOLDEN = ('resnext101_c1_512_train',)
