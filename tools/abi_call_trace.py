@@ -24,6 +24,9 @@ class Recorder:
         def fn(*args):
             ints = [a if isinstance(a, int) else getattr(a, 'value', None) for a in args]
             self.calls.append((name, [v for v in ints if isinstance(v, int) and 0 <= v < (1 << 24)]))
+            if name == 'semseg_winograd_tiles':          # the one return value the caller's later arguments depend on
+                n, h, w, d = ints[:4]
+                return n * d * d * (-(-(-(-h // d)) // 2)) * (-(-(-(-w // d)) // 2))
             return 1 << 20 if res is ctypes.c_size_t else 0
         return fn
 
