@@ -1,0 +1,63 @@
+// Which tile a block computes: the block-order arithmetic of the GEMM-shaped kernels (conv_split.hip, conv_igemm.hip,
+// conv_wgrad.hip) as plain inline functions, so that tests/native/block_order_emulate.cpp enumerates whole grids with the SAME
+// code on the host (tests/test_block_order_cpu.py: every (tile, split, batch) exactly once, and the XCD properties below).
+//
+// MI355X deals the blocks of a launch to its 8 XCDs round-robin in the order  b = x + gridDim.x * (y + gridDim.y * z),
+// and each XCD has its own 4 MB L2.  xcd_remap gives the blocks of one XCD (b, b + 8, b + 16, ...) CONSECUTIVE logical ids, so
+// "neighbouring logical ids" means "same L2"; the functions below decide what neighbours share.
+#pragma once
+
+#ifndef SEMSEG_HD
+#ifdef __HIPCC__
+#define SEMSEG_HD __host__ __device__ __forceinline__
+#else
+#define SEMSEG_HD static inline
+#endif
+#endif
+
+// bijection of [0, nblocks): hardware order b -> logical id; XCD x (b % 8 == x) owns one contiguous range of logical ids
+SEMSEG_HD int xcd_remap(int b, int nblocks) {
+    const int xcd = b & 7, q = nblocks >> 3, r = nblocks & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+// Forward / data-gradient GEMM (igemm_rs_kernel, igemm_dma_kernel): grid (tiles_m * tiles_n, splits, batches).
+//   batch  slowest: the batches of a batched GEMM (the 16 Winograd positions) go to the XCDs WHOLE -- both operands of a batch
+//          stay in one L2;
+//   split  next (a split-K slice is a channel range of both operands);
+//   inside: row tiles fastest (default) -- the blocks of an XCD share ONE weight slice and the halo rows of neighbouring pixel
+//          tiles (3x3 convs) -- or, `tn_fast`, column tiles fastest -- all column tiles of a row tile side by side, the pixel rows
+//          are fetched once and the small weight matrix streams through every L2 (1x1 convs; run_gemm decides).
+struct GemmBlock { int tm, tn, z, batch; };
+SEMSEG_HD GemmBlock gemm_block(int hw_linear, int tiles_m, int tiles_n, int splits, int batches, int tn_fast) {
+    const int per_batch = tiles_m * tiles_n * splits;
+    const int lin = xcd_remap(hw_linear, per_batch * batches);
+    GemmBlock b;
+    b.batch = lin / per_batch;
+    const int lid = lin - b.batch * per_batch;
+    if (tn_fast) {
+        b.tn = lid % tiles_n;
+        const int tmz = lid / tiles_n;
+        b.tm = tmz % tiles_m;
+        b.z = tmz / tiles_m;
+    } else {
+        b.tm = lid % tiles_m;
+        const int tnz = lid / tiles_m;
+        b.tn = tnz % tiles_n;
+        b.z = tnz / tiles_n;
+    }
+    return b;
+}
+
+// Weight-gradient kernels (wgrad_kernel, wgrad_dma_kernel): grid (ntiles, splits[, batches]); the remap runs over (tile, split)
+// TOGETHER: an XCD receives whole row chunks z, and the tiles of a chunk -- the taps / channel blocks that read the same rows of
+// x and dy -- meet in one L2.  (A remap of x alone is an XCD map only when gridDim.x % 8 == 0 and deals every chunk to all XCDs.)
+struct WgradBlock { int tile, z; };
+SEMSEG_HD WgradBlock wgrad_block(int hw_linear_xy, int ntiles, int splits) {
+    const int lin = xcd_remap(hw_linear_xy, ntiles * splits);
+    WgradBlock b;
+    b.z = lin / ntiles;
+    b.tile = lin - b.z * ntiles;
+    return b;
+}

@@ -51,10 +51,4 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// XCD-aware bijective remap of a 1-D block id: blocks b, b+8, b+16.. (same XCD, MI355X dispatches
-// block b to XCD b%8) receive CONSECUTIVE logical ids so tiles sharing an operand share that XCD's L2.
-__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
-    const int xcd = b & 7, q = nblocks >> 3, r = nblocks & 7;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (b >> 3);
-}
+#include "block_order.h"     // xcd_remap, gemm_block, wgrad_block (shared with the host-side enumeration test)

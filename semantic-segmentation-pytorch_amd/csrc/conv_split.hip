@@ -641,22 +641,9 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
     // block -> (tm, tn, z, batch): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
     // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows); the
     // batches of a batched GEMM (Winograd positions) are dealt to the XCDs WHOLE, so both operands of a batch stay in one L2
-    const int per_batch = p.tiles_m * p.tiles_n * p.splits;
-    const int lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), per_batch * gridDim.z);
-    const int bz = lin / per_batch;
-    const int lid = lin - bz * per_batch;
-    int tm, tn, z;
-    if (p.tn_fast) {          // all column tiles of a row tile side by side: the pixel rows are fetched once (run_gemm)
-        tn = lid % p.tiles_n;
-        const int tmz = lid / p.tiles_n;
-        tm = tmz % p.tiles_m;
-        z = tmz / p.tiles_m;
-    } else {
-        tm = lid % p.tiles_m;
-        const int tnz = lid / p.tiles_m;
-        tn = tnz % p.tiles_n;
-        z = tnz / p.tiles_n;
-    }
+    const GemmBlock gb = gemm_block(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), p.tiles_m, p.tiles_n, p.splits,
+                                    gridDim.z, p.tn_fast);      // block_order.h
+    const int tm = gb.tm, tn = gb.tn, z = gb.z, bz = gb.batch;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
@@ -890,22 +877,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     // block -> (tm, tn, z, batch): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
     // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows); the
     // batches of a batched GEMM (Winograd positions) are dealt to the XCDs WHOLE, so both operands of a batch stay in one L2
-    const int per_batch = p.tiles_m * p.tiles_n * p.splits;
-    const int lin = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), per_batch * gridDim.z);
-    const int bz = lin / per_batch;
-    const int lid = lin - bz * per_batch;
-    int tm, tn, z;
-    if (p.tn_fast) {          // all column tiles of a row tile side by side: the pixel rows are fetched once (run_gemm)
-        tn = lid % p.tiles_n;
-        const int tmz = lid / p.tiles_n;
-        tm = tmz % p.tiles_m;
-        z = tmz / p.tiles_m;
-    } else {
-        tm = lid % p.tiles_m;
-        const int tnz = lid / p.tiles_m;
-        tn = tnz % p.tiles_n;
-        z = tnz / p.tiles_n;
-    }
+    const GemmBlock gb = gemm_block(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), p.tiles_m, p.tiles_n, p.splits,
+                                    gridDim.z, p.tn_fast);      // block_order.h
+    const int tm = gb.tm, tn = gb.tn, z = gb.z, bz = gb.batch;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
@@ -1663,14 +1637,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
     // blocks that read the same rows of x and dy -- meet in ONE L2 (a remap of x alone assumes gridDim.x % 8 == 0 and still
     // deals every chunk to all eight XCDs: profiles/r4_pmc_step_traffic_cfg1.txt, 9 x 56 blocks fetched 9x their operands)
     const int ntiles = p.tiles_k * p.tiles_c * p.T;
-    const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, ntiles * gridDim.y);
-    const int tile = lin % ntiles;
+    const WgradBlock wb = wgrad_block(blockIdx.x + gridDim.x * blockIdx.y, ntiles, gridDim.y);      // block_order.h
+    const int tile = wb.tile;
     const int t = tile % p.T;
     const int tc = (tile / p.T) % p.tiles_c;
     const int tk = tile / (p.T * p.tiles_c);
     const int k0 = tk * BM, c0 = tc * BN;
     const int r = t / p.S, s = t - r * p.S;
-    const int z = lin / ntiles;
+    const int z = wb.z;
     const int m_begin = z * p.m_per_split;
     const int m_end = min(p.M, m_begin + p.m_per_split);
 
@@ -1853,14 +1827,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
     // blocks that read the same rows of x and dy -- meet in ONE L2 (a remap of x alone assumes gridDim.x % 8 == 0 and still
     // deals every chunk to all eight XCDs: profiles/r4_pmc_step_traffic_cfg1.txt, 9 x 56 blocks fetched 9x their operands)
     const int ntiles = p.tiles_k * p.tiles_c * p.T;
-    const int lin = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, ntiles * gridDim.y);
-    const int tile = lin % ntiles;
+    const WgradBlock wb = wgrad_block(blockIdx.x + gridDim.x * blockIdx.y, ntiles, gridDim.y);      // block_order.h
+    const int tile = wb.tile;
     const int t = tile % p.T;
     const int tc = (tile / p.T) % p.tiles_c;
     const int tk = tile / (p.T * p.tiles_c);
     const int k0 = tk * BM, c0 = tc * BN;
     const int r = t / p.S, s = t - r * p.S;
-    const int z = lin / ntiles;
+    const int z = wb.z;
     const int m_begin = z * p.m_per_split;
     const int m_end = min(p.M, m_begin + p.m_per_split);
     const int nk = (m_end - m_begin + 31) >> 5;
