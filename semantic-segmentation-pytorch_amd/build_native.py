@@ -42,7 +42,7 @@ def build(force=False, verbose=True):
 
 
 def _build_locked(force, verbose):
-    deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'split_layout.h'), os.path.join(CSRC, 'input_pipeline_math.h'), os.path.join(CSRC, 'depthwise_math.h'), os.path.join(CSRC, 'grouped_math.h'),
+    deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'block_order.h'), os.path.join(CSRC, 'split_layout.h'), os.path.join(CSRC, 'input_pipeline_math.h'), os.path.join(CSRC, 'depthwise_math.h'), os.path.join(CSRC, 'grouped_math.h'),
             os.path.join(ROOT, 'include', 'semseg_hip.h')]
     objs, jobs = [], []
     tag = '.tmp%d' % os.getpid()
