@@ -20,6 +20,33 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+def _depfile_deps(depfile):
+    """prerequisites of a compiler-written depfile (`hipcc -MMD -MF`: Makefile syntax, one rule per offload pass); None when
+    the file is missing or unreadable -- the object is then rebuilt"""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    deps = set()
+    for rule in text.replace('\\\n', ' ').splitlines():
+        if ':' not in rule:
+            continue
+        for tok in rule.split(':', 1)[1].split():
+            deps.add(tok)
+    return sorted(deps)
+
+
+def _stale(src, obj):
+    """an object is rebuilt when its source, any header the compiler saw last time (the depfile next to it), or this build
+    script's flags changed; system headers are part of the depfile too (-MD would add them; -MMD keeps the user headers)"""
+    if _newer(src, obj):
+        return True
+    deps = _depfile_deps(obj + '.d')
+    if deps is None:
+        return True
+    return any((not os.path.exists(d)) or _newer(d, obj) for d in deps)
+
+
 def _run(cmd, verbose):
     if verbose:
         print(' '.join(cmd), flush=True)
@@ -42,20 +69,20 @@ def build(force=False, verbose=True):
 
 
 def _build_locked(force, verbose):
-    deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'block_order.h'), os.path.join(CSRC, 'split_layout.h'), os.path.join(CSRC, 'input_pipeline_math.h'), os.path.join(CSRC, 'depthwise_math.h'), os.path.join(CSRC, 'grouped_math.h'),
-            os.path.join(ROOT, 'include', 'semseg_hip.h')]
     objs, jobs = [], []
     tag = '.tmp%d' % os.getpid()
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OUT_DIR, s.replace('.hip', '.o'))
         objs.append(obj)
-        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
-            jobs.append((obj, [HIPCC] + FLAGS + ['-c', src, '-o', obj + tag]))
+        if force or _stale(src, obj):
+            # -MMD: the compiler lists every user header it read (csrc/*.h, include/semseg_hip.h) in obj.d; no hand-kept list
+            jobs.append((obj, [HIPCC] + FLAGS + ['-MMD', '-MF', obj + '.d' + tag, '-c', src, '-o', obj + tag]))
     if jobs:
         def run(job):
             obj, cmd = job
             _run(cmd, verbose)
+            os.replace(obj + '.d' + tag, obj + '.d')
             os.replace(obj + tag, obj)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
