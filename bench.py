@@ -186,15 +186,24 @@ def time_dominant_kernel(dev, cfg, iters=10):
         ut = ops.weight_wino_t(wparam)
         dy = torch.randn(n, h, w, k, device=dev) * 1e-3
         dyp = ops.SCHEMES['h2'].split(dy, n * h * w, k, k)
-        t_pass = timed(lambda: ops._winograd_dgrad(L, dyp, ut, geom))
+        t_pass = timed(lambda: ops._winograd_dgrad(L, dyp, ut, geom))          # the form the step runs (tuner.choose)
         tiles = L.semseg_winograd_tiles(n, h, w, dil)
         v = torch.empty(L.semseg_split_h2_bytes(16 * tiles, k), dtype=torch.uint8, device=dev)
-        m = torch.empty((16 * tiles, c), dtype=torch.float32, device=dev)
         _native.check(L.semseg_winograd_input_planes_h2(P(dyp), P(v), n, h, w, k, dil, st()), 'winograd_input_planes_h2')
+        choice = tuner.tuned_plans().get(('h2', 4, tiles, n, dil, c, k, 3, 3, 1, h, w))
+        form = int(choice[0]) if choice else 0
+        executed = 3 * 16 * 2.0 * tiles * k * c * 1e-9
+        if form >= 1:
+            # GEMM over the 16 frequencies + output transform in ONE launch (wino_fused_kernel): the dominant launch
+            dx = ops.empty_nhwc(n, c, h, w, dev)
+            t_gemm = timed(lambda: _native.check(L.semseg_winograd_gemm_output_h2(P(v), P(ut), P(dx), c, n, h, w, k, c, dil, form - 1,
+                                                                                 st()), 'winograd_gemm_output_h2'))
+            return t_pass, gflop, {'form': 'winograd_fused', 'gemm_s': t_gemm, 'gemm_tile': form - 1, 'executed_gflop': executed}
+        m = torch.empty((16 * tiles, c), dtype=torch.float32, device=dev)
         t_gemm = timed(lambda: _native.check(L.semseg_winograd_gemm_h2(P(v), P(ut), P(m), tiles, k, c, st()), 'winograd_gemm_h2'))
         plan = tuner.tuned_plans().get(('h2', 3, tiles, 1, 1, k, c, 3, 3, 1, 1, 1))
         return t_pass, gflop, {'form': 'winograd', 'gemm_s': t_gemm, 'gemm_tile': plan[0] if plan else None,
-                               'executed_gflop': 3 * 16 * 2.0 * tiles * k * c * 1e-9}
+                               'executed_gflop': executed}
     if pass_id == 1:
         a = torch.randn(n, h, w, k, device=dev) * 1e-3                 # dy
         wt = torch.randn(c, r, s, k, device=dev) * 0.01                # CRSK
@@ -233,9 +242,10 @@ def roofline_entry(kt, gflop, cfg, cfg_id, extras=None):
     achieved = gflop / kt * 1e-3
     pass_id, geom, layer = cfg['dominant']
     what_pass = 'data gradient' if pass_id == 1 else 'forward'
-    wino = extras.get('form') == 'winograd'
+    wino = extras.get('form') in ('winograd', 'winograd_fused')
+    fused = extras.get('form') == 'winograd_fused'
     plan = (extras.get('gemm_tile'), 1) if wino else tuner.tuned_plans().get((ops.CONV_MODE, pass_id) + tuple(geom))
-    pmc = pmc_lookup(ops.CONV_MODE, pass_id, geom, plan, 'winograd' if wino else 'direct')
+    pmc = pmc_lookup(ops.CONV_MODE, pass_id, geom, plan, extras.get('form') if wino else 'direct')
     if pmc is None:
         print('[bench] no PMC pass in profiles/pmc_index.json for the %s form of %s pass %d %s plan %s: roofline.traffic is null'
               % (extras.get('form'), ops.CONV_MODE, pass_id, list(geom), list(plan[:2]) if plan else None),
@@ -250,12 +260,21 @@ def roofline_entry(kt, gflop, cfg, cfg_id, extras=None):
         if wino:
             # Winograd F(2x2,3x3): the GEMM launch executes 16/36 of the direct MACs (x `terms` products each)
             executed = extras['executed_gflop'] / extras['gemm_s'] * 1e-3
-            kernel = ('Winograd-domain %s of %s: input transform from the h2 planes of dy + ONE batched igemm_dma_kernel launch over '
-                      'the 16 frequencies (%s, tile id %s; the dominant launch: %.3f ms, %.1f executed 16-bit TFLOP/s) + output '
-                      'transform; achieved = the layer\'s %.2f algorithmic GFLOP / the %.3f ms of all three launches, HIP events; '
-                      'traffic = FETCH_SIZE*2+WRITE_SIZE summed over the three launches (PMC pass named in pmc_source): the fp32 '
-                      'intermediate of the 16 frequencies is written and read back'
-                      % (what_pass, layer, inst, extras.get('gemm_tile'), extras['gemm_s'] * 1e3, executed, gflop, kt * 1e3))
+            if fused:
+                kernel = ('Winograd-domain %s of %s: input transform from the h2 planes of dy + ONE wino_fused_kernel launch -- the GEMM '
+                          'over the 16 frequencies AND the output transform: every block owns 128 tiles x 128 channels for all '
+                          'frequencies, one accumulator set for M[f], four for the 2x2 outputs, ring form %s (%s; the dominant '
+                          'launch: %.3f ms, %.1f executed 16-bit TFLOP/s); achieved = the layer\'s %.2f algorithmic GFLOP / the '
+                          '%.3f ms of both launches, HIP events; traffic = FETCH_SIZE*2+WRITE_SIZE summed over the two launches '
+                          '(PMC pass named in pmc_source): no fp32 intermediate exists'
+                          % (what_pass, layer, extras.get('gemm_tile'), inst, extras['gemm_s'] * 1e3, executed, gflop, kt * 1e3))
+            else:
+                kernel = ('Winograd-domain %s of %s: input transform from the h2 planes of dy + ONE batched igemm_dma_kernel launch '
+                          'over the 16 frequencies (%s, tile id %s; the dominant launch: %.3f ms, %.1f executed 16-bit TFLOP/s) + '
+                          'output transform; achieved = the layer\'s %.2f algorithmic GFLOP / the %.3f ms of all three launches, HIP '
+                          'events; traffic = FETCH_SIZE*2+WRITE_SIZE summed over the three launches (PMC pass named in pmc_source): '
+                          'the fp32 intermediate of the 16 frequencies is written and read back'
+                          % (what_pass, layer, inst, extras.get('gemm_tile'), extras['gemm_s'] * 1e3, executed, gflop, kt * 1e3))
         else:
             executed = terms * achieved
             kernel = ('split-%s implicit-GEMM %s (%s per fp32-accurate MAC block, %s), %s (%.2f GFLOP/launch algorithmic, '
@@ -414,31 +433,135 @@ def launch_probe(args):
 
 
 def other_configs(skip, steps, warmup, budget_s=100):
-    """BASELINE configs[2..4] measured next to the headline (outside its timed region): one `bench.py --config N` leg each, in a
-    child process (own allocator pool, own launch plans), at most `budget_s` seconds per leg.  Returns {cfg: summary}."""
+    """BASELINE configs[2..4] measured next to the headline (outside its timed region, one after the other, nothing else running
+    on the host or the GPU): one `bench.py --config N` leg each, in a child process (own allocator pool, own launch plans).
+    Every leg is labelled with what it ran: mean pixels per image, distinct shapes, train GFLOP per image.  Returns {cfg: summary}."""
     import subprocess
     out = {}
     for cid in sorted(CONFIGS):
         if cid == skip:
             continue
         cmd = [sys.executable, os.path.abspath(__file__), '--config', str(cid), '--gpus', '1', '--steps', str(steps), '--warmup',
-               str(warmup), '--no-cpu-baseline', '--no-other-configs']
+               str(warmup), '--no-cpu-baseline', '--no-other-configs', '--repeats', '0', '--no-box', '--no-scaling-model']
+        limit = budget_s
         if CONFIGS[cid].get('variable'):
-            cmd += ['--shapes', '8']             # 8 instead of 16 distinct shapes (each is seen twice and captured before the timed
-                                                 # steps): the leg stays under a minute
+            # BASELINE's rule (dataset.py:110-142 over the ADE20K size histogram) on the first 16 distinct shapes of the stream,
+            # each seen twice (eager + capture) before the timed steps; K steps cycle through the stream's own repetition pattern
+            cmd += ['--shapes', '16', '--steps', str(max(steps, 32))]
+            limit = budget_s + 80
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit)
             line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+            c = line['config']
             out[str(cid)] = {'workload': CONFIGS[cid]['yaml'], 'img_s': line['value'], 'ms_per_step': line['ms_per_step'],
-                             'launch': line['config']['launch'], 'step_conv_tflops': line['config']['step_conv_tflops_per_gpu'],
+                             'launch': c['launch'], 'step_conv_tflops': c['step_conv_tflops_per_gpu'],
+                             'mean_px_per_image': c['mean_px_per_image'], 'mean_side_px': round(c['mean_px_per_image'] ** 0.5, 1),
+                             'distinct_shapes_timed': c['distinct_shapes_timed'],
+                             'train_gflop_per_image': c['train_gflop_per_image'],
                              'roofline_frac': line['roofline']['frac'], 'roofline_achieved_tflops': line['roofline']['achieved'],
-                             'final_loss': line['config']['final_loss'], 'steps': line['steps'],
+                             'final_loss': c['final_loss'], 'steps': line['steps'],
                              'leg_wall_s': round(time.perf_counter() - t0, 1)}
         except Exception as e:                                    # never lose the headline to a side leg
             out[str(cid)] = {'workload': CONFIGS[cid]['yaml'], 'img_s': None, 'error': repr(e)[:200],
                              'leg_wall_s': round(time.perf_counter() - t0, 1)}
     return out
+
+
+def box_probe(dev):
+    """What THIS box sustains, measured in this process right after the timed steps (C ABI semseg_probe_*, csrc/probe.hip): dense
+    fp16 MFMA rate and the shader clock held under it, float4 copy bandwidth, per-node cost of a hipGraph chain of empty kernels.
+    The same tree measured 137 ... 153 img/s on different boxes in round 3; with this block a slow box reads as a slow box."""
+    import ctypes
+    from mit_semseg import _native
+    L = _native.lib()
+    vp = ctypes.c_void_p
+    st = lambda: vp(torch.cuda.current_stream().cuda_stream)   # noqa: E731
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        return ts
+    try:
+        blocks, iters = 1024, 12000
+        sink = torch.zeros(4, device=dev)
+        cyc = torch.zeros(blocks, dtype=torch.int64, device=dev)
+        ts = timed(lambda: _native.check(L.semseg_probe_mfma_f16(vp(sink.data_ptr()), blocks, iters, vp(cyc.data_ptr()), st()),
+                                         'probe_mfma'), 4)
+        flop = blocks * 4.0 * iters * 8 * 2 * 32 * 32 * 16
+        t = sorted(ts)[len(ts) // 2]
+        out['mfma_f16_dense_tflops'] = round(flop / t * 1e-12, 1)
+        out['mfma_f16_frac_of_2500'] = round(flop / t * 1e-12 / PEAK_BF16_MFMA_TFLOPS, 4)
+        # every SIMD issues one 32x32x16 MFMA per 32 cycles at best: the rate IS a lower bound of the clock held by this
+        # (memory-free, low-power) loop; the dense GEMM kernels of the step hold less (roofline.clock_ghz_under_load, PMC)
+        out['mfma_implied_clock_ghz'] = round(flop / t * 1e-12 / PEAK_BF16_MFMA_TFLOPS * 2.4, 3)
+        out['s_memtime_ticks_per_ns'] = round(float(cyc.double().mean().item()) / ts[-1] * 1e-9, 3)
+        out['mfma_probe'] = '%d blocks x 4 waves x %d x 8 v_mfma_f32_32x32x16_f16, %.2f ms, median of %d' % (blocks, iters, t * 1e3, len(ts))
+    except Exception as e:
+        out['mfma_error'] = repr(e)[:160]
+    try:
+        nbytes = 1 << 30
+        a = torch.empty(nbytes // 4, device=dev).normal_()
+        b = torch.empty_like(a)
+        ts = timed(lambda: _native.check(L.semseg_probe_copy(vp(a.data_ptr()), vp(b.data_ptr()), nbytes, st()), 'probe_copy'), 5)
+        t = sorted(ts)[len(ts) // 2]
+        out['hbm_copy_GBps'] = round(2.0 * nbytes / t * 1e-9, 1)
+        out['hbm_copy_frac_of_8000'] = round(2.0 * nbytes / t * 1e-9 / 8000.0, 4)
+        ts = timed(lambda: b.copy_(a), 5)                     # cross-check: the runtime's own device-to-device copy
+        out['hbm_copy_runtime_GBps'] = round(2.0 * nbytes / sorted(ts)[len(ts) // 2] * 1e-9, 1)
+        out['hbm_probe'] = '1 GiB read + 1 GiB written per launch (16 B per lane, 4 loads in flight), median of 5; bytes counted both ways'
+        del a, b
+    except Exception as e:
+        out['copy_error'] = repr(e)[:160]
+    try:
+        nodes = 2000
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(nodes):
+                L.semseg_probe_empty(st())
+        ts = timed(g.replay, 5)
+        out['graph_node_us'] = round(sorted(ts)[len(ts) // 2] / nodes * 1e6, 3)
+        out['graph_probe'] = 'replay of a captured chain of %d empty one-wave kernels' % nodes
+        del g
+    except Exception as e:
+        out['graph_error'] = repr(e)[:160]
+    try:
+        out['device'] = torch.cuda.get_device_name(dev)
+        out['cus'] = torch.cuda.get_device_properties(dev).multi_processor_count
+    except Exception:
+        pass
+    return out
+
+
+def scaling_model_block(step, sm, feed, t1_ms):
+    """no multi-GPU box -> measured 1-GPU step + analytic comm model.  The step is re-captured with timestamp
+    markers (csrc/probe.hip) at forward end, at the completion of every gradient bucket of parallel.plan_bucket_groups, at
+    backward end and at step end; three replays, the last one's timeline scaled to the measured step feeds
+    mit_semseg/scaling_model.py.  MODEL, NOT MEASURED."""
+    from mit_semseg import scaling_model as smod
+    enc, dec = sm.encoder, sm.decoder
+    probe = smod.TimelineProbe(list(enc.parameters()) + list(dec.parameters()))
+    try:
+        step.timeline = probe
+        step._graphs.clear()
+        for _ in range(4):                       # capture + three replays with the markers inside the graph
+            step.step(feed)
+        torch.cuda.synchronize()
+        ticks = probe.read()
+    finally:
+        step.timeline = None
+        step._graphs.clear()
+        probe.detach()
+    return smod.model_line(t1_ms, ticks, probe.bucket_bytes, smod.syncbn_payloads(sm))
 
 
 def main():
@@ -450,6 +573,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='N = 1, default config: skip the short legs of BASELINE configs[2..4] (config.other_configs)')
+    ap.add_argument('--repeats', type=int, default=3,
+                    help='after the contract window (W warm-up + exactly K timed steps = `value`): this many more timed windows of '
+                         'max(K, 50) steps each; their ms/step, median, min and max go into config.repeat_windows')
+    ap.add_argument('--no-box', action='store_true', help='skip the box probes (MFMA rate, HBM copy, graph node latency)')
+    ap.add_argument('--no-scaling-model', action='store_true', help='N = 1: skip the analytic 2/4/8-GPU model')
     ap.add_argument('--shapes', type=int, default=16,
                     help='config 3: number of distinct batch shapes of the stream that the run cycles through, all seen (and '
                          'captured) before the timed steps; 0 = the raw stream, cold path included')
@@ -550,8 +678,29 @@ def main():
     imgs = 2 * world * args.steps
     value = imgs / dt
     lossv = loss.item()
+    timed = {k: step.stats[k] - before[k] for k in step.stats}          # launch mode of the contract window
+    # more windows of the same replayed step, so that the one contract number can be read against its own spread
+    # (round-3 review: one 0.29 s sample; driver 137.2 vs builder boxes 147-153 with nothing in the line to tell why)
+    windows = []
+    if args.repeats > 0:
+        n_rep = max(args.steps, 50)
+        for _ in range(args.repeats):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            for i in range(n_rep):
+                step.step(feeds[args.warmup + i % args.steps])
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            rt = time.perf_counter() - r0
+            if world > 1:
+                t = torch.tensor([rt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rt = t.item()
+            windows.append(rt / n_rep * 1e3)
 
-    timed = {k: step.stats[k] - before[k] for k in step.stats}
     px = [h * w for h, w in shapes[args.warmup:]]
     gflop_img = cfg['gflop'] * (sum(px) / len(px)) / (512.0 * 512.0)
     if rank == 0:
@@ -589,25 +738,37 @@ def main():
                        'images_per_sec_per_gpu': round(per_gpu, 3),
                        'step_conv_tflops_per_gpu': round(per_gpu * gflop_img * 1e-3, 2),
                        'train_gflop_per_image': round(gflop_img, 1),
+                       'mean_px_per_image': round(sum(px) / len(px), 1),
+                       'distinct_shapes_timed': len(set(shapes[args.warmup:])),
+                       'repeat_windows': ({'steps_per_window': max(args.steps, 50),
+                                           'ms_per_step': [round(w, 3) for w in windows],
+                                           'median_ms': round(sorted(windows)[len(windows) // 2], 3),
+                                           'min_ms': round(min(windows), 3), 'max_ms': round(max(windows), 3),
+                                           'median_img_s': round(2e3 * world / sorted(windows)[len(windows) // 2], 2),
+                                           'contract_window_ms': round(dt / args.steps * 1e3, 3),
+                                           'note': '`value` / `ms_per_step` are the contract window (W warm-up + exactly K '
+                                                   'steps); these windows follow it on the same replayed graph'}
+                                          if windows else None),
                        'final_loss': round(lossv, 5)},
             'roofline': roofline_entry(kt, kgflop, cfg, args.config, kextras),
         }
         if world != args.gpus:                  # cannot happen past the checks at the top; never print a mislabelled line
             raise SystemExit('[bench] world %d != --gpus %d' % (world, args.gpus))
-        cpu_thread, cpu_box = None, {}
-        if world == 1 and not args.no_cpu_baseline:
-            import threading
-            # the CPU leg (32 host threads, ~15 s) runs beside the GPU legs of the other configs (host-light): both are outside
-            # the timed region of every measurement they accompany
-            cpu_thread = threading.Thread(target=lambda: cpu_box.update(r=cpu_baseline(cfg)))
-            cpu_thread.start()
+        if not args.no_box:
+            out['box'] = box_probe(dev)
+        if world == 1 and not args.no_scaling_model and not cfg.get('variable') and not args.no_graph:
+            try:
+                out['scaling_model'] = scaling_model_block(step, sm, feeds[0], dt / args.steps * 1e3)
+            except Exception as e:                   # never lose the line to the model leg
+                out['scaling_model'] = {'error': repr(e)[:300]}
+        # the side legs run ONE AFTER THE OTHER (round-3 review / ADVICE: the 32-thread CPU leg used to run beside the child GPU
+        # legs and both numbers moved): first the GPU legs of configs[2..4] on an otherwise idle host, then the CPU baseline
         if world == 1 and args.config == 1 and not args.no_other_configs:
             del step, sm, feeds                  # the legs run in child processes on the same GPU: hand the memory back first
             torch.cuda.empty_cache()
             out['config']['other_configs'] = other_configs(args.config, args.steps, args.warmup)
-        if cpu_thread is not None:
-            cpu_thread.join()
-            out['cpu_baseline'] = cpu_box.get('r')
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
         from mit_semseg import comm

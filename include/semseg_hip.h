@@ -409,6 +409,13 @@ int semseg_winograd_input_h2(const float* x, int x_ld, const float* const* bound
 int semseg_winograd_input_planes_h2(const void* src_planes, void* v_planes, int N, int H, int W, int C, int dil, void* stream);
 int semseg_winograd_gemm_h2(const void* v_planes, const void* u_planes, float* M, int tiles, int C, int K, void* stream);
 int semseg_winograd_output(const float* M, float* z, int z_ld, int N, int H, int W, int K, int dil, void* stream);
+/* gemm + output in ONE launch (round 4): every block owns [128 tiles] x [128 output channels] for all 16 frequencies -- an f-loop
+ * over the same LDS-DMA ring, one accumulator set for M[f], four for the 2 x 2 outputs -- and writes z = A^T M A as pixels; the fp32
+ * intermediate M (16 * tiles * K floats written by _gemm_h2 and read back by _output) never exists.  C = channels of V / U (the
+ * reduction), K = output channels; used for the data gradients of the wide 3x3 convs (models.py:455-465, 538-540; there C = the
+ * layer's filters, K = its input channels, u_planes = field `wino_t`).  form: 0 / 1 / 2 = 8 waves (32 x 64 per wave) on a 3- / 4- / 5-slot ring, 3 / 4 = 4 waves (64 x 64 per wave) on 4 / 5 slots. */
+int semseg_winograd_gemm_output_h2(const void* v_planes, const void* u_planes, float* z, int z_ld,
+                                   int N, int H, int W, int C, int K, int dil, int form, void* stream);
 /* Weight gradient of the same layers in the Winograd domain (the autograd of nn.Conv2d.weight at those call sites):
  *   semseg_winograd_dm_h2         : h2 planes of dz [N*H*W][K] -> dM = A dz A^T as h2 planes, rows 16*tiles (f, tile)
  *   semseg_winograd_wgrad_gemm_h2 : dU[f] = dM[f]^T V[f] (V = the forward's input transform), fp32 [16][K][C], one batched
@@ -520,6 +527,21 @@ int semseg_peer_attach_local(void* peer, int src_rank, void* other_peer);
 int semseg_peer_allreduce_sum_f64(void* peer, double* buf, size_t count, void* stream);   /* in place, on `stream` */
 int semseg_peer_status(void* peer);                    /* 0, or SEMSEG_ECOMM once an exchange timed out (no device sync) */
 int semseg_peer_destroy(void* peer);
+
+/* ---------------- box probes (bench.py `box` block and the backward timeline of its scaling model; no reference call site:
+ *                  the reference measures nothing about the device it runs on, train.py:50-66 prints wall-clock averages only) ----
+ * timestamp: one constant-rate timestamp (s_memrealtime) into the 8-byte aligned device word `slot` -- an ordinary kernel, so a
+ *   captured training step can carry markers (when each gradient bucket of parallel.GradientBuckets is complete) and a replay
+ *   yields the timeline; differences of two slots are scaled by the host with the replay's HIP-event time.
+ * mfma_f16: `blocks` x 4 waves x `iters` x 8 back-to-back v_mfma_f32_32x32x16_f16 (2*32*32*16 flop each) on register operands;
+ *   cycles[block] (uint64, may be NULL) = shader cycles (s_memtime) of wave 0's loop: flop / time = what the matrix pipes of
+ *   this box sustain, cycles / time = the clock it holds while they are busy.
+ * copy: 16 bytes per lane streaming copy of `bytes` (multiple of 16) -- achievable HBM bandwidth = 2 * bytes / time.
+ * empty: a one-wave kernel that does nothing -- N of them in a captured chain measure the per-node cost of a hipGraph replay. */
+int semseg_probe_timestamp(void* slot, void* stream);
+int semseg_probe_mfma_f16(void* sink, int blocks, int iters, void* cycles, void* stream);
+int semseg_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
+int semseg_probe_empty(void* stream);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,27 @@ SEMSEG_HD GemmBlock gemm_block(int hw_linear, int tiles_m, int tiles_n, int spli
     return b;
 }
 
+// Fused Winograd GEMM + output transform (wino_fused_kernel): grid tiles_m * tiles_n, every block walks all 16 frequencies in
+// step with its neighbours, so what an XCD's L2 has to hold per frequency is (row tiles resident) x BM x C of V + (column tiles
+// resident) x BN x C of U.  An XCD runs ~32 blocks at a time: they are dealt as SR x SC = 4 x 8 super-tiles (12 operand tiles per
+// 32 blocks instead of the 18 of a 16 x 2 strip); grids that the super-tile does not divide fall back to rows fastest.
+struct WinoFusedBlock { int tm, tn; };
+SEMSEG_HD WinoFusedBlock wino_fused_block(int hw_linear, int tiles_m, int tiles_n) {
+    const int lin = xcd_remap(hw_linear, tiles_m * tiles_n);
+    WinoFusedBlock b;
+    const int SR = 4, SC = 8;
+    if (tiles_m % SR == 0 && tiles_n % SC == 0) {
+        const int sup = lin / (SR * SC), in = lin - sup * (SR * SC);
+        const int sups_m = tiles_m / SR;
+        b.tm = (sup % sups_m) * SR + in % SR;
+        b.tn = (sup / sups_m) * SC + in / SR;
+    } else {
+        b.tm = lin % tiles_m;
+        b.tn = lin / tiles_m;
+    }
+    return b;
+}
+
 // Weight-gradient kernels (wgrad_kernel, wgrad_dma_kernel): grid (ntiles, splits[, batches]); the remap runs over (tile, split)
 // TOGETHER: an XCD receives whole row chunks z, and the tiles of a chunk -- the taps / channel blocks that read the same rows of
 // x and dy -- meet in one L2.  (A remap of x alone is an XCD map only when gridDim.x % 8 == 0 and deals every chunk to all XCDs.)

@@ -1523,6 +1523,296 @@ extern "C" int semseg_winograd_gemm_h2(const void* v_planes, const void* u_plane
 }
 
 // ------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3): batched GEMM AND output transform in one kernel.
+//
+// The unfused form (semseg_winograd_gemm_h2 + semseg_winograd_output) writes M[f] = V[f] U[f]^T for the 16 frequencies as fp32
+// and reads it back -- 16 x tiles x K x 4 B each way; for the data gradient of conv_last (512 -> 4096 @ 64 x 64) that is 537 MB
+// written + 537 MB read around a GEMM whose operands are 200 MB (profiles/r4_pmc_conv_last_dgrad_winograd_batch_xcd.txt:
+// 1.7 GB moved for 226 MB of algorithmic bytes), and its 16 reductions are only C / 32 = 16 k-tiles long, so every block spends
+// its time in prologue and epilogue.  Here ONE block owns a [BM tiles] x [BN output channels] tile for ALL 16 frequencies: an
+// outer loop over f, the same LDS-DMA ring over the C / 32 k-tiles of V[f] / U[f] inside, one accumulator set for M[f] and four
+// for the outputs y[i][j] = sum_{a,b} At[i][a] At[j][b] M[a][b]  (At = [[1, 1, 1, 0], [0, 1, -1, -1]], coefficients 0 / +-1):
+// after the last k-tile of a frequency its M is added to / subtracted from the (up to four) outputs it feeds and cleared.  The
+// loop is 16 x C / 32 k-tiles long with a single prologue, nothing but the result reaches memory, and the result is written
+// once, as pixels.  Register budget: wave tile 32 x 64 -> 32 (M) + 128 (y) accumulator registers + 48 of fragments on 8 waves
+// (two per SIMD, 256 registers each): 128 x 128 per block.  Worth it where K (output channels) is large against C (reduction):
+// the data gradients of the wide 3x3 convs (models.py:455-465, 538-540); the forward of those layers has few output tiles and a
+// small M and keeps the batched launch.
+// ------------------------------------------------------------------------------------------------
+struct WFParams {
+    const uint16_t* v;       // [NP][16 * tiles][pitch]
+    const uint16_t* u;       // [NP][16 * Cout][pitch]
+    const int* v_exp;
+    const int* u_exp;
+    uint32_t v_plane, u_plane;      // elements per plane
+    float* out;                     // [N][H][W] pixels x out_ld
+    int out_ld;
+    int tiles, Cout, chunks, pitch;
+    int tiles_m, tiles_n;
+    int N, H, W, dil, TH, TW;
+};
+
+template <int BM, int BN, int WGM, int WGN, int NSLOT>
+__global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFParams p) {
+    constexpr int NP = 2;
+    typedef SchH2::frag frag;
+    constexpr int NW = WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int FM = WM / 32, FN = WN / 32;
+    constexpr int AG = BM / 16 / NW, BG = BN / 16 / NW;
+    constexpr int LPT = NP * (AG + BG);
+    constexpr int A_BYTES = NP * BM * 64, B_BYTES = NP * BN * 64, BUF_BYTES = A_BYTES + B_BYTES;
+    static_assert(AG >= 1 && BG >= 1 && FM >= 1 && FN >= 1, "tile");
+    static_assert(NSLOT >= 3 && NSLOT <= 5 && (NSLOT - 1) * LPT < 64, "ring");
+
+    extern __shared__ __align__(16) uint4 smem4[];
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const WinoFusedBlock gb = wino_fused_block(blockIdx.x, p.tiles_m, p.tiles_n);     // block_order.h
+    const int m0 = gb.tm * BM, n0 = gb.tn * BN;
+
+    const uint32_t a_zero = 2u * NP * p.v_plane, b_zero = 2u * NP * p.u_plane;
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.v, 0, (int)(a_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, (int)(b_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+    const uint32_t a_plane_b = 2u * p.v_plane, b_plane_b = 2u * p.u_plane;
+    const uint32_t row_b = 2u * (uint32_t)p.pitch;
+    const uint32_t fa_b = (uint32_t)p.tiles * row_b, fb_b = (uint32_t)p.Cout * row_b;      // frequency strides (bytes)
+
+    const int lrow = lane >> 2;
+    const int q = (lane & 3) ^ ((lane >> 4) & 3);
+    uint32_t a_src[AG], a_msk[AG], b_src[BG], b_msk[BG];
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        const int m = m0 + (wave + NW * i) * 16 + lrow;
+        const bool ok = m < p.tiles;
+        a_src[i] = ok ? (uint32_t)m * row_b + 16u * q : a_zero;
+        a_msk[i] = ok ? 0xffffffffu : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int n = n0 + (wave + NW * i) * 16 + lrow;
+        const bool ok = n < p.Cout;
+        b_src[i] = ok ? (uint32_t)n * row_b + 16u * q : b_zero;
+        b_msk[i] = ok ? 0xffffffffu : 0u;
+    }
+    const int nk = 16 * p.chunks;
+    int i_f = 0, i_c = 0;                  // (frequency, chunk) of the next k-tile to ISSUE
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem + (uint32_t)wave * 1024u;
+    auto issue = [&](int kt, int slot) {
+        const uint32_t abuf = lds0 + (uint32_t)slot * BUF_BYTES;
+        const uint32_t bbuf = abuf + A_BYTES;
+        const bool live = kt < nk;                               // wave-uniform
+        const uint32_t ka = (uint32_t)i_f * fa_b + 64u * (uint32_t)i_c;
+        const uint32_t kb = (uint32_t)i_f * fb_b + 64u * (uint32_t)i_c;
+        if (live) {
+            if (++i_c == p.chunks) { i_c = 0; ++i_f; }
+        }
+#pragma unroll
+        for (int i = 0; i < AG; ++i)
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const uint32_t vo = live ? a_src[i] + ((ka + s * a_plane_b) & a_msk[i]) : a_zero;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)(abuf + (s * BM + NW * i * 16) * 64), 16, vo, 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < BG; ++i)
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const uint32_t vo = live ? b_src[i] + ((kb + s * b_plane_b) & b_msk[i]) : b_zero;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)(bbuf + (s * BN + NW * i * 16) * 64), 16, vo, 0, 0, 0);
+            }
+    };
+
+    f32x16 acc[FM][FN], y[4][FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                y[0][i][j][e] = 0.f; y[1][i][j][e] = 0.f; y[2][i][j][e] = 0.f; y[3][i][j][e] = 0.f;
+            }
+
+    const int frow = lane & 31;
+    const int kb2 = lane >> 5;
+    auto read_frags = [&](int slot, int ks, frag (&av)[FM][NP], frag (&bv)[FN][NP]) {
+        const uint4* As = reinterpret_cast<const uint4*>(smem + slot * BUF_BYTES);
+        const uint4* Bs = reinterpret_cast<const uint4*>(smem + slot * BUF_BYTES + A_BYTES);
+        const int ch = 2 * ks + kb2;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int r = wn * WN + j * 32 + frow;
+#pragma unroll
+            for (int s = 0; s < NP; ++s) bv[j][s] = *reinterpret_cast<const frag*>(&Bs[s * BN * 4 + s_slot(r, ch)]);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int r = wm * WM + i * 32 + frow;
+#pragma unroll
+            for (int s = 0; s < NP; ++s) av[i][s] = *reinterpret_cast<const frag*>(&As[s * BM * 4 + s_slot(r, ch)]);
+        }
+    };
+    auto mma = [&](const frag (&av)[FM][NP], const frag (&bv)[FN][NP]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) SchH2::mac(av[i], bv[j], acc[i][j]);
+    };
+    // M[f] complete: y[i][j] += At[i][a] At[j][b] M  (f = 4 a + b), then clear M.  Coefficients are wave-uniform.
+    auto fold = [&](int f) {
+        const int a = f >> 2, b = f & 3;
+        const float ra[2] = {a < 3 ? 1.f : 0.f, a == 0 ? 0.f : (a == 1 ? 1.f : -1.f)};
+        const float cb[2] = {b < 3 ? 1.f : 0.f, b == 0 ? 0.f : (b == 1 ? 1.f : -1.f)};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float c = ra[o >> 1] * cb[o & 1];
+            if (c != 0.f) {                                   // uniform branch
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) y[o][i][j][e] = fmaf(c, acc[i][j][e], y[o][i][j][e]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+
+    // ring of NSLOT slots, NSLOT - 1 tiles in flight behind ONE barrier per k-tile, fragment reads software-pipelined as in
+    // igemm_dma_kernel (NSLOT == 13 form)
+#pragma unroll
+    for (int t = 0; t < NSLOT; ++t) issue(t, t);
+    frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+    wait_vm_barrier<(NSLOT - 1) * LPT>();                     // tile 0 has landed for every wave
+    read_frags(0, 0, a0, b0);
+    int slot = 0, c_c = 0, c_f = 0;                            // (frequency, chunk) of the tile being MULTIPLIED
+    for (int it = 0; it < nk; ++it) {
+        const int next = (slot == NSLOT - 1) ? 0 : slot + 1;
+        read_frags(slot, 1, a1, b1);
+        mma(a0, b0);
+        wait_vm_barrier<(NSLOT - 2) * LPT>();                 // my reads of `slot` are done, tile it+1 has landed
+        issue(it + NSLOT, slot);
+        read_frags(next, 0, a0, b0);                          // past the last tile: zero tail, never multiplied
+        mma(a1, b1);
+        if (++c_c == p.chunks) {
+            c_c = 0;
+            fold(c_f);
+            ++c_f;
+        }
+        slot = next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                           // the ring is dead: LDS becomes the row -> pixel table
+
+    // row (tile) -> offsets of its 2 x 2 output pixels (floats from p.out), -1 where the pixel is outside the image
+    int* tab = reinterpret_cast<int*>(smem);                   // [BM][4]
+    for (int r = tid; r < BM; r += NW * 64) {
+        int t = m0 + r;
+        int o4[4] = {-1, -1, -1, -1};
+        if (t < p.tiles) {
+            const int tx = t % p.TW; t /= p.TW;
+            const int ty = t % p.TH; t /= p.TH;
+            const int pw = t % p.dil; t /= p.dil;
+            const int ph = t % p.dil;
+            const int n = t / p.dil;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int h = (2 * ty + i) * p.dil + ph, w = (2 * tx + j) * p.dil + pw;
+                    if (h < p.H && w < p.W) o4[i * 2 + j] = ((n * p.H + h) * p.W + w);
+                }
+        }
+        tab[r * 4 + 0] = o4[0]; tab[r * 4 + 1] = o4[1]; tab[r * 4 + 2] = o4[2]; tab[r * 4 + 3] = o4[3];
+    }
+    __syncthreads();
+    float f1, f2;
+    descale_factors<SchH2>(p.v_exp, p.u_exp, f1, f2);
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + col_l;
+        if (col >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
+                const int4 px = *reinterpret_cast<const int4*>(&tab[r * 4]);
+                if (px.x >= 0) p.out[(size_t)px.x * p.out_ld + col] = (y[0][i][j][e] * f1) * f2;
+                if (px.y >= 0) p.out[(size_t)px.y * p.out_ld + col] = (y[1][i][j][e] * f1) * f2;
+                if (px.z >= 0) p.out[(size_t)px.z * p.out_ld + col] = (y[2][i][j][e] * f1) * f2;
+                if (px.w >= 0) p.out[(size_t)px.w * p.out_ld + col] = (y[3][i][j][e] * f1) * f2;
+            }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int NSLOT>
+static int launch_wino_fused(const WFParams& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)NSLOT * 2 * (BM + BN) * 64;
+    static_assert(smem <= 160 * 1024 && smem >= (size_t)BM * 16, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino_fused_kernel<BM, BN, WGM, WGN, NSLOT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((wino_fused_kernel<BM, BN, WGM, WGN, NSLOT>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), smem, st, p);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// z[n, h, w, k] = A^T (sum_c V[f][tile, c] U[f][k, c]) A written as pixels: GEMM over the 16 frequencies + output transform in
+// one launch.  v_planes: h2 planes of V, rows (f, tile) x C (semseg_winograd_input_h2 / _input_planes_h2); u_planes: rows (f, k) x C.
+// form: 0 = 128 x 128 block on 8 waves, 3-slot ring; 1 / 2 = the same on a 4- / 5-slot ring (5 x 32 KiB = the whole LDS of a CU;
+// the kernel runs one block per CU either way -- 205 registers x 8 waves -- so the ring depth is free); 3 / 4 = the block on 4
+// waves of 64 x 64 (one per SIMD, 452 registers) on 4 / 5 slots
+extern "C" int semseg_winograd_gemm_output_h2(const void* v_planes, const void* u_planes, float* z, int z_ld,
+                                              int N, int H, int W, int C, int K, int dil, int form, void* stream) {
+    if (!v_planes || !u_planes || !z || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || dil <= 0 || z_ld < K ||
+        !aligned16(v_planes) || !aligned16(u_planes))
+        return SEMSEG_EINVAL;
+    WFParams p = {};
+    p.N = N; p.H = H; p.W = W; p.dil = dil;
+    p.TH = (ceil_div(H, dil) + 1) / 2;
+    p.TW = (ceil_div(W, dil) + 1) / 2;
+    p.tiles = N * dil * dil * p.TH * p.TW;
+    p.v = (const uint16_t*)v_planes; p.u = (const uint16_t*)u_planes; p.out = z; p.out_ld = z_ld;
+    p.Cout = K; p.chunks = round_up32(C) / 32; p.pitch = split_pitch(C);
+    p.v_exp = h2_exp_ptr(v_planes, (size_t)16 * p.tiles, C);
+    p.u_exp = h2_exp_ptr(u_planes, (size_t)16 * K, C);
+    const size_t v_plane = (size_t)16 * p.tiles * p.pitch, u_plane = (size_t)16 * K * p.pitch;
+    if (2 * H2_NP * v_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) || 2 * H2_NP * u_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
+        (size_t)N * H * W * z_ld >= ((size_t)1 << 31))
+        return SEMSEG_EINVAL;
+    p.v_plane = (uint32_t)v_plane;
+    p.u_plane = (uint32_t)u_plane;
+    p.tiles_m = ceil_div(p.tiles, 128);
+    p.tiles_n = ceil_div(K, 128);
+    hipStream_t st = (hipStream_t)stream;
+    switch (form) {
+        case 0: return launch_wino_fused<128, 128, 4, 2, 3>(p, st);
+        case 1: return launch_wino_fused<128, 128, 4, 2, 4>(p, st);
+        case 2: return launch_wino_fused<128, 128, 4, 2, 5>(p, st);
+        case 3: return launch_wino_fused<128, 128, 2, 2, 4>(p, st);      // 4 waves, 64 x 64 per wave (a third less LDS read traffic per MFMA)
+        case 4: return launch_wino_fused<128, 128, 2, 2, 5>(p, st);
+        default: return SEMSEG_EINVAL;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bias gradient: db[k] = sum_m dy[m][k]   (two deterministic passes, fp64 combine)
 // ------------------------------------------------------------------------------------------------
 // block = 64 channels x 4 row lanes; grid = (channel groups, row chunks); partial[chunk][k] (fp64)

@@ -117,6 +117,7 @@ SIGNATURES = {
     'semseg_winograd_input_h2': (c_int, [vp, c_int, ctypes.POINTER(vp), c_int, vp, c_int, c_int, c_int, c_int, c_int, vp]),
     'semseg_winograd_input_planes_h2': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
     'semseg_winograd_gemm_h2': (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
+    'semseg_winograd_gemm_output_h2': (c_int, [vp, vp, vp, c_int] + [c_int] * 7 + [vp]),
     'semseg_winograd_output': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'semseg_winograd_dm_h2': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
     'semseg_winograd_wgrad_workspace_bytes': (c_sz, [c_int, c_int, c_int]),
@@ -155,6 +156,10 @@ SIGNATURES = {
     'semseg_peer_allreduce_sum_f64': (c_int, [vp, vp, c_sz, vp]),
     'semseg_peer_status': (c_int, [vp]),
     'semseg_peer_destroy': (c_int, [vp]),
+    'semseg_probe_timestamp': (c_int, [vp, vp]),
+    'semseg_probe_mfma_f16': (c_int, [vp, c_int, c_int, vp, vp]),
+    'semseg_probe_copy': (c_int, [vp, vp, c_sz, vp]),
+    'semseg_probe_empty': (c_int, [vp]),
 }
 
 

@@ -198,6 +198,7 @@ class TrainStep:
         self._pool = None
         self._graph = None                            # the graph of the most recent replay (bench.py reports the launch mode)
         self.warmup_eager = 2
+        self.timeline = None                          # scaling_model.TimelineProbe: timestamp markers inside the (captured) step
         self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0}
 
     def adjust_learning_rate(self):
@@ -214,17 +215,28 @@ class TrainStep:
     def _eager(self, feed):
         if not self._weights_ready:
             self._prepare_weights()
+        tl = self.timeline
+        if tl is not None:
+            tl.mark('step_begin')
         self.opt.zero_grad()
         loss, acc = self.sm(feed)
         if self.buckets is not None:
             self.buckets.prepare()            # hooks launch each bucket's all-reduce as backward completes it
+        if tl is not None:
+            tl.mark('fwd_end')
+            tl.arm()                          # its hooks mark each gradient bucket when backward completes it
         loss.backward()
+        if tl is not None:
+            tl.armed = False
+            tl.mark('bwd_end')
         scale = 1.0
         if self.buckets is not None:
             self.buckets.finish()
             scale = 1.0 / self.world          # loss.mean() over replicas (train.py:42)
         self.opt.step(grad_scale=scale)
         self._prepare_weights()               # planes of the UPDATED weights, for the next step
+        if tl is not None:
+            tl.mark('step_end')
         return loss.detach(), acc.detach()
 
     def launch_mode(self):

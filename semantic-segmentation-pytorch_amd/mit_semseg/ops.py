@@ -888,23 +888,51 @@ def _winograd_wgrad(L, v, dzp, geom):
     return dwb.permute(0, 3, 1, 2)
 
 
-def _winograd_dgrad(L, dzp, ut_planes, geom):
+# The GEMM over the 16 frequencies and the output transform of the Winograd data gradient as ONE kernel
+# (semseg_winograd_gemm_output_h2, csrc/conv_split.hip wino_fused_kernel): no fp32 intermediate M (16 x tiles x C floats written
+# and read back by the unfused pair).  Which form runs is measured per geometry (tuner.choose); SEMSEG_WINOGRAD_FUSED=0 keeps
+# the batched GEMM + output transform everywhere.
+WINOGRAD_FUSED = os.environ.get('SEMSEG_WINOGRAD_FUSED', '1') != '0'
+WINOGRAD_FUSED_FORMS = 5          # library forms of the fused kernel (8 waves on a 3- / 4- / 5-slot ring, 4 waves on 4 / 5 slots)
+
+
+def _winograd_dgrad(L, dzp, ut_planes, geom, form=None):
     """dx of a 3x3 stride-1 pad == dil convolution in the Winograd domain, from the h2 planes of dz: the convolution of dz (k
-    channels) with the flipped, transposed weights (U' planes, csrc/weights_prep.hip) -- input transform from planes, the batched
-    GEMM of the forward with the roles of c and k swapped, output transform into dx"""
+    channels) with the flipped, transposed weights (U' planes, csrc/weights_prep.hip) -- input transform from planes, then
+    either the batched GEMM of the forward with the roles of c and k swapped + the output transform into dx (form 0), or both in
+    the fused kernel (form 1 + library form).  form None: the fastest on this geometry (timed once, tuner.choose)."""
     n, h, wd, c, k, r, s, stride, pad, dil = geom
     dev = dzp.device
     tiles = L.semseg_winograd_tiles(n, h, wd, dil)
     v = torch.empty(L.semseg_split_h2_bytes(16 * tiles, k), dtype=torch.uint8, device=dev)
-    m = torch.empty((16 * tiles, c), dtype=torch.float32, device=dev)
     dx = empty_nhwc(n, c, h, wd, dev)
     _native.check(L.semseg_winograd_input_planes_h2(_p(dzp), _p(v), n, h, wd, k, dil, _st()), 'winograd_input_planes_h2')
+    box = {}
 
-    def gemm():
-        _native.check(L.semseg_winograd_gemm_h2(_p(v), _p(ut_planes), _p(m), tiles, k, c, _st()), 'winograd_gemm_h2')
-    tuner.ensure_winograd_gemm(tiles, k, c, gemm)
-    gemm()
-    _native.check(L.semseg_winograd_output(_p(m), _p(dx), c, n, h, wd, c, dil, _st()), 'winograd_output')
+    def unfused():
+        if 'm' not in box:
+            box['m'] = torch.empty((16 * tiles, c), dtype=torch.float32, device=dev)
+        m = box['m']
+
+        def gemm():
+            _native.check(L.semseg_winograd_gemm_h2(_p(v), _p(ut_planes), _p(m), tiles, k, c, _st()), 'winograd_gemm_h2')
+        tuner.ensure_winograd_gemm(tiles, k, c, gemm)
+        gemm()
+        _native.check(L.semseg_winograd_output(_p(m), _p(dx), c, n, h, wd, c, dil, _st()), 'winograd_output')
+
+    def fused(lib_form):
+        def run():
+            _native.check(L.semseg_winograd_gemm_output_h2(_p(v), _p(ut_planes), _p(dx), c, n, h, wd, k, c, dil, lib_form, _st()),
+                          'winograd_gemm_output_h2')
+        return run
+    cands = [unfused]
+    # the fused kernel has one block per 128 tiles x 128 channels for ALL frequencies: it needs enough of them to fill the chip
+    if WINOGRAD_FUSED and ((tiles + 127) // 128) * ((c + 127) // 128) >= 96 and (n * h * wd * c) < (1 << 31):
+        cands += [fused(i) for i in range(WINOGRAD_FUSED_FORMS)]
+    if form is None:
+        form = tuner.choose((tiles, n, dil, c, k, 3, 3, 1, h, wd), cands) if len(cands) > 1 else 0
+    cands[form if form < len(cands) else 0]()
+    box.clear()
     return dx
 
 

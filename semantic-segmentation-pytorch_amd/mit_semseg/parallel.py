@@ -44,6 +44,35 @@ def world_size(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def plan_bucket_groups(params_in_backward_order, bucket_bytes=64 << 20, tail_bytes=None):
+    """parameters (already in the order backward produces their gradients) -> list of buckets (lists of parameters).
+    Greedy fill up to `bucket_bytes`; the LAST bucket (the first layers of the network) is complete only when backward is, so
+    its all-reduce overlaps with nothing: it is kept small (`tail_bytes`, default 1/16 of a bucket) -- what backward produces in
+    its last fraction of a millisecond -- and everything before it travels while backward is still running.  Shared by
+    GradientBuckets and the analytic scaling model (mit_semseg/scaling_model.py), which prices exactly these buckets."""
+    groups, cur, cur_n = [], [], 0
+    cap = max(1, bucket_bytes // 4)
+    for p in params_in_backward_order:
+        n = p.numel()
+        if cur and cur_n + n > cap:
+            groups.append(cur)
+            cur, cur_n = [], 0
+        cur.append(p)
+        cur_n += n
+    if cur:
+        groups.append(cur)
+    tail = max(1, (bucket_bytes // 16 if tail_bytes is None else tail_bytes) // 4)
+    if groups and len(groups[-1]) > 1 and sum(p.numel() for p in groups[-1]) > tail:
+        last, keep, n = groups.pop(), [], 0
+        while len(last) > 1 and n + last[-1].numel() <= tail:
+            n += last[-1].numel()
+            keep.insert(0, last.pop())
+        groups.append(last)
+        if keep:
+            groups.append(keep)
+    return groups
+
+
 class GradientBuckets:
     """Flat gradient buckets + all-reduce overlapped with backward.
 
@@ -60,29 +89,7 @@ class GradientBuckets:
         self.group = group
         self.params = [p for p in reversed(list(params)) if p.requires_grad]
         self.buckets = []          # dict(flat, items=[(param, offset, numel)], pending, launched)
-        groups, cur, cur_n = [], [], 0
-        cap = max(1, bucket_bytes // 4)
-        for p in self.params:
-            n = p.numel()
-            if cur and cur_n + n > cap:
-                groups.append(cur)
-                cur, cur_n = [], 0
-            cur.append(p)
-            cur_n += n
-        if cur:
-            groups.append(cur)
-        # The LAST bucket (the first layers of the network) is complete only when backward is, so its all-reduce overlaps with
-        # nothing: keep it small -- what backward produces in its last fraction of a millisecond -- and let everything before
-        # it travel while backward is still running.
-        tail = max(1, (bucket_bytes // 16 if tail_bytes is None else tail_bytes) // 4)
-        if groups and len(groups[-1]) > 1 and sum(p.numel() for p in groups[-1]) > tail:
-            last, keep, n = groups.pop(), [], 0
-            while len(last) > 1 and n + last[-1].numel() <= tail:
-                n += last[-1].numel()
-                keep.insert(0, last.pop())
-            groups.append(last)
-            if keep:
-                groups.append(keep)
+        groups = plan_bucket_groups(self.params, bucket_bytes, tail_bytes)
         for grp in groups:
             items, off = [], 0
             for p in grp:

@@ -50,6 +50,8 @@ def _load_cache():
         parts = k.split(',')
         key = (parts[0],) + tuple(int(t) for t in parts[1:])
         _done[key] = tuple(v)
+        if key[1] == 4:                   # a choice between launch forms (choose()), not a library plan
+            continue
         if v[0] >= 0:
             _native.check(_set_plan(L, key[0])(key[1], *key[2:], int(v[0]), int(v[1])), 'set_plan')
         _bucket_plans.setdefault(_bucket_key(key[0], key[1], key[2:]), (int(v[0]), int(v[1])))
@@ -157,6 +159,36 @@ def ensure_winograd_gemm(tiles, c, k, launch):
             set_plan(3, *geom, best[0], 1)
     _done[key] = best
     _save_cache()
+
+
+def choose(geom, candidates, default=0):
+    """which of several launch FORMS of one pass runs (e.g. the Winograd data gradient as batched GEMM + output transform, or as
+    the fused kernel on a 3- / 4-slot ring): every candidate -- a closure that issues the whole alternative on the current stream --
+    is timed once per geometry on the real buffers, outside graph capture, and the index of the fastest is remembered as plan
+    pass 4 (host-side only; the library has no plan for it).  Returns the index to run."""
+    key = ('h2', 4) + tuple(int(g) for g in geom)
+    if ENABLED and not _cache_loaded:
+        _load_cache()
+    rec = _done.get(key)
+    if rec is not None:
+        return int(rec[0]) if 0 <= int(rec[0]) < len(candidates) else default
+    if not ENABLED or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return default
+    stats['timed'] += 1
+    best = None
+    for i, fn in enumerate(candidates):
+        try:
+            fn()
+            ms = min(_time(fn, 6), _time(fn, 6))        # forms a few per cent apart: four rounds each, best one counts
+        except RuntimeError:
+            continue
+        if best is None or ms < best[2]:
+            best = (i, 1, ms)
+    if best is None:
+        return default
+    _done[key] = best
+    _save_cache()
+    return best[0]
 
 
 def ensure(scheme, pass_id, geom, launch):

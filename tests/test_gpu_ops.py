@@ -936,10 +936,27 @@ def test_winograd_dgrad(n, c, h, w, k, dil, monkeypatch):
     ut = ops.weight_wino_t(wp)
     assert ut is not None
     dzp = ops.SCHEMES['h2'].split(cl(dz).permute(0, 2, 3, 1), n * h * w, k, k)
-    dx = ops._winograd_dgrad(L, dzp, ut, geom)
+    dx = ops._winograd_dgrad(L, dzp, ut, geom, form=0)
     torch.cuda.synchronize()
     assert dx.shape == ref.shape
     e_wino = rel_err(dx, ref)
+    # the fused kernel (GEMM over the 16 frequencies + output transform in one launch, no fp32 intermediate), both ring depths:
+    # same arithmetic per output up to the order in which the 16 frequency terms are added
+    monkeypatch.setattr(ops, 'WINOGRAD_FUSED', True)
+    tiles = L.semseg_winograd_tiles(n, h, w, dil)
+    v = torch.empty(L.semseg_split_h2_bytes(16 * tiles, k), dtype=torch.uint8, device=dzp.device)
+    _native.check(L.semseg_winograd_input_planes_h2(ops._p(dzp), ops._p(v), n, h, w, k, dil, ops._st()), 'input_planes')
+    for lib_form in range(ops.WINOGRAD_FUSED_FORMS):
+        dxf = ops.empty_nhwc(n, c, h, w, dzp.device)
+        dxf.fill_(float('nan'))
+        _native.check(L.semseg_winograd_gemm_output_h2(ops._p(v), ops._p(ut), ops._p(dxf), c, n, h, w, k, c, dil, lib_form,
+                                                       ops._st()), 'gemm_output')
+        torch.cuda.synchronize()
+        e_f = rel_err(dxf, ref)
+        print('   fused form %d: rel err %.2e, max |fused - unfused| / max|dx| %.2e'
+              % (lib_form, e_f, float((dxf - dx).abs().max() / dx.abs().max())))
+        assert e_f < REL * 4, (lib_form, e_f, e_wino)
+        assert float((dxf - dx).abs().max() / dx.abs().max()) < 2e-6
     _, wtp = ops.weight_planes(wp, 'h2')
     dx_direct, _ = ops._split_conv_grads(L, ops.SCHEMES['h2'], 'h2', geom, None, dzp, wp.detach(), wtp, True, False)
     torch.cuda.synchronize()

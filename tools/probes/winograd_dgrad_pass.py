@@ -18,6 +18,9 @@ def main():
     ap.add_argument('--tile', type=int, default=14)
     ap.add_argument('--geom', default='2,64,64,4096,512,1', help='n,h,w,c,k,dil of the 3x3 stride-1 conv (default: conv_last)')
     ap.add_argument('--mode', default='dgrad', choices=('dgrad', 'fwd'))
+    ap.add_argument('--form', type=int, default=0,
+                    help='dgrad: 0 = batched GEMM + output transform, 1 / 2 / 3 = the fused kernel on its 3- / 4- / 5-slot ring')
+    ap.add_argument('--time', action='store_true', help='dgrad: HIP-event time of every form on this geometry (ms per pass)')
     args = ap.parse_args()
     from mit_semseg import ops, _native
     L = _native.lib()
@@ -50,10 +53,26 @@ def main():
     from mit_semseg import tuner
     tuner.ENABLED = False
     _native.check(L.semseg_conv2d_h2_set_plan(3, tiles, 1, 1, k, c, 3, 3, 1, 1, 1, args.tile, 1), 'set_plan')
+    if args.time:
+        gflop = 2.0 * n * h * w * c * k * 9 * 1e-9
+        for form in range(1 + ops.WINOGRAD_FUSED_FORMS):
+            for _ in range(3):
+                ops._winograd_dgrad(L, dyp, ut, geom, form=form)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                ops._winograd_dgrad(L, dyp, ut, geom, form=form)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            print('geom %s form %d: %.4f ms per pass (input transform + GEMM + output), %.1f algorithmic TFLOP/s'
+                  % (args.geom, form, ms, gflop / ms))
+        return
     for _ in range(args.iters):
-        ops._winograd_dgrad(L, dyp, ut, geom)
+        ops._winograd_dgrad(L, dyp, ut, geom, form=args.form)
     torch.cuda.synchronize()
-    print('done: %d passes, tiles %d, gemm tile %d' % (args.iters, tiles, args.tile))
+    print('done: %d passes, tiles %d, gemm tile %d, form %d' % (args.iters, tiles, args.tile, args.form))
 
 
 if __name__ == '__main__':
