@@ -1552,7 +1552,10 @@ struct WFParams {
     int N, H, W, dil, TH, TW;
 };
 
-template <int BM, int BN, int WGM, int WGN, int NSLOT>
+// PROBE: 0 = the kernel; 1 = DMA stream only (no fragment reads, no MFMAs: what the LDS-DMA ring alone sustains on this access
+// pattern); 2 = fragment reads + MFMAs on whatever the LDS holds, ONE tile fetched (what the multiply side alone sustains).
+// The probes write garbage and exist for tools/probes/winograd_dgrad_pass.py --form 101.. only.
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int PROBE = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFParams p) {
     constexpr int NP = 2;
     typedef SchH2::frag frag;
@@ -1606,7 +1609,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFPara
     auto issue = [&](int kt, int slot) {
         const uint32_t abuf = lds0 + (uint32_t)slot * BUF_BYTES;
         const uint32_t bbuf = abuf + A_BYTES;
-        const bool live = kt < nk;                               // wave-uniform
+        const bool live = kt < nk && (PROBE != 2 || kt < NSLOT);                               // wave-uniform
+        if (PROBE == 2 && kt >= NSLOT) return;
         const uint32_t ka = (uint32_t)i_f * fa_b + 64u * (uint32_t)i_c;
         const uint32_t kb = (uint32_t)i_f * fb_b + 64u * (uint32_t)i_c;
         if (live) {
@@ -1699,12 +1703,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFPara
     int slot = 0, c_c = 0, c_f = 0;                            // (frequency, chunk) of the tile being MULTIPLIED
     for (int it = 0; it < nk; ++it) {
         const int next = (slot == NSLOT - 1) ? 0 : slot + 1;
-        read_frags(slot, 1, a1, b1);
-        mma(a0, b0);
-        wait_vm_barrier<(NSLOT - 2) * LPT>();                 // my reads of `slot` are done, tile it+1 has landed
+        if (PROBE != 1) {
+            read_frags(slot, 1, a1, b1);
+            mma(a0, b0);
+        }
+        if (PROBE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else wait_vm_barrier<(NSLOT - 2) * LPT>();            // my reads of `slot` are done, tile it+1 has landed
         issue(it + NSLOT, slot);
-        read_frags(next, 0, a0, b0);                          // past the last tile: zero tail, never multiplied
-        mma(a1, b1);
+        if (PROBE != 1) {
+            read_frags(next, 0, a0, b0);                      // past the last tile: zero tail, never multiplied
+            mma(a1, b1);
+        }
         if (++c_c == p.chunks) {
             c_c = 0;
             fold(c_f);
@@ -1758,18 +1767,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFPara
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NSLOT>
+template <int BM, int BN, int WGM, int WGN, int NSLOT, int PROBE = 0>
 static int launch_wino_fused(const WFParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)NSLOT * 2 * (BM + BN) * 64;
     static_assert(smem <= 160 * 1024 && smem >= (size_t)BM * 16, "LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino_fused_kernel<BM, BN, WGM, WGN, NSLOT>,
+        hipError_t e = hipFuncSetAttribute((const void*)wino_fused_kernel<BM, BN, WGM, WGN, NSLOT, PROBE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((wino_fused_kernel<BM, BN, WGM, WGN, NSLOT>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), smem, st, p);
+    hipLaunchKernelGGL((wino_fused_kernel<BM, BN, WGM, WGN, NSLOT, PROBE>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -1808,6 +1817,8 @@ extern "C" int semseg_winograd_gemm_output_h2(const void* v_planes, const void* 
         case 2: return launch_wino_fused<128, 128, 4, 2, 5>(p, st);
         case 3: return launch_wino_fused<128, 128, 2, 2, 4>(p, st);      // 4 waves, 64 x 64 per wave (a third less LDS read traffic per MFMA)
         case 4: return launch_wino_fused<128, 128, 2, 2, 5>(p, st);
+        case 100: return launch_wino_fused<128, 128, 4, 2, 5, 1>(p, st);      // probes of form 2 (garbage results)
+        case 101: return launch_wino_fused<128, 128, 4, 2, 5, 2>(p, st);
         default: return SEMSEG_EINVAL;
     }
 }

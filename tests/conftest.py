@@ -24,3 +24,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """the parity lines of the run (max|dlogp|, argmax flips, band ratios per case) in the log, with or without -s"""
+    try:
+        from tests.util import PARITY_LINES
+    except Exception:
+        return
+    if PARITY_LINES:
+        terminalreporter.section('parity lines')
+        for ln in PARITY_LINES:
+            terminalreporter.write_line(ln)

@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.util import (golden_cases, load_golden, anchor_ratios, check_anchor_ratios, is_head_tensor, scale_error, post_step_bands,
+from tests.util import (parity_line, load_fullsize_golden, check_fullsize_golden, golden_cases, load_golden, anchor_ratios, check_anchor_ratios, is_head_tensor, scale_error, post_step_bands,
                         HEAD_SCALE_ERR, HEURISTIC_PLAN_GOLDEN, KNIFE_EDGE_GOLDEN)
 from oracle import semseg_oracle as O
 
@@ -45,7 +45,7 @@ def argmax_check(got_logp, ref_logp, what):
     margin = top2[:, 0] - top2[:, 1]
     diff = got != ref
     hard = diff & (margin >= 1e-4)
-    print('%s: %d/%d argmax flips, %d of them outside near-ties (margin>=1e-4); min margin %.2e' % (
+    parity_line('%s: %d/%d argmax flips, %d of them outside near-ties (margin>=1e-4); min margin %.2e' % (
         what, diff.sum().item(), diff.numel(), hard.sum().item(), margin.min().item()))
     assert hard.sum().item() == 0
 
@@ -82,7 +82,7 @@ def test_native_matches_reference_golden(name, monkeypatch):
     out = cap['out']
     pred, pred_ds = out if isinstance(out, tuple) else (out, None)
     pred = pred.detach().cpu().contiguous()
-    print('%s: max|dlogp| %.3e loss %.6f vs %.6f' % (name, (pred - g['pred']).abs().max().item(), loss.item(), g['loss'].item()))
+    parity_line('%s: max|dlogp| %.3e loss %.6f vs %.6f' % (name, (pred - g['pred']).abs().max().item(), loss.item(), g['loss'].item()))
     torch.testing.assert_close(pred, g['pred'], atol=LOGP_ATOL, rtol=0)
     argmax_check(pred, g['pred'], name)
     if pred_ds is not None:
@@ -101,7 +101,7 @@ def test_native_matches_reference_golden(name, monkeypatch):
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue
             items.append((side + k, sd[k], want[k]))
-    print(check_anchor_ratios(anchor_ratios(items, post_step_bands(g, m['lr'])), name + ' after-step state'))
+    parity_line(check_anchor_ratios(anchor_ratios(items, post_step_bands(g, m['lr'])), name + ' after-step state'))
 
 
 def _native_grads(g, dev):
@@ -137,11 +137,11 @@ def test_native_gradients_vs_reference_anchor(name, monkeypatch):
             items.append((side + k, p.grad, want[k]))
             if side == 'dec.' and is_head_tensor(k, p):
                 heads.append((scale_error(p.grad, want[k]), side + k))
-    print(check_anchor_ratios(anchor_ratios(items), name + ' gradients'))
+    parity_line(check_anchor_ratios(anchor_ratios(items), name + ' gradients'))
     # the classifier convs: no ReLU gate between them and the loss, so their gradients agree elementwise at roundoff level
     # (measured 2e-6 ... 1.2e-5 of the tensor's scale on every case, h2 and exact-fp32 alike)
     assert heads, 'no classifier tensors found'
-    print('%s classifier gradients: max |err| / scale %.2e (%s)' % ((name,) + max(heads)))
+    parity_line('%s classifier gradients: max |err| / scale %.2e (%s)' % ((name,) + max(heads)))
     assert max(heads)[0] <= HEAD_SCALE_ERR, heads
 
 
@@ -211,7 +211,11 @@ def test_full_size_vs_oracle(case):
                                   dropout=drop, deep_sup_scale=dss)
     ref2['loss'].backward()
     rp = ref['pred'].detach()
-    print('%s: max|dlogp| %.3e  loss %.6f vs %.6f' % (case, (pred - rp).abs().max().item(), loss.item(), ref['loss'].item()))
+    parity_line('%s vs the oracle on this box: max|dlogp| %.3e  loss %.6f vs %.6f' % (case, (pred - rp).abs().max().item(), loss.item(),
+                                                                                      ref['loss'].item()))
+    fx = load_fullsize_golden(case)
+    if fx is not None:          # configs[1] / [2]: the same forward of the UNMODIFIED reference, stored (make_fullsize_golden.py)
+        check_fullsize_golden(pred, loss.item(), acc.item(), fx, case, LOGP_ATOL)
     torch.testing.assert_close(pred, rp, atol=LOGP_ATOL, rtol=0)
     argmax_check(pred, rp, case)
     assert abs(loss.item() - ref['loss'].item()) < 1e-3
@@ -229,7 +233,7 @@ def test_full_size_vs_oracle(case):
             err = min((g_ - a).abs().max().item(), (g_ - b).abs().max().item())
             worst = max(worst, (err / tol, k))
             assert err <= tol, '%s: |native - oracle| %.3e > 2e-5 + 8 x %.3e (spread of two fp32 oracle runs)' % (k, err, spread)
-    print('%s: updated weights, worst error / allowed %.2f (%s)' % (case, worst[0], worst[1]))
+    parity_line('%s: updated weights, worst error / allowed %.2f (%s)' % (case, worst[0], worst[1]))
 
 
 def test_inference_graph_replay_equals_eager():

@@ -41,6 +41,35 @@ def test_oracle_matches_reference(name):
             check_summary(sd[k], want[k], 1e-4, 1e-3, 'after-step ' + k)
 
 
+@pytest.mark.parametrize('case', ['cfg1_r50d_ppmds_512', 'cfg2_r50_upernet_512'])
+def test_oracle_matches_reference_at_full_size(case):
+    """BASELINE configs[1] / configs[2] at 2 x 512 x 512: the oracle's training-mode forward against the stored forward of the
+    unmodified reference (tests/golden/make_fullsize_golden.py) -- the oracle the 512 x 512 GPU parity test runs on the box is
+    pinned at that size too"""
+    import json
+    from oracle import semseg_oracle as O
+    from tests.util import load_fullsize_golden
+    fx = load_fullsize_golden(case)
+    assert fx is not None
+    m = fx['meta']
+    man = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'manifests.json')))
+    enc_sd = O.synth_state_dict(man[m['arch_encoder']], m['seed_weights'][0])
+    dec_sd = O.synth_state_dict(man['%s@%d' % (m['arch_decoder'], m['fc_dim'])], m['seed_weights'][1])
+    drop = {'main': O.synth_dropout_mask(2, 512, seed=m['seed_dropout'][0])} if 'ppm' in m['arch_decoder'] else {}
+    if m['arch_decoder'] == 'ppm_deepsup':
+        drop['deepsup'] = O.synth_dropout_mask(2, m['fc_dim'] // 4, seed=m['seed_dropout'][1])
+    img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=m['seed_batch'])
+    with torch.no_grad():
+        res = O.segmentation_forward(O.clone_sd(enc_sd, False), O.clone_sd(dec_sd, False), m['arch_encoder'], m['arch_decoder'], img, lab,
+                                     training=True, dropout=drop, deep_sup_scale=m['deep_sup_scale'])
+    n, c, h, w = res['pred'].shape
+    rows = res['pred'].permute(0, 2, 3, 1).reshape(n * h * w, c)
+    torch.testing.assert_close(rows[fx['pixels']], fx['logp'], atol=ATOL * 10, rtol=RTOL)
+    assert torch.equal(rows.argmax(1).reshape(n, h, w), fx['argmax'].long())
+    torch.testing.assert_close(res['loss'], fx['loss'], atol=ATOL, rtol=RTOL)
+    torch.testing.assert_close(res['acc'], fx['acc'], atol=0, rtol=0)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # evaluation metrics (SURVEY 8f-2): the numpy oracle against outputs of the unmodified reference functions
 # ---------------------------------------------------------------------------------------------------------

@@ -26,6 +26,43 @@ HEAVY_GOLDEN = ('resnext101_c1_512_train',)
 KNIFE_EDGE_GOLDEN = ('hrnetv2_c1_64_train',)
 
 
+PARITY_LINES = []          # what the parity tests measured, one line per case: printed at once in pytest's terminal summary
+                            # (tests/conftest.py), so that a log kept without -s still shows max|dlogp|, flips and band ratios
+
+
+def parity_line(text):
+    PARITY_LINES.append(text)
+    print(text)
+
+
+FULLSIZE = os.path.join(GOLDEN, 'fullsize')
+
+
+def load_fullsize_golden(case):
+    """forward fixture of the UNMODIFIED reference at 2 x 512 x 512 (tests/golden/make_fullsize_golden.py), or None"""
+    path = os.path.join(FULLSIZE, case + '.pt')
+    return torch.load(path, weights_only=False) if os.path.exists(path) else None
+
+
+def check_fullsize_golden(pred, loss, acc, fx, what, atol=1e-3):
+    """log-probabilities `pred` [N, C, H, W] of a training-mode forward against the reference fixture: the stored pixel sample to
+    `atol`, the arg-max of EVERY pixel identical outside the reference's own near-ties (margin < 1e-4), loss / accuracy"""
+    n, c, h, w = pred.shape
+    assert [n, c, h, w] == list(fx['meta']['pred_shape']), (pred.shape, fx['meta']['pred_shape'])
+    rows = pred.detach().float().cpu().permute(0, 2, 3, 1).reshape(n * h * w, c)
+    dl = (rows[fx['pixels']] - fx['logp']).abs().max().item()
+    got = rows.argmax(1).reshape(n, h, w)
+    diff = got != fx['argmax'].long()
+    hard = diff & (fx['margin'] >= 1e-4)
+    parity_line('%s vs the UNMODIFIED reference (full-size fixture): max|dlogp| %.3e over %d sampled pixels x %d classes, %d/%d argmax '
+                'flips, %d outside near-ties (margin >= 1e-4), loss %.6f vs %.6f, acc %.6f vs %.6f'
+                % (what, dl, fx['pixels'].numel(), c, int(diff.sum()), diff.numel(), int(hard.sum()), float(loss), fx['loss'].item(),
+                   float(acc), fx['acc'].item()))
+    assert dl <= atol, (what, dl)
+    assert int(hard.sum()) == 0, what
+    assert abs(float(loss) - fx['loss'].item()) < 1e-3 and abs(float(acc) - fx['acc'].item()) < 1e-6, what
+
+
 def golden_cases():
     return sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*.pt')))
 

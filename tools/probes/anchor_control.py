@@ -6,6 +6,8 @@ limit, the f32 column would sit visibly lower.  Also prints, for the tensors wit
 classifier convs), the plain elementwise error relative to the tensor's scale.
 
     python tools/probes/anchor_control.py            # runs itself under both modes, prints / writes one table per mode
+    python tools/probes/anchor_control.py --cases r50_upernet_128_train --modes h2 f32 s3 h2:SEMSEG_WINOGRAD=0 h2:SEMSEG_TUNE=0
+        # which approximation carries an outlier: any number of modes `conv[:ENV=V[,ENV=V]]`, one column per mode
 """
 import json
 import os
@@ -34,7 +36,8 @@ def worker():
     from mit_semseg import ops, tuner
     dev = torch.device('cuda:0')
     rows = []
-    for name in GRAD_CASES:
+    cases = [c for c in os.environ.get('ANCHOR_CONTROL_CASES', '').split(',') if c] or GRAD_CASES
+    for name in cases:
         if name in util.HEURISTIC_PLAN_GOLDEN or name.startswith('mnv2d'):
             tuner.ENABLED = False
         g = util.load_golden(name)
@@ -78,34 +81,43 @@ def worker():
 def main():
     if os.environ.get('ANCHOR_CONTROL_WORKER') == '1':
         return worker()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', nargs='*', default=[])
+    ap.add_argument('--modes', nargs='*', default=['h2', 'f32'])
+    ap.add_argument('--tag', default='anchor_control_h2_vs_f32')
+    args = ap.parse_args()
     out_dir = os.path.join(ROOT, 'gpurun_out', 'anchor_control')
     os.makedirs(out_dir, exist_ok=True)
     tables = {}
-    for mode in ('h2', 'f32'):
-        env = dict(os.environ, SEMSEG_CONV=mode, ANCHOR_CONTROL_WORKER='1')
+    for spec in args.modes:
+        conv, _, envs = spec.partition(':')
+        env = dict(os.environ, SEMSEG_CONV=conv, ANCHOR_CONTROL_WORKER='1', ANCHOR_CONTROL_CASES=','.join(args.cases))
+        for kv in (e for e in envs.split(',') if e):
+            k, _, v = kv.partition('=')
+            env[k] = v
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=1500)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('ANCHOR_TABLE ')]
         if not line:
-            print('mode %s failed:\n%s\n%s' % (mode, r.stdout[-1500:], r.stderr[-3000:]))
+            print('mode %s failed:\n%s\n%s' % (spec, r.stdout[-1500:], r.stderr[-3000:]))
             continue
-        tables[mode] = json.loads(line[-1][len('ANCHOR_TABLE '):])['rows']
+        tables[spec] = json.loads(line[-1][len('ANCHOR_TABLE '):])['rows']
     lines = ['deviation from the float64 anchor of the unmodified reference, in units of the reference\'s own fp32 band (no tensor held',
              'to a tighter relative band than the median tensor of its case, tests/util.anchor_ratio; `raw` = without that lower limit;',
-             '`scale` = largest |err| / max|ref| over the tensors of the case)',
-             '%-31s %-10s %5s %8s | %-40s | %-40s | worst tensor (h2 / f32)' % ('case', 'what', 'n', 'relband', 'h2: median p95 max (raw max) scale',
-                                                                            'f32: median p95 max (raw max) scale')]
+             '`scale` = largest |err| / max|ref| over the tensors of the case); one block per mode: median p95 max (raw max) scale, worst tensor']
     fmt = lambda r: '%5.2f %5.2f %6.2f (%8.2f) %.1e' % (r['median'], r['p95'], r['max'], r['raw_max'], r['worst_scale_err'])   # noqa: E731
-    for i, row in enumerate(tables.get('h2', [])):
-        f = tables['f32'][i] if 'f32' in tables else None
-        lines.append('%-31s %-10s %5d %8.1e | %-40s | %-40s | %s / %s%s' % (
-            row['case'], row['what'], row['n'], row['rel_band'], fmt(row), fmt(f) if f else 'n/a', row['worst'], f['worst'] if f else '',
-            ('   classifier |err|/scale: h2 %.1e f32 %.1e' % (row['head_rel_err_max'], f['head_rel_err_max']))
-            if (row['head_rel_err_max'] is not None and f) else ''))
+    first = next(iter(tables.values()), [])
+    for i, row in enumerate(first):
+        lines.append('%-31s %-10s n=%d relband %.1e' % (row['case'], row['what'], row['n'], row['rel_band']))
+        for spec, rows in tables.items():
+            r = rows[i]
+            lines.append('    %-36s %s   %s%s' % (spec, fmt(r), r['worst'],
+                                                 ('   classifier |err|/scale %.1e' % r['head_rel_err_max']) if r['head_rel_err_max'] is not None else ''))
     text = '\n'.join(lines)
     print(text)
-    with open(os.path.join(out_dir, 'anchor_control_h2_vs_f32.txt'), 'w') as fh:
+    with open(os.path.join(out_dir, args.tag + '.txt'), 'w') as fh:
         fh.write(text + '\n')
-    with open(os.path.join(out_dir, 'anchor_control_h2_vs_f32.json'), 'w') as fh:
+    with open(os.path.join(out_dir, args.tag + '.json'), 'w') as fh:
         json.dump(tables, fh)
 
 

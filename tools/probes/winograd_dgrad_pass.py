@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--mode', default='dgrad', choices=('dgrad', 'fwd'))
     ap.add_argument('--form', type=int, default=0,
                     help='dgrad: 0 = batched GEMM + output transform, 1 / 2 / 3 = the fused kernel on its 3- / 4- / 5-slot ring')
+    ap.add_argument('--probes', action='store_true', help='with --time: also the DMA-only / multiply-only probes of the fused kernel')
     ap.add_argument('--time', action='store_true', help='dgrad: HIP-event time of every form on this geometry (ms per pass)')
     args = ap.parse_args()
     from mit_semseg import ops, _native
@@ -55,7 +56,27 @@ def main():
     _native.check(L.semseg_conv2d_h2_set_plan(3, tiles, 1, 1, k, c, 3, 3, 1, 1, 1, args.tile, 1), 'set_plan')
     if args.time:
         gflop = 2.0 * n * h * w * c * k * 9 * 1e-9
-        for form in range(1 + ops.WINOGRAD_FUSED_FORMS):
+        forms = list(range(1 + ops.WINOGRAD_FUSED_FORMS)) + ([101, 102] if args.probes else [])
+        for form in forms:
+            if form > 100:      # 101 = the fused kernel's DMA stream alone, 102 = its fragment reads + MFMAs alone (garbage results)
+                tiles = L.semseg_winograd_tiles(n, h, w, dil)
+                v = torch.empty(L.semseg_split_h2_bytes(16 * tiles, k), dtype=torch.uint8, device=dev)
+                _native.check(L.semseg_winograd_input_planes_h2(ops._p(dyp), ops._p(v), n, h, w, k, dil, ops._st()), 'input')
+                dx = ops.empty_nhwc(n, c, h, w, dev)
+                run = lambda: _native.check(L.semseg_winograd_gemm_output_h2(ops._p(v), ops._p(ut), ops._p(dx), c, n, h, w, k, c, dil,   # noqa: E731
+                                                                             form - 1, ops._st()), 'probe')
+                for _ in range(3):
+                    run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                print('geom %s probe %d (%s): %.4f ms per launch' % (args.geom, form, 'DMA stream only' if form == 101 else
+                                                                     'fragment reads + MFMAs only', e0.elapsed_time(e1) / args.iters))
+                continue
             for _ in range(3):
                 ops._winograd_dgrad(L, dyp, ut, geom, form=form)
             torch.cuda.synchronize()
