@@ -125,11 +125,12 @@ int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, floa
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* semseg_conv2d_fwd_h2 (no bias) that ALSO gathers the BatchNorm statistics of its result in the GEMM epilogue -- the conv -> BN
- * pairs of resnet.py:72-92 / models.py:160-167 without the statistics sweep over the conv output: every wave writes the fp64
- * column sums / sums of squares and fp32 column min / max of its sub-tile as one partial row into stats_ws
- * (semseg_conv2d_fwd_stats_bytes(K) bytes), zeroes *bound_word, and *parts_out (host) = the number of partial rows, to be
- * handed to semseg_bn_fwd_finish_fused.  *parts_out == 0: the launch plan of this geometry splits the reduction (or has more
- * than 512 wave rows) and nothing was gathered -- run semseg_bn_fwd_stats_fused on y instead. */
+ * pairs of resnet.py:72-92 / models.py:160-167 without the statistics sweep over the conv output: the waves of a block that share a
+ * column range combine the fp64 column sums / sums of squares and fp32 column min / max of their sub-tiles through LDS, and every
+ * BLOCK ROW TILE writes one partial row into stats_ws (semseg_conv2d_fwd_stats_bytes(K) bytes = room for 512 rows), zeroes
+ * *bound_word, and *parts_out (host) = the number of partial rows (= row tiles of the launch plan), to be handed to
+ * semseg_bn_fwd_finish_fused.  *parts_out == 0: the launch plan of this geometry splits the reduction (or has more than 512
+ * row tiles) and nothing was gathered -- run semseg_bn_fwd_stats_fused on y instead. */
 size_t semseg_conv2d_fwd_stats_bytes(int K);
 int semseg_conv2d_fwd_stats_h2(const void* xs, const void* ws, float* y, int y_ld,
                                int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

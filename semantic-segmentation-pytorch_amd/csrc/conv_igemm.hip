@@ -58,12 +58,14 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const IGemmParams p) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
+    // the remap runs over (tile, split) together (block_order.h): a remap of x alone is an XCD map only when gridDim.x % 8 == 0
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const WgradBlock tb = wgrad_block(blockIdx.x + gridDim.x * blockIdx.y, ntiles, gridDim.y);
+    const int tile = tb.tile;
     const int tn = tile % p.tiles_n;
     const int tm = tile / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
+    const int z = tb.z;
     const int kt_begin = z * p.kt_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
 

@@ -101,12 +101,13 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
 // software-pipelined fragment reads.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 9 : 1) : (sch == SchH2::ID ? 18 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 10 : 1) : (sch == SchH2::ID ? 18 : 3); }
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
     // pass 3: the batched GEMM of the Winograd forward (semseg_winograd_gemm_h2), keyed (tiles, 1, 1, C, K, 3, 3, 1, 1, 1); no split
-    if (pass < 0 || pass > 3 || tile > max_tile(sch, pass == 3 ? 0 : pass) || split > 64) return SEMSEG_EINVAL;
+    // split <= 64, except the all-taps weight-gradient tile (pass 2, tile 10): its tiles are 9x fewer, its splits fill the chip
+    if (pass < 0 || pass > 3 || tile > max_tile(sch, pass == 3 ? 0 : pass) || split > ((pass == 2 && tile == 10) ? 512 : 64)) return SEMSEG_EINVAL;
     if (pass == 3 && tile >= 0 && (sch != SchH2::ID || split != 1 || !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 ||
                                                                        tile == 10 || tile == 14)))
         return SEMSEG_EINVAL;
@@ -2088,6 +2089,172 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient of a 3x3, stride-1, pad == dil convolution with ALL NINE TAPS in one block (wtile 10).
+// wgrad_kernel gives every tap its own block, so the nine blocks of a pixel chunk each read the chunk's dy rows and (shifted) x
+// rows: the 64 x 64 launches of the 64 - 128-channel layers fetched 3.5 - 5x their operands (profiles/r4_pmc_step_traffic_cfg1.txt:
+// 3.97 GB per step for `wgrad_kernel<SchH2, 64, 64>`).  Here a block walks its pixel range in chunks of 32 consecutive output
+// pixels of ONE image row (OW % 32 == 0): the dy tile [32 pixels][64 k] is staged once, the x tile as a HALO -- 3 image rows
+// (oh - dil, oh, oh + dil) x (32 + 2 dil) pixels x 64 channels -- once, and tap (r, s) multiplies dy with the window
+// [row r][s dil ... s dil + 31] of the halo: the same transposed LDS reads as wgrad_kernel at a row offset, nine accumulator
+// fragments per wave (2 x 2 waves, 32 k x 32 c each: 144 accumulator registers).  102 staged pixel rows per chunk instead of 288,
+// one launch block per chunk instead of nine.  Replaces the weight-gradient half of nn.Conv2d.backward at resnet.py:100-108,
+// 61-66 (the 3x3 convs of the stem, layer1, layer2) and hrnet.py:26-29 (branch convs with OW % 32 == 0).
+// ------------------------------------------------------------------------------------------------
+constexpr int WT_STRIDE = 64 * 2 + 64;        // bytes per staged pixel row (64 channels + the 64-byte skew of WTile)
+static inline int wtaps_halo_w(int dil) { return 32 + 2 * dil; }
+static inline size_t wtaps_smem(int NP, int dil) { return (size_t)NP * (32 + 3 * wtaps_halo_w(dil)) * WT_STRIDE; }
+
+template <class SCH>
+__global__ __launch_bounds__(256, 2) void wgrad_taps_kernel(const WParams p) {
+    constexpr int NP = SCH::NP;
+    typedef typename SCH::frag frag;
+    constexpr int XPASS = 4;                     // 3 x (32 + 2 dil) x 8 16-byte chunks <= 1024 for dil <= 5
+    extern __shared__ __align__(16) unsigned char smem_t[];
+    const int HWp = 32 + 2 * p.dil;
+    unsigned char* As = smem_t;                                   // dy tile  [NP][32][WT_STRIDE]
+    unsigned char* Xs = smem_t + NP * 32 * WT_STRIDE;             // x halo   [NP][3][HWp][WT_STRIDE]
+    const int x_plane_lds = 3 * HWp * WT_STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_k * p.tiles_c;
+    const WgradBlock wb = wgrad_block(blockIdx.x + gridDim.x * blockIdx.y, ntiles, gridDim.y);
+    const int tc = wb.tile % p.tiles_c, tk = wb.tile / p.tiles_c;
+    const int k0 = tk * 64, c0 = tc * 64;
+    const int z = wb.z;
+    const int m_begin = z * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+
+    const int q8 = tid & 7, rowa = tid >> 3;                       // dy: 32 rows x 8 chunks = one pass
+    const bool ka_ok = (k0 + 8 * q8) < p.Kp;
+    const bool cb_ok = (c0 + 8 * q8) < p.Cp;
+    const int HWo = p.OH * p.OW;
+    const int nx = 3 * HWp * 8;                                    // 16-byte chunks of the halo per plane
+
+    uint4 ra[NP], rb[XPASS][NP];
+    auto load_chunk = [&](int mt) {
+        // the chunk's 32 output pixels: image n, row oh, columns ow0 ... ow0 + 31 (block-uniform)
+        const int n = mt / HWo;
+        const int rem = mt - n * HWo;
+        const int oh = rem / p.OW;
+        const int ow0 = rem - oh * p.OW;
+        {
+            const int m = mt + rowa;
+            const bool ok = (m < m_end) && ka_ok;
+            const uint32_t o = ok ? (uint32_t)m * (uint32_t)p.dypitch + k0 + 8 * q8 : 0u;
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p.dys + (size_t)h * p.dy_plane + o);
+                ra[h] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int idx = tid + i * 256;
+            const int ps = idx >> 3;                               // halo pixel slot: row r, column j
+            const int r = ps / HWp, j = ps - r * HWp;
+            const int ih = oh + (r - 1) * p.dil, iw = ow0 - p.dil + j;
+            const bool ok = (idx < nx) & (ih >= 0) & (ih < p.H) & (iw >= 0) & (iw < p.W) & cb_ok;
+            const uint32_t o = ok ? (uint32_t)((n * p.H + ih) * p.W + iw) * (uint32_t)p.xpitch + c0 + 8 * q8 : 0u;
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p.xs + (size_t)h * p.x_plane + o);
+                rb[i][h] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int h = 0; h < NP; ++h) *reinterpret_cast<uint4*>(As + (h * 32 + rowa) * WT_STRIDE + 16 * q8) = ra[h];
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < nx) {
+#pragma unroll
+                for (int h = 0; h < NP; ++h)
+                    *reinterpret_cast<uint4*>(Xs + h * x_plane_lds + (idx >> 3) * WT_STRIDE + 16 * q8) = rb[i][h];
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int G = lane >> 4, i16 = lane & 15;
+    const int tr_row = 8 * (G >> 1) + (i16 >> 2);
+    const int tr_col = 16 * (G & 1) + 4 * (i16 & 3);
+    const unsigned char* a_base = As + tr_row * WT_STRIDE + (wm * 32 + tr_col) * 2;
+    const unsigned char* b_base = Xs + tr_row * WT_STRIDE + (wn * 32 + tr_col) * 2;
+
+    auto compute_chunk = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            frag av[NP];
+#pragma unroll
+            for (int h = 0; h < NP; ++h) {
+                const unsigned char* q0 = a_base + (h * 32 + 16 * ks) * WT_STRIDE;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * WT_STRIDE));
+                av[h] = __builtin_bit_cast(frag, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    frag bv[NP];
+#pragma unroll
+                    for (int h = 0; h < NP; ++h) {
+                        const unsigned char* q0 = b_base + h * x_plane_lds + (r * HWp + s2 * p.dil + 16 * ks) * WT_STRIDE;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * WT_STRIDE));
+                        bv[h] = __builtin_bit_cast(frag, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                    SCH::mac(av, bv, acc[r * 3 + s2]);
+                }
+        }
+    };
+
+    if (m_begin < m_end) {
+        load_chunk(m_begin);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int mt = m_begin; mt + 32 < m_end; mt += 32) {
+        load_chunk(mt + 32);
+        compute_chunk();
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+    }
+    if (m_begin < m_end) compute_chunk();
+    S_MFMA_DRAIN();
+
+    float f1 = 1.f, f2 = 1.f;
+    descale_factors<SCH>(p.x_exp, p.dy_exp, f1, f2);
+    float* dst = (p.splits == 1) ? p.dw : p.partial + (size_t)z * p.K * 9 * p.C;
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+    const int c = c0 + wn * 32 + col_l;
+    if (c < p.C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * 32 + (e & 3) + 8 * (e >> 2) + row_l;
+                float v = acc[t][e];
+                if constexpr (SCH::SCALED) v = (v * f1) * f2;
+                if (k < p.K) dst[((size_t)k * 9 + t) * p.C + c] = v;
+            }
+    }
+}
+
+static bool wtaps_eligible(int R, int S, int stride, int pad, int dil, int OW, int M) {
+    return R == 3 && S == 3 && stride == 1 && pad == dil && dil >= 1 && dil <= 5 && OW % 32 == 0 && M % 32 == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS-DMA weight gradient: the same contraction as wgrad_kernel, but the 32-pixel x (BM | BN)-channel operand tiles go
 // global -> LDS by buffer_load_dwordx4 ... lds (no staging VGPRs and, above all, no ds_write_b128: at ~79 B/clk/CU the
 // LDS store path of the register-staged kernel costs more cycles per k-tile than its transposed reads).
@@ -2370,25 +2537,27 @@ struct WPlan {
 // wgrad tiles (k x c): 0 = 128x128, 1 = 64x64 (register staged); h2 only: 2 = 128x128 LDS-DMA 2-slot (4 waves),
 // 3 = 256x128 LDS-DMA 3-slot ring (8 waves), 4 = 256x256 LDS-DMA 2-slot (8 waves), 5 / 6 = 2 / 4 software pipelined -- chosen by
 // the tuner / overrides only
-static const int kWTiles[10][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
-                                    {128, 128}, {128, 128}};
+// 10 = 64x64 with all nine taps of a 3x3 stride-1 conv in the block (wgrad_taps_kernel): tiles = tiles_k * tiles_c, not * T
+static const int kWTiles[11][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
+                                    {128, 128}, {128, 128}, {64, 64}};
+constexpr int kWTileTaps = 10;
 
 // tuning overrides: SEMSEG_W3_TILE=0..3, SEMSEG_W3_SPLIT=n
 static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_split = 0) {
     WPlan pl;
     const int mtiles = ceil_div(M, 32);
-    const double tile_cost[10] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0, 1.0, 1.0};
-    const int slots[10] = {512, 1024, 512, 256, 256, 512, 256, 256, 512, 512};
+    const double tile_cost[11] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0, 1.0, 1.0, 2.9};
+    const int slots[11] = {512, 1024, 512, 256, 256, 512, 256, 256, 512, 512, 512};
     const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_W3_TILE", -1);
     const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_W3_SPLIT", 0);
     double best = 1e30;
     int best_t = 1, best_s = 1;
-    for (int t = 0; t < 10; ++t) {
+    for (int t = 0; t < 11; ++t) {
         if (force_tile >= 0 && t != force_tile) continue;
         if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
-        const long tiles = (long)ceil_div(K, kWTiles[t][0]) * ceil_div(C, kWTiles[t][1]) * T;
-        const int max_split = 64;      // a cap of 256 measured nothing better (profiles/r3i-m_ab_tile_forms.txt)
+        const long tiles = (long)ceil_div(K, kWTiles[t][0]) * ceil_div(C, kWTiles[t][1]) * (t == kWTileTaps ? 1 : T);
+        const int max_split = (t == kWTileTaps) ? 512 : 64;      // a cap of 256 measured nothing better (profiles/r3i-m_ab_tile_forms.txt)
         for (int sp = 1; sp <= max_split; ++sp) {
             if (force_split > 0 && sp != min(force_split, mtiles)) continue;
             if (force_split <= 0 && sp > 1 && mtiles / sp < 8) break;
@@ -2517,6 +2686,21 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
         case 9:
             if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 4, 12>(p, st);     // 16 waves, 32x32 per wave
             break;
+        case kWTileTaps: {
+            if (!wtaps_eligible(R, S, stride, pad, dil, OW, p.M)) return SEMSEG_EINVAL;
+            const size_t smem = wtaps_smem(SCH::NP, dil);
+            static size_t attr_smem = 0;
+            if (smem > attr_smem) {
+                hipError_t e = hipFuncSetAttribute((const void*)wgrad_taps_kernel<SCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)smem);
+                if (e != hipSuccess) return (int)e;
+                attr_smem = smem;
+            }
+            hipLaunchKernelGGL((wgrad_taps_kernel<SCH>), dim3(p.tiles_k * p.tiles_c, p.splits), dim3(256), smem, st, p);
+            SEMSEG_LAUNCH_CHECK();
+            rc = 0;
+            break;
+        }
     }
     if (rc) return rc;
     if (pl.splits > 1) {

@@ -44,13 +44,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     // tile id -> (tap, k tile, c tile); taps vary fastest among blocks of one XCD so that the 9 taps of a
     // (k,c) tile re-use the same dy rows / overlapping x rows from that XCD's L2
     const int ntiles = p.tiles_k * p.tiles_c * p.T;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const WgradBlock tb = wgrad_block(blockIdx.x + gridDim.x * blockIdx.y, ntiles, gridDim.y);     // (tile, split) together: block_order.h
+    const int tile = tb.tile;
     const int t = tile % p.T;
     const int tc = (tile / p.T) % p.tiles_c;
     const int tk = tile / (p.T * p.tiles_c);
     const int k0 = tk * BM, c0 = tc * BN;
     const int r = t / p.S, s = t - r * p.S;
-    const int z = blockIdx.y;
+    const int z = tb.z;
     const int m_begin = z * p.m_per_split;
     const int m_end = min(p.M, m_begin + p.m_per_split);
 

@@ -989,7 +989,7 @@ class ConvBNActFn(Function):
         if wino is None:
             wsp = wp if wp is not None else sch.split(w, k * r * s, c, c)
             if fused_stats and EPILOGUE_STATS:
-                # the BN statistics of z are gathered in the GEMM epilogue (one partial row per wave row; csrc/conv_split.hip
+                # the BN statistics of z are gathered in the GEMM epilogue (one partial row per block row tile; csrc/conv_split.hip
                 # gemm_epilogue) when the launch plan of this geometry does not split the reduction: no sweep over z for them
                 stats_bytes = L.semseg_conv2d_fwd_stats_bytes(k)
 
@@ -1006,7 +1006,9 @@ class ConvBNActFn(Function):
                         # a candidate that splits the reduction pays the statistics sweep on top: part of what the tuner compares
                         _native.check(L.semseg_bn_stats_mm_partial(_p(z), P, k, vp(base + conv_bytes), stats_bytes, _st()),
                                       'bn_stats_mm_partial')
+                    stats_owner[0] = ws          # the tensor the partials live in stays referenced until the finish kernel is issued
                     return base + conv_bytes
+                stats_owner = [None]
                 tuner.ensure('h2', 0, geom, launch)
                 stats_ws = launch()
             else:

@@ -72,7 +72,7 @@ _WSPLITS = _SPLITS
 # 14 = 256x256 on 16 waves, 15..17 = 64x64 / 128x64 on the LDS-DMA ring (4 waves).  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).
 _TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18)}
 # weight-gradient tile ids: 0 = 128x128, 1 = 64x64 register staged; h2 only: 2 = 128x128 LDS-DMA, 3 = 256x128 LDS-DMA ring
-_WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)}
+_WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)}      # 10: all nine taps of a 3x3 stride-1 conv in one block
 _ALLOW = os.environ.get('SEMSEG_TUNE_TILES', '')
 if _ALLOW:
     _allow = tuple(int(t) for t in _ALLOW.split(','))
@@ -234,7 +234,11 @@ def ensure(scheme, pass_id, geom, launch):
         best = (-1, 0, base)
         ranked.append((base, -1, 0))
         for tile in tiles:
-            for split in (_WSPLITS if pass_id == 2 else _SPLITS):
+            splits = _SPLITS
+            if pass_id == 2:
+                # the all-taps tile (10) has 9x fewer tiles than the per-tap kernels: its split over the pixels fills the chip
+                splits = (16, 32, 64, 96, 128, 192, 256, 384, 512) if tile == 10 else _WSPLITS
+            for split in splits:
                 if split > 1 and kt // split < 4:
                     break
                 _native.check(set_plan(pass_id, *geom, tile, split), 'set_plan')
@@ -246,7 +250,7 @@ def ensure(scheme, pass_id, geom, launch):
                 ranked.append((ms, tile, split))
                 if ms < best[2]:
                     best = (tile, split, ms)
-                if ms > 3.0 * best[2] and split >= 4:
+                if ms > 3.0 * best[2] and split >= 4 and not (pass_id == 2 and tile == 10):
                     break
         # play-off: with ~200 candidates per geometry a 5 % timing outlier picks the wrong plan now and then; the three
         # fastest are timed again (more launches per round) and the best mean of the two measurements wins

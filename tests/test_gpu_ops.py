@@ -735,6 +735,49 @@ def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
     assert rel_err(got, ref) < (REL * 4 if pass_id == 2 else REL), (pass_id, tile, split, rel_err(got, ref))
 
 
+# wgrad tile 10 (wgrad_taps_kernel: all nine taps of a 3x3 stride-1 pad == dil conv in one block, x staged as a halo) on the
+# geometries it accepts -- OW a multiple of 32 -- incl. channel counts that 64 does not divide, several (k, c) tiles, dilation,
+# two images (a chunk never crosses an image row), with and without a split over the pixels
+@pytest.mark.parametrize('case', [(2, 64, 32, 32, 64, 1), (1, 48, 16, 64, 80, 1), (2, 160, 24, 32, 96, 2), (1, 64, 40, 96, 128, 4),
+                                  (2, 3, 32, 64, 64, 1)], ids=str)
+@pytest.mark.parametrize('split', [1, 3, 16])
+def test_h2_wgrad_all_taps_in_one_block(case, split, monkeypatch):
+    from mit_semseg import ops, _native, tuner
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    monkeypatch.setattr(tuner, 'ENABLED', False)
+    L = _native.lib()
+    n, c, h, w, k, dil = case
+    geom = (n, h, w, c, k, 3, 3, 1, dil, dil)
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    gy = torch.randn(n, k, h, w, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (k, c, 3, 3), gy.double(), stride=1, padding=dil, dilation=dil)
+    grads = {}
+    for tile in (1, 10):                      # the one-block-per-tap kernel and the all-taps kernel on the same operands
+        _native.check(L.semseg_conv2d_h2_set_plan(2, *geom, tile, split), 'set_plan')
+        try:
+            xg, wg = cl(x).requires_grad_(True), cl(wt).requires_grad_(True)
+            ops.conv2d(xg, wg, None, 1, dil, dil).backward(cl(gy))
+            torch.cuda.synchronize()
+        finally:
+            L.semseg_conv2d_h2_set_plan(2, *geom, -1, 0)
+        grads[tile] = wg.grad
+        assert rel_err(wg.grad, ref) < REL * 4, (tile, split, rel_err(wg.grad, ref))
+    # same products, same order inside a chunk; only the chunk boundaries of the split may differ
+    assert float((grads[10] - grads[1]).abs().max() / grads[1].abs().max()) < 1e-5
+    # a geometry the kernel does not accept (OW = 24) is refused, not mis-computed
+    bad = (1, 24, 24, 64, 64, 3, 3, 1, 1, 1)
+    _native.check(L.semseg_conv2d_h2_set_plan(2, *bad, 10, 1), 'set_plan')
+    try:
+        with pytest.raises(RuntimeError):
+            xb = cl(torch.randn(1, 64, 24, 24)).requires_grad_(True)
+            wb = cl(torch.randn(64, 64, 3, 3)).requires_grad_(True)
+            ops.conv2d(xb, wb, None, 1, 1, 1).sum().backward()
+    finally:
+        L.semseg_conv2d_h2_set_plan(2, *bad, -1, 0)
+
+
 @pytest.mark.parametrize('case', PLAN_CASES + [(2, 64, 40, 40, 64, 3, 1, 1, 1), (2, 1024, 8, 8, 48, 1, 1, 0, 1)], ids=str)
 @pytest.mark.parametrize('tile', list(range(19)))
 def test_conv_epilogue_statistics_match_the_sweep(case, tile):

@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r5e
-python __graft_entry__.py > gpurun_out/r5e/build.log 2>&1
-timeout 300 python tools/probes/winograd_dgrad_pass.py --time --probes --iters 10 --geom 2,64,64,4096,512,1 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r5e/probes.txt
+mkdir -p gpurun_out/r5h; python __graft_entry__.py > gpurun_out/r5h/build.log 2>&1
+timeout 800 python tools/conv_bench.py --mode h2 --passes wgrad --sweep --verify --layers stem_conv2,stem_conv3,l1_conv2,l2_conv2,hr_48,hr_96,l3_conv2_d2 > gpurun_out/r5h/wgrad_sweep.txt 2>&1
+grep -v "amdgpu.ids" gpurun_out/r5h/wgrad_sweep.txt | tail -60 | cut -c1-300
