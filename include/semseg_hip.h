@@ -528,6 +528,10 @@ int semseg_peer_attach_local(void* peer, int src_rank, void* other_peer);
 int semseg_peer_allreduce_sum_f64(void* peer, double* buf, size_t count, void* stream);   /* in place, on `stream` */
 int semseg_peer_status(void* peer);                    /* 0, or SEMSEG_ECOMM once an exchange timed out (no device sync) */
 int semseg_peer_destroy(void* peer);
+/* widest BatchNorm (channels) whose in-kernel exchange (the _fused_peer entry points above: ceil(C / 16) blocks that wait for the
+ * peers' payloads) fits the CURRENT device at once; checked by every rank when the exchange is built (comm.peer_init), so that no
+ * rank can drop out of an exchange inside a step.  0: the occupancy query failed. */
+int semseg_bn_peer_channel_capacity(void);
 
 /* ---------------- box probes (bench.py `box` block and the backward timeline of its scaling model; no reference call site:
  *                  the reference measures nothing about the device it runs on, train.py:50-66 prints wall-clock averages only) ----

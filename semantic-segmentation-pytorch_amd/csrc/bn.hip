@@ -1230,19 +1230,25 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
 // the reliance on that.)  ceil(C/16) blocks of 256 threads against CUs x resident blocks per CU: 256 blocks for the widest BN
 // of the path (4096 channels) against >= 2048 on an MI355X.
 template <class K>
-static bool exchange_grid_fits(K kernel, int blocks) {
-    static int capacity = -1;                    // per kernel instantiation
-    if (capacity < 0) {
-        int dev = 0, cus = 0, per = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+static int exchange_capacity(K kernel) {         // resident blocks of `kernel` on the CURRENT device; -1: the query failed
+    static int capacity[64];                     // per kernel instantiation AND device (round-3 advice: the cache was per process)
+    static bool known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return -1; }
+    if (!known[dev]) {
+        int cus = 0, per = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, 0) != hipSuccess) {
             (void)hipGetLastError();
-            return false;
+            return -1;
         }
-        capacity = cus * per;
+        capacity[dev] = cus * per;
+        known[dev] = true;
     }
-    return blocks <= capacity;
+    return capacity[dev];
 }
+template <class K>
+static bool exchange_grid_fits(K kernel, int blocks) { return blocks <= exchange_capacity(kernel); }
 
 // `pre_parts` > 0: the partial sums exist already -- `workspace` holds pre_parts rows of [2C] fp64 sums followed by pre_parts rows
 // of [2C] fp32 min / max, written by the convolution's epilogue (semseg_conv2d_fwd_stats_h2, which also zeroed the bound word)
@@ -1255,6 +1261,9 @@ static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, 
                                    float* absmax_out, int pre_parts = 0) {
     semseg_peer::PeerArgs pa = {};
     if (peer && (!semseg_peer::peer_args(peer, &pa) || 2 * C + 1 > pa.cap)) return SEMSEG_EINVAL;
+    // BEFORE anything is launched: a rank that cannot co-schedule the exchanging grid leaves with nothing in flight (and the ranks
+    // have agreed on semseg_bn_peer_channel_capacity() when the exchange was built, comm.peer_init -- this is the backstop)
+    if (peer && !exchange_grid_fits(bn_fwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;
     if ((!z && pre_parts <= 0) || !stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || !blockbound ||
         P <= 0 || C <= 0 || (C % 4) || (z && !aligned16(z)))
         return SEMSEG_EINVAL;
@@ -1271,7 +1280,6 @@ static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, 
                            g.rows_per_block, partial, mm, absmax_out);
         SEMSEG_LAUNCH_CHECK();
     }
-    if (peer && !exchange_grid_fits(bn_fwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;
     if (peer)
         hipLaunchKernelGGL(bn_fwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
                            (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
@@ -1428,6 +1436,7 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
                                     void* stream, void* peer) {
     semseg_peer::PeerArgs pa = {};
     if (peer && (!semseg_peer::peer_args(peer, &pa) || 2 * C > pa.cap)) return SEMSEG_EINVAL;
+    if (peer && !exchange_grid_fits(bn_bwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;      // before any launch
     if (!dy || !z || !mean || !invstd || !sums || !gamma || !blockbound || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) ||
         dy_ld < C)
         return SEMSEG_EINVAL;
@@ -1450,7 +1459,6 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
     else LAUNCH_PARTIAL(2);
 #undef LAUNCH_PARTIAL
     SEMSEG_LAUNCH_CHECK();
-    if (peer && !exchange_grid_fits(bn_bwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;
     if (peer)
         hipLaunchKernelGGL(bn_bwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
                            (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
@@ -1482,4 +1490,14 @@ extern "C" int semseg_bn_bwd_reduce_fused_peer(const float* dy, int dy_ld, const
     if (!peer) return SEMSEG_EINVAL;
     return bn_bwd_reduce_fused_impl(dy, dy_ld, y, y_ld, z, mean, invstd, gate_scale, gate_shift, relu, P, C, stats_count, zmm, gamma,
                                     training, sums, dgamma, dbeta, blockbound, workspace, workspace_bytes, stream, peer);
+}
+
+// widest BN (channels) whose exchanging finish kernels -- ceil(C / 16) blocks that poll each other's peers inside the kernel -- are
+// co-resident on the CURRENT device; 0 when the occupancy query fails.  comm.peer_init gathers this from every rank when the
+// exchange is built and keeps the peer exchange only if every rank can hold the widest payload it was created for (round-3 advice:
+// a rank that failed the check inside a step left its peers spinning until the timeout).
+extern "C" int semseg_bn_peer_channel_capacity(void) {
+    const int a = exchange_capacity(bn_fwd_finish_fused_kernel<true>), b = exchange_capacity(bn_bwd_finish_fused_kernel<true>);
+    const int blocks = a < b ? a : b;
+    return blocks > 0 ? (blocks > (1 << 26) ? (1 << 30) : blocks * 16) : 0;
 }

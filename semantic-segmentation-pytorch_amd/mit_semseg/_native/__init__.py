@@ -156,6 +156,7 @@ SIGNATURES = {
     'semseg_peer_allreduce_sum_f64': (c_int, [vp, vp, c_sz, vp]),
     'semseg_peer_status': (c_int, [vp]),
     'semseg_peer_destroy': (c_int, [vp]),
+    'semseg_bn_peer_channel_capacity': (c_int, []),
     'semseg_probe_timestamp': (c_int, [vp, vp]),
     'semseg_probe_mfma_f16': (c_int, [vp, c_int, c_int, vp, vp]),
     'semseg_probe_copy': (c_int, [vp, vp, c_sz, vp]),

@@ -219,6 +219,10 @@ def peer_init(group=None, max_doubles=PEER_MAX_DOUBLES, selftest=True):
             if r != rank and L.semseg_peer_attach(handle, r, (ctypes.c_ubyte * 64)(*h)) != 0:
                 ok = False
                 break
+    # the exchanging BN finish kernels wait for their peers INSIDE the kernel: their whole grid -- one block per 16 channels -- must
+    # be resident at once on every rank's device, for the widest payload this exchange was created for ((max_doubles - 1) / 2
+    # channels).  Checked here, collectively, not inside a step (a rank that failed it there left the others spinning).
+    ok = ok and L.semseg_bn_peer_channel_capacity() >= (max_doubles - 1) // 2
     # every rank knows whether every rank could map every inbox BEFORE anybody launches an exchange (an exchange with a rank
     # that is not taking part would only end by its timeout)
     ok = _unanimous(ok, group)
