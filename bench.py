@@ -87,6 +87,15 @@ def ops_mode():
     return ops.CONV_MODE
 
 
+def launch_plan_provenance():
+    """where the (tile, split) launch plans of this run came from: the shipped performance database (plans measured on an MI355X
+    by the same tuner, mit_semseg/perfdb), a read-write cache (SEMSEG_TUNE_CACHE), or timed in this process"""
+    from mit_semseg import tuner
+    return {'from_perfdb': tuner.stats_db['from_perfdb'], 'from_cache': tuner.stats_db['from_cache'],
+            'timed_in_this_run': tuner.stats['timed'], 'inherited_by_pixel_bucket': tuner.stats['inherited'],
+            'perfdb': os.path.relpath(tuner.PERFDB, ROOT) if (tuner.USE_PERFDB and os.path.exists(tuner.PERFDB)) else None}
+
+
 def build_model(dev, cfg, seed=304):
     from mit_semseg.models import ModelBuilder, SegmentationModule
     from mit_semseg.models import resnet, hrnet
@@ -735,6 +744,7 @@ def main():
                        'ddp_graph_selftest': selftest_ok,
                        'collectives': collectives_used(world),
                        'conv_path': ops_mode(),
+                       'launch_plans': launch_plan_provenance(),
                        'images_per_sec_per_gpu': round(per_gpu, 3),
                        'step_conv_tflops_per_gpu': round(per_gpu * gflop_img * 1e-3, 2),
                        'train_gflop_per_image': round(gflop_img, 1),

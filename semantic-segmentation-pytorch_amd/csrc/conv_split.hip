@@ -101,13 +101,22 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
 // software-pipelined fragment reads.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 10 : 1) : (sch == SchH2::ID ? 18 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 12 : 1) : (sch == SchH2::ID ? 22 : 3); }
+
+// wgrad tile 10 (wgrad_taps_kernel) takes 3x3 stride-1 pad == dil convolutions whose output rows are whole 32-pixel chunks
+static bool wtaps_geometry_ok(int N, int H, int W, int R, int S, int stride, int pad, int dil) {
+    if (!(R == 3 && S == 3 && stride == 1 && pad == dil && dil >= 1 && dil <= 5)) return false;
+    return W % 32 == 0 && ((long)N * H * W) % 32 == 0;          // OH = H, OW = W for these convolutions
+}
 
 static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int tile,
                     int split) {
     // pass 3: the batched GEMM of the Winograd forward (semseg_winograd_gemm_h2), keyed (tiles, 1, 1, C, K, 3, 3, 1, 1, 1); no split
     // split <= 64, except the all-taps weight-gradient tile (pass 2, tile 10): its tiles are 9x fewer, its splits fill the chip
     if (pass < 0 || pass > 3 || tile > max_tile(sch, pass == 3 ? 0 : pass) || split > ((pass == 2 && tile == 10) ? 512 : 64)) return SEMSEG_EINVAL;
+    // a plan is refused where its kernel does not take the geometry (the tuner then skips the candidate; a plan inherited from
+    // another image size of the same layer -- mit_semseg/tuner.py buckets -- is re-timed instead of failing at launch)
+    if (pass == 2 && tile == 10 && !wtaps_geometry_ok(N, H, W, R, S, stride, pad, dil)) return SEMSEG_EINVAL;
     if (pass == 3 && tile >= 0 && (sch != SchH2::ID || split != 1 || !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 ||
                                                                        tile == 10 || tile == 14)))
         return SEMSEG_EINVAL;
@@ -864,8 +873,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     constexpr int LPT = NP * (AG + BG);                // DMA instructions per wave per tile
     constexpr int A_BYTES = NP * BM * 64, B_BYTES = NP * BN * 64, BUF_BYTES = A_BYTES + B_BYTES;
     static_assert(AG >= 1 && BG >= 1 && FM >= 1 && FN >= 1, "tile");
-    static_assert(NSLOT == 2 || NSLOT == 3 || NSLOT == 12 || NSLOT == 13, "slots");     // 12 / 13: 2 / 3 slots, software-pipelined fragment reads
-    static_assert(3 * LPT < 64, "vmcnt range");
+    static_assert(NSLOT == 2 || NSLOT == 3 || (NSLOT >= 12 && NSLOT <= 15), "slots");     // 12 ... 15: 2 ... 5 slots, software-pipelined fragment reads
+    constexpr int RING = NSLOT >= 12 ? NSLOT - 10 : NSLOT;
+    static_assert((RING > 3 ? RING - 1 : 3) * LPT < 64, "vmcnt range");
 
     extern __shared__ __align__(16) uint4 smem4[];
     unsigned char* smem = reinterpret_cast<unsigned char*>(smem4);
@@ -1068,20 +1078,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     // the newest LPT have landed" == "tile `it` has landed" at the top of every iteration.
     issue(kt_begin, 0);
     issue(kt_begin + 1, 1);
-    if constexpr (NSLOT == 13) {
-        // 3-slot ring with the same software pipeline: tile it+3 is issued into the slot of tile it right after the
-        // barrier, two k-tiles before it is needed (the 2-slot form leaves one)
-        issue(kt_begin + 2, 2);
+    if constexpr (NSLOT >= 13) {
+        // RING-slot ring (3 ... 5) with the same software pipeline: tile it+RING is issued into the slot of tile it right after the
+        // barrier, RING - 1 k-tiles before it is needed (the 2-slot form leaves one).  Round 4 (slots 4 / 5): the short-reduction
+        // launches are bound by the latency of one DMA round trip per k-tile, not by its bandwidth (the DMA stream of the fused
+        // Winograd kernel alone: profiles/r5_winograd_dgrad_forms.txt), and the small tiles have the LDS to keep more in flight
+#pragma unroll
+        for (int t = 2; t < RING; ++t) issue(kt_begin + t, t);
         frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
-        wait_vm_barrier<2 * LPT>();                           // tile 0 has landed for every wave
+        wait_vm_barrier<(RING - 1) * LPT>();                  // tile 0 has landed for every wave
         read_frags(0, 0, a0, b0);
         int slot = 0;
         for (int it = 0; it < nk; ++it) {
-            const int next = (slot == 2) ? 0 : slot + 1;
+            const int next = (slot == RING - 1) ? 0 : slot + 1;
             read_frags(slot, 1, a1, b1);
             mma(a0, b0);
-            wait_vm_barrier<LPT>();                           // my reads of `slot` are done, tile it+1 has landed
-            issue(kt_begin + it + 3, slot);
+            wait_vm_barrier<(RING - 2) * LPT>();              // my reads of `slot` are done, tile it+1 has landed
+            issue(kt_begin + it + RING, slot);
             read_frags(next, 0, a0, b0);
             mma(a1, b1);
             slot = next;
@@ -1178,9 +1191,10 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[19][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
+static const int kTiles[23][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
                                    {256, 128}, {256, 256}, {128, 128}, {256, 128}, {256, 256}, {256, 128}, {256, 128},
-                                   {256, 256}, {64, 64}, {128, 64}, {64, 64}, {128, 128}};
+                                   {256, 256}, {64, 64}, {128, 64}, {64, 64}, {128, 128},
+                                   {64, 64}, {128, 64}, {128, 128}, {128, 128}};      // 19 ... 22: deep rings (round 4)
 
 constexpr int kMaxEpilogueParts = 512;      // partial rows (= block row tiles) the BN finish kernel is asked to reduce; beyond
                                             // that (the 256 x 256 maps of the stem on small tiles) the separate sweep is cheaper
@@ -1253,7 +1267,7 @@ static int launch_rs(const SParams& p, hipStream_t st) {
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 static int launch_dma(const SParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)(NSLOT == 12 ? 2 : NSLOT == 13 ? 3 : NSLOT) * SCH::NP * (BM + BN) * 64;
+    constexpr size_t smem = (size_t)(NSLOT >= 12 ? NSLOT - 10 : NSLOT) * SCH::NP * (BM + BN) * 64;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (!attr_done) {
@@ -1362,6 +1376,19 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
         case 18:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 2, 2, 13>(p, st);      // 4 waves, 64x64 per wave, 3-slot ring
+            break;
+        // deep rings on the small tiles (round 4): 4 / 5 k-tiles in flight behind one barrier per tile
+        case 19:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 64, 64, 2, 2, 15>(p, st);        // 5 x 16 KiB: two blocks per CU
+            break;
+        case 20:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 64, 2, 2, 15>(p, st);       // 5 x 24 KiB: one block per CU
+            break;
+        case 21:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 4, 2, 14>(p, st);      // 8 waves, 4 x 32 KiB
+            break;
+        case 22:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 4, 2, 15>(p, st);      // 8 waves, 5 x 32 KiB
             break;
     }
     if (rc) return rc;
@@ -2283,7 +2310,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
     constexpr int A_BYTES = NP * CBA * 32 * 256, B_BYTES = NP * CBB * 32 * 256, BUF_BYTES = A_BYTES + B_BYTES;
     static_assert(BM % 128 == 0 && BN % 128 == 0 && (NW == 4 || NW == 8 || NW == 16) && FM >= 1 && FN >= 1, "tile");
     static_assert(!SPLIT_AB || CBA == CBB, "16 waves: equal operand widths");
-    static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3 || NSLOT == 12) && 2 * LPT < 64, "tile");
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3 || NSLOT == 12 || NSLOT == 14 || NSLOT == 15), "tile");
+    constexpr int RING = NSLOT >= 12 ? NSLOT - 10 : NSLOT;              // 14 / 15: 4- / 5-slot ring, software pipelined (round 4)
+    static_assert((RING > 2 ? RING - 1 : 2) * LPT < 64, "vmcnt range");
 
     extern __shared__ __align__(16) unsigned char smem_w[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2443,7 +2472,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
 
     issue(m_begin, 0);
     issue(m_begin + 32, 1);
-    if constexpr (NSLOT == 12) {
+    if constexpr (NSLOT >= 14) {
+        // RING-slot ring, RING - 1 pixel tiles in flight behind one barrier per tile (igemm_dma_kernel's NSLOT >= 13 form)
+#pragma unroll
+        for (int t = 2; t < RING; ++t) issue(m_begin + t * 32, t);
+        frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+        wait_vm_barrier<(RING - 1) * LPT>();
+        read_frags(0, 0, a0, b0);
+        int slot = 0;
+        for (int it = 0; it < nk; ++it) {
+            const int next = (slot == RING - 1) ? 0 : slot + 1;
+            read_frags(slot, 1, a1, b1);
+            mma(a0, b0);
+            wait_vm_barrier<(RING - 2) * LPT>();
+            issue(m_begin + (it + RING) * 32, slot);
+            read_frags(next, 0, a0, b0);
+            mma(a1, b1);
+            slot = next;
+        }
+    } else if constexpr (NSLOT == 12) {
         // software-pipelined 2-slot loop, one barrier per k-tile (see igemm_dma_kernel)
         frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
         wait_vm_barrier<LPT>();
@@ -2538,21 +2585,22 @@ struct WPlan {
 // 3 = 256x128 LDS-DMA 3-slot ring (8 waves), 4 = 256x256 LDS-DMA 2-slot (8 waves), 5 / 6 = 2 / 4 software pipelined -- chosen by
 // the tuner / overrides only
 // 10 = 64x64 with all nine taps of a 3x3 stride-1 conv in the block (wgrad_taps_kernel): tiles = tiles_k * tiles_c, not * T
-static const int kWTiles[11][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
-                                    {128, 128}, {128, 128}, {64, 64}};
+// 11 / 12 = 128x128 LDS-DMA on 8 / 16 waves with a 5- / 4-slot ring (round 4)
+static const int kWTiles[13][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
+                                    {128, 128}, {128, 128}, {64, 64}, {128, 128}, {128, 128}};
 constexpr int kWTileTaps = 10;
 
 // tuning overrides: SEMSEG_W3_TILE=0..3, SEMSEG_W3_SPLIT=n
 static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_split = 0) {
     WPlan pl;
     const int mtiles = ceil_div(M, 32);
-    const double tile_cost[11] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0, 1.0, 1.0, 2.9};
-    const int slots[11] = {512, 1024, 512, 256, 256, 512, 256, 256, 512, 512, 512};
+    const double tile_cost[13] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0, 1.0, 1.0, 2.9, 1.0, 1.0};
+    const int slots[13] = {512, 1024, 512, 256, 256, 512, 256, 256, 512, 512, 512, 256, 256};
     const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_W3_TILE", -1);
     const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_W3_SPLIT", 0);
     double best = 1e30;
     int best_t = 1, best_s = 1;
-    for (int t = 0; t < 11; ++t) {
+    for (int t = 0; t < 13; ++t) {
         if (force_tile >= 0 && t != force_tile) continue;
         if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
@@ -2606,7 +2654,7 @@ static int launch_wgrad(const WParams& p, hipStream_t st) {
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)(NSLOT == 12 ? 2 : NSLOT) * SCH::NP * (BM / 128 + BN / 128) * 32 * 256;
+    constexpr size_t smem = (size_t)(NSLOT >= 12 ? NSLOT - 10 : NSLOT) * SCH::NP * (BM / 128 + BN / 128) * 32 * 256;
     static_assert(smem <= 160 * 1024, "LDS");
     // 32-bit byte offsets in the buffer descriptors
     if ((size_t)2 * SCH::NP * p.x_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
@@ -2685,6 +2733,12 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
             break;
         case 9:
             if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 4, 12>(p, st);     // 16 waves, 32x32 per wave
+            break;
+        case 11:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 2, 15>(p, st);     // 8 waves, 5-slot ring
+            break;
+        case 12:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 4, 14>(p, st);     // 16 waves, 4-slot ring
             break;
         case kWTileTaps: {
             if (!wtaps_eligible(R, S, stride, pad, dil, OW, p.M)) return SEMSEG_EINVAL;

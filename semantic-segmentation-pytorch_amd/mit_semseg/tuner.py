@@ -18,8 +18,17 @@ ENABLED = os.environ.get('SEMSEG_TUNE', '1') != '0'
 # optional plan cache (JSON): plans tuned by one process are pinned without re-timing by the next (e.g. a profiled run
 # after a tuned run on the same box).  Unset -> no file is read or written.
 CACHE = os.environ.get('SEMSEG_TUNE_CACHE', '')
+# Shipped performance database (round 4): launch plans MEASURED by this tuner on an MI355X with the library of this tree, for the
+# conv geometries of the BASELINE configurations (mit_semseg/perfdb/gfx950_h2.json; regenerate with tools/make_perfdb.sh).  It is
+# read before anything is timed, so a fresh process starts from measured plans instead of re-timing ~200 candidates per geometry
+# (the driver's bench run and every test process did), and two runs of one tree launch the same plans -- the run-to-run spread of
+# the tuner's own choices no longer enters the number.  A geometry that is not in it is timed as before.  SEMSEG_TUNE_DB=0 ignores
+# the file (everything is timed afresh); SEMSEG_TUNE_CACHE still names a read-write cache that takes precedence.
+PERFDB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'perfdb', 'gfx950_h2.json')
+USE_PERFDB = os.environ.get('SEMSEG_TUNE_DB', '1') != '0'
 _done = {}          # (scheme, pass, geom) -> (tile, split, ms)
 _cache_loaded = False
+stats_db = {'from_perfdb': 0, 'from_cache': 0}
 # Variable-size batches (BASELINE configs[3]: every per-GPU batch has its own H x W) would put a full tile x split sweep of every
 # conv of the network in front of every new shape.  The winning plan of a layer depends on its channel configuration and on how
 # many output pixels it has, not on how they are arranged, so a geometry that has not been seen inherits the plan tuned for the
@@ -40,21 +49,33 @@ def _bucket_key(scheme, pass_id, geom):
 
 
 def _load_cache():
+    """perf database first (read-only), then the read-write cache of SEMSEG_TUNE_CACHE on top of it"""
     global _cache_loaded
     _cache_loaded = True
-    if not CACHE or not os.path.exists(CACHE):
-        return
     import json
     L = _native.lib()
-    for k, v in json.load(open(CACHE)).items():
-        parts = k.split(',')
-        key = (parts[0],) + tuple(int(t) for t in parts[1:])
-        _done[key] = tuple(v)
-        if key[1] == 4:                   # a choice between launch forms (choose()), not a library plan
+    for path, counter in (((PERFDB if USE_PERFDB else ''), 'from_perfdb'), (CACHE, 'from_cache')):
+        if not path or not os.path.exists(path):
             continue
-        if v[0] >= 0:
-            _native.check(_set_plan(L, key[0])(key[1], *key[2:], int(v[0]), int(v[1])), 'set_plan')
-        _bucket_plans.setdefault(_bucket_key(key[0], key[1], key[2:]), (int(v[0]), int(v[1])))
+        try:
+            entries = json.load(open(path))
+        except ValueError:
+            continue
+        for k, v in entries.items():
+            if k.startswith('_'):
+                continue
+            parts = k.split(',')
+            key = (parts[0],) + tuple(int(t) for t in parts[1:])
+            if key[1] == 4:                   # a choice between launch forms (choose()), not a library plan
+                _done[key] = tuple(v)
+                stats_db[counter] += 1
+                continue
+            if v[0] >= 0 and _set_plan(L, key[0])(key[1], *key[2:], int(v[0]), int(v[1])) != 0:
+                continue                      # a plan this build of the library does not know: the geometry is timed afresh
+            _done[key] = tuple(v)
+            stats_db[counter] += 1
+            if key[1] in (0, 1, 2):
+                _bucket_plans.setdefault(_bucket_key(key[0], key[1], key[2:]), (int(v[0]), int(v[1])))
 
 
 def _save_cache():
@@ -70,9 +91,9 @@ _WSPLITS = _SPLITS
 # fwd/dgrad tile ids per scheme (csrc/conv_split.hip): 0..2 register staged, 3 = 256x128 LDS-DMA, h2 only: 4 = 256x128
 # 3-slot ring, 5 = 256x256, 6..10 their software-pipelined / 128x128 forms, 11..13 = 4-wave forms (256x256, 256x128 2- and 3-slot),
 # 14 = 256x256 on 16 waves, 15..17 = 64x64 / 128x64 on the LDS-DMA ring (4 waves).  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).
-_TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18)}
+_TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22)}      # 19..22: 4- / 5-slot rings on the small tiles
 # weight-gradient tile ids: 0 = 128x128, 1 = 64x64 register staged; h2 only: 2 = 128x128 LDS-DMA, 3 = 256x128 LDS-DMA ring
-_WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)}      # 10: all nine taps of a 3x3 stride-1 conv in one block
+_WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12)}      # 10: all nine taps of a 3x3 stride-1 conv in one block; 11 / 12: deep rings
 _ALLOW = os.environ.get('SEMSEG_TUNE_TILES', '')
 if _ALLOW:
     _allow = tuple(int(t) for t in _ALLOW.split(','))
@@ -217,13 +238,15 @@ def ensure(scheme, pass_id, geom, launch):
     bkey = _bucket_key(scheme, pass_id, geom)
     if BUCKETS and bkey in _bucket_plans:
         tile, split = _bucket_plans[bkey]
+        ok = True
         if tile >= 0:
             while split > 1 and kt // split < 4:              # the same validity rule as the sweep below
                 split = max(s for s in _SPLITS if s < split)
-            _native.check(set_plan(pass_id, *geom, tile, split), 'set_plan')
-        _done[key] = (tile, split if tile >= 0 else 0, None)
-        stats['inherited'] += 1
-        return
+            ok = set_plan(pass_id, *geom, tile, split) == 0   # refused: this geometry is not one the inherited kernel takes
+        if ok:
+            _done[key] = (tile, split if tile >= 0 else 0, None)
+            stats['inherited'] += 1
+            return
     stats['timed'] += 1
     best = None
     ranked = []                                     # (ms, tile, split) of every candidate that ran
@@ -241,7 +264,8 @@ def ensure(scheme, pass_id, geom, launch):
             for split in splits:
                 if split > 1 and kt // split < 4:
                     break
-                _native.check(set_plan(pass_id, *geom, tile, split), 'set_plan')
+                if set_plan(pass_id, *geom, tile, split) != 0:
+                    break                                   # the library refuses this tile for this geometry
                 try:
                     launch()
                     ms = _time(launch, 2)

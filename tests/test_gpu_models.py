@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from tests.util import (parity_line, load_fullsize_golden, check_fullsize_golden, golden_cases, load_golden, anchor_ratios, check_anchor_ratios, is_head_tensor, scale_error, post_step_bands,
-                        HEAD_SCALE_ERR, HEURISTIC_PLAN_GOLDEN, KNIFE_EDGE_GOLDEN, KNIFE_EDGE_SCALE_ERR)
+                        HEAD_SCALE_ERR, HEURISTIC_PLAN_GOLDEN, KNIFE_EDGE_GOLDEN, KNIFE_EDGE_SCALE_ERR, KNIFE_EDGE_MEDIAN_SCALE_ERR)
 from oracle import semseg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -240,21 +240,25 @@ def test_full_size_vs_oracle(case):
 def test_knife_edge_case_gradients_stay_within_a_loose_elementwise_limit(name):
     """`hrnetv2_c1_64_train` is exempt from the band acceptance of its gradients (tests/util.KNIFE_EDGE_GOLDEN: its coarsest branch
     is a 2 x 2 map, the result sits 0.00 or 3.7 bands from the anchor depending on the launch plans).  It is NOT exempt from
-    being right: every gradient tensor within KNIFE_EDGE_SCALE_ERR of its scale (a flip of the knife edge is 2.8e-3), the
-    classifier gradients at roundoff level as everywhere -- so a regression that moves a 64 x 64 HRNet tensor by a few per cent,
-    or breaks the 2 x 2 BN path in backward, fails here."""
+    being right: the MEDIAN gradient tensor within KNIFE_EDGE_MEDIAN_SCALE_ERR of its scale (a flip of the knife edge moves it by
+    2.8e-3), every tensor within KNIFE_EDGE_SCALE_ERR (single tensors of the 2 x 2 branch move by 13 ... 25 % on a flip), the
+    classifier gradients at roundoff level as everywhere -- so a regression that moves the 64 x 64 HRNet gradients by a few per
+    cent across the board, or breaks the 2 x 2 BN path in backward, fails here."""
     g = load_golden(name)
     sm = _native_grads(g, torch.device('cuda:0'))
-    worst, heads = (0.0, ''), []
+    worst, heads, errs = (0.0, ''), [], []
     for mod, want, side in ((sm.encoder, g['anchor_grads_enc'], 'enc.'), (sm.decoder, g['anchor_grads_dec'], 'dec.')):
         for k, p in mod.named_parameters():
             assert torch.isfinite(p.grad).all(), side + k
             e = scale_error(p.grad, want[k])
+            errs.append(e)
             worst = max(worst, (e, side + k))
             if side == 'dec.' and is_head_tensor(k, p):
                 heads.append((e, side + k))
-    parity_line('%s gradients (knife-edge case, loose limit): worst |err| / scale %.2e (%s), classifier %.2e' % (
-        name, worst[0], worst[1], max(heads)[0]))
+    median = sorted(errs)[len(errs) // 2]
+    parity_line('%s gradients (knife-edge case, loose limits): |err| / scale median %.2e, worst %.2e (%s), classifier %.2e' % (
+        name, median, worst[0], worst[1], max(heads)[0]))
+    assert median <= KNIFE_EDGE_MEDIAN_SCALE_ERR, median
     assert worst[0] <= KNIFE_EDGE_SCALE_ERR, worst
     assert max(heads)[0] <= HEAD_SCALE_ERR, heads
 

@@ -128,8 +128,12 @@ def anchor_ratio(got, rec, what, rel_band=0.0, abs_band=0.0):
 
 
 CASE_REL_BAND_CAP = 2e-2      # largest case-median relative band of the committed fixtures: 1.3e-2 (mnv2d_c1ds_192_train gradients)
-KNIFE_EDGE_SCALE_ERR = 2e-2   # loose elementwise limit for the gradients of the knife-edge case (|err| / max|ref| per tensor): a 3.7-band
-                              # flip of that case is 2.8e-3 of the tensors' scale; a kernel bug moves a tensor by O(1)
+# loose limits for the gradients of the knife-edge case (|err| / max|ref| per tensor): when its knife edge resolves the other way the
+# MEDIAN tensor moves by 3.7 bands = 2.8e-3 of its scale and single tensors of the 2 x 2 branch by 13 ... 25 % (gpurun r5i:
+# 0.129 on enc.stage3.0.branches.2.1.bn1.bias; the exact-fp32 kernels: 0.25, profiles/r4_anchor_control_h2_vs_f32.txt); a kernel
+# bug moves most tensors by O(1)
+KNIFE_EDGE_SCALE_ERR = 0.5
+KNIFE_EDGE_MEDIAN_SCALE_ERR = 1e-2
 
 
 def case_rel_band(records):
