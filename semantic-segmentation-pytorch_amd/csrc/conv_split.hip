@@ -101,7 +101,7 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
 // software-pipelined fragment reads.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 12 : 1) : (sch == SchH2::ID ? 22 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 10 : 1) : (sch == SchH2::ID ? 21 : 3); }
 
 // wgrad tile 10 (wgrad_taps_kernel) takes 3x3 stride-1 pad == dil convolutions whose output rows are whole 32-pixel chunks
 static bool wtaps_geometry_ok(int N, int H, int W, int R, int S, int stride, int pad, int dil) {
@@ -1191,10 +1191,10 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[23][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
+static const int kTiles[22][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
                                    {256, 128}, {256, 256}, {128, 128}, {256, 128}, {256, 256}, {256, 128}, {256, 128},
                                    {256, 256}, {64, 64}, {128, 64}, {64, 64}, {128, 128},
-                                   {64, 64}, {128, 64}, {128, 128}, {128, 128}};      // 19 ... 22: deep rings (round 4)
+                                   {64, 64}, {128, 128}, {128, 128}};      // 19 ... 21: deep rings (round 4)
 
 constexpr int kMaxEpilogueParts = 512;      // partial rows (= block row tiles) the BN finish kernel is asked to reduce; beyond
                                             // that (the 256 x 256 maps of the stem on small tiles) the separate sweep is cheaper
@@ -1377,17 +1377,17 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
         case 18:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 2, 2, 13>(p, st);      // 4 waves, 64x64 per wave, 3-slot ring
             break;
-        // deep rings on the small tiles (round 4): 4 / 5 k-tiles in flight behind one barrier per tile
+        // deep rings on the small tiles (round 4): 4 / 5 k-tiles in flight behind one barrier per tile.  Sweep of the net's layers
+        // (profiles/r5_conv_sweep_deep_rings.txt): +3 ... 5 % on layer3's dilated 3x3 convs and two of layer4's 1x1 convs, neutral on
+        // HRNet's branches, worse wherever the shallower ring lets two blocks share a CU; the 128x64 tile on five slots and the
+        // weight-gradient tiles on 4 / 5 slots won no layer and were dropped again.
         case 19:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 64, 64, 2, 2, 15>(p, st);        // 5 x 16 KiB: two blocks per CU
             break;
         case 20:
-            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 64, 2, 2, 15>(p, st);       // 5 x 24 KiB: one block per CU
-            break;
-        case 21:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 4, 2, 14>(p, st);      // 8 waves, 4 x 32 KiB
             break;
-        case 22:
+        case 21:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 4, 2, 15>(p, st);      // 8 waves, 5 x 32 KiB
             break;
     }
@@ -2310,9 +2310,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
     constexpr int A_BYTES = NP * CBA * 32 * 256, B_BYTES = NP * CBB * 32 * 256, BUF_BYTES = A_BYTES + B_BYTES;
     static_assert(BM % 128 == 0 && BN % 128 == 0 && (NW == 4 || NW == 8 || NW == 16) && FM >= 1 && FN >= 1, "tile");
     static_assert(!SPLIT_AB || CBA == CBB, "16 waves: equal operand widths");
-    static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3 || NSLOT == 12 || NSLOT == 14 || NSLOT == 15), "tile");
-    constexpr int RING = NSLOT >= 12 ? NSLOT - 10 : NSLOT;              // 14 / 15: 4- / 5-slot ring, software pipelined (round 4)
-    static_assert((RING > 2 ? RING - 1 : 2) * LPT < 64, "vmcnt range");
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3 || NSLOT == 12) && 2 * LPT < 64, "tile");
 
     extern __shared__ __align__(16) unsigned char smem_w[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2472,25 +2470,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
 
     issue(m_begin, 0);
     issue(m_begin + 32, 1);
-    if constexpr (NSLOT >= 14) {
-        // RING-slot ring, RING - 1 pixel tiles in flight behind one barrier per tile (igemm_dma_kernel's NSLOT >= 13 form)
-#pragma unroll
-        for (int t = 2; t < RING; ++t) issue(m_begin + t * 32, t);
-        frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
-        wait_vm_barrier<(RING - 1) * LPT>();
-        read_frags(0, 0, a0, b0);
-        int slot = 0;
-        for (int it = 0; it < nk; ++it) {
-            const int next = (slot == RING - 1) ? 0 : slot + 1;
-            read_frags(slot, 1, a1, b1);
-            mma(a0, b0);
-            wait_vm_barrier<(RING - 2) * LPT>();
-            issue(m_begin + (it + RING) * 32, slot);
-            read_frags(next, 0, a0, b0);
-            mma(a1, b1);
-            slot = next;
-        }
-    } else if constexpr (NSLOT == 12) {
+    if constexpr (NSLOT == 12) {
         // software-pipelined 2-slot loop, one barrier per k-tile (see igemm_dma_kernel)
         frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
         wait_vm_barrier<LPT>();
@@ -2585,22 +2565,21 @@ struct WPlan {
 // 3 = 256x128 LDS-DMA 3-slot ring (8 waves), 4 = 256x256 LDS-DMA 2-slot (8 waves), 5 / 6 = 2 / 4 software pipelined -- chosen by
 // the tuner / overrides only
 // 10 = 64x64 with all nine taps of a 3x3 stride-1 conv in the block (wgrad_taps_kernel): tiles = tiles_k * tiles_c, not * T
-// 11 / 12 = 128x128 LDS-DMA on 8 / 16 waves with a 5- / 4-slot ring (round 4)
-static const int kWTiles[13][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
-                                    {128, 128}, {128, 128}, {64, 64}, {128, 128}, {128, 128}};
+static const int kWTiles[11][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
+                                    {128, 128}, {128, 128}, {64, 64}};
 constexpr int kWTileTaps = 10;
 
 // tuning overrides: SEMSEG_W3_TILE=0..3, SEMSEG_W3_SPLIT=n
 static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_split = 0) {
     WPlan pl;
     const int mtiles = ceil_div(M, 32);
-    const double tile_cost[13] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0, 1.0, 1.0, 2.9, 1.0, 1.0};
-    const int slots[13] = {512, 1024, 512, 256, 256, 512, 256, 256, 512, 512, 512, 256, 256};
+    const double tile_cost[11] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0, 1.0, 1.0, 2.9};
+    const int slots[11] = {512, 1024, 512, 256, 256, 512, 256, 256, 512, 512, 512};
     const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_W3_TILE", -1);
     const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_W3_SPLIT", 0);
     double best = 1e30;
     int best_t = 1, best_s = 1;
-    for (int t = 0; t < 13; ++t) {
+    for (int t = 0; t < 11; ++t) {
         if (force_tile >= 0 && t != force_tile) continue;
         if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
@@ -2654,7 +2633,7 @@ static int launch_wgrad(const WParams& p, hipStream_t st) {
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)(NSLOT >= 12 ? NSLOT - 10 : NSLOT) * SCH::NP * (BM / 128 + BN / 128) * 32 * 256;
+    constexpr size_t smem = (size_t)(NSLOT == 12 ? 2 : NSLOT) * SCH::NP * (BM / 128 + BN / 128) * 32 * 256;
     static_assert(smem <= 160 * 1024, "LDS");
     // 32-bit byte offsets in the buffer descriptors
     if ((size_t)2 * SCH::NP * p.x_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
@@ -2733,12 +2712,6 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
             break;
         case 9:
             if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 4, 12>(p, st);     // 16 waves, 32x32 per wave
-            break;
-        case 11:
-            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 2, 15>(p, st);     // 8 waves, 5-slot ring
-            break;
-        case 12:
-            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 4, 14>(p, st);     // 16 waves, 4-slot ring
             break;
         case kWTileTaps: {
             if (!wtaps_eligible(R, S, stride, pad, dil, OW, p.M)) return SEMSEG_EINVAL;

@@ -707,7 +707,7 @@ PLAN_CASES = [
 
 
 @pytest.mark.parametrize('case', PLAN_CASES, ids=str)
-@pytest.mark.parametrize('pass_id,tile', [(0, t) for t in range(23)] + [(1, t) for t in range(23)] + [(2, t) for t in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12)])
+@pytest.mark.parametrize('pass_id,tile', [(0, t) for t in range(22)] + [(1, t) for t in range(22)] + [(2, t) for t in range(10)])
 @pytest.mark.parametrize('split', [1, 3])
 def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
     from mit_semseg import ops, _native, tuner
@@ -773,7 +773,7 @@ def test_h2_wgrad_all_taps_in_one_block(case, split, monkeypatch):
 
 
 @pytest.mark.parametrize('case', PLAN_CASES + [(2, 64, 40, 40, 64, 3, 1, 1, 1), (2, 1024, 8, 8, 48, 1, 1, 0, 1)], ids=str)
-@pytest.mark.parametrize('tile', list(range(23)))
+@pytest.mark.parametrize('tile', list(range(22)))
 def test_conv_epilogue_statistics_match_the_sweep(case, tile):
     """semseg_conv2d_fwd_stats_h2 (BN statistics of the conv result gathered per wave row in the GEMM epilogue) +
     semseg_bn_fwd_finish_fused against the statistics sweep over the same result (semseg_bn_fwd_stats_fused), for EVERY tile
