@@ -218,7 +218,8 @@ int semseg_bn_finalize_mm(const double* stats, const float* zmm, int C, const fl
 /* semseg_bn_apply (y dense, ld C) that ALSO writes the h2 split planes of y into y_planes (semseg_split_h2_bytes(P, C)).
  * C % 8 == 0.  Exponent: blockbound == NULL -> the header word set by semseg_bn_finalize_mm; else the maximum of the
  * ceil(C/16) per-block bounds left by semseg_bn_fwd_stats_fused (the kernel then also publishes the header word and, if
- * absmax_out != NULL, the bound itself). */
+ * absmax_out != NULL, the bound itself).  y == NULL (round 4): only the planes are written -- a BN output whose one consumer is the
+ * next convolution's planes (bn1 / bn2 of a bottleneck, resnet.py:72-82) needs no fp32 copy. */
 int semseg_bn_apply_h2(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
                        int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
                        void* stream);

@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restric
             if (RELU) {
                 t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
             }
-            *reinterpret_cast<float4*>(y + p * C + c + 4 * h) = t;
+            if (y) *reinterpret_cast<float4*>(y + p * C + c + 4 * h) = t;      // y == nullptr: the planes are the only consumer
             o[4 * h] = t.x; o[4 * h + 1] = t.y; o[4 * h + 2] = t.z; o[4 * h + 3] = t.w;
         }
         if (RELU && gate) {                     // the ReLU decisions of these 8 channels, one bit each (y > 0): backward's gate
@@ -723,7 +723,8 @@ __global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restric
 static int bn_apply_h2_impl(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
                             int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
                             void* stream, uint8_t* gate) {
-    if (!z || !scale || !shift || !y || !y_planes || P <= 0 || C <= 0 || (C % 8) || !aligned16(z) || !aligned16(y) ||
+    // y == nullptr (not with a gate bitmask: that form's y is the next block's shortcut): only the planes are written
+    if (!z || !scale || !shift || (!y && gate) || !y_planes || P <= 0 || C <= 0 || (C % 8) || !aligned16(z) || (y && !aligned16(y)) ||
         !aligned16(y_planes))
         return SEMSEG_EINVAL;
     if (residual && ((res_ld % 4) || res_ld < C || !aligned16(residual))) return SEMSEG_EINVAL;

@@ -43,7 +43,8 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out, x = conv_bn(self.conv1, self.bn1, x, relu=True, passthrough=True)    # the shortcut hangs off conv1's node
+        out, x = conv_bn(self.conv1, self.bn1, x, relu=True, passthrough=True,    # the shortcut hangs off conv1's node;
+                         only_feeds=self.conv2)                                    # bn1's output feeds conv2 only (planes, no fp32 copy)
         residual = x if self.downsample is None else self.downsample(x)
         return conv_bn(self.conv2, self.bn2, out, residual=residual, relu=True)
 
@@ -65,9 +66,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out, x = conv_bn(self.conv1, self.bn1, x, relu=True, passthrough=True)    # the shortcut hangs off conv1's node
+        out, x = conv_bn(self.conv1, self.bn1, x, relu=True, passthrough=True,    # the shortcut hangs off conv1's node
+                         only_feeds=self.conv2)
         residual = x if self.downsample is None else self.downsample(x)
-        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True, only_feeds=self.conv3)
         return conv_bn(self.conv3, self.bn3, out, residual=residual, relu=True)
 
 

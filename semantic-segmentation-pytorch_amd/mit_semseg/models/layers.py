@@ -121,25 +121,28 @@ def conv_bn_relu6(conv, bn, x):
     return ops.clamp_max(conv_bn(conv, bn, x, relu=True), 6.0)
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False, passthrough=False):
+def conv_bn(conv, bn, x, residual=None, relu=False, passthrough=False, only_feeds=None):
     """bn(conv(x), residual=..., relu=...) -- the conv -> BN [-> +residual] [-> ReLU] unit every block of the reference
     is made of (resnet.py:72-92, models.py:160-167, hrnet.py:45-61) -- dispatched as ONE fused autograd node when the
     h2 path can run it (ops.conv_bn_act), else as the two modules.  passthrough=True returns (y, x'): x has a second consumer
-    (the block's shortcut) and x' is the alias to hand to it."""
+    (the block's shortcut) and x' is the alias to hand to it.  only_feeds=<Conv2d>: the result's ONE consumer is that convolution
+    (bn1 -> conv2, bn2 -> conv3 of a block): when it reads its input as planes, the fp32 copy of the result is not written."""
     if passthrough:
         if torch.is_grad_enabled() and x.requires_grad:
             # fork x so that the two gradients are added by the native add kernel instead of autograd's torch-side
             # accumulation; the planes this conv splits serve the shortcut's conv too
             xa, xb = ops.fork(x)
-            y = conv_bn(conv, bn, xa, residual=residual, relu=relu)
+            y = conv_bn(conv, bn, xa, residual=residual, relu=relu, only_feeds=only_feeds)
             ops.share_planes(xa, xb)
             return y, xb
-        return conv_bn(conv, bn, x, residual=residual, relu=relu), x
+        return conv_bn(conv, bn, x, residual=residual, relu=relu, only_feeds=only_feeds), x
     if conv.bias is None and x.dim() == 4 and type(conv) is Conv2d and isinstance(bn, SynchronizedBatchNorm2d) and bn.affine:
         return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                bn.num_batches_tracked, residual=residual, stride=conv.stride[0],
                                padding=conv.padding[0], dilation=conv.dilation[0], training=bn.training,
-                               momentum=bn.momentum, eps=bn.eps, relu=relu)
+                               momentum=bn.momentum, eps=bn.eps, relu=relu,
+                               planes_only=(only_feeds is not None and type(only_feeds) is Conv2d and only_feeds.bias is None and
+                                            only_feeds.weight.shape[0] % 8 == 0 and not ops.reads_fp32_input(only_feeds)))
     return bn(conv(x), residual=residual, relu=relu)
 
 

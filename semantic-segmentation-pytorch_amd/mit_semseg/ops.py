@@ -197,6 +197,9 @@ def as_nhwc(x):
     _require_cuda(x)
     if x.dtype != torch.float32:
         raise RuntimeError('native hot path computes in fp32, got %s' % x.dtype)
+    if getattr(x, '_semseg_planes_only', False):
+        raise RuntimeError('this BN output was written as h2 planes only (conv_bn_act(..., planes_only=True)): its fp32 values do '
+                           'not exist; its one consumer must be a convolution of the h2 path')
     ld = nhwc_ld(x)
     if ld is not None:
         return x, ld
@@ -950,7 +953,9 @@ class ConvBNActFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg, box):
         wut = box.get('wino_t')             # U' planes of the Winograd data gradient (None: direct kernel)
-        stride, pad, dil, momentum, eps, relu, emit = cfg
+        stride, pad, dil, momentum, eps, relu, emit = cfg[:7]
+        planes_only = len(cfg) > 7 and cfg[7]
+        box['planes_only'] = False
         L = _native.lib()
         sch = SCHEMES['h2']
         w = krsc(weight.detach())
@@ -1048,7 +1053,12 @@ class ConvBNActFn(Function):
                 _native.check(L.semseg_bn_apply_h2_gate(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y),
                                                         _p(yp), P, k, _p(bb), _p(absmax), _st(), _p(gate)), 'bn_apply_h2_gate')
             elif yp is not None:
-                _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), _p(yp),
+                # planes_only: the caller vouches that the next convolution's planes are the ONLY consumer of y (bn1 / bn2 of a
+                # bottleneck): the fp32 copy is not written (4 of the 12 bytes per element this kernel moves)
+                skip_y = planes_only and residual is None
+                box['planes_only'] = skip_y
+                _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu),
+                                                   _p(None) if skip_y else _p(y), _p(yp),
                                                    P, k, _p(bb), _p(absmax), _st()), 'bn_apply_h2')
             else:
                 _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), k, P, k,
@@ -1144,8 +1154,21 @@ class ConvBNActFn(Function):
                 None, None, None, None, None, None, None, None, None)
 
 
+# A BN output whose only consumer is the next convolution of the h2 path is read as planes, never as fp32: its fp32 copy need not
+# be written (semseg_bn_apply_h2 with y == NULL).  The CALLER knows that (models/resnet.py: bn1 / bn2 of a block), says so with
+# planes_only=True, and the tensor that comes back raises if anything asks for its fp32 values (as_nhwc).  SEMSEG_PLANES_ONLY=0
+# writes every output in full.
+PLANES_ONLY = os.environ.get('SEMSEG_PLANES_ONLY', '1') != '0'
+
+
+def reads_fp32_input(conv):
+    """True if ops.conv_bn_act would read the fp32 values of this convolution's input (the Winograd forward transforms x itself)"""
+    k, c, r, s = conv.weight.shape
+    return conv.stride[0] == 1 and conv.padding[0] == conv.dilation[0] and _wino_eligible(k, c, r, s)
+
+
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, residual=None, stride=1,
-                padding=0, dilation=1, training=False, momentum=0.1, eps=1e-5, relu=False):
+                padding=0, dilation=1, training=False, momentum=0.1, eps=1e-5, relu=False, planes_only=False):
     """act(BN(conv(x)) + residual) for a bias-free conv.  Training on the h2 path with K % 8 == 0 runs the fused node
     (ConvBNActFn); everything else composes conv2d + batch_norm_act."""
     if not (FUSE and CONV_MODE == 'h2' and training and weight.shape[0] % 8 == 0):
@@ -1155,9 +1178,11 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
     _require_cuda(x)
     wp, wtp = weight_planes(weight, 'h2')
     kk, cc, rr, ss = weight.shape
-    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu))
+    cfg = (int(stride), int(padding), int(dilation), float(momentum), float(eps), bool(relu), bool(relu),
+           bool(planes_only and PLANES_ONLY and relu and residual is None and torch.is_grad_enabled()))
     box = {}
-    if int(stride) == 1 and int(padding) == int(dilation) and _wino_eligible(kk, cc, rr, ss):
+    x_planes_only = getattr(x, '_semseg_planes_only', False)       # then the Winograd forward (it reads fp32 x) is not an option
+    if int(stride) == 1 and int(padding) == int(dilation) and _wino_eligible(kk, cc, rr, ss) and not x_planes_only:
         xb = bounds_of(x)
         if xb is not None and len(xb) <= 8:
             box['wino'] = weight_wino(weight)            # None until prepare_conv_weights has run for this weight state
@@ -1176,6 +1201,8 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
         attach_planes(y, yp, 'h2', y.shape[0] * y.shape[2] * y.shape[3], y.shape[1])
     if absmax is not None:
         attach_absmax(y, absmax)
+    if box.get('planes_only'):
+        y._semseg_planes_only = True
     return y
 
 

@@ -27,7 +27,7 @@ def batch_norm_act(z, gamma, beta, running_mean, running_var, residual=None, tra
 
 
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, residual=None, stride=1, padding=0,
-                dilation=1, training=False, momentum=0.1, eps=1e-5, relu=False, passthrough=False):
+                dilation=1, training=False, momentum=0.1, eps=1e-5, relu=False, passthrough=False, planes_only=False):
     y = batch_norm_act(F.conv2d(x, weight, None, stride, padding, dilation), gamma, beta, running_mean, running_var, residual,
                        training, momentum, eps, relu, num_batches_tracked)
     return (y, x) if passthrough else y

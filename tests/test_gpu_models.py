@@ -330,6 +330,9 @@ SWITCH_CASES = [
     ('SEMSEG_TUNE_BUCKETS=0', 'r18d_ppmds_64_train'),
     ('SEMSEG_FORCE_SYNC_PATH=1', 'r18d_ppmds_64_train'),     # the unfused SyncBN kernel sequence on one rank
     ('SEMSEG_BRANCH_STREAMS=0', 'hrnetv2_c1_128_train'),
+    ('SEMSEG_PLANES_ONLY=0', 'r50d_ppmds_64_train'),         # every BN output also as fp32 (round 4: bn1 / bn2 of a block are planes only)
+    ('SEMSEG_WINOGRAD_FUSED=0', 'r50d_ppmds_64_train'),      # Winograd data gradients as batched GEMM + output transform
+    ('SEMSEG_TUNE_DB=0', 'r18d_ppmds_64_train'),             # no shipped launch plans: every geometry timed in the process
     ('SEMSEG_DEPTHWISE_DIRECT=0', 'mnv2d_c1ds_64_train'),
     ('SEMSEG_GROUPED_DIRECT=0', 'resnext101_upernet_128_eval'),
 ]

@@ -696,6 +696,45 @@ def test_conv_bn_act_fused_vs_float64(case, relu, res, monkeypatch):
         assert e < 3e-3, (nm, e)      # relative L2; a ReLU gate flipped by a 1e-6 difference moves it by ~1e-3
 
 
+def test_conv_bn_act_planes_only_output(monkeypatch):
+    """conv_bn_act(planes_only=True): the BN output exists as h2 planes only (semseg_bn_apply_h2 with y == NULL) -- the planes are
+    bit-identical to those of the full output, the convolution that consumes them gives bit-identical results and gradients, and
+    anything that asks for the fp32 values of such a tensor is refused"""
+    from mit_semseg import ops, tuner
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    monkeypatch.setattr(tuner, 'ENABLED', False)
+    n, c, h, w, k = 2, 64, 24, 32, 96
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, c, h, w, generator=g).relu()
+    w1 = torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    w2 = torch.randn(64, k, 1, 1, generator=g) / k ** 0.5
+    gy = torch.randn(n, 64, h, w, generator=g)
+
+    def run(planes_only):
+        ts = [cl(x).requires_grad_(True), torch.nn.Parameter(cl(w1)), torch.nn.Parameter(cl(w2))]
+        xg, w1g, w2g = ts
+        ops.prepare_conv_weights([w1g, w2g])
+        bn = lambda ch: (torch.ones(ch, device=dev(), requires_grad=True), torch.zeros(ch, device=dev(), requires_grad=True),      # noqa: E731
+                         torch.zeros(ch, device=dev()), torch.ones(ch, device=dev()), torch.zeros((), dtype=torch.long, device=dev()))
+        b1, b2 = bn(k), bn(64)
+        t = ops.conv_bn_act(xg, w1g, *b1, stride=1, padding=1, dilation=1, training=True, relu=True, planes_only=planes_only)
+        planes = ops.planes_of(t, 'h2', n * h * w, k)
+        assert planes is not None
+        assert bool(getattr(t, '_semseg_planes_only', False)) == planes_only
+        if planes_only:
+            with pytest.raises(RuntimeError):
+                ops.as_nhwc(t)
+        u = ops.conv_bn_act(t, w2g, *b2, stride=1, padding=0, dilation=1, training=True, relu=True)
+        u.backward(cl(gy))
+        torch.cuda.synchronize()
+        return planes.clone(), u.detach().clone(), [p.grad.clone() for p in ts] + [b1[0].grad.clone(), b1[1].grad.clone()]
+    p0, u0, g0 = run(False)
+    p1, u1, g1 = run(True)
+    assert torch.equal(p0, p1) and torch.equal(u0, u1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+
+
 # every tile variant of the h2 kernels under a PINNED plan (the tuner only ever runs the fastest one): fwd/dgrad tiles
 # 0..5 (register staged 128x128 / 128x64 / 64x64, LDS-DMA 256x128 2-slot / 3-slot ring / 256x256), wgrad tiles 0..3
 # (register staged 128 / 64, LDS-DMA 128x128 2-slot / 256x128 3-slot ring / 256x256 2-slot), with and without split-K / split-M

@@ -19,7 +19,7 @@ for p in (ROOT, os.path.join(ROOT, 'semantic-segmentation-pytorch_amd')):
 from oracle import semseg_oracle as O  # noqa: E402
 
 
-def _cpu_conv_bn(conv, bn, x, residual=None, relu=False, passthrough=False):
+def _cpu_conv_bn(conv, bn, x, residual=None, relu=False, passthrough=False, only_feeds=None):
     w = conv.dense_weight() if hasattr(conv, 'dense_weight') else conv.weight
     y = F.conv2d(x, w, conv.bias, conv.stride, conv.padding, conv.dilation)
     y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
