@@ -13,6 +13,10 @@ for c in 1 2 4 3; do
   echo "cfg$c rc=$? $(python -c "import json,sys; d=json.loads([l for l in open('$OUT/bench_cfg$c.json') if l.startswith('{')][-1]); print(d['ms_per_step'],'ms')" 2>/dev/null)"
 done
 timeout 300 python tools/bench_infer.py > $OUT/infer.log 2>&1; echo "infer rc=$?"
+# the geometries of the parity suite as well: with every plan of a test process coming from the database, a test launches the SAME
+# plans on every box and in every run -- the summation order of a split reduction, and with it which way a knife-edge ReLU gate
+# resolves, no longer depends on what the tuner happened to time in that process
+timeout 2000 python -m pytest tests -m gpu -q -x -p no:cacheprovider > $OUT/pytest_tuning.log 2>&1; echo "pytest (tuning pass) rc=$?"; tail -3 $OUT/pytest_tuning.log | cut -c1-200
 python - <<'PY'
 import json, os, subprocess
 out = os.path.join('gpurun_out', 'perfdb')
