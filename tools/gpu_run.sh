@@ -32,7 +32,7 @@ PY
 }
 q() { name=$1; shift; env "$@" timeout 400 python bench.py --steps 40 --warmup 6 --no-cpu-baseline --no-other-configs > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "$name rc=$?: $(show $OUT/bench_$name.json)"; tail -2 $OUT/bench_$name.err | cut -c1-200; }
 profile() { name=$1; shift
-  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_$name -o bench -- python $ROOT/bench.py --steps 10 --warmup 6 --no-cpu-baseline --no-other-configs "$@" > $ROOT/$OUT/rocprof_$name.log 2>&1 ); echo "rocprof rc=$?"
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_$name -o bench -- python $ROOT/bench.py --steps 10 --warmup 6 --no-cpu-baseline --no-other-configs --repeats 0 --no-box --no-scaling-model "$@" > $ROOT/$OUT/rocprof_$name.log 2>&1 ); echo "rocprof rc=$?"
   db=$(find $OUT/prof_$name -name '*.db' | head -1); tr=$(find $OUT/prof_$name -name '*kernel_trace.csv' | head -1); src=${db:-$tr}
   python tools/rocprof_summary.py $src $OUT/kernel_stats_$name.csv
   python tools/rocprof_summary.py $src $OUT/kernel_stats_by_grid_$name.csv --by-grid
