@@ -415,7 +415,8 @@ int semseg_winograd_output(const float* M, float* z, int z_ld, int N, int H, int
  * over the same LDS-DMA ring, one accumulator set for M[f], four for the 2 x 2 outputs -- and writes z = A^T M A as pixels; the fp32
  * intermediate M (16 * tiles * K floats written by _gemm_h2 and read back by _output) never exists.  C = channels of V / U (the
  * reduction), K = output channels; used for the data gradients of the wide 3x3 convs (models.py:455-465, 538-540; there C = the
- * layer's filters, K = its input channels, u_planes = field `wino_t`).  form: 0 / 1 / 2 = 8 waves (32 x 64 per wave) on a 3- / 4- / 5-slot ring, 3 / 4 = 4 waves (64 x 64 per wave) on 4 / 5 slots. */
+ * layer's filters, K = its input channels, u_planes = field `wino_t`).  form: 0 / 1 / 2 = 8 waves (32 x 64 per wave) on a 3- / 4- / 5-slot ring, 3 / 4 = 4 waves (64 x 64 per wave) on 4 / 5 slots, 5 / 6 = 64-deep
+ * k-tiles (C % 64 == 0 after padding to 32) with full 128-byte lines per DMA piece on a ring of five half tiles, 8 / 4 waves. */
 int semseg_winograd_gemm_output_h2(const void* v_planes, const void* u_planes, float* z, int z_ld,
                                    int N, int H, int W, int C, int K, int dil, int form, void* stream);
 /* Weight gradient of the same layers in the Winograd domain (the autograd of nn.Conv2d.weight at those call sites):

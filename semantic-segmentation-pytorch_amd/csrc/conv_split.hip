@@ -101,8 +101,9 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
 // software-pipelined fragment reads.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 10 : 1) : (sch == SchH2::ID ? 21 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 10 : 1) : (sch == SchH2::ID ? 24 : 3); }
 
+static inline bool tile_is_k64(int tile);
 // wgrad tile 10 (wgrad_taps_kernel) takes 3x3 stride-1 pad == dil convolutions whose output rows are whole 32-pixel chunks
 static bool wtaps_geometry_ok(int N, int H, int W, int R, int S, int stride, int pad, int dil) {
     if (!(R == 3 && S == 3 && stride == 1 && pad == dil && dil >= 1 && dil <= 5)) return false;
@@ -117,8 +118,11 @@ static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R,
     // a plan is refused where its kernel does not take the geometry (the tuner then skips the candidate; a plan inherited from
     // another image size of the same layer -- mit_semseg/tuner.py buckets -- is re-timed instead of failing at launch)
     if (pass == 2 && tile == 10 && !wtaps_geometry_ok(N, H, W, R, S, stride, pad, dil)) return SEMSEG_EINVAL;
+    // tiles 22 ... 24 (64-deep k-tiles): the reduction -- C forward and in the batched Winograd GEMM, K in the data gradient -- padded
+    // to 32 channels must be whole 64-channel chunks
+    if ((pass == 0 || pass == 1 || pass == 3) && tile_is_k64(tile) && (((pass == 1 ? K : C) + 31) / 32) % 2) return SEMSEG_EINVAL;
     if (pass == 3 && tile >= 0 && (sch != SchH2::ID || split != 1 || !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 ||
-                                                                       tile == 10 || tile == 14)))
+                                                                       tile == 10 || tile == 14 || tile == 22 || tile == 24)))
         return SEMSEG_EINVAL;
     std::lock_guard<std::mutex> lk(g_plans_mu);
     const SKey key{sch, pass, N, H, W, C, K, R, S, stride, pad, dil};
@@ -1140,6 +1144,252 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
 }
 
+// ------------------------------------------------------------------------------------------------
+// igemm_dma_kernel on 64-deep k-tiles (round 4; tiles 22 / 23).  What the 32-deep loop leaves on the table was measured on the fused
+// Winograd kernel (profiles/r5_winograd_dgrad_forms.txt: the same block on 64-deep tiles runs 10 - 15 % faster): every DMA piece of
+// the 32-deep form gathers 16 rows x 64 B -- half a cache line per row -- and every 32 channels cost a barrier and a restart of the
+// fragment reads.  Here a k-tile is one tap x 64 channels: a piece is 8 rows x 128 B (whole lines), the LDS row is 128 B with chunk
+// c of row r stored at c ^ ((r >> 1) & 7) (applied on the DMA source address; a ds_read_b128 lane group covers the 64 banks once),
+// four k16 steps per barrier.  Two planes per operand make a whole 64-deep tile of a 128 x 128 block 64 KiB, so the ring holds HALF
+// tiles -- entry j = the A rows (j even) or the B rows (j odd) of tile j / 2 -- five entries (160 KiB at 128 x 128: one block per
+// CU; 80 KiB at 64 x 64: two), 1.5 tiles in flight behind the one being multiplied.  Needs BM == BN and a reduction that is whole
+// 64-channel chunks (channels padded to 32 must be a multiple of 64); everything else -- tap algebra, split-K, batches, block order,
+// epilogue incl. the BN statistics -- is igemm_dma_kernel's.
+// ------------------------------------------------------------------------------------------------
+template <class SCH, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma64_kernel(const SParams p) {
+    constexpr int NP = SCH::NP, NENT = 5;
+    typedef typename SCH::frag frag;
+    constexpr int NW = WGM * WGN;
+    static_assert(BM == BN && (NW == 4 || NW == 8 || NW == 16), "tile");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int FM = WM / 32, FN = WN / 32;
+    constexpr int G8 = BM / 8 / NW;                    // 8-row groups per wave and plane, A and B alike
+    constexpr int PPE = NP * G8;                       // DMA pieces per wave per ring entry
+    constexpr int ENT_BYTES = NP * BM * 128;
+    static_assert(G8 >= 1 && FM >= 1 && FN >= 1 && 3 * PPE < 64, "tile");
+
+    extern __shared__ __align__(16) uint4 smem4[];
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem4);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const GemmBlock gb = gemm_block(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), p.tiles_m, p.tiles_n, p.splits,
+                                    gridDim.z, p.tn_fast);
+    const int tm = gb.tm, tn = gb.tn, z = gb.z, bz = gb.batch;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt_begin = z * p.kt_per_split;
+    const int kt_end = min(p.ktiles, kt_begin + p.kt_per_split);
+    const int nk = kt_end - kt_begin;
+
+    const uint32_t a_zero = 2u * NP * p.in_plane, b_zero = 2u * NP * p.w_plane;
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)(a_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (int)(b_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+    const uint32_t a_plane_b = 2u * p.in_plane, b_plane_b = 2u * p.w_plane;
+
+    // DMA lane constants: row inside an 8-row piece; the physical chunk l & 7 of row r holds the logical chunk (l & 7) ^ ((r >> 1) & 7),
+    // r = 8 g + (l >> 3), g = wave + NW i (NW even: the parity of g is the wave's)
+    const int lrow = lane >> 3;
+    const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+
+    int a_ih0[G8], a_iw0[G8], a_base[G8];
+    const int HWout = p.Hout * p.Wout;
+#pragma unroll
+    for (int i = 0; i < G8; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + lrow;
+        if (m < p.M) {
+            const int n = m / HWout;
+            const int rem = m - n * HWout;
+            const int oh = rem / p.Wout;
+            const int ow = rem - oh * p.Wout;
+            a_ih0[i] = oh * p.a + p.off;
+            a_iw0[i] = ow * p.a + p.off;
+            a_base[i] = n * p.Hin * p.Win + bz * p.batch_in_rows;
+        } else {
+            a_ih0[i] = -(1 << 28);
+            a_iw0[i] = -(1 << 28);
+            a_base[i] = 0;
+        }
+    }
+    uint32_t b_src[G8], b_msk[G8];
+    const uint32_t w_row_b = 2u * (uint32_t)p.T * p.pitch;
+#pragma unroll
+    for (int i = 0; i < G8; ++i) {
+        const int n = n0 + (wave + NW * i) * 8 + lrow;
+        const bool ok = n < p.Cout;
+        b_src[i] = ok ? (uint32_t)(n + bz * p.batch_w_rows) * w_row_b + 16u * q : b_zero;
+        b_msk[i] = ok ? 0xffffffffu : 0u;
+    }
+    uint32_t a_src[G8], a_msk[G8];
+    KWalk kw;
+    kw.init(p, kt_begin);
+    const bool fast_tap = (p.div == 1) && (p.T <= 32);
+    uint32_t a_row[G8], a_vm[G8];
+    if (fast_tap) {
+#pragma unroll
+        for (int i = 0; i < G8; ++i) {
+            a_row[i] = 2u * (((uint32_t)a_base[i] + (uint32_t)a_ih0[i] * (uint32_t)p.Win + (uint32_t)a_iw0[i]) *
+                             (uint32_t)p.pitch) + 16u * q;
+            uint32_t vm = 0;
+            int r = 0, s2 = 0;
+            for (int t = 0; t < p.T; ++t) {
+                const int nh = a_ih0[i] + r * p.step, nw = a_iw0[i] + s2 * p.step;
+                vm |= ((nh >= 0) & (nw >= 0) & (nh < p.Hin) & (nw < p.Win)) ? (1u << t) : 0u;
+                if (++s2 == p.S) { s2 = 0; ++r; }
+            }
+            a_vm[i] = vm;
+        }
+    }
+    auto set_tap = [&](int t, int r, int s) {
+        if (fast_tap) {
+            const uint32_t delta = 2u * ((uint32_t)((r * p.Win + s) * p.step) * (uint32_t)p.pitch);
+#pragma unroll
+            for (int i = 0; i < G8; ++i) {
+                const bool ok = (a_vm[i] >> t) & 1u;
+                a_src[i] = ok ? a_row[i] + delta : a_zero;
+                a_msk[i] = ok ? 0xffffffffu : 0u;
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < G8; ++i) {
+            int nh = a_ih0[i] + r * p.step;
+            int nw = a_iw0[i] + s * p.step;
+            bool ok = (nh >= 0) & (nw >= 0);
+            if (p.div > 1) {
+                ok = ok & ((nh % p.div) == 0) & ((nw % p.div) == 0);
+                nh /= p.div;
+                nw /= p.div;
+            }
+            ok = ok & (nh < p.Hin) & (nw < p.Win);
+            a_src[i] = ok ? 2u * ((uint32_t)(a_base[i] + nh * p.Win + nw) * (uint32_t)p.pitch) + 16u * q : a_zero;
+            a_msk[i] = ok ? 0xffffffffu : 0u;
+        }
+    };
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+    int i_ent = 0, i_slot = 0;                         // ring entry to issue next (even: A rows of tile i_ent / 2, odd: its B rows)
+    auto issue_entry = [&]() {
+        const bool live = kt_begin + (i_ent >> 1) < kt_end;                 // wave-uniform
+        const bool is_b = i_ent & 1;
+        const uint32_t base = lds0 + (uint32_t)i_slot * ENT_BYTES;
+        if (!is_b) {
+            uint32_t ka_b = 0;
+            if (live) {
+                if (kw.dirty) {
+                    set_tap(kw.t, kw.r, kw.s);
+                    kw.dirty = false;
+                }
+                ka_b = 2u * 64u * (uint32_t)kw.cc;
+            }
+#pragma unroll
+            for (int i = 0; i < G8; ++i)
+#pragma unroll
+                for (int s = 0; s < NP; ++s) {
+                    const uint32_t vo = live ? a_src[i] + ((ka_b + s * a_plane_b) & a_msk[i]) : a_zero;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)(base + (s * BM + (wave + NW * i) * 8) * 128), 16,
+                                                             vo, 0, 0, 0);
+                }
+        } else {
+            uint32_t kb_b = 0;
+            if (live) {
+                kb_b = 2u * ((uint32_t)kw.t * p.pitch + 64u * (uint32_t)kw.cc);
+                kw.advance(p);                          // the tile's B entry closes it
+            }
+#pragma unroll
+            for (int i = 0; i < G8; ++i)
+#pragma unroll
+                for (int s = 0; s < NP; ++s) {
+                    const uint32_t vo = live ? b_src[i] + ((kb_b + s * b_plane_b) & b_msk[i]) : b_zero;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)(base + (s * BN + (wave + NW * i) * 8) * 128), 16,
+                                                             vo, 0, 0, 0);
+                }
+        }
+        ++i_ent;
+        i_slot = (i_slot == NENT - 1) ? 0 : i_slot + 1;
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31;
+    const int kb2 = lane >> 5;
+    auto read_frags = [&](int sa, int sb, int ks, frag (&av)[FM][NP], frag (&bv)[FN][NP]) {
+        const unsigned char* As = smem + sa * ENT_BYTES;
+        const unsigned char* Bs = smem + sb * ENT_BYTES;
+        const int ch = 2 * ks + kb2;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int r = wn * WN + j * 32 + frow;
+            const int off = r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+            for (int s = 0; s < NP; ++s) bv[j][s] = *reinterpret_cast<const frag*>(Bs + s * BN * 128 + off);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int r = wm * WM + i * 32 + frow;
+            const int off = r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+            for (int s = 0; s < NP; ++s) av[i][s] = *reinterpret_cast<const frag*>(As + s * BM * 128 + off);
+        }
+    };
+    auto mma = [&](const frag (&av)[FM][NP], const frag (&bv)[FN][NP]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) SCH::mac(av[i], bv[j], acc[i][j]);
+    };
+
+#pragma unroll
+    for (int j = 0; j < NENT; ++j) issue_entry();
+    frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+    wait_vm_barrier<3 * PPE>();                               // entries 0 and 1 have landed for every wave
+    int sa = 0, sb = 1;
+    read_frags(sa, sb, 0, a0, b0);
+    for (int it = 0; it < nk; ++it) {
+        read_frags(sa, sb, 1, a1, b1);
+        mma(a0, b0);
+        read_frags(sa, sb, 2, a0, b0);
+        mma(a1, b1);
+        read_frags(sa, sb, 3, a1, b1);
+        mma(a0, b0);
+        wait_vm_barrier<1 * PPE>();                           // my reads of this tile are done, the next tile's two entries have landed
+        issue_entry();
+        issue_entry();
+        sa = (sb == NENT - 1) ? 0 : sb + 1;
+        sb = (sa == NENT - 1) ? 0 : sa + 1;
+        read_frags(sa, sb, 0, a0, b0);                        // past the last tile: zero tails, never multiplied
+        mma(a1, b1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S_MFMA_DRAIN();
+    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
+}
+
+template <class SCH, int BM, int BN, int WGM, int WGN>
+static int launch_dma64(const SParams& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)5 * SCH::NP * BM * 128;
+    static_assert(smem <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_dma64_kernel<SCH, BM, BN, WGM, WGN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
+    hipLaunchKernelGGL((igemm_dma64_kernel<SCH, BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, st, p);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 // out[m*out_ld + n] = bias[n] + sum_z partial[z][m*Cout + n]   (fixed order => deterministic)
 template <bool VEC>
 __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
@@ -1191,10 +1441,12 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[22][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
+static const int kTiles[25][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
                                    {256, 128}, {256, 256}, {128, 128}, {256, 128}, {256, 256}, {256, 128}, {256, 128},
                                    {256, 256}, {64, 64}, {128, 64}, {64, 64}, {128, 128},
-                                   {64, 64}, {128, 128}, {128, 128}};      // 19 ... 21: deep rings (round 4)
+                                   {64, 64}, {128, 128}, {128, 128},      // 19 ... 21: deep rings (round 4)
+                                   {128, 128}, {64, 64}, {128, 128}};     // 22 ... 24: 64-deep k-tiles (igemm_dma64_kernel)
+static inline bool tile_is_k64(int tile) { return tile >= 22 && tile <= 24; }
 
 constexpr int kMaxEpilogueParts = 512;      // partial rows (= block row tiles) the BN finish kernel is asked to reduce; beyond
                                             // that (the 256 x 256 maps of the stem on small tiles) the separate sweep is cheaper
@@ -1291,7 +1543,15 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
         return SEMSEG_EINVAL;      // 32-bit byte offsets (buffer descriptors of the LDS-DMA kernel)
     p.in_plane = (uint32_t)in_plane;
     p.w_plane = (uint32_t)w_plane;
-    const SPlan pl = plan_gemm(SCH::ID, p.M, p.Cout, p.Cp, p.T, ov_tile, ov_split);
+    SPlan pl = plan_gemm(SCH::ID, p.M, p.Cout, p.Cp, p.T, ov_tile, ov_split);
+    if (tile_is_k64(pl.tile)) {
+        // 64-deep k-tiles: the reduction is counted in 64-channel chunks; the split of the plan is kept (never more slabs than planned)
+        if (p.Cp % 64) return SEMSEG_EINVAL;
+        pl.chunks = p.Cp / 64;
+        pl.ktiles = p.T * pl.chunks;
+        pl.kt_per_split = ceil_div(pl.ktiles, pl.splits);
+        pl.splits = ceil_div(pl.ktiles, pl.kt_per_split);
+    }
     p.chunks = pl.chunks;
     p.ktiles = pl.ktiles;
     p.kt_per_split = pl.kt_per_split;
@@ -1389,6 +1649,16 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
         case 21:
             if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 128, 128, 4, 2, 15>(p, st);      // 8 waves, 5 x 32 KiB
+            break;
+        // 64-deep k-tiles, whole 128-byte lines per DMA piece, ring of five half tiles (igemm_dma64_kernel)
+        case 22:
+            if constexpr (SCH::NP == 2) rc = launch_dma64<SCH, 128, 128, 4, 2>(p, st);        // 8 waves, 160 KiB: one block per CU
+            break;
+        case 23:
+            if constexpr (SCH::NP == 2) rc = launch_dma64<SCH, 64, 64, 2, 2>(p, st);          // 4 waves, 80 KiB: two blocks per CU
+            break;
+        case 24:
+            if constexpr (SCH::NP == 2) rc = launch_dma64<SCH, 128, 128, 4, 4>(p, st);        // 16 waves (32 x 32 each), one block per CU
             break;
     }
     if (rc) return rc;
@@ -1546,6 +1816,11 @@ extern "C" int semseg_winograd_gemm_h2(const void* v_planes, const void* u_plane
         case 9: return launch_dma<SchH2, 128, 128, 4, 2, 12>(p, st);
         case 10: return launch_dma<SchH2, 256, 128, 4, 2, 13>(p, st);
         case 14: return launch_dma<SchH2, 256, 256, 4, 4, 12>(p, st);
+        case 22:
+        case 24:
+            if (p.Cp % 64) return SEMSEG_EINVAL;
+            p.chunks = p.Cp / 64; p.ktiles = p.chunks; p.kt_per_split = p.ktiles;
+            return tile == 22 ? launch_dma64<SchH2, 128, 128, 4, 2>(p, st) : launch_dma64<SchH2, 128, 128, 4, 4>(p, st);
         default: return SEMSEG_EINVAL;
     }
 }
@@ -1795,6 +2070,239 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFPara
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same kernel on 64-deep k-tiles with FULL 128-byte lines per DMA piece (round 4, form 5).
+// The 32-deep loop above gathers 16 rows x 64 B per DMA piece -- half a cache line per row, the other half eight pieces later --
+// and passes one barrier per 32 channels.  Here a k-tile is 64 channels: a piece is 8 rows x 128 B (a whole line per row), the LDS
+// row is 128 B with the 16-byte chunk c of row r stored at c ^ ((r >> 1) & 7) (a ds_read_b128 lane group -- 16 rows, one chunk index
+// -- then covers all 64 banks once; the swizzle is applied on the DMA source address), four k16 steps per barrier.  With two planes
+// per operand a whole 64-deep tile of a 128 x 128 block is 64 KiB, so the ring holds HALF tiles: entry j = the A rows (j even) or the
+// B rows (j odd) of tile j / 2, five entries of 32 KiB, 1.5 tiles in flight behind the tile being multiplied.
+// ------------------------------------------------------------------------------------------------
+template <int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void wino_fused64_kernel(const WFParams p) {
+    constexpr int NP = 2, BM = 128, BN = 128, NENT = 5;
+    typedef SchH2::frag frag;
+    constexpr int NW = WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int FM = WM / 32, FN = WN / 32;
+    constexpr int GPW = BM / 8 / NW;                   // 8-row groups per wave and plane (A and B alike: BM == BN)
+    constexpr int PPE = NP * GPW;                      // DMA pieces per wave per ring entry
+    constexpr int ENT_BYTES = NP * BM * 128;           // 32 KiB
+    static_assert(GPW >= 1 && FM >= 1 && FN >= 1 && 4 * PPE < 64, "tile");
+
+    extern __shared__ __align__(16) uint4 smem4[];
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem4);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const WinoFusedBlock gb = wino_fused_block(blockIdx.x, p.tiles_m, p.tiles_n);
+    const int m0 = gb.tm * BM, n0 = gb.tn * BN;
+
+    const uint32_t a_zero = 2u * NP * p.v_plane, b_zero = 2u * NP * p.u_plane;
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.v, 0, (int)(a_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, (int)(b_zero + SPLIT_ZERO_TAIL_BYTES), 0x00020000);
+    const uint32_t a_plane_b = 2u * p.v_plane, b_plane_b = 2u * p.u_plane;
+    const uint32_t row_b = 2u * (uint32_t)p.pitch;
+    const uint32_t fa_b = (uint32_t)p.tiles * row_b, fb_b = (uint32_t)p.Cout * row_b;
+    const int chunks64 = p.chunks >> 1;                // host: chunks even
+    const int nk = 16 * chunks64;                      // k-tiles; ring entries 0 .. 2 nk - 1
+
+    // DMA lane constants: row inside an 8-row piece, physical chunk l & 7 holds logical chunk (l & 7) ^ ((row >> 1) & 7);
+    // row = 8 g + (l >> 3) with g = wave + NW i (NW is even: the parity of g is the wave's) -> (row >> 1) & 7 = (4 (wave & 1) + (l >> 4)) & 7
+    const int lrow = lane >> 3;
+    const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+    uint32_t a_src[GPW], a_msk[GPW], b_src[GPW], b_msk[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + lrow;
+        const bool oka = m < p.tiles;
+        a_src[i] = oka ? (uint32_t)m * row_b + 16u * q : a_zero;
+        a_msk[i] = oka ? 0xffffffffu : 0u;
+        const int n = n0 + (wave + NW * i) * 8 + lrow;
+        const bool okb = n < p.Cout;
+        b_src[i] = okb ? (uint32_t)n * row_b + 16u * q : b_zero;
+        b_msk[i] = okb ? 0xffffffffu : 0u;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+    int i_f = 0, i_c = 0, i_ent = 0, i_slot = 0;       // (frequency, 64-chunk) of the tile the next entry belongs to; entry index; its slot
+    auto issue_entry = [&]() {
+        const bool live = i_ent < 2 * nk;               // wave-uniform
+        const bool is_b = i_ent & 1;
+        const uint32_t base = lds0 + (uint32_t)i_slot * ENT_BYTES;
+        const uint32_t koff = (uint32_t)i_f * (is_b ? fb_b : fa_b) + 128u * (uint32_t)i_c;
+#pragma unroll
+        for (int i = 0; i < GPW; ++i)
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                const uint32_t dst = base + (uint32_t)((s * BM + (wave + NW * i) * 8) * 128);
+                if (is_b) {
+                    const uint32_t vo = live ? b_src[i] + ((koff + s * b_plane_b) & b_msk[i]) : b_zero;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)dst, 16, vo, 0, 0, 0);
+                } else {
+                    const uint32_t vo = live ? a_src[i] + ((koff + s * a_plane_b) & a_msk[i]) : a_zero;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)dst, 16, vo, 0, 0, 0);
+                }
+            }
+        if (is_b && live) {                             // the tile's B entry closes it: advance (frequency, chunk)
+            if (++i_c == chunks64) { i_c = 0; ++i_f; }
+        }
+        ++i_ent;
+        i_slot = (i_slot == NENT - 1) ? 0 : i_slot + 1;
+    };
+
+    f32x16 acc[FM][FN], y[4][FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                y[0][i][j][e] = 0.f; y[1][i][j][e] = 0.f; y[2][i][j][e] = 0.f; y[3][i][j][e] = 0.f;
+            }
+
+    const int frow = lane & 31;
+    const int kb2 = lane >> 5;
+    auto read_frags = [&](int sa, int sb, int ks, frag (&av)[FM][NP], frag (&bv)[FN][NP]) {
+        const unsigned char* As = smem + sa * ENT_BYTES;
+        const unsigned char* Bs = smem + sb * ENT_BYTES;
+        const int ch = 2 * ks + kb2;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int r = wn * WN + j * 32 + frow;
+            const int off = r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+            for (int s = 0; s < NP; ++s) bv[j][s] = *reinterpret_cast<const frag*>(Bs + s * BN * 128 + off);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int r = wm * WM + i * 32 + frow;
+            const int off = r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
+#pragma unroll
+            for (int s = 0; s < NP; ++s) av[i][s] = *reinterpret_cast<const frag*>(As + s * BM * 128 + off);
+        }
+    };
+    auto mma = [&](const frag (&av)[FM][NP], const frag (&bv)[FN][NP]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) SchH2::mac(av[i], bv[j], acc[i][j]);
+    };
+    auto fold = [&](int f) {
+        const int a = f >> 2, b = f & 3;
+        const float ra[2] = {a < 3 ? 1.f : 0.f, a == 0 ? 0.f : (a == 1 ? 1.f : -1.f)};
+        const float cb[2] = {b < 3 ? 1.f : 0.f, b == 0 ? 0.f : (b == 1 ? 1.f : -1.f)};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float c = ra[o >> 1] * cb[o & 1];
+            if (c != 0.f) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) y[o][i][j][e] = fmaf(c, acc[i][j][e], y[o][i][j][e]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+
+    // entries 0 .. 4 = A(0) B(0) A(1) B(1) A(2); tile t is multiplied from slots (2t) % 5 and (2t + 1) % 5 and frees them
+#pragma unroll
+    for (int j = 0; j < NENT; ++j) issue_entry();
+    frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+    wait_vm_barrier<3 * PPE>();                               // entries 0 and 1 have landed for every wave
+    int sa = 0, sb = 1;
+    read_frags(sa, sb, 0, a0, b0);
+    int c_c = 0, c_f = 0;
+    for (int it = 0; it < nk; ++it) {
+        read_frags(sa, sb, 1, a1, b1);
+        mma(a0, b0);
+        read_frags(sa, sb, 2, a0, b0);
+        mma(a1, b1);
+        read_frags(sa, sb, 3, a1, b1);
+        mma(a0, b0);
+        // my reads of this tile's two slots are done; the next tile's two entries (the oldest two of the three in flight) have landed
+        wait_vm_barrier<1 * PPE>();
+        issue_entry();                                        // into slot sa
+        issue_entry();                                        // into slot sb
+        sa = (sb == NENT - 1) ? 0 : sb + 1;
+        sb = (sa == NENT - 1) ? 0 : sa + 1;
+        read_frags(sa, sb, 0, a0, b0);                        // past the last tile: zero tails, never multiplied
+        mma(a1, b1);
+        if (++c_c == chunks64) {
+            c_c = 0;
+            fold(c_f);
+            ++c_f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int* tab = reinterpret_cast<int*>(smem);                   // [BM][4]
+    for (int r = tid; r < BM; r += NW * 64) {
+        int t = m0 + r;
+        int o4[4] = {-1, -1, -1, -1};
+        if (t < p.tiles) {
+            const int tx = t % p.TW; t /= p.TW;
+            const int ty = t % p.TH; t /= p.TH;
+            const int pw = t % p.dil; t /= p.dil;
+            const int ph = t % p.dil;
+            const int n = t / p.dil;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int h = (2 * ty + i) * p.dil + ph, w = (2 * tx + j) * p.dil + pw;
+                    if (h < p.H && w < p.W) o4[i * 2 + j] = ((n * p.H + h) * p.W + w);
+                }
+        }
+        tab[r * 4 + 0] = o4[0]; tab[r * 4 + 1] = o4[1]; tab[r * 4 + 2] = o4[2]; tab[r * 4 + 3] = o4[3];
+    }
+    __syncthreads();
+    float f1, f2;
+    descale_factors<SchH2>(p.v_exp, p.u_exp, f1, f2);
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + col_l;
+        if (col >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + row_l;
+                const int4 px = *reinterpret_cast<const int4*>(&tab[r * 4]);
+                if (px.x >= 0) p.out[(size_t)px.x * p.out_ld + col] = (y[0][i][j][e] * f1) * f2;
+                if (px.y >= 0) p.out[(size_t)px.y * p.out_ld + col] = (y[1][i][j][e] * f1) * f2;
+                if (px.z >= 0) p.out[(size_t)px.z * p.out_ld + col] = (y[2][i][j][e] * f1) * f2;
+                if (px.w >= 0) p.out[(size_t)px.w * p.out_ld + col] = (y[3][i][j][e] * f1) * f2;
+            }
+    }
+}
+
+template <int WGM, int WGN>
+static int launch_wino_fused64(const WFParams& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)5 * 2 * 128 * 128;
+    if (p.chunks & 1) return SEMSEG_EINVAL;                  // the reduction must be whole 64-channel tiles
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino_fused64_kernel<WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((wino_fused64_kernel<WGM, WGN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), smem, st, p);
+    SEMSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, int WGM, int WGN, int NSLOT, int PROBE = 0>
 static int launch_wino_fused(const WFParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)NSLOT * 2 * (BM + BN) * 64;
@@ -1845,6 +2353,8 @@ extern "C" int semseg_winograd_gemm_output_h2(const void* v_planes, const void* 
         case 2: return launch_wino_fused<128, 128, 4, 2, 5>(p, st);
         case 3: return launch_wino_fused<128, 128, 2, 2, 4>(p, st);      // 4 waves, 64 x 64 per wave (a third less LDS read traffic per MFMA)
         case 4: return launch_wino_fused<128, 128, 2, 2, 5>(p, st);
+        case 5: return launch_wino_fused64<4, 2>(p, st);                       // 64-deep k-tiles, full-line DMA pieces, half-tile ring
+        case 6: return launch_wino_fused64<2, 2>(p, st);
         case 100: return launch_wino_fused<128, 128, 4, 2, 5, 1>(p, st);      // probes of form 2 (garbage results)
         case 101: return launch_wino_fused<128, 128, 4, 2, 5, 2>(p, st);
         default: return SEMSEG_EINVAL;

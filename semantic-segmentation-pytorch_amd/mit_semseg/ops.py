@@ -896,7 +896,8 @@ def _winograd_wgrad(L, v, dzp, geom):
 # and read back by the unfused pair).  Which form runs is measured per geometry (tuner.choose); SEMSEG_WINOGRAD_FUSED=0 keeps
 # the batched GEMM + output transform everywhere.
 WINOGRAD_FUSED = os.environ.get('SEMSEG_WINOGRAD_FUSED', '1') != '0'
-WINOGRAD_FUSED_FORMS = 5          # library forms of the fused kernel (8 waves on a 3- / 4- / 5-slot ring, 4 waves on 4 / 5 slots)
+WINOGRAD_FUSED_FORMS = 7          # library forms of the fused kernel: 32-deep k-tiles (8 waves on a 3- / 4- / 5-slot ring, 4 waves on 4 / 5
+                                  # slots), 64-deep k-tiles with full-line DMA pieces on a half-tile ring (8 / 4 waves)
 
 
 def _winograd_dgrad(L, dzp, ut_planes, geom, form=None):

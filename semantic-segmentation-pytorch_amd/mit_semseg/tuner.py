@@ -91,7 +91,7 @@ _WSPLITS = _SPLITS
 # fwd/dgrad tile ids per scheme (csrc/conv_split.hip): 0..2 register staged, 3 = 256x128 LDS-DMA, h2 only: 4 = 256x128
 # 3-slot ring, 5 = 256x256, 6..10 their software-pipelined / 128x128 forms, 11..13 = 4-wave forms (256x256, 256x128 2- and 3-slot),
 # 14 = 256x256 on 16 waves, 15..17 = 64x64 / 128x64 on the LDS-DMA ring (4 waves).  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).
-_TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21)}      # 19..21: 4- / 5-slot rings on the small tiles
+_TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24)}      # 19..21: 4- / 5-slot rings on the small tiles; 22..24: 64-deep k-tiles
 # weight-gradient tile ids: 0 = 128x128, 1 = 64x64 register staged; h2 only: 2 = 128x128 LDS-DMA, 3 = 256x128 LDS-DMA ring
 _WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)}      # 10: all nine taps of a 3x3 stride-1 conv in one block
 _ALLOW = os.environ.get('SEMSEG_TUNE_TILES', '')
@@ -138,7 +138,7 @@ def timing():
     return _TIMING[0]
 
 
-WINO_TILES = (6, 7, 8, 9, 10, 14)       # tile forms the batched Winograd forward GEMM can run on (csrc/conv_split.hip, plan pass 3)
+WINO_TILES = (6, 7, 8, 9, 10, 14, 22, 24)       # tile forms the batched Winograd forward GEMM can run on (csrc/conv_split.hip, plan pass 3)
 
 
 def ensure_winograd_gemm(tiles, c, k, launch):

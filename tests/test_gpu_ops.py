@@ -747,7 +747,7 @@ PLAN_CASES = [
 
 
 @pytest.mark.parametrize('case', PLAN_CASES, ids=str)
-@pytest.mark.parametrize('pass_id,tile', [(0, t) for t in range(22)] + [(1, t) for t in range(22)] + [(2, t) for t in range(10)])
+@pytest.mark.parametrize('pass_id,tile', [(0, t) for t in range(25)] + [(1, t) for t in range(25)] + [(2, t) for t in range(10)])
 @pytest.mark.parametrize('split', [1, 3])
 def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
     from mit_semseg import ops, _native, tuner
@@ -763,7 +763,10 @@ def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
     yr = F.conv2d(xr, wr, None, stride, pad, dil)
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(gy.double())
-    _native.check(L.semseg_conv2d_h2_set_plan(pass_id, *geom, tile, split), 'set_plan')
+    if L.semseg_conv2d_h2_set_plan(pass_id, *geom, tile, split) != 0:
+        # tiles 22 ... 24 (64-deep k-tiles) take reductions of whole 64-channel chunks only; the library says so at set_plan
+        assert tile in (22, 23, 24) and pass_id < 2 and ((((k if pass_id == 1 else c) + 31) // 32) % 2 == 1), (pass_id, tile, case)
+        pytest.skip('tile %d does not take this reduction length' % tile)
     try:
         xg, wg = cl(x).requires_grad_(True), cl(wt).requires_grad_(True)
         y = ops.conv2d(xg, wg, None, stride, pad, dil)
@@ -813,7 +816,7 @@ def test_h2_wgrad_all_taps_in_one_block(case, split, monkeypatch):
 
 
 @pytest.mark.parametrize('case', PLAN_CASES + [(2, 64, 40, 40, 64, 3, 1, 1, 1), (2, 1024, 8, 8, 48, 1, 1, 0, 1)], ids=str)
-@pytest.mark.parametrize('tile', list(range(22)))
+@pytest.mark.parametrize('tile', list(range(25)))
 def test_conv_epilogue_statistics_match_the_sweep(case, tile):
     """semseg_conv2d_fwd_stats_h2 (BN statistics of the conv result gathered per wave row in the GEMM epilogue) +
     semseg_bn_fwd_finish_fused against the statistics sweep over the same result (semseg_bn_fwd_stats_fused), for EVERY tile
@@ -847,7 +850,9 @@ def test_conv_epilogue_statistics_match_the_sweep(case, tile):
         return (P_(gamma), P_(beta), P_(o['rm']), P_(o['rv']), P_(o['nbt']), 0.1, 1e-5, 1, vp(0), P_(o['coef'][0]), P_(o['coef'][1]),
                 P_(o['coef'][2]), P_(o['coef'][3]), P_(o['bb']))
     for split in (1, 2):
-        _native.check(L.semseg_conv2d_h2_set_plan(0, *geom, tile, split), 'set_plan')
+        if L.semseg_conv2d_h2_set_plan(0, *geom, tile, split) != 0:
+            assert tile in (22, 23, 24) and ((c + 31) // 32) % 2 == 1, (tile, case)        # 64-deep k-tiles: whole 64-channel chunks only
+            pytest.skip('tile %d does not take this reduction length' % tile)
         try:
             conv_ws = torch.empty(max(256, L.semseg_conv2d_h2_workspace_bytes(*geom)), dtype=torch.uint8, device=dev())
             stats_ws = torch.empty(L.semseg_conv2d_fwd_stats_bytes(k), dtype=torch.uint8, device=dev())

@@ -141,7 +141,7 @@ def main():
                     cfgs += [('t%d_s%d' % (t, sp), {pre + '_TILE': str(t), pre + '_SPLIT': str(sp)})
                              for t in wtiles for sp in ((32, 64, 128, 256, 512) if t == 10 else (1, 2, 4, 8, 16))]
                 elif which != 'split':
-                    tiles = tuple(range(22)) if args.mode == 'h2' else (0, 1, 2, 3)
+                    tiles = tuple(range(25)) if args.mode == 'h2' else (0, 1, 2, 3)
                     cfgs += [('t%d_s%d' % (t, sp), {pre2 + '_TILE': str(t), pre2 + '_SPLITK': str(sp)})
                              for t in tiles for sp in (1, 2, 4, 8, 16)]
             ref = None

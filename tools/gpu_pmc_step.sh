@@ -3,8 +3,8 @@
 #   gpurun --timeout 600 -- 'bash tools/gpu_pmc_step.sh <tag> [config] [step_ms]'
 TAG=${1:-pmcstep}; CFG=${2:-1}; STEP_MS=${3:-}; ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-# launch plans: the committed tuned plans of configs[1]; other configs run on the heuristic plans (SEMSEG_TUNE=0) so that no tuner launch is counted
-cp profiles/r4z_tuned_plans_h2.json /tmp/plans_step.json; export SEMSEG_TUNE_CACHE=/tmp/plans_step.json; [ "$CFG" != 1 ] && export SEMSEG_TUNE=0
+# launch plans: the shipped performance database (mit_semseg/perfdb: every geometry of configs[1-4] is in it, so no tuner launch is counted)
+unset SEMSEG_TUNE_CACHE
 cd /tmp
 CMD="python $ROOT/tools/probes/step_traffic.py --config $CFG --steps 3"
 run() { n=$1; shift
