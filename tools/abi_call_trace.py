@@ -43,6 +43,14 @@ def main():
     ops._st = lambda: ctypes.c_void_p(0)
     ops._WS = {}
     tuner.ENABLED = False
+    # nothing is timed here, but WHICH launch form runs (Winograd data gradient: three launches or the fused kernel) is a measured
+    # choice: take it from the shipped performance database, as the step on the device does
+    import json
+    if tuner.USE_PERFDB and os.path.exists(tuner.PERFDB):
+        for k, v in json.load(open(tuner.PERFDB)).items():
+            parts = k.split(',')
+            if not k.startswith('_') and parts[1] == '4':
+                tuner._done[(parts[0],) + tuple(int(t) for t in parts[1:])] = tuple(v)
     import bench
     from mit_semseg.engine import TrainStep
     cfg = bench.CONFIGS[args.config]

@@ -15,4 +15,9 @@ grep -q "eager steps" $OUT/fetch.log || { echo "first pass did not finish"; tail
 run write WRITE_SIZE
 cd $ROOT
 python tools/pmc_step_summary.py $OUT $STEP_MS > $OUT/summary.txt 2>&1; head -60 $OUT/summary.txt
+# the floor of this decomposition (per launch: MFMA time / operand bytes / launch floor) from the same passes, before the big CSVs go
+if [ "$CFG" = 1 ]; then
+  python tools/abi_call_trace.py > $OUT/abi_calls.txt 2> $OUT/abi_calls.err && python tools/step_floor_model.py $OUT $OUT/abi_calls.txt > $OUT/floor_model.txt 2>&1
+  head -8 $OUT/floor_model.txt
+fi
 find $OUT -name '*.csv' -size +2M -delete

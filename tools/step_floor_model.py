@@ -14,7 +14,8 @@ import sys
 MFMA = 2.5e15 * 1.7 / 2.4
 HBM = 5.5e12
 LAUNCH = 2.5e-6
-CONV_CALLS = ('conv2d_dgrad_h2', 'conv2d_fwd_h2', 'conv2d_fwd_stats_h2', 'conv2d_wgrad_h2', 'winograd_gemm_h2', 'winograd_wgrad_gemm_h2')
+CONV_CALLS = ('conv2d_dgrad_h2', 'conv2d_fwd_h2', 'conv2d_fwd_stats_h2', 'conv2d_wgrad_h2', 'winograd_gemm_h2', 'winograd_wgrad_gemm_h2',
+              'winograd_gemm_output_h2')
 
 
 def short(n):
@@ -45,7 +46,7 @@ def main():
     p, tail = last_period([short(tr[i]['Kernel_Name']) for i in ids])
     step = ids[len(ids) - tail - p:len(ids) - tail]
     calls = [l.split() for l in open(calls_path) if l.split() and l.split()[0] in CONV_CALLS]
-    convs = [i for i in step if short(tr[i]['Kernel_Name']).startswith(('igemm', 'wgrad_kernel', 'wgrad_dma'))]
+    convs = [i for i in step if short(tr[i]['Kernel_Name']).startswith(('igemm', 'wgrad_kernel', 'wgrad_dma', 'wgrad_taps', 'wino_fused'))]
     assert len(convs) == len(calls), (len(convs), len(calls))
     geom = dict(zip(convs, calls))
     rows = []
@@ -68,6 +69,12 @@ def main():
                 alg = {'conv2d_fwd_stats_h2': x + wt + y, 'conv2d_fwd_h2': x + wt + y, 'conv2d_dgrad_h2': y + wt + x,
                        'conv2d_wgrad_h2': x + y + wt}[c[0]]
                 label = '%s %dx%dx%d %d->%d %dx%d s%d d%d' % (c[0][7:-3], n, h, w, ci, k, rr, ss, st, dil)
+            elif c[0] == 'winograd_gemm_output_h2':  # fused GEMM + output transform: z_ld, N, H, W, C (reduction), K, dil, form
+                zld, n, h, w, ci, k, dil = a[:7]
+                tiles = n * dil * dil * ((-(-h // dil) + 1) // 2) * ((-(-w // dil) + 1) // 2)
+                flops = 3 * 2.0 * 16 * tiles * ci * k
+                alg = 16 * 4 * (tiles * ci + ci * k) + 4 * n * h * w * k
+                label = 'winograd_gemm_output tiles %d %d->%d' % (tiles, ci, k)
             else:                                   # batched Winograd GEMMs: tiles, C, K (16 positions)
                 tiles, ci, k = a[:3]
                 flops = 3 * 2.0 * 16 * tiles * ci * k
