@@ -120,6 +120,18 @@ int semseg_bound_sum(const float* const* bounds_host, int nbounds, float* out, v
  * The bound the Winograd input transform needs when no producer kernel carried one (evaluation-mode forward). */
 int semseg_absmax(const float* x, int x_ld, int rows, int C, float* out, void* workspace, size_t workspace_bytes,
                   void* stream);
+/* Weight gradients of a whole backward pass reduced in ONE launch (round 4).  semseg_conv2d_wgrad_slabs_h2 = the kernel of
+ * semseg_conv2d_wgrad_h2 on the same launch plan with its per-pixel-chunk partial sums left in `slabs` ([*splits_out][K*R*S*C] fp32,
+ * KRSC order; semseg_conv2d_wgrad_slabs_bytes bytes, 16-byte aligned) and no reduce launch; semseg_reduce_slabs_multi sums the slabs
+ * of any number of such tensors -- out = slabs[0] + slabs[1] + ... in slab order, the order of the per-tensor reduce, so the result is
+ * bit-identical -- once per training step (autograd of nn.Conv2d.weight at every call site of the path; train.py:44 loss.backward()). */
+typedef struct {
+    const float* slabs; float* out; int64_t numel; int splits;
+} semseg_slab_tensor;
+size_t semseg_conv2d_wgrad_slabs_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
+int semseg_conv2d_wgrad_slabs_h2(const void* xs, const void* dys, float* slabs, size_t slabs_bytes, int* splits_out,
+                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream);
+int semseg_reduce_slabs_multi(const semseg_slab_tensor* tensors_host, int n, void* stream);
 size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

@@ -3162,11 +3162,14 @@ static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
     return 0;
 }
 
+// splits_out != nullptr: "slabs only" -- the partial sums of the `*splits_out` pixel chunks are left in `workspace` as
+// [splits][K*T*C] fp32 (a plan without a split writes its one slab there too) and NO reduce is launched: the caller sums the slabs
+// of many weight gradients in one multi-tensor launch (semseg_reduce_slabs_multi); `dw` is not touched.
 template <class SCH>
 static int conv_wgrad(const void* xs, const void* dys, float* dw,
                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                      void* workspace, size_t workspace_bytes, void* stream) {
-    if (!xs || !dys || !dw || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0) return SEMSEG_EINVAL;
+                      void* workspace, size_t workspace_bytes, void* stream, int* splits_out = nullptr) {
+    if (!xs || !dys || (!dw && !splits_out) || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0) return SEMSEG_EINVAL;
     if (!aligned16(xs) || !aligned16(dys)) return SEMSEG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
@@ -3190,10 +3193,14 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
     const WPlan pl = plan_wgrad(p.M, K, C, p.T, ov_tile, ov_split);
     p.tiles_k = pl.tiles_k; p.tiles_c = pl.tiles_c;
     p.m_per_split = pl.m_per_split; p.splits = pl.splits;
-    if (pl.splits > 1) {
+    if (pl.splits > 1 || splits_out) {
         const size_t need = (size_t)pl.splits * K * p.T * C * sizeof(float);
-        if (!workspace || workspace_bytes < need) return SEMSEG_EWORKSPACE;
+        if (!workspace || workspace_bytes < need || !aligned16(workspace)) return SEMSEG_EWORKSPACE;
         p.partial = (float*)workspace;
+        if (splits_out) {
+            *splits_out = pl.splits;
+            if (pl.splits == 1) p.dw = (float*)workspace;          // the one slab
+        }
     }
     int rc = SEMSEG_EINVAL;
     switch (pl.tile) {
@@ -3240,7 +3247,7 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
         }
     }
     if (rc) return rc;
-    if (pl.splits > 1) {
+    if (pl.splits > 1 && !splits_out) {
         const size_t total = (size_t)K * p.T * C;
         if (total % 4 == 0 && aligned16(p.partial) && aligned16(dw)) {
             const int blocks = (int)min((size_t)2048, ceil_div_sz(total / 4, 256));
@@ -3310,6 +3317,82 @@ extern "C" int semseg_conv2d_wgrad_h2(const void* xs, const void* dys, float* dw
                                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                       void* workspace, size_t workspace_bytes, void* stream) {
     return conv_wgrad<SchH2>(xs, dys, dw, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, stream);
+}
+
+// The weight gradient as SLABS: the kernel of semseg_conv2d_wgrad_h2 on the same launch plan, its per-chunk partial sums left in
+// `slabs` ([*splits_out][K*R*S*C] fp32, KRSC order; slabs_bytes >= semseg_conv2d_wgrad_slabs_bytes), no reduce launch.
+extern "C" size_t semseg_conv2d_wgrad_slabs_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || dil <= 0) return 0;
+    const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
+    if (OH <= 0 || OW <= 0) return 0;
+    int t2 = -1, s2 = 0;
+    lookup_plan(SchH2::ID, 2, N, H, W, C, K, R, S, stride, pad, dil, &t2, &s2);
+    const WPlan pl = plan_wgrad(N * OH * OW, K, C, R * S, t2, s2);
+    return (size_t)pl.splits * K * R * S * C * sizeof(float);
+}
+extern "C" int semseg_conv2d_wgrad_slabs_h2(const void* xs, const void* dys, float* slabs, size_t slabs_bytes, int* splits_out,
+                                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                            void* stream) {
+    if (!splits_out) return SEMSEG_EINVAL;
+    return conv_wgrad<SchH2>(xs, dys, nullptr, N, H, W, C, K, R, S, stride, pad, dil, slabs, slabs_bytes, stream, splits_out);
+}
+
+// out[i] = slabs[0][i] + slabs[1][i] + ... (slab order: the order split_wgrad_reduce_kernel adds in) for MANY tensors in one launch:
+// blockIdx.y = tensor, the blocks of a row walk the tensor's float4 lanes.  One launch per training step instead of one per weight
+// gradient with a split plan (58 on configs[1], 270 on HRNetV2: launches of 4 - 7 us each at the launch floor).
+constexpr int SLAB_MAX_TENSORS = 64;
+struct SlabBatch {
+    semseg_slab_tensor t[SLAB_MAX_TENSORS];
+};
+__global__ __launch_bounds__(256) void reduce_slabs_multi_kernel(const SlabBatch b) {
+    const semseg_slab_tensor t = b.t[blockIdx.y];
+    const size_t total = (size_t)t.numel;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool vec = (total % 4 == 0) && (((reinterpret_cast<uintptr_t>(t.slabs) | reinterpret_cast<uintptr_t>(t.out)) & 15) == 0);
+    if (vec) {
+        const size_t quads = total >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(t.slabs);
+        float4* o4 = reinterpret_cast<float4*>(t.out);
+        for (size_t i = tid; i < quads; i += stride) {
+            float4 s = p4[i];
+            for (int z = 1; z < t.splits; z += 4) {       // 4 loads in flight, additions in slab order
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (z + u < t.splits) v[u] = p4[(size_t)(z + u) * quads + i];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (z + u < t.splits) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            }
+            o4[i] = s;
+        }
+    } else {
+        for (size_t i = tid; i < total; i += stride) {
+            float s = t.slabs[i];
+            for (int z = 1; z < t.splits; ++z) s += t.slabs[(size_t)z * total + i];
+            t.out[i] = s;
+        }
+    }
+}
+extern "C" int semseg_reduce_slabs_multi(const semseg_slab_tensor* tensors_host, int n, void* stream) {
+    if (n < 0 || (n > 0 && !tensors_host)) return SEMSEG_EINVAL;
+    for (int base = 0; base < n; base += SLAB_MAX_TENSORS) {
+        const int cnt = n - base < SLAB_MAX_TENSORS ? n - base : SLAB_MAX_TENSORS;
+        SlabBatch b;
+        size_t most = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const semseg_slab_tensor& t = tensors_host[base + i];
+            if (!t.slabs || !t.out || t.numel <= 0 || t.splits < 1) return SEMSEG_EINVAL;
+            b.t[i] = t;
+            if ((size_t)t.numel > most) most = (size_t)t.numel;
+        }
+        int gx = (int)ceil_div_sz(most / 4 + 1, 256 * 4);          // ~4 float4 lanes per thread for the largest tensor of the batch
+        gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+        hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, b);
+        SEMSEG_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 static size_t split_conv_workspace_bytes(int sch, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {

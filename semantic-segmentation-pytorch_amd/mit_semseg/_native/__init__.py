@@ -21,6 +21,10 @@ class SgdTensor(ctypes.Structure):
                 ('weight_decay', c_f), ('first_step', c_int)]
 
 
+class SlabTensor(ctypes.Structure):
+    _fields_ = [('slabs', vp), ('out', vp), ('numel', ctypes.c_int64), ('splits', c_int)]
+
+
 class WPrepTensor(ctypes.Structure):
     _fields_ = [('w', vp), ('krsc', vp), ('crsk', vp), ('K', c_int), ('T', c_int), ('C', c_int), ('wino', vp), ('wino_t', vp)]
 
@@ -51,6 +55,9 @@ SIGNATURES = {
     'semseg_conv2d_fwd_stats_h2': (c_int, [vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp, c_sz, vp, ctypes.POINTER(c_int), vp]),
     'semseg_conv2d_dgrad_h2': (c_int, [vp, vp, vp, c_int] + [c_int] * 10 + [vp, c_sz, vp]),
     'semseg_conv2d_wgrad_h2': (c_int, [vp, vp, vp] + [c_int] * 10 + [vp, c_sz, vp]),
+    'semseg_conv2d_wgrad_slabs_bytes': (c_sz, [c_int] * 10),
+    'semseg_conv2d_wgrad_slabs_h2': (c_int, [vp, vp, vp, c_sz, ctypes.POINTER(c_int)] + [c_int] * 10 + [vp]),
+    'semseg_reduce_slabs_multi': (c_int, [ctypes.POINTER(SlabTensor), c_int, vp]),
     'semseg_conv2d_h2_set_plan': (c_int, [c_int] * 13),
     'semseg_bias_grad': (c_int, [vp, c_int, vp, c_int, c_int, vp, c_sz, vp]),
     'semseg_bn_workspace_bytes': (c_sz, [c_int, c_int]),

@@ -225,7 +225,12 @@ class TrainStep:
         if tl is not None:
             tl.mark('fwd_end')
             tl.arm()                          # its hooks mark each gradient bucket when backward completes it
-        loss.backward()
+        if self.buckets is None:
+            # one rank: the split weight gradients of the whole backward pass are summed by ONE launch after it (ops.defer_wgrad_reduces)
+            with ops.defer_wgrad_reduces():
+                loss.backward()
+        else:
+            loss.backward()
         if tl is not None:
             tl.armed = False
             tl.mark('bwd_end')

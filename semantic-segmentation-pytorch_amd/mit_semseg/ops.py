@@ -568,6 +568,45 @@ class Conv2dSplitFn(Function):
         return dx, dw, db, None, None, None, None, None, None, None
 
 
+# Weight gradients whose launch plan splits the pixels leave per-chunk partial sums (slabs) that a reduce launch adds up -- 58
+# launches of 4 - 7 us per configs[1] step, 270 on HRNetV2, all at the launch floor.  Inside `defer_wgrad_reduces()` (TrainStep: one
+# rank, gradients zeroed before backward, nothing reads a weight gradient before backward has returned) the slabs stay where they are
+# and ONE multi-tensor launch sums all of them after backward (flush_wgrad_reduces): same slab order per tensor, bit-identical sums.
+# Not under SyncBN / gradient buckets (their hooks read a gradient as soon as autograd has accumulated it) and never for plain
+# autograd callers (a second backward would accumulate into an unreduced gradient).  SEMSEG_DEFER_WGRAD_REDUCE=0 disables.
+DEFER_WGRAD_REDUCE = os.environ.get('SEMSEG_DEFER_WGRAD_REDUCE', '1') != '0'
+_DEFER = [False]
+_PENDING_SLABS = []          # (slab tensor, gradient buffer, numel, splits)
+
+
+class defer_wgrad_reduces:
+    def __enter__(self):
+        self.prev = _DEFER[0]
+        _DEFER[0] = DEFER_WGRAD_REDUCE and CONV_MODE == 'h2' and not _sync_active()
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER[0] = self.prev
+        flush_wgrad_reduces()
+        return False
+
+
+def flush_wgrad_reduces():
+    """sum the slabs of every weight gradient deferred since the last flush, one launch per 64 tensors (on the current stream: after
+    backward() has returned autograd has made it wait for the streams the gradients were produced on)"""
+    if not _PENDING_SLABS:
+        return
+    items, _PENDING_SLABS[:] = list(_PENDING_SLABS), []
+    arr = (_native.SlabTensor * len(items))()
+    cur = torch.cuda.current_stream() if items[0][0].is_cuda else None
+    for i, (slabs, out, numel, splits) in enumerate(items):
+        arr[i].slabs, arr[i].out, arr[i].numel, arr[i].splits = slabs.data_ptr(), out.data_ptr(), numel, splits
+        if cur is not None:                  # slabs / gradient allocated on a branch stream, summed on this one
+            slabs.record_stream(cur)
+            out.record_stream(cur)
+    _native.check(_native.lib().semseg_reduce_slabs_multi(arr, len(items), _st()), 'reduce_slabs_multi')
+
+
 def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
     """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys)."""
     n, h, wd, c, k, r, s, stride, pad, dil = geom
@@ -580,8 +619,16 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
             ws = workspace(sch.fn(L, 'workspace_bytes')(*geom), dev)
             _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
                           'conv2d_wgrad_' + scheme)
-        tuner.ensure(scheme, 2, geom, launch_w)
-        launch_w()
+        tuner.ensure(scheme, 2, geom, launch_w)        # candidates are timed WITH their reduce: what a plan costs either way
+        if _DEFER[0] and scheme == 'h2':
+            nbytes = L.semseg_conv2d_wgrad_slabs_bytes(*geom)
+            slabs = torch.empty((max(16, nbytes) + 3) // 4, device=dev, dtype=torch.float32)
+            splits = ctypes.c_int(0)
+            _native.check(L.semseg_conv2d_wgrad_slabs_h2(_p(xs), _p(dys), _p(slabs), slabs.numel() * 4, ctypes.byref(splits), *geom,
+                                                         _st()), 'conv2d_wgrad_slabs_h2')
+            _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value)))
+        else:
+            launch_w()
         dw = dwb.permute(0, 3, 1, 2)
     if need_dx:
         wts = wtp if wtp is not None else _weight_crsk_planes(L, sch, w, dev)

@@ -263,6 +263,34 @@ def test_knife_edge_case_gradients_stay_within_a_loose_elementwise_limit(name):
     assert max(heads)[0] <= HEAD_SCALE_ERR, heads
 
 
+def test_deferred_wgrad_reduce_is_bit_identical(monkeypatch):
+    """TrainStep sums the slabs of all split weight gradients in ONE multi-tensor launch after backward (ops.defer_wgrad_reduces):
+    same slab order per tensor as the per-tensor reduce, so the state after two steps is bit-identical to the step that reduces every
+    weight gradient where it is produced"""
+    from mit_semseg import ops, tuner
+    from mit_semseg.engine import TrainStep
+    monkeypatch.setattr(tuner, 'ENABLED', False)          # heuristic plans: both runs launch the same plans
+    g = load_golden('r18d_ppmds_64_train')
+    m = g['meta']
+    dev = torch.device('cuda:0')
+    img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=304 + m['seed'])
+    feed = {'img_data': img.to(dev), 'seg_label': lab.to(dev)}
+    states = []
+    for defer in (True, False):
+        monkeypatch.setattr(ops, 'DEFER_WGRAD_REDUCE', defer)
+        sm, _, _ = build_native(g, dev)
+        ts = TrainStep(sm, lr_encoder=m['lr'], lr_decoder=m['lr'], max_iters=10 ** 9)
+        for _ in range(2):
+            loss, _ = ts.step(feed)
+        torch.cuda.synchronize()
+        assert not ops._PENDING_SLABS
+        states.append(({k: v.clone() for k, v in sm.state_dict().items()}, loss.clone()))
+    (a, la), (b, lb) = states
+    assert torch.equal(la, lb)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_inference_graph_replay_equals_eager():
     """engine.InferenceGraph: the captured inference branch returns exactly what the eager call returns, for new inputs too"""
     from mit_semseg.engine import InferenceGraph
@@ -332,7 +360,8 @@ SWITCH_CASES = [
     ('SEMSEG_BRANCH_STREAMS=0', 'hrnetv2_c1_128_train'),
     ('SEMSEG_PLANES_ONLY=0', 'r50d_ppmds_64_train'),         # every BN output also as fp32 (round 4: bn1 / bn2 of a block are planes only)
     ('SEMSEG_WINOGRAD_FUSED=0', 'r50d_ppmds_64_train'),      # Winograd data gradients as batched GEMM + output transform
-    ('SEMSEG_TUNE_DB=0', 'r18d_ppmds_64_train'),             # no shipped launch plans: every geometry timed in the process
+    ('SEMSEG_TUNE_DB=0', 'r18d_ppmds_64_train'),
+    ('SEMSEG_DEFER_WGRAD_REDUCE=0', 'r50d_ppmds_64_train'),  # one reduce launch per split weight gradient instead of ONE per step             # no shipped launch plans: every geometry timed in the process
     ('SEMSEG_DEPTHWISE_DIRECT=0', 'mnv2d_c1ds_64_train'),
     ('SEMSEG_GROUPED_DIRECT=0', 'resnext101_upernet_128_eval'),
 ]

@@ -77,7 +77,8 @@ def test_train_step_host_logic(stub, cfg, mode, monkeypatch):
     names = set(stub.calls)
     conv = {'f32': ('semseg_conv2d_fwd', 'semseg_conv2d_dgrad', 'semseg_conv2d_wgrad'),
             's3': ('semseg_split3', 'semseg_conv2d_fwd_s3', 'semseg_conv2d_dgrad_s3', 'semseg_conv2d_wgrad_s3', 'semseg_bias_grad'),
-            'h2': ('semseg_split_h2', 'semseg_conv2d_fwd_h2', 'semseg_conv2d_dgrad_h2', 'semseg_conv2d_wgrad_h2',
+            # h2 inside TrainStep on one rank: the weight gradients leave slabs, ONE multi-tensor launch sums them after backward
+            'h2': ('semseg_split_h2', 'semseg_conv2d_fwd_h2', 'semseg_conv2d_dgrad_h2', 'semseg_conv2d_wgrad_slabs_h2', 'semseg_reduce_slabs_multi',
                    'semseg_bias_grad')}[mode]
     # h2: conv -> BN pairs run as the fused node (BN kernels that emit / consume split planes, multi-tensor weight prep)
     bn = ('semseg_bn_fwd_stats_fused', 'semseg_bn_apply_h2', 'semseg_bn_bwd_reduce_fused', 'semseg_bn_bwd_apply_h2',

@@ -18,10 +18,12 @@ class Recorder:
     def __init__(self, signatures):
         self.calls = []
         for name, (res, args) in signatures.items():
-            setattr(self, name, self._make(name, res))
+            setattr(self, name, self._make(name, res, args))
 
-    def _make(self, name, res):
+    def _make(self, name, res, argtypes=()):
         def fn(*args):
+            # byte counts (size_t arguments) are not geometry: leave them out so that the columns of a call are always the same
+            args = [a for a, t in zip(args, list(argtypes) + [None] * len(args)) if t is not ctypes.c_size_t]
             ints = [a if isinstance(a, int) else getattr(a, 'value', None) for a in args]
             self.calls.append((name, [v for v in ints if isinstance(v, int) and 0 <= v < (1 << 24)]))
             if name == 'semseg_winograd_tiles':          # the one return value the caller's later arguments depend on

@@ -14,7 +14,7 @@ import sys
 MFMA = 2.5e15 * 1.7 / 2.4
 HBM = 5.5e12
 LAUNCH = 2.5e-6
-CONV_CALLS = ('conv2d_dgrad_h2', 'conv2d_fwd_h2', 'conv2d_fwd_stats_h2', 'conv2d_wgrad_h2', 'winograd_gemm_h2', 'winograd_wgrad_gemm_h2',
+CONV_CALLS = ('conv2d_dgrad_h2', 'conv2d_fwd_h2', 'conv2d_fwd_stats_h2', 'conv2d_wgrad_h2', 'conv2d_wgrad_slabs_h2', 'winograd_gemm_h2', 'winograd_wgrad_gemm_h2',
               'winograd_gemm_output_h2')
 
 
@@ -60,15 +60,15 @@ def main():
             c = geom[i]
             a = [int(v) for v in c[1:]]
             if c[0].startswith('conv2d'):
-                if c[0] != 'conv2d_wgrad_h2':
+                if c[0] not in ('conv2d_wgrad_h2', 'conv2d_wgrad_slabs_h2'):
                     a = a[1:]                       # leading dimension of the output
                 n, h, w, ci, k, rr, ss, st, pad, dil = a[:10]
                 oh, ow = (h + 2 * pad - dil * (rr - 1) - 1) // st + 1, (w + 2 * pad - dil * (ss - 1) - 1) // st + 1
                 flops = 3 * 2.0 * n * oh * ow * k * ci * rr * ss
                 x, y, wt = n * h * w * ci * 4, n * oh * ow * k * 4, ci * k * rr * ss * 4
                 alg = {'conv2d_fwd_stats_h2': x + wt + y, 'conv2d_fwd_h2': x + wt + y, 'conv2d_dgrad_h2': y + wt + x,
-                       'conv2d_wgrad_h2': x + y + wt}[c[0]]
-                label = '%s %dx%dx%d %d->%d %dx%d s%d d%d' % (c[0][7:-3], n, h, w, ci, k, rr, ss, st, dil)
+                       'conv2d_wgrad_h2': x + y + wt, 'conv2d_wgrad_slabs_h2': x + y + wt}[c[0]]
+                label = '%s %dx%dx%d %d->%d %dx%d s%d d%d' % (c[0][7:-3].replace('_slabs', ''), n, h, w, ci, k, rr, ss, st, dil)
             elif c[0] == 'winograd_gemm_output_h2':  # fused GEMM + output transform: z_ld, N, H, W, C (reduction), K, dil, form
                 zld, n, h, w, ci, k, dil = a[:7]
                 tiles = n * dil * dil * ((-(-h // dil) + 1) // 2) * ((-(-w // dil) + 1) // 2)
