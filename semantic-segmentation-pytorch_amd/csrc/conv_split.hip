@@ -38,6 +38,7 @@
 #include "common.h"
 #include "split_layout.h"
 #include <stdlib.h>
+#include <vector>
 #include <array>
 #include <map>
 #include <mutex>
@@ -2454,8 +2455,10 @@ struct WTile {
     static constexpr int BYTES = NP * 32 * STRIDE;
 };
 
+// the block of wgrad_kernel: `lin` = the block's position in the launch order x + gridDim.x * y of a (tiles, splits) grid, `nsplits`
+// = that grid's y extent -- parameters, so that wgrad_multi_kernel can run the blocks of MANY problems in one launch
 template <class SCH, int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
+__device__ __forceinline__ void wgrad_block_body(const WParams& p, int lin, int nsplits) {
     constexpr int NP = SCH::NP;
     typedef typename SCH::frag frag;
     using TA = WTile<NP, BM>;
@@ -2476,7 +2479,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
     // blocks that read the same rows of x and dy -- meet in ONE L2 (a remap of x alone assumes gridDim.x % 8 == 0 and still
     // deals every chunk to all eight XCDs: profiles/r4_pmc_step_traffic_cfg1.txt, 9 x 56 blocks fetched 9x their operands)
     const int ntiles = p.tiles_k * p.tiles_c * p.T;
-    const WgradBlock wb = wgrad_block(blockIdx.x + gridDim.x * blockIdx.y, ntiles, gridDim.y);      // block_order.h
+    const WgradBlock wb = wgrad_block(lin, ntiles, nsplits);      // block_order.h
     const int tile = wb.tile;
     const int t = tile % p.T;
     const int tc = (tile / p.T) % p.tiles_c;
@@ -2623,6 +2626,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
             }
         }
     }
+}
+
+template <class SCH, int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
+    wgrad_block_body<SCH, BM, BN>(p, blockIdx.x + gridDim.x * blockIdx.y, gridDim.y);
+}
+
+// MANY weight gradients in one launch (semseg_conv2d_wgrad_multi_h2): the weight gradients of a backward pass are read by the
+// optimizer only, so the host may hold the small ones back (their operands stay alive) and run their blocks side by side -- HRNet's
+// 241 launches of 2 - 60 blocks each occupy a fraction of the 256 CUs one after the other; here the blocks of up to kWMulti
+// problems form one grid.  Block b belongs to problem j with first[j] <= b < first[j + 1] and runs wgrad_kernel's block
+// b - first[j] of that problem's (tiles, splits) grid UNCHANGED (same block order, same summation order: bit-identical results).
+constexpr int kWMulti = 24;     // 24 x sizeof(WParams) + the offsets stay below the 4 KB kernel-argument segment
+struct WMultiParams {
+    WParams p[kWMulti];
+    int first[kWMulti + 1];
+    int n;
+};
+static_assert(sizeof(WMultiParams) <= 4000, "kernel arguments");
+
+template <class SCH, int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_multi_kernel(const WMultiParams mp) {
+    const int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < mp.n && b >= mp.first[j + 1]) ++j;       // block-uniform: scalar loads from the argument segment
+    const WParams& p = mp.p[j];
+    wgrad_block_body<SCH, BM, BN>(p, b - mp.first[j], p.splits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3162,19 +3192,16 @@ static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
     return 0;
 }
 
-// splits_out != nullptr: "slabs only" -- the partial sums of the `*splits_out` pixel chunks are left in `workspace` as
-// [splits][K*T*C] fp32 (a plan without a split writes its one slab there too) and NO reduce is launched: the caller sums the slabs
-// of many weight gradients in one multi-tensor launch (semseg_reduce_slabs_multi); `dw` is not touched.
+// the kernel parameters and the launch plan of one weight gradient (everything of conv_wgrad before the launch)
 template <class SCH>
-static int conv_wgrad(const void* xs, const void* dys, float* dw,
-                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                      void* workspace, size_t workspace_bytes, void* stream, int* splits_out = nullptr) {
+static int wgrad_prepare(const void* xs, const void* dys, float* dw,
+                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                         void* workspace, size_t workspace_bytes, int* splits_out, WParams& p, WPlan& pl) {
     if (!xs || !dys || (!dw && !splits_out) || N <= 0 || C <= 0 || K <= 0 || stride <= 0 || dil <= 0) return SEMSEG_EINVAL;
     if (!aligned16(xs) || !aligned16(dys)) return SEMSEG_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
     const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
     if (OH <= 0 || OW <= 0) return SEMSEG_EINVAL;
-    WParams p = {};
+    p = {};
     p.xs = (const uint16_t*)xs; p.dys = (const uint16_t*)dys; p.dw = dw;
     p.Cp = round_up32(C); p.Kp = round_up32(K); p.xpitch = split_pitch(C); p.dypitch = split_pitch(K);
     p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
@@ -3190,7 +3217,7 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
     }
     int ov_tile = -1, ov_split = 0;
     lookup_plan(SCH::ID, 2, N, H, W, C, K, R, S, stride, pad, dil, &ov_tile, &ov_split);
-    const WPlan pl = plan_wgrad(p.M, K, C, p.T, ov_tile, ov_split);
+    pl = plan_wgrad(p.M, K, C, p.T, ov_tile, ov_split);
     p.tiles_k = pl.tiles_k; p.tiles_c = pl.tiles_c;
     p.m_per_split = pl.m_per_split; p.splits = pl.splits;
     if (pl.splits > 1 || splits_out) {
@@ -3202,6 +3229,23 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
             if (pl.splits == 1) p.dw = (float*)workspace;          // the one slab
         }
     }
+    return 0;
+}
+
+// splits_out != nullptr: "slabs only" -- the partial sums of the `*splits_out` pixel chunks are left in `workspace` as
+// [splits][K*T*C] fp32 (a plan without a split writes its one slab there too) and NO reduce is launched: the caller sums the slabs
+// of many weight gradients in one multi-tensor launch (semseg_reduce_slabs_multi); `dw` is not touched.
+template <class SCH>
+static int conv_wgrad(const void* xs, const void* dys, float* dw,
+                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                      void* workspace, size_t workspace_bytes, void* stream, int* splits_out = nullptr) {
+    hipStream_t st = (hipStream_t)stream;
+    WParams p;
+    WPlan pl;
+    const int prc = wgrad_prepare<SCH>(xs, dys, dw, N, H, W, C, K, R, S, stride, pad, dil, workspace, workspace_bytes, splits_out,
+                                       p, pl);
+    if (prc) return prc;
+    const int OW = p.OW;
     int rc = SEMSEG_EINVAL;
     switch (pl.tile) {
         case 0: rc = launch_wgrad<SCH, 128>(p, st); break;
@@ -3335,6 +3379,54 @@ extern "C" int semseg_conv2d_wgrad_slabs_h2(const void* xs, const void* dys, flo
                                             void* stream) {
     if (!splits_out) return SEMSEG_EINVAL;
     return conv_wgrad<SchH2>(xs, dys, nullptr, N, H, W, C, K, R, S, stride, pad, dil, slabs, slabs_bytes, stream, splits_out);
+}
+
+// MANY weight gradients as slabs in ONE launch (wgrad_multi_kernel): problem i leaves its `splits` partial sums in
+// problems[i].slabs exactly as semseg_conv2d_wgrad_slabs_h2 would -- same plan, same blocks, same bits.  Only problems whose launch
+// plan is the register-staged 64 x 64 tile (semseg_conv2d_wgrad_tile_h2 == 1: the small layers, the ones that do not fill the chip
+// on their own) can be batched; any other plan -> SEMSEG_EINVAL before anything is launched.
+extern "C" int semseg_conv2d_wgrad_tile_h2(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || dil <= 0) return SEMSEG_EINVAL;
+    const int OH = out_dim(H, R, stride, pad, dil), OW = out_dim(W, S, stride, pad, dil);
+    if (OH <= 0 || OW <= 0) return SEMSEG_EINVAL;
+    int t2 = -1, s2 = 0;
+    lookup_plan(SchH2::ID, 2, N, H, W, C, K, R, S, stride, pad, dil, &t2, &s2);
+    return plan_wgrad(N * OH * OW, K, C, R * S, t2, s2).tile;
+}
+extern "C" int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host, int n, void* stream) {
+    if (n < 0 || (n > 0 && !problems_host)) return SEMSEG_EINVAL;
+    std::vector<WParams> ps((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        semseg_wgrad_problem& q = problems_host[i];
+        WPlan pl;
+        const int rc = wgrad_prepare<SchH2>(q.xs, q.dys, nullptr, q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil,
+                                            q.slabs, q.slabs_bytes, &q.splits, ps[i], pl);
+        if (rc) return rc;
+        if (pl.tile != 1) return SEMSEG_EINVAL;
+    }
+    constexpr size_t smem = (size_t)2 * WTile<SchH2::NP, 64>::BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_multi_kernel<SchH2, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    for (int base = 0; base < n; base += kWMulti) {
+        WMultiParams mp = {};
+        mp.n = n - base < kWMulti ? n - base : kWMulti;
+        long blocks = 0;
+        for (int i = 0; i < mp.n; ++i) {
+            mp.p[i] = ps[base + i];
+            mp.first[i] = (int)blocks;
+            blocks += (long)mp.p[i].tiles_k * mp.p[i].tiles_c * mp.p[i].T * mp.p[i].splits;
+        }
+        if (blocks >= ((long)1 << 31)) return SEMSEG_EINVAL;
+        mp.first[mp.n] = (int)blocks;
+        hipLaunchKernelGGL((wgrad_multi_kernel<SchH2, 64, 64>), dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, mp);
+        SEMSEG_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 // out[i] = slabs[0][i] + slabs[1][i] + ... (slab order: the order split_wgrad_reduce_kernel adds in) for MANY tensors in one launch:

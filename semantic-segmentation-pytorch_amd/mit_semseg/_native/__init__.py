@@ -25,6 +25,11 @@ class SlabTensor(ctypes.Structure):
     _fields_ = [('slabs', vp), ('out', vp), ('numel', ctypes.c_int64), ('splits', c_int)]
 
 
+class WgradProblem(ctypes.Structure):
+    _fields_ = [('xs', vp), ('dys', vp), ('slabs', vp), ('slabs_bytes', c_sz)] + \
+               [(k, c_int) for k in ('N', 'H', 'W', 'C', 'K', 'R', 'S', 'stride', 'pad', 'dil', 'splits')]
+
+
 class WPrepTensor(ctypes.Structure):
     _fields_ = [('w', vp), ('krsc', vp), ('crsk', vp), ('K', c_int), ('T', c_int), ('C', c_int), ('wino', vp), ('wino_t', vp)]
 
@@ -58,6 +63,8 @@ SIGNATURES = {
     'semseg_conv2d_wgrad_slabs_bytes': (c_sz, [c_int] * 10),
     'semseg_conv2d_wgrad_slabs_h2': (c_int, [vp, vp, vp, c_sz, ctypes.POINTER(c_int)] + [c_int] * 10 + [vp]),
     'semseg_reduce_slabs_multi': (c_int, [ctypes.POINTER(SlabTensor), c_int, vp]),
+    'semseg_conv2d_wgrad_tile_h2': (c_int, [c_int] * 10),
+    'semseg_conv2d_wgrad_multi_h2': (c_int, [ctypes.POINTER(WgradProblem), c_int, vp]),
     'semseg_conv2d_h2_set_plan': (c_int, [c_int] * 13),
     'semseg_bias_grad': (c_int, [vp, c_int, vp, c_int, c_int, vp, c_sz, vp]),
     'semseg_bn_workspace_bytes': (c_sz, [c_int, c_int]),

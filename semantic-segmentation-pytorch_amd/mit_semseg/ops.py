@@ -544,6 +544,7 @@ class Conv2dSplitFn(Function):
         ctx.geom = geom
         ctx.has_bias = bias is not None
         ctx.scheme = scheme
+        ctx.w_leaf = _is_leaf_weight(weight)
         return y
 
     @staticmethod
@@ -559,7 +560,8 @@ class Conv2dSplitFn(Function):
         dev = w.device
         dy, dy_ld = as_nhwc(dy)
         dys = sch.split(dy, n * oh * ow, k, dy_ld)
-        dx, dw = _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dw = _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                   may_defer=ctx.w_leaf)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty((k,), device=dev, dtype=torch.float32)
@@ -575,8 +577,14 @@ class Conv2dSplitFn(Function):
 # Not under SyncBN / gradient buckets (their hooks read a gradient as soon as autograd has accumulated it) and never for plain
 # autograd callers (a second backward would accumulate into an unreduced gradient).  SEMSEG_DEFER_WGRAD_REDUCE=0 disables.
 DEFER_WGRAD_REDUCE = os.environ.get('SEMSEG_DEFER_WGRAD_REDUCE', '1') != '0'
+# ... and the small weight gradients themselves wait too: a geometry whose launch plan is the register-staged 64 x 64 tile (2 - 60
+# blocks on 256 CUs; 241 such launches per HRNetV2 step, 30 on configs[1]) keeps its operand planes alive until backward has returned,
+# and flush_wgrad_reduces runs the blocks of up to 24 of them side by side in one launch (semseg_conv2d_wgrad_multi_h2: the blocks
+# of the per-layer launches unchanged, bit-identical slabs).  SEMSEG_DEFER_WGRAD_LAUNCH=0 launches them where autograd reaches them.
+DEFER_WGRAD_LAUNCH = os.environ.get('SEMSEG_DEFER_WGRAD_LAUNCH', '1') != '0'
 _DEFER = [False]
 _PENDING_SLABS = []          # (slab tensor, gradient buffer, numel, splits)
+_PENDING_WGRADS = []         # (x planes, dy planes, slab tensor, gradient buffer, geometry)
 
 
 class defer_wgrad_reduces:
@@ -594,6 +602,20 @@ class defer_wgrad_reduces:
 def flush_wgrad_reduces():
     """sum the slabs of every weight gradient deferred since the last flush, one launch per 64 tensors (on the current stream: after
     backward() has returned autograd has made it wait for the streams the gradients were produced on)"""
+    if _PENDING_WGRADS:
+        probs, _PENDING_WGRADS[:] = list(_PENDING_WGRADS), []
+        parr = (_native.WgradProblem * len(probs))()
+        cur = torch.cuda.current_stream() if probs[0][2].is_cuda else None
+        for i, (xs, dys, slabs, out, geom) in enumerate(probs):
+            q = parr[i]
+            q.xs, q.dys, q.slabs, q.slabs_bytes = xs.data_ptr(), dys.data_ptr(), slabs.data_ptr(), slabs.numel() * 4
+            q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil = geom
+            if cur is not None:              # planes produced on a branch stream, read on this one
+                xs.record_stream(cur)
+                dys.record_stream(cur)
+        _native.check(_native.lib().semseg_conv2d_wgrad_multi_h2(parr, len(probs), _st()), 'conv2d_wgrad_multi_h2')
+        for i, (xs, dys, slabs, out, geom) in enumerate(probs):
+            _PENDING_SLABS.append((slabs, out, geom[4] * geom[5] * geom[6] * geom[3], int(parr[i].splits)))
     if not _PENDING_SLABS:
         return
     items, _PENDING_SLABS[:] = list(_PENDING_SLABS), []
@@ -607,8 +629,16 @@ def flush_wgrad_reduces():
     _native.check(_native.lib().semseg_reduce_slabs_multi(arr, len(items), _st()), 'reduce_slabs_multi')
 
 
-def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
-    """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys)."""
+def _is_leaf_weight(weight):
+    """a weight whose gradient autograd only ACCUMULATES (into .grad, after this node) -- the one case in which the weight gradient
+    may be completed after backward() has returned.  A weight computed from parameters (GroupedConv2d's block-diagonal expansion)
+    has its gradient read by the next autograd node right away."""
+    return bool(weight.requires_grad and weight.is_leaf and weight.grad_fn is None)
+
+
+def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, may_defer=False):
+    """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys).  may_defer: the weight
+    is a leaf (_is_leaf_weight) -- inside defer_wgrad_reduces() its gradient may be finished by flush_wgrad_reduces."""
     n, h, wd, c, k, r, s, stride, pad, dil = geom
     dev = w.device
     dx = dw = None
@@ -620,13 +650,16 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw):
             _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
                           'conv2d_wgrad_' + scheme)
         tuner.ensure(scheme, 2, geom, launch_w)        # candidates are timed WITH their reduce: what a plan costs either way
-        if _DEFER[0] and scheme == 'h2':
+        if _DEFER[0] and may_defer and scheme == 'h2':
             nbytes = L.semseg_conv2d_wgrad_slabs_bytes(*geom)
             slabs = torch.empty((max(16, nbytes) + 3) // 4, device=dev, dtype=torch.float32)
-            splits = ctypes.c_int(0)
-            _native.check(L.semseg_conv2d_wgrad_slabs_h2(_p(xs), _p(dys), _p(slabs), slabs.numel() * 4, ctypes.byref(splits), *geom,
-                                                         _st()), 'conv2d_wgrad_slabs_h2')
-            _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value)))
+            if DEFER_WGRAD_LAUNCH and L.semseg_conv2d_wgrad_tile_h2(*geom) == 1:
+                _PENDING_WGRADS.append((xs, dys, slabs, dwb, tuple(geom)))
+            else:
+                splits = ctypes.c_int(0)
+                _native.check(L.semseg_conv2d_wgrad_slabs_h2(_p(xs), _p(dys), _p(slabs), slabs.numel() * 4, ctypes.byref(splits),
+                                                             *geom, _st()), 'conv2d_wgrad_slabs_h2')
+                _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value)))
         else:
             launch_w()
         dw = dwb.permute(0, 3, 1, 2)
@@ -1129,6 +1162,7 @@ class ConvBNActFn(Function):
         ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate, wut)
         ctx.geom = geom
         ctx.cfg = (bool(relu), residual is not None)
+        ctx.w_leaf = _is_leaf_weight(weight)
         box['planes'], box['absmax'] = yp, absmax
         return y
 
@@ -1193,7 +1227,7 @@ class ConvBNActFn(Function):
         if wut is not None and need_dx:
             dx_wino = _winograd_dgrad(L, dzp, wut, geom)
             need_dx = False
-        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, need_dx, need_dw)
+        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, need_dx, need_dw, may_defer=ctx.w_leaf)
         if dw_wino is not None:
             dw = dw_wino
         if dx_wino is not None:

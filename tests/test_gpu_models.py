@@ -264,31 +264,43 @@ def test_knife_edge_case_gradients_stay_within_a_loose_elementwise_limit(name):
 
 
 def test_deferred_wgrad_reduce_is_bit_identical(monkeypatch):
-    """TrainStep sums the slabs of all split weight gradients in ONE multi-tensor launch after backward (ops.defer_wgrad_reduces):
-    same slab order per tensor as the per-tensor reduce, so the state after two steps is bit-identical to the step that reduces every
-    weight gradient where it is produced"""
+    """TrainStep sums the slabs of all split weight gradients in ONE multi-tensor launch after backward (ops.defer_wgrad_reduces)
+    and runs the small weight gradients themselves side by side in one launch per 24 (semseg_conv2d_wgrad_multi_h2): same blocks,
+    same slab order per tensor as the per-layer launches, so the state after two steps is bit-identical to the step that computes
+    and reduces every weight gradient where autograd reaches it"""
     from mit_semseg import ops, tuner
     from mit_semseg.engine import TrainStep
-    monkeypatch.setattr(tuner, 'ENABLED', False)          # heuristic plans: both runs launch the same plans
+    monkeypatch.setattr(tuner, 'ENABLED', False)          # heuristic plans: all runs launch the same plans
     g = load_golden('r18d_ppmds_64_train')
     m = g['meta']
     dev = torch.device('cuda:0')
     img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=304 + m['seed'])
     feed = {'img_data': img.to(dev), 'seg_label': lab.to(dev)}
+    batched = []
+    real = ops.flush_wgrad_reduces
+
+    def counting():
+        batched.append(len(ops._PENDING_WGRADS))
+        return real()
+    monkeypatch.setattr(ops, 'flush_wgrad_reduces', counting)
     states = []
-    for defer in (True, False):
+    for defer, launch in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(ops, 'DEFER_WGRAD_REDUCE', defer)
+        monkeypatch.setattr(ops, 'DEFER_WGRAD_LAUNCH', launch)
         sm, _, _ = build_native(g, dev)
         ts = TrainStep(sm, lr_encoder=m['lr'], lr_decoder=m['lr'], max_iters=10 ** 9)
+        del batched[:]
         for _ in range(2):
             loss, _ = ts.step(feed)
         torch.cuda.synchronize()
-        assert not ops._PENDING_SLABS
+        assert not ops._PENDING_SLABS and not ops._PENDING_WGRADS
+        assert (max(batched) >= 8) == (defer and launch), batched      # the path under test ran (r18: more than 8 small layers)
         states.append(({k: v.clone() for k, v in sm.state_dict().items()}, loss.clone()))
-    (a, la), (b, lb) = states
-    assert torch.equal(la, lb)
-    for k in a:
-        assert torch.equal(a[k], b[k]), k
+    for (b, lb) in states[1:]:
+        a, la = states[0]
+        assert torch.equal(la, lb)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
 
 
 def test_inference_graph_replay_equals_eager():
@@ -362,6 +374,7 @@ SWITCH_CASES = [
     ('SEMSEG_WINOGRAD_FUSED=0', 'r50d_ppmds_64_train'),      # Winograd data gradients as batched GEMM + output transform
     ('SEMSEG_TUNE_DB=0', 'r18d_ppmds_64_train'),
     ('SEMSEG_DEFER_WGRAD_REDUCE=0', 'r50d_ppmds_64_train'),  # one reduce launch per split weight gradient instead of ONE per step             # no shipped launch plans: every geometry timed in the process
+    ('SEMSEG_DEFER_WGRAD_LAUNCH=0', 'hrnetv2_c1_128_train'), # every small weight gradient its own launch instead of 24 per launch
     ('SEMSEG_DEPTHWISE_DIRECT=0', 'mnv2d_c1ds_64_train'),
     ('SEMSEG_GROUPED_DIRECT=0', 'resnext101_upernet_128_eval'),
 ]

@@ -815,6 +815,95 @@ def test_h2_wgrad_all_taps_in_one_block(case, split, monkeypatch):
         assert L.semseg_conv2d_h2_set_plan(2, *bad, 10, 1) != 0, bad
 
 
+def test_deferred_wgrad_leaves_computed_weights_alone(monkeypatch):
+    """inside ops.defer_wgrad_reduces() only the gradient of a LEAF weight may be finished after backward has returned; a weight
+    computed from a parameter (GroupedConv2d's dense expansion) has its gradient read by the next autograd node at once -- it must be
+    complete there (found by the SEMSEG_DEPTHWISE_DIRECT=0 golden: garbage of 1e36 in the MobileNetV2 state)"""
+    from mit_semseg import ops, tuner
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    monkeypatch.setattr(tuner, 'ENABLED', False)
+    g = torch.Generator().manual_seed(5)
+    x = cl(torch.randn(2, 64, 16, 16, generator=g))
+    w0 = torch.randn(64, 64, 3, 3, generator=g) / 24
+    gy = cl(torch.randn(2, 64, 16, 16, generator=g))
+    grads = {}
+    for defer in (False, True):
+        for leaf in (True, False):
+            p = cl(w0.clone()).requires_grad_(True)
+            w = p if leaf else p * 2.0
+            if defer:
+                with ops.defer_wgrad_reduces():
+                    ops.conv2d(x, w, None, 1, 1, 1).backward(gy)
+            else:
+                ops.conv2d(x, w, None, 1, 1, 1).backward(gy)
+            torch.cuda.synchronize()
+            assert not ops._PENDING_SLABS and not ops._PENDING_WGRADS
+            grads[defer, leaf] = p.grad.clone()
+    assert torch.equal(grads[True, True], grads[False, True])
+    assert torch.equal(grads[True, False], grads[False, False])
+    assert rel_err(grads[True, False], 2.0 * grads[True, True].cpu()) < 1e-5      # w = 2 p: products differ by an exact power of two only
+
+
+# (n, h, w, c, k, r, stride, pad, dil, split) -- ragged channel counts, strides, dilation, 1x1 and 3x3, with and without a split
+WGRAD_MULTI_GEOMS = [(2, 16, 16, 64, 64, 3, 1, 1, 1, 1), (2, 16, 16, 64, 64, 3, 1, 1, 1, 2), (1, 24, 20, 18, 36, 3, 1, 1, 1, 3),
+                     (2, 17, 13, 48, 96, 3, 2, 1, 1, 1), (1, 32, 32, 144, 72, 1, 1, 0, 1, 4), (2, 16, 16, 32, 40, 3, 1, 2, 2, 2),
+                     (1, 8, 8, 256, 19, 1, 1, 0, 1, 1), (1, 40, 40, 24, 24, 3, 1, 1, 1, 5)]
+
+
+@pytest.mark.parametrize('count', [1, 5, 24, 25, 53])
+def test_h2_wgrad_many_problems_in_one_launch(count):
+    """semseg_conv2d_wgrad_multi_h2: the blocks of up to 24 weight gradients side by side in one launch leave, problem by problem,
+    the SAME slabs (bit for bit) as semseg_conv2d_wgrad_slabs_h2 launched per problem -- across the 24-problem launch boundary too;
+    a geometry whose plan is not the 64 x 64 register-staged tile is refused before anything runs."""
+    import ctypes
+    from mit_semseg import ops, _native
+    L = _native.lib()
+    vp = ctypes.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator().manual_seed(count)
+    probs, pinned = [], set()
+    try:
+        for i in range(count):
+            n, h, w, c, k, r, stride, pad, dil, split = WGRAD_MULTI_GEOMS[i % len(WGRAD_MULTI_GEOMS)]
+            geom = (n, h, w, c, k, r, r, stride, pad, dil)
+            if geom not in pinned:
+                _native.check(L.semseg_conv2d_h2_set_plan(2, *geom, 1, split), 'set_plan')
+                pinned.add(geom)
+            assert L.semseg_conv2d_wgrad_tile_h2(*geom) == 1
+            oh, ow = ops.conv_out_size(h, r, stride, pad, dil), ops.conv_out_size(w, r, stride, pad, dil)
+            x = (torch.randn(n, h, w, c, generator=gen) * (1 + i % 3)).to(dev())
+            dy = torch.randn(n, oh, ow, k, generator=gen).to(dev())
+            xs = ops.SCHEMES['h2'].split(x, n * h * w, c, c)
+            dys = ops.SCHEMES['h2'].split(dy, n * oh * ow, k, k)
+            nbytes = L.semseg_conv2d_wgrad_slabs_bytes(*geom)
+            want = torch.full((nbytes // 4,), float('nan'), device=dev())
+            got = torch.full((nbytes // 4,), float('nan'), device=dev())
+            splits = ctypes.c_int(0)
+            _native.check(L.semseg_conv2d_wgrad_slabs_h2(vp(xs.data_ptr()), vp(dys.data_ptr()), vp(want.data_ptr()), nbytes,
+                                                         ctypes.byref(splits), *geom, st), 'slabs')
+            probs.append((geom, xs, dys, want, got, splits.value))
+        arr = (_native.WgradProblem * count)()
+        for q, (geom, xs, dys, want, got, _) in zip(arr, probs):
+            q.xs, q.dys, q.slabs, q.slabs_bytes = xs.data_ptr(), dys.data_ptr(), got.data_ptr(), got.numel() * 4
+            q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil = geom
+        _native.check(L.semseg_conv2d_wgrad_multi_h2(arr, count, st), 'multi')
+        torch.cuda.synchronize()
+        for i, (geom, xs, dys, want, got, splits) in enumerate(probs):
+            assert arr[i].splits == splits, (i, geom)
+            assert not torch.isnan(want).any()
+            assert torch.equal(got, want), (i, geom)
+        # a plan on another tile: refused, nothing written
+        geom = probs[0][0]
+        _native.check(L.semseg_conv2d_h2_set_plan(2, *geom, 0, 1), 'set_plan')
+        probs[0][4].fill_(7.0)
+        assert L.semseg_conv2d_wgrad_multi_h2(arr, count, st) != 0
+        torch.cuda.synchronize()
+        assert bool((probs[0][4] == 7.0).all())
+    finally:
+        for geom in pinned:
+            L.semseg_conv2d_h2_set_plan(2, *geom, -1, 0)
+
+
 @pytest.mark.parametrize('case', PLAN_CASES + [(2, 64, 40, 40, 64, 3, 1, 1, 1), (2, 1024, 8, 8, 48, 1, 1, 0, 1)], ids=str)
 @pytest.mark.parametrize('tile', list(range(25)))
 def test_conv_epilogue_statistics_match_the_sweep(case, tile):

@@ -4,7 +4,9 @@ algorithmic operand bytes at the achievable HBM rate, a launch floor)  next to t
 far from what the hardware allows" without another GPU run.
     python tools/abi_call_trace.py > /tmp/abi_calls.txt;  python tools/step_floor_model.py gpurun_out/<tag> /tmp/abi_calls.txt
 Constants: 2.5 PFLOP/s dense 16-bit MFMA at 2.4 GHz scaled to the 1.7 GHz the MFMA-dense kernels run at under load,
-5.5 TB/s for streaming kernels (what add / BN-apply / SGD reach here), 2.5 us per launch inside a hipGraph."""
+5.5 TB/s for streaming kernels (what add / BN-apply / SGD reach here), 2.5 us per launch inside a hipGraph.
+The batched small weight gradients (wgrad_multi_kernel, one launch per 24 layers) carry no per-layer geometry in the call trace: they are
+priced by the bytes they moved only (their MFMA time is a few per cent of the launch)."""
 import csv
 import glob
 import os
