@@ -143,7 +143,12 @@ typedef struct {
     int splits;     /* out */
 } semseg_wgrad_problem;
 int semseg_conv2d_wgrad_tile_h2(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
-int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host, int n, void* stream);
+/* table == NULL: up to 24 problems per launch (the table travels in the kernel arguments).  table != NULL
+ * (semseg_conv2d_wgrad_multi_table_bytes(n) bytes of device memory, 16-byte aligned, alive until the launches have run): the table is
+ * written there by one-block kernels (no host-to-device copy: capturable in a hipGraph) and ONE launch runs the blocks of all n
+ * problems, longest blocks first. */
+size_t semseg_conv2d_wgrad_multi_table_bytes(int n);
+int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host, int n, void* table, size_t table_bytes, void* stream);
 size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

@@ -582,6 +582,8 @@ DEFER_WGRAD_REDUCE = os.environ.get('SEMSEG_DEFER_WGRAD_REDUCE', '1') != '0'
 # and flush_wgrad_reduces runs the blocks of up to 24 of them side by side in one launch (semseg_conv2d_wgrad_multi_h2: the blocks
 # of the per-layer launches unchanged, bit-identical slabs).  SEMSEG_DEFER_WGRAD_LAUNCH=0 launches them where autograd reaches them.
 DEFER_WGRAD_LAUNCH = os.environ.get('SEMSEG_DEFER_WGRAD_LAUNCH', '1') != '0'
+# 1: the problem table in device memory, ONE launch for all problems -- measured no faster than 24 per launch (profiles/r5y_*): off
+WGRAD_MULTI_TABLE = os.environ.get('SEMSEG_WGRAD_MULTI_TABLE', '0') == '1'
 _DEFER = [False]
 _PENDING_SLABS = []          # (slab tensor, gradient buffer, numel, splits)
 _PENDING_WGRADS = []         # (x planes, dy planes, slab tensor, gradient buffer, geometry)
@@ -613,7 +615,12 @@ def flush_wgrad_reduces():
             if cur is not None:              # planes produced on a branch stream, read on this one
                 xs.record_stream(cur)
                 dys.record_stream(cur)
-        _native.check(_native.lib().semseg_conv2d_wgrad_multi_h2(parr, len(probs), _st()), 'conv2d_wgrad_multi_h2')
+        L = _native.lib()
+        table = None
+        if WGRAD_MULTI_TABLE:               # the problem table in device memory: ONE launch for all of them instead of one per 24
+            table = torch.empty(L.semseg_conv2d_wgrad_multi_table_bytes(len(probs)), dtype=torch.uint8, device=probs[0][2].device)
+        _native.check(L.semseg_conv2d_wgrad_multi_h2(parr, len(probs), _p(table), table.numel() if table is not None else 0, _st()),
+                      'conv2d_wgrad_multi_h2')
         for i, (xs, dys, slabs, out, geom) in enumerate(probs):
             _PENDING_SLABS.append((slabs, out, geom[4] * geom[5] * geom[6] * geom[3], int(parr[i].splits)))
     if not _PENDING_SLABS:

@@ -375,6 +375,7 @@ SWITCH_CASES = [
     ('SEMSEG_TUNE_DB=0', 'r18d_ppmds_64_train'),
     ('SEMSEG_DEFER_WGRAD_REDUCE=0', 'r50d_ppmds_64_train'),  # one reduce launch per split weight gradient instead of ONE per step             # no shipped launch plans: every geometry timed in the process
     ('SEMSEG_DEFER_WGRAD_LAUNCH=0', 'hrnetv2_c1_128_train'), # every small weight gradient its own launch instead of 24 per launch
+    ('SEMSEG_WGRAD_MULTI_TABLE=1', 'hrnetv2_c1_128_train'),  # the batched weight gradients in ONE launch (problem table in device memory) instead of 24 per launch
     ('SEMSEG_DEPTHWISE_DIRECT=0', 'mnv2d_c1ds_64_train'),
     ('SEMSEG_GROUPED_DIRECT=0', 'resnext101_upernet_128_eval'),
 ]
