@@ -557,20 +557,35 @@ def scaling_model_block(step, sm, feed, t1_ms):
     backward end and at step end; three replays, the last one's timeline scaled to the measured step feeds
     mit_semseg/scaling_model.py.  MODEL, NOT MEASURED."""
     from mit_semseg import scaling_model as smod
+    from mit_semseg import ops
     enc, dec = sm.encoder, sm.decoder
     probe = smod.TimelineProbe(list(enc.parameters()) + list(dec.parameters()))
+    # the timeline of a RANK: under gradient buckets every weight gradient is complete when autograd accumulates it (no deferral,
+    # ops.defer_wgrad_reduces), so the markers are captured -- and the step is timed -- in that form
+    defer = ops.DEFER_WGRAD_REDUCE
+    t_rank_ms = None
     try:
+        ops.DEFER_WGRAD_REDUCE = False
         step.timeline = probe
         step._graphs.clear()
         for _ in range(4):                       # capture + three replays with the markers inside the graph
             step.step(feed)
         torch.cuda.synchronize()
         ticks = probe.read()
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            step.step(feed)
+        e1.record()
+        torch.cuda.synchronize()
+        t_rank_ms = e0.elapsed_time(e1) / reps
     finally:
+        ops.DEFER_WGRAD_REDUCE = defer
         step.timeline = None
         step._graphs.clear()
         probe.detach()
-    return smod.model_line(t1_ms, ticks, probe.bucket_bytes, smod.syncbn_payloads(sm))
+    return smod.model_line(t1_ms, ticks, probe.bucket_bytes, smod.syncbn_payloads(sm), t_rank_ms=t_rank_ms)
 
 
 def main():

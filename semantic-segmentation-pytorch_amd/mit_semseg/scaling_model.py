@@ -99,9 +99,12 @@ def allreduce_ms(nbytes, n, a):
     return (a['allreduce_launch_us'] + 2 * (n - 1) * a['ring_hop_us']) * 1e-3 + 2.0 * (n - 1) / n * nbytes / bw * 1e3
 
 
-def predict(t1_ms, marks_ms, bucket_bytes, bn_channels, n, assumptions=None, syncbn='peer', segments=None):
+def predict(t1_ms, marks_ms, bucket_bytes, bn_channels, n, assumptions=None, syncbn='peer', segments=None, t_ref_ms=None):
     """marks_ms: {'fwd_end', 'bucket<i>', 'bwd_end', 'step_end'} in ms from the begin of the replayed single-GPU step, scaled so
-    that step_end == t1_ms.  Returns the predicted step of an n-rank job and its parts."""
+    that step_end == t1_ms.  Returns the predicted step of an n-rank job and its parts.  t1_ms is the compute of ONE RANK of the
+    job; t_ref_ms (default: the same) is the single-GPU step the efficiency is quoted against -- they differ when the single-GPU
+    step uses something a rank cannot (the deferred weight gradients of engine.TrainStep: gradient buckets read every gradient as soon
+    as autograd has accumulated it)."""
     a = dict(ASSUMPTIONS)
     a.update(assumptions or {})
     free, busy = 0.0, 0.0
@@ -128,14 +131,19 @@ def predict(t1_ms, marks_ms, bucket_bytes, bn_channels, n, assumptions=None, syn
     # profiles/r3c_segmented_probe.txt): reported, not on the critical path
     step = t1_ms + exposed + slowdown + sync
     return {'n': n, 'ms_per_step': round(step, 3), 'img_s': round(2.0 * n / step * 1e3, 1),
-            'efficiency_vs_1gpu': round(t1_ms / step, 4),
+            'efficiency_vs_1gpu': round((t_ref_ms if t_ref_ms is not None else t1_ms) / step, 4),
             'exposed_allreduce_ms': round(exposed, 3), 'overlap_slowdown_ms': round(slowdown, 3), 'syncbn_ms': round(sync, 3),
             'allreduce_busy_ms': round(busy, 3), 'syncbn_transport': syncbn, 'segments': nseg,
             'host_segment_launch_ms': round(nseg * a['segment_launch_us'] * 1e-3, 3)}
 
 
-def model_line(t1_ms, ticks, bucket_bytes, bn_channels, assumptions=None):
-    """ticks: TimelineProbe.read() of one replay; scaled with t1_ms (the measured step) -> the block bench.py prints"""
+def model_line(t1_ms, ticks, bucket_bytes, bn_channels, assumptions=None, t_rank_ms=None):
+    """ticks: TimelineProbe.read() of one replay; scaled with the measured step -> the block bench.py prints.  t_rank_ms: the measured
+    step in the form a rank of an N > 1 job runs it (the timeline's form: every weight gradient complete when autograd accumulates it);
+    default t1_ms.  Predictions are built on t_rank_ms, efficiencies quoted against t1_ms."""
+    t_ref = t1_ms
+    if t_rank_ms is not None:
+        t1_ms = t_rank_ms
     t0, t_end = ticks['step_begin'], ticks['step_end']
     span = max(1, t_end - t0)
     marks = {k: (v - t0) / span * t1_ms for k, v in ticks.items()}
@@ -143,13 +151,16 @@ def model_line(t1_ms, ticks, bucket_bytes, bn_channels, assumptions=None):
     a.update(assumptions or {})
     out = {'kind': 'MODEL, not measured (no multi-GPU box was available to this run): single-GPU replay timeline + ring '
                    'all-reduce over one xGMI link per hop + per-exchange SyncBN cost; mit_semseg/scaling_model.py',
-           'measured_1gpu_ms_per_step': round(t1_ms, 3),
+           'measured_1gpu_ms_per_step': round(t_ref, 3),
+           'measured_rank_form_ms_per_step': round(t1_ms, 3),
+           'rank_form': 'the same step with every weight gradient launched and reduced where autograd reaches it (what a rank under '
+                        'gradient buckets runs; the single-GPU step batches them after backward), timed on this GPU',
            'timeline_ms': {k: round(v, 3) for k, v in marks.items()},
            'bucket_bytes': list(bucket_bytes), 'gradient_bytes': int(sum(bucket_bytes)),
            'syncbn_exchanges_per_step': 2 * len(bn_channels),
            'syncbn_payload_doubles': {'fwd': int(sum(2 * c + 1 for c in bn_channels)), 'bwd': int(sum(2 * c for c in bn_channels))},
            'assumptions': a, 'predicted': {}}
     for n in (2, 4, 8):
-        out['predicted'][str(n)] = {'peer_exchange': predict(t1_ms, marks, bucket_bytes, bn_channels, n, a, 'peer'),
-                                    'rccl_syncbn': predict(t1_ms, marks, bucket_bytes, bn_channels, n, a, 'rccl')}
+        out['predicted'][str(n)] = {'peer_exchange': predict(t1_ms, marks, bucket_bytes, bn_channels, n, a, 'peer', t_ref_ms=t_ref),
+                                    'rccl_syncbn': predict(t1_ms, marks, bucket_bytes, bn_channels, n, a, 'rccl', t_ref_ms=t_ref)}
     return out

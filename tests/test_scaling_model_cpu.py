@@ -64,3 +64,20 @@ def test_model_line_scales_ticks_to_the_measured_step():
     assert 'MODEL' in line['kind']
     e = [line['predicted'][n]['peer_exchange']['efficiency_vs_1gpu'] for n in ('2', '4', '8')]
     assert e[0] >= e[1] >= e[2]
+
+
+def test_model_line_builds_on_the_rank_form_of_the_step():
+    """the single-GPU step batches its weight gradients after backward; a rank under gradient buckets cannot (its hooks read every
+    gradient when autograd accumulates it): predictions are built on the step timed in the rank's form, efficiencies are quoted
+    against the single-GPU step"""
+    ticks = {'step_begin': 1000, 'fwd_end': 1500, 'bucket0': 1800, 'bucket1': 1990, 'bwd_end': 2000, 'step_end': 2100}
+    base = smod.model_line(11.0, ticks, [10 << 20, 1 << 20], [64, 128, 256])
+    line = smod.model_line(11.0, ticks, [10 << 20, 1 << 20], [64, 128, 256], t_rank_ms=11.5)
+    assert line['measured_1gpu_ms_per_step'] == 11.0 and line['measured_rank_form_ms_per_step'] == 11.5
+    assert abs(line['timeline_ms']['step_end'] - 11.5) < 1e-9
+    for n in ('2', '4', '8'):
+        p, q = line['predicted'][n]['peer_exchange'], base['predicted'][n]['peer_exchange']
+        assert p['ms_per_step'] > q['ms_per_step'] + 0.45            # the rank's compute is 0.5 ms longer
+        assert abs(p['efficiency_vs_1gpu'] - 11.0 / p['ms_per_step']) < 1e-3
+        assert p['efficiency_vs_1gpu'] < q['efficiency_vs_1gpu']
+    assert base['measured_rank_form_ms_per_step'] == 11.0
