@@ -579,7 +579,7 @@ class Conv2dSplitFn(Function):
 # autograd callers (a second backward would accumulate into an unreduced gradient).  SEMSEG_DEFER_WGRAD_REDUCE=0 disables.
 DEFER_WGRAD_REDUCE = os.environ.get('SEMSEG_DEFER_WGRAD_REDUCE', '1') != '0'
 # ... and the small weight gradients themselves wait too: a geometry whose launch plan is the register-staged 64 x 64 tile (2 - 60
-# blocks on 256 CUs; 241 such launches per HRNetV2 step, 30 on configs[1]) keeps its operand planes alive until backward has returned,
+# blocks on 256 CUs; 233 such launches per HRNetV2 step, 32 on configs[1]) keeps its operand planes alive until backward has returned,
 # and flush_wgrad_reduces runs the blocks of up to 24 of them side by side in one launch (semseg_conv2d_wgrad_multi_h2: the blocks
 # of the per-layer launches unchanged, bit-identical slabs).  SEMSEG_DEFER_WGRAD_LAUNCH=0 launches them where autograd reaches them.
 DEFER_WGRAD_LAUNCH = os.environ.get('SEMSEG_DEFER_WGRAD_LAUNCH', '1') != '0'
