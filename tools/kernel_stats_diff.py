@@ -13,7 +13,7 @@ def family(name):
     name = re.sub(r'\(.*', '', name).replace('void ', '').strip()
     for key, fam in (('igemm_dma', 'GEMM fwd/dgrad (LDS-DMA)'), ('igemm_rs', 'GEMM fwd/dgrad (register staged)'),
                      ('wino_fused', 'Winograd fused dgrad'), ('wgrad_dma', 'weight gradient (LDS-DMA)'), ('wgrad_taps', 'weight gradient (all taps)'),
-                     ('wgrad_kernel', 'weight gradient (register staged)'), ('split_wgrad_reduce', 'split reduces'),
+                     ('wgrad_kernel', 'weight gradient (register staged)'), ('wgrad_multi', 'weight gradient (register staged)'), ('split_wgrad_reduce', 'split reduces'),
                      ('split_gemm_reduce', 'split reduces'), ('bn_apply', 'BN apply fwd'), ('bn_bwd_apply', 'BN apply bwd'),
                      ('bn_bwd_mm_partial', 'BN partial sums bwd'), ('bn_stats_mm_partial', 'BN statistics sweep'),
                      ('finish_fused', 'BN finish kernels'), ('wino_', 'Winograd transforms'), ('wprep', 'weight preparation'),
