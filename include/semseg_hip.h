@@ -133,7 +133,7 @@ int semseg_conv2d_wgrad_slabs_h2(const void* xs, const void* dys, float* slabs, 
                                  int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream);
 int semseg_reduce_slabs_multi(const semseg_slab_tensor* tensors_host, int n, void* stream);
 /* MANY weight gradients as slabs in ONE launch (round 4): the weight gradients are read by the optimizer only, so the host may hold
- * the small ones of a backward pass back and run their blocks side by side instead of one launch of 2 - 60 blocks each (HRNetV2: 241 such
+ * the small ones of a backward pass back and run their blocks side by side, 24 problems per launch and the longest blocks first, instead of one launch of 2 - 60 blocks each (HRNetV2: 241 such
  * launches).  Problem i leaves problems[i].splits partial sums in problems[i].slabs exactly as semseg_conv2d_wgrad_slabs_h2 would
  * (same launch plan, same blocks, same summation order: same bits).  Only geometries whose launch plan is the register-staged 64 x 64
  * tile -- semseg_conv2d_wgrad_tile_h2(geometry) == 1 -- can be batched; any other -> SEMSEG_EINVAL before anything is launched. */
@@ -143,12 +143,7 @@ typedef struct {
     int splits;     /* out */
 } semseg_wgrad_problem;
 int semseg_conv2d_wgrad_tile_h2(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
-/* table == NULL: up to 24 problems per launch (the table travels in the kernel arguments).  table != NULL
- * (semseg_conv2d_wgrad_multi_table_bytes(n) bytes of device memory, 16-byte aligned, alive until the launches have run): the table is
- * written there by one-block kernels (no host-to-device copy: capturable in a hipGraph) and ONE launch runs the blocks of all n
- * problems, longest blocks first. */
-size_t semseg_conv2d_wgrad_multi_table_bytes(int n);
-int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host, int n, void* table, size_t table_bytes, void* stream);
+int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host, int n, void* stream);
 size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

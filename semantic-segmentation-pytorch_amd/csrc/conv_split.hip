@@ -2656,31 +2656,6 @@ __global__ __launch_bounds__(256) void wgrad_multi_kernel(const WMultiParams mp)
     wgrad_block_body<SCH, BM, BN>(p, b - mp.first[j], p.splits);
 }
 
-// ... and of ANY number of problems: the table lives in device memory (the caller's `table`: n WParams, then n + 1 block offsets),
-// written by wgrad_table_write_kernel from kernel arguments, 24 problems per (one-block) launch -- no host-to-device copy, so the
-// sequence can be captured in a hipGraph -- and ONE launch runs all blocks; a block finds its problem by bisection.
-template <class SCH, int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad_multi_table_kernel(const WParams* __restrict__ table, const int* __restrict__ first,
-                                                                int n) {
-    const int b = blockIdx.x;
-    int lo = 0, hi = n - 1;                                   // largest j with first[j] <= b
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (first[mid] <= b) lo = mid; else hi = mid - 1;
-    }
-    const WParams p = table[lo];
-    wgrad_block_body<SCH, BM, BN>(p, b - first[lo], p.splits);
-}
-__global__ __launch_bounds__(64) void wgrad_table_write_kernel(const WMultiParams mp, WParams* __restrict__ table,
-                                                               int* __restrict__ first, int base) {
-    constexpr int WORDS = (int)(sizeof(WParams) / 4);
-    static_assert(sizeof(WParams) % 4 == 0, "WParams words");
-    const int* src = reinterpret_cast<const int*>(&mp.p[0]);
-    int* dst = reinterpret_cast<int*>(table + base);
-    for (int i = threadIdx.x; i < mp.n * WORDS; i += 64) dst[i] = src[i];
-    for (int i = threadIdx.x; i <= mp.n; i += 64) first[base + i] = mp.first[i];     // first[] here: offsets in the WHOLE grid
-}
-
 // ------------------------------------------------------------------------------------------------
 // Weight gradient of a 3x3, stride-1, pad == dil convolution with ALL NINE TAPS in one block (wtile 10).
 // wgrad_kernel gives every tap its own block, so the nine blocks of a pixel chunk each read the chunk's dy rows and (shifted) x
@@ -3419,13 +3394,8 @@ extern "C" int semseg_conv2d_wgrad_tile_h2(int N, int H, int W, int C, int K, in
     lookup_plan(SchH2::ID, 2, N, H, W, C, K, R, S, stride, pad, dil, &t2, &s2);
     return plan_wgrad(N * OH * OW, K, C, R * S, t2, s2).tile;
 }
-extern "C" size_t semseg_conv2d_wgrad_multi_table_bytes(int n) {
-    return n > 0 ? (size_t)n * sizeof(WParams) + ((size_t)n + 1) * sizeof(int) + 16 : 0;
-}
-extern "C" int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host, int n, void* table, size_t table_bytes,
-                                            void* stream) {
+extern "C" int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host, int n, void* stream) {
     if (n < 0 || (n > 0 && !problems_host)) return SEMSEG_EINVAL;
-    if (table && (table_bytes < semseg_conv2d_wgrad_multi_table_bytes(n) || !aligned16(table))) return SEMSEG_EWORKSPACE;
     if (n == 0) return 0;
     std::vector<WParams> ps((size_t)n);
     for (int i = 0; i < n; ++i) {
@@ -3441,26 +3411,19 @@ extern "C" int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host,
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)wgrad_multi_kernel<SchH2, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)smem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)wgrad_multi_table_kernel<SchH2, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     // longest blocks first: a block's run time is its pixel range (m_per_split rows through a 64 x 64 tile), and the hardware starts
-    // the blocks of a launch in order -- in the order of the backward pass the stem's long blocks would start last and be the tail
+    // the blocks of a launch in order -- in the order of the backward pass the stem's long blocks would start last and be the tail.
+    // (ONE launch for all problems, the table in device memory, was measured no faster than 24 per launch: DESIGN, item 11.)
     std::vector<int> order((size_t)n);
     for (int i = 0; i < n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ps[a].m_per_split > ps[b].m_per_split; });
-    hipStream_t st = (hipStream_t)stream;
-    WParams* d_table = (WParams*)table;
-    int* d_first = table ? (int*)((char*)table + (size_t)n * sizeof(WParams)) : nullptr;
-    static_assert(sizeof(WParams) % 16 == 0, "the offsets behind the table stay 4-byte aligned");
-    long grid_total = 0;
     for (int base = 0; base < n; base += kWMulti) {
         WMultiParams mp = {};
         mp.n = n - base < kWMulti ? n - base : kWMulti;
-        long blocks = table ? grid_total : 0;           // table form: offsets in the one grid of all problems
+        long blocks = 0;
         for (int i = 0; i < mp.n; ++i) {
             mp.p[i] = ps[order[base + i]];
             mp.first[i] = (int)blocks;
@@ -3468,17 +3431,7 @@ extern "C" int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host,
         }
         if (blocks >= ((long)1 << 31)) return SEMSEG_EINVAL;
         mp.first[mp.n] = (int)blocks;
-        if (table) {
-            hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, st, mp, d_table, d_first, base);
-            grid_total = blocks;
-        } else {
-            hipLaunchKernelGGL((wgrad_multi_kernel<SchH2, 64, 64>), dim3((unsigned)blocks), dim3(256), smem, st, mp);
-        }
-        SEMSEG_LAUNCH_CHECK();
-    }
-    if (table) {
-        hipLaunchKernelGGL((wgrad_multi_table_kernel<SchH2, 64, 64>), dim3((unsigned)grid_total), dim3(256), smem, st,
-                           (const WParams*)d_table, (const int*)d_first, n);
+        hipLaunchKernelGGL((wgrad_multi_kernel<SchH2, 64, 64>), dim3((unsigned)blocks), dim3(256), smem, (hipStream_t)stream, mp);
         SEMSEG_LAUNCH_CHECK();
     }
     return 0;

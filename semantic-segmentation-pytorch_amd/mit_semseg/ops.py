@@ -9,7 +9,6 @@ train.py:41) is converted once by the nchw_to_nhwc kernel.
 
 There is no CPU / eager fallback: non-CUDA tensors raise.
 """
-import contextlib
 import ctypes
 import os
 
@@ -583,15 +582,6 @@ DEFER_WGRAD_REDUCE = os.environ.get('SEMSEG_DEFER_WGRAD_REDUCE', '1') != '0'
 # and flush_wgrad_reduces runs the blocks of up to 24 of them side by side in one launch (semseg_conv2d_wgrad_multi_h2: the blocks
 # of the per-layer launches unchanged, bit-identical slabs).  SEMSEG_DEFER_WGRAD_LAUNCH=0 launches them where autograd reaches them.
 DEFER_WGRAD_LAUNCH = os.environ.get('SEMSEG_DEFER_WGRAD_LAUNCH', '1') != '0'
-# 1: the problem table in device memory, ONE launch for all problems -- measured no faster than 24 per launch (profiles/r5y_*): off
-WGRAD_MULTI_TABLE = os.environ.get('SEMSEG_WGRAD_MULTI_TABLE', '0') == '1'
-# ... and the LARGE ones (every other launch plan) may run beside the chain that needs the stream: inside the deferral their slab
-# launches go to ONE side stream per device that waits for the operands (an event on the producing stream) and that the flush joins
-# before it sums the slabs -- the weight-gradient GEMMs fill the CUs that the chain's BN finish / apply launches leave idle.  Same
-# kernels, same plans, same slabs: bit-identical.  SEMSEG_WGRAD_SIDE_STREAM=1 enables (measured: DESIGN item 12).
-WGRAD_SIDE_STREAM = os.environ.get('SEMSEG_WGRAD_SIDE_STREAM', '0') == '1'
-_SIDE_STREAMS = {}           # device index -> the side stream
-_SIDE_USED = []              # side streams with work since the last flush
 _DEFER = [False]
 _PENDING_SLABS = []          # (slab tensor, gradient buffer, numel, splits)
 _PENDING_WGRADS = []         # (x planes, dy planes, slab tensor, gradient buffer, geometry)
@@ -612,10 +602,6 @@ class defer_wgrad_reduces:
 def flush_wgrad_reduces():
     """sum the slabs of every weight gradient deferred since the last flush, one launch per 64 tensors (on the current stream: after
     backward() has returned autograd has made it wait for the streams the gradients were produced on)"""
-    if _SIDE_USED:                           # the weight gradients on the side stream: their slabs are read below
-        used, _SIDE_USED[:] = list(_SIDE_USED), []
-        for side in used:
-            torch.cuda.current_stream(side.device).wait_stream(side)
     if _PENDING_WGRADS:
         probs, _PENDING_WGRADS[:] = list(_PENDING_WGRADS), []
         parr = (_native.WgradProblem * len(probs))()
@@ -627,12 +613,7 @@ def flush_wgrad_reduces():
             if cur is not None:              # planes produced on a branch stream, read on this one
                 xs.record_stream(cur)
                 dys.record_stream(cur)
-        L = _native.lib()
-        table = None
-        if WGRAD_MULTI_TABLE:               # the problem table in device memory: ONE launch for all of them instead of one per 24
-            table = torch.empty(L.semseg_conv2d_wgrad_multi_table_bytes(len(probs)), dtype=torch.uint8, device=probs[0][2].device)
-        _native.check(L.semseg_conv2d_wgrad_multi_h2(parr, len(probs), _p(table), table.numel() if table is not None else 0, _st()),
-                      'conv2d_wgrad_multi_h2')
+        _native.check(_native.lib().semseg_conv2d_wgrad_multi_h2(parr, len(probs), _st()), 'conv2d_wgrad_multi_h2')
         for i, (xs, dys, slabs, out, geom) in enumerate(probs):
             _PENDING_SLABS.append((slabs, out, geom[4] * geom[5] * geom[6] * geom[3], int(parr[i].splits)))
     if not _PENDING_SLABS:
@@ -646,13 +627,6 @@ def flush_wgrad_reduces():
             slabs.record_stream(cur)
             out.record_stream(cur)
     _native.check(_native.lib().semseg_reduce_slabs_multi(arr, len(items), _st()), 'reduce_slabs_multi')
-
-
-def _side_stream(dev):
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx not in _SIDE_STREAMS:
-        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
-    return _SIDE_STREAMS[idx]
 
 
 def _is_leaf_weight(weight):
@@ -683,16 +657,8 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, m
                 _PENDING_WGRADS.append((xs, dys, slabs, dwb, tuple(geom)))
             else:
                 splits = ctypes.c_int(0)
-                side = _side_stream(dev) if (WGRAD_SIDE_STREAM and xs.is_cuda) else None
-                if side is not None:
-                    side.wait_stream(torch.cuda.current_stream(dev))       # the planes of dy (and of x) are complete there
-                    for t in (xs, dys, slabs):
-                        t.record_stream(side)
-                    if side not in _SIDE_USED:
-                        _SIDE_USED.append(side)
-                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                    _native.check(L.semseg_conv2d_wgrad_slabs_h2(_p(xs), _p(dys), _p(slabs), slabs.numel() * 4, ctypes.byref(splits),
-                                                                 *geom, _st()), 'conv2d_wgrad_slabs_h2')
+                _native.check(L.semseg_conv2d_wgrad_slabs_h2(_p(xs), _p(dys), _p(slabs), slabs.numel() * 4, ctypes.byref(splits),
+                                                             *geom, _st()), 'conv2d_wgrad_slabs_h2')
                 _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value)))
         else:
             launch_w()

@@ -284,17 +284,16 @@ def test_deferred_wgrad_reduce_is_bit_identical(monkeypatch):
         return real()
     monkeypatch.setattr(ops, 'flush_wgrad_reduces', counting)
     states = []
-    for defer, launch, side in ((True, True, False), (True, False, False), (False, False, False), (True, True, True), (True, False, True)):
+    for defer, launch in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(ops, 'DEFER_WGRAD_REDUCE', defer)
         monkeypatch.setattr(ops, 'DEFER_WGRAD_LAUNCH', launch)
-        monkeypatch.setattr(ops, 'WGRAD_SIDE_STREAM', side)     # the large weight gradients on the side stream, joined by the flush
         sm, _, _ = build_native(g, dev)
         ts = TrainStep(sm, lr_encoder=m['lr'], lr_decoder=m['lr'], max_iters=10 ** 9)
         del batched[:]
         for _ in range(2):
             loss, _ = ts.step(feed)
         torch.cuda.synchronize()
-        assert not ops._PENDING_SLABS and not ops._PENDING_WGRADS and not ops._SIDE_USED
+        assert not ops._PENDING_SLABS and not ops._PENDING_WGRADS
         assert (max(batched) >= 8) == (defer and launch), batched      # the path under test ran (r18: more than 8 small layers)
         states.append(({k: v.clone() for k, v in sm.state_dict().items()}, loss.clone()))
     for (b, lb) in states[1:]:
@@ -376,15 +375,12 @@ SWITCH_CASES = [
     ('SEMSEG_TUNE_DB=0', 'r18d_ppmds_64_train'),
     ('SEMSEG_DEFER_WGRAD_REDUCE=0', 'r50d_ppmds_64_train'),  # one reduce launch per split weight gradient instead of ONE per step             # no shipped launch plans: every geometry timed in the process
     ('SEMSEG_DEFER_WGRAD_LAUNCH=0', 'hrnetv2_c1_128_train'), # every small weight gradient its own launch instead of 24 per launch
-    ('SEMSEG_WGRAD_SIDE_STREAM=1', 'r50d_ppmds_64_train'),    # the large weight gradients on a side stream beside the data-gradient chain
-    ('SEMSEG_WGRAD_SIDE_STREAM=1', 'hrnetv2_c1_128_train'),   # ... under HRNetV2's branch streams
-    ('SEMSEG_WGRAD_MULTI_TABLE=1', 'hrnetv2_c1_128_train'),  # the batched weight gradients in ONE launch (problem table in device memory) instead of 24 per launch
     ('SEMSEG_DEPTHWISE_DIRECT=0', 'mnv2d_c1ds_64_train'),
     ('SEMSEG_GROUPED_DIRECT=0', 'resnext101_upernet_128_eval'),
 ]
 
 
-@pytest.mark.parametrize('switch,case', SWITCH_CASES, ids=[s if [x for x, _ in SWITCH_CASES].count(s) == 1 else s + '-' + c for s, c in SWITCH_CASES])
+@pytest.mark.parametrize('switch,case', SWITCH_CASES, ids=[s for s, _ in SWITCH_CASES])
 def test_env_switch_keeps_model_parity(switch, case):
     """the golden tests of `case` (forward bounds, post-step state and, where stored, every gradient against the float64
     anchors) in a child process with `switch` set"""

@@ -850,12 +850,11 @@ WGRAD_MULTI_GEOMS = [(2, 16, 16, 64, 64, 3, 1, 1, 1, 1), (2, 16, 16, 64, 64, 3, 
                      (1, 8, 8, 256, 19, 1, 1, 0, 1, 1), (1, 40, 40, 24, 24, 3, 1, 1, 1, 5)]
 
 
-@pytest.mark.parametrize('table', [False, True], ids=['args', 'table'])
 @pytest.mark.parametrize('count', [1, 5, 24, 25, 53])
-def test_h2_wgrad_many_problems_in_one_launch(count, table):
-    """semseg_conv2d_wgrad_multi_h2: the blocks of many weight gradients side by side in one launch (24 per launch with the table
-    in the kernel arguments, all of them with the table in device memory) leave, problem by problem, the SAME slabs (bit for bit) as
-    semseg_conv2d_wgrad_slabs_h2 launched per problem -- across the 24-problem boundary of either form too;
+def test_h2_wgrad_many_problems_in_one_launch(count):
+    """semseg_conv2d_wgrad_multi_h2: the blocks of up to 24 weight gradients side by side in one launch (packed longest first) leave,
+    problem by problem, the SAME slabs (bit for bit) as semseg_conv2d_wgrad_slabs_h2 launched per problem -- across the 24-problem
+    launch boundary too;
     a geometry whose plan is not the 64 x 64 register-staged tile is refused before anything runs."""
     import ctypes
     from mit_semseg import ops, _native
@@ -888,10 +887,7 @@ def test_h2_wgrad_many_problems_in_one_launch(count, table):
         for q, (geom, xs, dys, want, got, _) in zip(arr, probs):
             q.xs, q.dys, q.slabs, q.slabs_bytes = xs.data_ptr(), dys.data_ptr(), got.data_ptr(), got.numel() * 4
             q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil = geom
-        # the problem table in the kernel arguments (24 problems per launch) or in device memory (one launch for all)
-        tws = torch.empty(L.semseg_conv2d_wgrad_multi_table_bytes(count), dtype=torch.uint8, device=dev()) if table else None
-        targs = (vp(tws.data_ptr()), tws.numel()) if table else (vp(0), 0)
-        _native.check(L.semseg_conv2d_wgrad_multi_h2(arr, count, *targs, st), 'multi')
+        _native.check(L.semseg_conv2d_wgrad_multi_h2(arr, count, st), 'multi')
         torch.cuda.synchronize()
         for i, (geom, xs, dys, want, got, splits) in enumerate(probs):
             assert arr[i].splits == splits, (i, geom)
@@ -901,7 +897,7 @@ def test_h2_wgrad_many_problems_in_one_launch(count, table):
         geom = probs[0][0]
         _native.check(L.semseg_conv2d_h2_set_plan(2, *geom, 0, 1), 'set_plan')
         probs[0][4].fill_(7.0)
-        assert L.semseg_conv2d_wgrad_multi_h2(arr, count, *targs, st) != 0
+        assert L.semseg_conv2d_wgrad_multi_h2(arr, count, st) != 0
         torch.cuda.synchronize()
         assert bool((probs[0][4] == 7.0).all())
     finally:
