@@ -37,9 +37,9 @@ def _depfile_deps(depfile):
 
 
 def _stale(src, obj):
-    """an object is rebuilt when its source, any header the compiler saw last time (the depfile next to it), or this build
-    script's flags changed; system headers are part of the depfile too (-MD would add them; -MMD keeps the user headers)"""
-    if _newer(src, obj):
+    """an object is rebuilt when its source, any user header the compiler saw last time (the -MMD depfile next to it) or
+    this build script itself (its flags live here) is newer than the object"""
+    if _newer(src, obj) or _newer(os.path.abspath(__file__), obj):
         return True
     deps = _depfile_deps(obj + '.d')
     if deps is None:

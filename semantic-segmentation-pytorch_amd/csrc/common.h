@@ -13,6 +13,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (e__ != hipSuccess) return (int)e__;     \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): one cache per launch site, one entry per device,
+// so a process that drives several devices (the in-process peer tests) sets it on each of them before its first > 64 KiB launch.
+struct SmemAttrCache {
+    size_t set[32] = {};
+};
+static inline int ensure_smem_attr(SmemAttrCache& c, const void* kernel, size_t smem) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = -1;
+    if (dev >= 0 && c.set[dev] >= smem) return 0;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0) c.set[dev] = smem;
+    return 0;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t ceil_div_sz(size_t a, size_t b) { return (a + b - 1) / b; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

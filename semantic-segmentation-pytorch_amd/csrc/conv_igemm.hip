@@ -360,13 +360,8 @@ static IGemmPlan plan_igemm(int M, int Cout, int Cin, int T, bool vec) {
 template <int BM, int BN, int BK, bool VEC>
 static int launch_igemm(const IGemmParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_conv_kernel<BM, BN, BK, VEC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_conv_kernel<BM, BN, BK, VEC>, smem)) return e;
     dim3 grid(p.tiles_m * p.tiles_n, p.splits);
     hipLaunchKernelGGL((igemm_conv_kernel<BM, BN, BK, VEC>), grid, dim3(256), smem, st, p);
     SEMSEG_LAUNCH_CHECK();

@@ -1379,13 +1379,8 @@ template <class SCH, int BM, int BN, int WGM, int WGN>
 static int launch_dma64(const SParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)5 * SCH::NP * BM * 128;
     static_assert(smem <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_dma64_kernel<SCH, BM, BN, WGM, WGN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_dma64_kernel<SCH, BM, BN, WGM, WGN>, smem)) return e;
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
     hipLaunchKernelGGL((igemm_dma64_kernel<SCH, BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
@@ -1506,13 +1501,8 @@ static SPlan plan_gemm(int sch, int M, int Cout, int Cp, int T, int ov_tile = -1
 template <class SCH, int BM, int BN>
 static int launch_rs(const SParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)SCH::NP * (BM + BN) * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_rs_kernel<SCH, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_rs_kernel<SCH, BM, BN>, smem)) return e;
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
     hipLaunchKernelGGL((igemm_rs_kernel<SCH, BM, BN>), grid, dim3(256), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
@@ -1523,13 +1513,8 @@ template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 static int launch_dma(const SParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)(NSLOT >= 12 ? NSLOT - 10 : NSLOT) * SCH::NP * (BM + BN) * 64;
     static_assert(smem <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>, smem)) return e;
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
     hipLaunchKernelGGL((igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(64 * WGM * WGN), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
@@ -2294,12 +2279,8 @@ template <int WGM, int WGN>
 static int launch_wino_fused64(const WFParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)5 * 2 * 128 * 128;
     if (p.chunks & 1) return SEMSEG_EINVAL;                  // the reduction must be whole 64-channel tiles
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino_fused64_kernel<WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)wino_fused64_kernel<WGM, WGN>, smem)) return e;
     hipLaunchKernelGGL((wino_fused64_kernel<WGM, WGN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -2309,13 +2290,8 @@ template <int BM, int BN, int WGM, int WGN, int NSLOT, int PROBE = 0>
 static int launch_wino_fused(const WFParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)NSLOT * 2 * (BM + BN) * 64;
     static_assert(smem <= 160 * 1024 && smem >= (size_t)BM * 16, "LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino_fused_kernel<BM, BN, WGM, WGN, NSLOT, PROBE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)wino_fused_kernel<BM, BN, WGM, WGN, NSLOT, PROBE>, smem)) return e;
     hipLaunchKernelGGL((wino_fused_kernel<BM, BN, WGM, WGN, NSLOT, PROBE>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -3159,13 +3135,8 @@ static size_t wgrad_split_workspace_bytes(int M, int K, int C, int T, int ov_til
 template <class SCH, int BT>
 static int launch_wgrad(const WParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)2 * WTile<SCH::NP, BT>::BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<SCH, BT, BT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)wgrad_kernel<SCH, BT, BT>, smem)) return e;
     dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits);
     hipLaunchKernelGGL((wgrad_kernel<SCH, BT, BT>), grid, dim3(256), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
@@ -3180,13 +3151,8 @@ static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
     if ((size_t)2 * SCH::NP * p.x_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
         (size_t)2 * SCH::NP * p.dy_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31))
         return SEMSEG_EINVAL;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)wgrad_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>, smem)) return e;
     dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits, p.batches > 0 ? p.batches : 1);
     hipLaunchKernelGGL((wgrad_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(WGM * WGN * 64), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
@@ -3278,13 +3244,8 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
         case kWTileTaps: {
             if (!wtaps_eligible(R, S, stride, pad, dil, OW, p.M)) return SEMSEG_EINVAL;
             const size_t smem = wtaps_smem(SCH::NP, dil);
-            static size_t attr_smem = 0;
-            if (smem > attr_smem) {
-                hipError_t e = hipFuncSetAttribute((const void*)wgrad_taps_kernel<SCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)smem);
-                if (e != hipSuccess) return (int)e;
-                attr_smem = smem;
-            }
+            static SmemAttrCache attr_cache;
+            if (int e = ensure_smem_attr(attr_cache, (const void*)wgrad_taps_kernel<SCH>, smem)) return e;
             hipLaunchKernelGGL((wgrad_taps_kernel<SCH>), dim3(p.tiles_k * p.tiles_c, p.splits), dim3(256), smem, st, p);
             SEMSEG_LAUNCH_CHECK();
             rc = 0;
@@ -3407,13 +3368,8 @@ extern "C" int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host,
         if (pl.tile != 1) return SEMSEG_EINVAL;
     }
     constexpr size_t smem = (size_t)2 * WTile<SchH2::NP, 64>::BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_multi_kernel<SchH2, 64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)wgrad_multi_kernel<SchH2, 64, 64>, smem)) return e;
     // longest blocks first: a block's run time is its pixel range (m_per_split rows through a 64 x 64 tile), and the hardware starts
     // the blocks of a launch in order -- in the order of the backward pass the stem's long blocks would start last and be the tail.
     // (ONE launch for all problems, the table in device memory, was measured no faster than 24 per launch: DESIGN, item 11.)

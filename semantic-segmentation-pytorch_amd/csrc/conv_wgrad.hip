@@ -270,13 +270,8 @@ template <int BM, int BN, bool VEC>
 static int launch_wgrad(const WgradParams& p, hipStream_t st) {
     constexpr int BKP = 32;
     constexpr size_t smem = (size_t)2 * BKP * (BM + 4 + BN + 4) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<BM, BN, BKP, VEC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static SmemAttrCache attr_cache;
+    if (int e = ensure_smem_attr(attr_cache, (const void*)wgrad_kernel<BM, BN, BKP, VEC>, smem)) return e;
     dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits);
     hipLaunchKernelGGL((wgrad_kernel<BM, BN, BKP, VEC>), grid, dim3(256), smem, st, p);
     SEMSEG_LAUNCH_CHECK();

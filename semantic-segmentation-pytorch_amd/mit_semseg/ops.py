@@ -192,14 +192,25 @@ def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
     return torch.empty((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
 
 
+def _refuse_planes_only(x):
+    if getattr(x, '_semseg_planes_only', False):
+        raise RuntimeError('this BN output was written as h2 planes only (conv_bn_act(..., planes_only=True)): its fp32 values do '
+                           'not exist; its one consumer must be a convolution of the h2 path')
+
+
+def as_nhwc_of(x):
+    """as_nhwc of the detached tensor.  The planes-only mark is a Python attribute of the tensor OBJECT and detach() makes a
+    new object, so it is read here, before the detach (every Function.forward takes its fp32 operands through this)."""
+    _refuse_planes_only(x)
+    return as_nhwc(x.detach())
+
+
 def as_nhwc(x):
     """Returns (tensor, ld): `tensor` is logical NCHW over NHWC memory."""
     _require_cuda(x)
     if x.dtype != torch.float32:
         raise RuntimeError('native hot path computes in fp32, got %s' % x.dtype)
-    if getattr(x, '_semseg_planes_only', False):
-        raise RuntimeError('this BN output was written as h2 planes only (conv_bn_act(..., planes_only=True)): its fp32 values do '
-                           'not exist; its one consumer must be a convolution of the h2 path')
+    _refuse_planes_only(x)
     ld = nhwc_ld(x)
     if ld is not None:
         return x, ld
@@ -269,7 +280,7 @@ class Conv2dFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil):
         L = _native.lib()
-        x, x_ld = as_nhwc(x.detach())
+        x, x_ld = as_nhwc_of(x)
         w = krsc(weight.detach())
         _require_cuda(w, bias)
         n, c, h, wd = x.shape
@@ -345,7 +356,7 @@ def input_planes(x, scheme):
     n, c, h, w = x.shape
     xp = planes_of(x, scheme, n * h * w, c)
     if xp is None:
-        xn, ld = as_nhwc(x.detach())
+        xn, ld = as_nhwc_of(x)
         bounds = bounds_of(x) if scheme == 'h2' else None
         if bounds is not None and len(bounds) <= 8:
             # an upper bound of max|x| travels with the tensor (BN outputs, pooling / concat / sums of them): the exponent comes
@@ -544,7 +555,7 @@ class Conv2dSplitFn(Function):
         ctx.geom = geom
         ctx.has_bias = bias is not None
         ctx.scheme = scheme
-        ctx.w_leaf = _is_leaf_weight(weight)
+        ctx.w_param = _note_weight_use(weight)
         return y
 
     @staticmethod
@@ -561,7 +572,7 @@ class Conv2dSplitFn(Function):
         dy, dy_ld = as_nhwc(dy)
         dys = sch.split(dy, n * oh * ow, k, dy_ld)
         dx, dw = _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                   may_defer=ctx.w_leaf)
+                                   param=ctx.w_param)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty((k,), device=dev, dtype=torch.float32)
@@ -583,8 +594,27 @@ DEFER_WGRAD_REDUCE = os.environ.get('SEMSEG_DEFER_WGRAD_REDUCE', '1') != '0'
 # of the per-layer launches unchanged, bit-identical slabs).  SEMSEG_DEFER_WGRAD_LAUNCH=0 launches them where autograd reaches them.
 DEFER_WGRAD_LAUNCH = os.environ.get('SEMSEG_DEFER_WGRAD_LAUNCH', '1') != '0'
 _DEFER = [False]
-_PENDING_SLABS = []          # (slab tensor, gradient buffer, numel, splits)
-_PENDING_WGRADS = []         # (x planes, dy planes, slab tensor, gradient buffer, geometry)
+_PENDING_SLABS = []          # (slab tensor, gradient buffer, numel, splits, parameter)
+_PENDING_WGRADS = []         # (x planes, dy planes, slab tensor, gradient buffer, geometry, parameter)
+# forward uses of each leaf weight since the last flush, keyed by id(): a weight used at two sites of one graph has its second
+# gradient ADDED to the first by autograd -- which would read the first while it is still unreduced -- so only a weight with
+# exactly one recorded use is deferred (no record, e.g. a flush between forward and backward: not deferred either)
+_FWD_USES = {}
+
+
+def _note_weight_use(weight):
+    """called by the forward of every convolution node; returns the parameter to hand to backward when its gradient is one
+    autograd only accumulates (see _is_leaf_weight), else None"""
+    if not (torch.is_grad_enabled() and _is_leaf_weight(weight)):
+        return None
+    _FWD_USES[id(weight)] = _FWD_USES.get(id(weight), 0) + 1
+    return weight
+
+
+def _may_defer(param):
+    """backward-time half of the deferral contract: the gradient buffer this node returns must BECOME param.grad (autograd's
+    AccumulateGrad steals it only if .grad is empty and the strides match the parameter's) and nothing else may add to it"""
+    return bool(param is not None and param.grad is None and _FWD_USES.get(id(param), 0) == 1)
 
 
 class defer_wgrad_reduces:
@@ -595,6 +625,11 @@ class defer_wgrad_reduces:
 
     def __exit__(self, *exc):
         _DEFER[0] = self.prev
+        if exc and exc[0] is not None:           # backward raised: nothing of the half-built lists is launched, the caller's
+            _PENDING_WGRADS[:] = []              # exception is the one that propagates
+            _PENDING_SLABS[:] = []
+            _FWD_USES.clear()
+            return False
         flush_wgrad_reduces()
         return False
 
@@ -606,7 +641,7 @@ def flush_wgrad_reduces():
         probs, _PENDING_WGRADS[:] = list(_PENDING_WGRADS), []
         parr = (_native.WgradProblem * len(probs))()
         cur = torch.cuda.current_stream() if probs[0][2].is_cuda else None
-        for i, (xs, dys, slabs, out, geom) in enumerate(probs):
+        for i, (xs, dys, slabs, out, geom, _) in enumerate(probs):
             q = parr[i]
             q.xs, q.dys, q.slabs, q.slabs_bytes = xs.data_ptr(), dys.data_ptr(), slabs.data_ptr(), slabs.numel() * 4
             q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil = geom
@@ -614,14 +649,22 @@ def flush_wgrad_reduces():
                 xs.record_stream(cur)
                 dys.record_stream(cur)
         _native.check(_native.lib().semseg_conv2d_wgrad_multi_h2(parr, len(probs), _st()), 'conv2d_wgrad_multi_h2')
-        for i, (xs, dys, slabs, out, geom) in enumerate(probs):
-            _PENDING_SLABS.append((slabs, out, geom[4] * geom[5] * geom[6] * geom[3], int(parr[i].splits)))
+        for i, (xs, dys, slabs, out, geom, param) in enumerate(probs):
+            _PENDING_SLABS.append((slabs, out, geom[4] * geom[5] * geom[6] * geom[3], int(parr[i].splits), param))
+    _FWD_USES.clear()
     if not _PENDING_SLABS:
         return
     items, _PENDING_SLABS[:] = list(_PENDING_SLABS), []
+    for slabs, out, numel, splits, param in items:
+        # the contract checked where it is cheap (once per eager step / capture pass): the buffer being completed below IS
+        # the parameter's gradient.  Anything else -- autograd copied or accumulated the unreduced buffer -- is garbage already.
+        if param is not None and (param.grad is None or param.grad.data_ptr() != out.data_ptr()):
+            raise RuntimeError('deferred weight gradient of a %s parameter did not become its .grad (layout %s, grad %s): '
+                               'set SEMSEG_DEFER_WGRAD_REDUCE=0 or keep conv weights as KRSC leaves used once per step'
+                               % (tuple(param.shape), param.stride(), 'missing' if param.grad is None else 'copied'))
     arr = (_native.SlabTensor * len(items))()
     cur = torch.cuda.current_stream() if items[0][0].is_cuda else None
-    for i, (slabs, out, numel, splits) in enumerate(items):
+    for i, (slabs, out, numel, splits, _) in enumerate(items):
         arr[i].slabs, arr[i].out, arr[i].numel, arr[i].splits = slabs.data_ptr(), out.data_ptr(), numel, splits
         if cur is not None:                  # slabs / gradient allocated on a branch stream, summed on this one
             slabs.record_stream(cur)
@@ -633,12 +676,18 @@ def _is_leaf_weight(weight):
     """a weight whose gradient autograd only ACCUMULATES (into .grad, after this node) -- the one case in which the weight gradient
     may be completed after backward() has returned.  A weight computed from parameters (GroupedConv2d's block-diagonal expansion)
     has its gradient read by the next autograd node right away."""
-    return bool(weight.requires_grad and weight.is_leaf and weight.grad_fn is None)
+    if not (weight.requires_grad and weight.is_leaf and weight.grad_fn is None):
+        return False
+    # ... and whose memory is KRSC (layers.Conv2d keeps it so; any layout when R = S = 1): only then do the strides of the
+    # returned [K, C, R, S] view of the KRSC gradient buffer match the parameter's and AccumulateGrad adopts the buffer itself.
+    # A KCRS-contiguous nn.Parameter would get a COPY, taken before the deferred launches have run.
+    return bool(weight.dim() == 4 and weight.permute(0, 2, 3, 1).is_contiguous())
 
 
-def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, may_defer=False):
-    """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys).  may_defer: the weight
-    is a leaf (_is_leaf_weight) -- inside defer_wgrad_reduces() its gradient may be finished by flush_wgrad_reduces."""
+def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, param=None):
+    """Data and weight gradient of a split convolution from the planes of the input (xs) and of dy (dys).  param: the leaf
+    parameter behind w (_note_weight_use) or None -- inside defer_wgrad_reduces() the gradient of a parameter that passes
+    _may_defer may be finished by flush_wgrad_reduces."""
     n, h, wd, c, k, r, s, stride, pad, dil = geom
     dev = w.device
     dx = dw = None
@@ -650,16 +699,16 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, m
             _native.check(sch.fn(L, 'wgrad')(_p(xs), _p(dys), _p(dwb), *geom, _p(ws), ws.numel(), _st()),
                           'conv2d_wgrad_' + scheme)
         tuner.ensure(scheme, 2, geom, launch_w)        # candidates are timed WITH their reduce: what a plan costs either way
-        if _DEFER[0] and may_defer and scheme == 'h2':
+        if _DEFER[0] and scheme == 'h2' and _may_defer(param):
             nbytes = L.semseg_conv2d_wgrad_slabs_bytes(*geom)
             slabs = torch.empty((max(16, nbytes) + 3) // 4, device=dev, dtype=torch.float32)
             if DEFER_WGRAD_LAUNCH and L.semseg_conv2d_wgrad_tile_h2(*geom) == 1:
-                _PENDING_WGRADS.append((xs, dys, slabs, dwb, tuple(geom)))
+                _PENDING_WGRADS.append((xs, dys, slabs, dwb, tuple(geom), param))
             else:
                 splits = ctypes.c_int(0)
                 _native.check(L.semseg_conv2d_wgrad_slabs_h2(_p(xs), _p(dys), _p(slabs), slabs.numel() * 4, ctypes.byref(splits),
                                                              *geom, _st()), 'conv2d_wgrad_slabs_h2')
-                _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value)))
+                _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value), param))
         else:
             launch_w()
         dw = dwb.permute(0, 3, 1, 2)
@@ -689,7 +738,7 @@ class DepthwiseConv3x3Fn(Function):
     @staticmethod
     def forward(ctx, x, weight, stride, pad, dil):
         L = _native.lib()
-        x, x_ld = as_nhwc(x.detach())
+        x, x_ld = as_nhwc_of(x)
         n, c, h, w = x.shape
         if tuple(weight.shape) != (c, 1, 3, 3) or c % 4:
             raise RuntimeError('depthwise3x3: expected a [C, 1, 3, 3] weight with C %% 4 == 0, got %s for C = %d'
@@ -740,7 +789,7 @@ class GroupedConv3x3Fn(Function):
     @staticmethod
     def forward(ctx, x, weight, groups, stride, pad, dil):
         L = _native.lib()
-        x, x_ld = as_nhwc(x.detach())
+        x, x_ld = as_nhwc_of(x)
         n, c, h, w = x.shape
         k, cg = int(weight.shape[0]), int(weight.shape[1])
         if tuple(weight.shape[2:]) != (3, 3) or cg * groups != c or k % groups or cg % 4 or (k // groups) % 4:
@@ -860,7 +909,7 @@ class BatchNormActFn(Function):
     @staticmethod
     def forward(ctx, z, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, nbt):
         L = _native.lib()
-        z, z_ld = as_nhwc(z.detach())
+        z, z_ld = as_nhwc_of(z)
         n, c, h, w = z.shape
         if z_ld != c:
             z = z.contiguous(memory_format=torch.channels_last)
@@ -887,7 +936,7 @@ class BatchNormActFn(Function):
                           'bn_eval_coeffs')
         res, res_ld = (None, 0)
         if residual is not None:
-            res, res_ld = as_nhwc(residual.detach())
+            res, res_ld = as_nhwc_of(residual)
         y = empty_nhwc(n, c, h, w, dev)
         _native.check(L.semseg_bn_apply(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu), _p(y), c, P, c,
                                         _st()), 'bn_apply')
@@ -1062,7 +1111,7 @@ class ConvBNActFn(Function):
                 wino_v = None
         res, res_ld = (None, 0)
         if residual is not None:
-            res, res_ld = as_nhwc(residual.detach())
+            res, res_ld = as_nhwc_of(residual)
         bound_ok = residual is None or res_absmax is not None
         absmax = torch.empty((1,), device=dev, dtype=torch.float32) if bound_ok else None
         yp = torch.empty(L.semseg_split_h2_bytes(P, k), dtype=torch.uint8, device=dev) if (emit and bound_ok) else None
@@ -1138,6 +1187,8 @@ class ConvBNActFn(Function):
                 # bottleneck): the fp32 copy is not written (4 of the 12 bytes per element this kernel moves)
                 skip_y = planes_only and residual is None
                 box['planes_only'] = skip_y
+                if skip_y and PLANES_ONLY_POISON:         # tests: a reader that slipped past the mark sees NaN, not stale memory
+                    y.fill_(float('nan'))
                 _native.check(L.semseg_bn_apply_h2(_p(z), _p(coef[2]), _p(coef[3]), _p(res), res_ld, int(relu),
                                                    _p(None) if skip_y else _p(y), _p(yp),
                                                    P, k, _p(bb), _p(absmax), _st()), 'bn_apply_h2')
@@ -1162,7 +1213,7 @@ class ConvBNActFn(Function):
         ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate, wut)
         ctx.geom = geom
         ctx.cfg = (bool(relu), residual is not None)
-        ctx.w_leaf = _is_leaf_weight(weight)
+        ctx.w_param = _note_weight_use(weight)
         box['planes'], box['absmax'] = yp, absmax
         return y
 
@@ -1227,7 +1278,7 @@ class ConvBNActFn(Function):
         if wut is not None and need_dx:
             dx_wino = _winograd_dgrad(L, dzp, wut, geom)
             need_dx = False
-        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, need_dx, need_dw, may_defer=ctx.w_leaf)
+        dx, dw = _split_conv_grads(L, sch, 'h2', geom, xp, dzp, w, wtp, need_dx, need_dw, param=ctx.w_param)
         if dw_wino is not None:
             dw = dw_wino
         if dx_wino is not None:
@@ -1241,6 +1292,7 @@ class ConvBNActFn(Function):
 # planes_only=True, and the tensor that comes back raises if anything asks for its fp32 values (as_nhwc).  SEMSEG_PLANES_ONLY=0
 # writes every output in full.
 PLANES_ONLY = os.environ.get('SEMSEG_PLANES_ONLY', '1') != '0'
+PLANES_ONLY_POISON = os.environ.get('SEMSEG_PLANES_ONLY_POISON', '0') == '1'
 
 
 def reads_fp32_input(conv):
@@ -1295,8 +1347,8 @@ class AddActFn(Function):
     @staticmethod
     def forward(ctx, a, b, relu):
         L = _native.lib()
-        a, a_ld = as_nhwc(a.detach())
-        b, b_ld = as_nhwc(b.detach())
+        a, a_ld = as_nhwc_of(a)
+        b, b_ld = as_nhwc_of(b)
         n, c, h, w = a.shape
         out = empty_nhwc(n, c, h, w, a.device)
         _native.check(L.semseg_add_act(_p(a), a_ld, _p(b), b_ld, int(relu), _p(out), c, n * h * w, c, _st()), 'add_act')
@@ -1327,7 +1379,7 @@ class ClampMaxFn(Function):
 
     @staticmethod
     def forward(ctx, x, cap):
-        x, ld = as_nhwc(x.detach())
+        x, ld = as_nhwc_of(x)
         n, c, h, w = x.shape
         y = empty_nhwc(n, c, h, w, x.device)
         _native.check(_native.lib().semseg_clamp_max(_p(x), ld, float(cap), _p(y), c, n * h * w, c, _st()), 'clamp_max')
@@ -1432,7 +1484,7 @@ class ConcatFn(Function):
     @staticmethod
     def forward(ctx, *xs):
         L = _native.lib()
-        xs = [as_nhwc(x.detach()) for x in xs]
+        xs = [as_nhwc_of(x) for x in xs]
         n, _, h, w = xs[0][0].shape
         ctot = sum(x.shape[1] for x, _ in xs)
         out = empty_nhwc(n, ctot, h, w, xs[0][0].device)
@@ -1469,7 +1521,7 @@ class ScaleNCFn(Function):
 
     @staticmethod
     def forward(ctx, x, mask):
-        x, ld = as_nhwc(x.detach())
+        x, ld = as_nhwc_of(x)
         n, c, h, w = x.shape
         if ld != c:
             x = x.contiguous(memory_format=torch.channels_last)
@@ -1502,7 +1554,7 @@ def scale_nc(x, mask):
 class MaxPool3x3s2Fn(Function):
     @staticmethod
     def forward(ctx, x):
-        x, ld = as_nhwc(x.detach())
+        x, ld = as_nhwc_of(x)
         n, c, h, w = x.shape
         if ld != c:
             x = x.contiguous(memory_format=torch.channels_last)
@@ -1538,7 +1590,7 @@ def max_pool_3x3_s2(x):
 class AdaptiveAvgPoolFn(Function):
     @staticmethod
     def forward(ctx, x, oh, ow):
-        x, ld = as_nhwc(x.detach())
+        x, ld = as_nhwc_of(x)
         n, c, h, w = x.shape
         y = empty_nhwc(n, c, oh, ow, x.device)
         _native.check(_native.lib().semseg_adaptive_avgpool_fwd(_p(x), ld, _p(y), n, h, w, c, oh, ow, _st()),
@@ -1572,7 +1624,7 @@ class MultiAdaptiveAvgPoolFn(Function):
     def forward(ctx, x, sizes):
         L = _native.lib()
         ctx.set_materialize_grads(False)              # backward builds the zero gradient of an unused scale itself (it is tiny)
-        x, ld = as_nhwc(x.detach())
+        x, ld = as_nhwc_of(x)
         n, c, h, w = x.shape
         ns = len(sizes)
         ys = [empty_nhwc(n, c, s, s, x.device) for s in sizes]
@@ -1625,12 +1677,12 @@ class BilinearFn(Function):
     @staticmethod
     def forward(ctx, x, oh, ow, base, relu):
         L = _native.lib()
-        x, ld = as_nhwc(x.detach())
+        x, ld = as_nhwc_of(x)
         n, c, h, w = x.shape
         y = empty_nhwc(n, c, oh, ow, x.device)
         acc = 0
         if base is not None:
-            b, b_ld = as_nhwc(base.detach())
+            b, b_ld = as_nhwc_of(base)
             _native.check(L.semseg_copy2d(_p(b), b_ld, _p(y), c, n * oh * ow, c, 0, _st()), 'copy2d')
             acc = 1
         _native.check(L.semseg_bilinear_fwd(_p(x), ld, _p(y), c, acc, int(relu), n, h, w, oh, ow, c, _st()),
@@ -1742,7 +1794,7 @@ def upsample_softmax(z, size):
     """Inference head (models.py:480-484): softmax over the classes of the logits bilinearly up-sampled to `size`, one fused
     kernel (csrc/pool_resize.hip semseg_upsample_softmax).  Returns [N, C, H, W] probabilities (times the weight of an enclosing
     ops.head_output context, into its buffer)."""
-    z, ld = as_nhwc(z.detach())
+    z, ld = as_nhwc_of(z)
     n, c, h, w = z.shape
     oh, ow = int(size[0]), int(size[1])
     out, weight, acc = _HEAD['out'], _HEAD['weight'], _HEAD['accumulate']

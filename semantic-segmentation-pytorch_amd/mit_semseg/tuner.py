@@ -75,7 +75,9 @@ def _load_cache():
             _done[key] = tuple(v)
             stats_db[counter] += 1
             if key[1] in (0, 1, 2):
-                _bucket_plans.setdefault(_bucket_key(key[0], key[1], key[2:]), (int(v[0]), int(v[1])))
+                bk = _bucket_key(key[0], key[1], key[2:])
+                if counter == 'from_cache' or bk not in _bucket_plans:      # the later source (the user's cache) wins, as for _done;
+                    _bucket_plans[bk] = (int(v[0]), int(v[1]))               # within one source the first entry of a bucket stays
 
 
 def _save_cache():

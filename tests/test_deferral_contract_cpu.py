@@ -1,0 +1,100 @@
+"""Host-side contract of the deferred weight gradients (ops.defer_wgrad_reduces, round-4 advice): a gradient buffer may be
+completed after backward() has returned only if autograd ADOPTS that very buffer as the parameter's .grad -- a KRSC leaf, an
+empty .grad, exactly one use in the graph.  Everything here is pure Python over torch CPU tensors: no launch is made."""
+import pytest
+import torch
+import torch.nn as nn
+
+from mit_semseg import ops
+
+
+@pytest.fixture(autouse=True)
+def _clean():
+    ops._FWD_USES.clear()
+    yield
+    ops._FWD_USES.clear()
+    del ops._PENDING_SLABS[:], ops._PENDING_WGRADS[:]
+
+
+def _krsc(k, c, r, s):
+    return nn.Parameter(torch.randn(k, r, s, c).permute(0, 3, 1, 2))
+
+
+def test_only_krsc_leaves_qualify():
+    assert ops._is_leaf_weight(_krsc(8, 4, 3, 3))
+    assert ops._is_leaf_weight(nn.Parameter(torch.randn(8, 4, 1, 1)))           # R = S = 1: both layouts coincide
+    assert not ops._is_leaf_weight(nn.Parameter(torch.randn(8, 4, 3, 3)))       # a standard KCRS nn.Parameter: autograd would COPY
+    w = _krsc(8, 4, 3, 3)
+    assert not ops._is_leaf_weight(w * 2.0)                                      # computed from a parameter
+    assert not ops._is_leaf_weight(_krsc(8, 4, 3, 3).detach())                   # no gradient wanted
+
+
+def test_autograd_adopts_exactly_the_layouts_that_qualify():
+    """the premise itself, on this torch build: AccumulateGrad keeps the returned buffer for a KRSC leaf and copies for a KCRS one"""
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w):
+            ctx.shape = w.shape
+            return w.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            k, c, r, s = ctx.shape
+            Fn.buf = torch.ones(k, r, s, c)
+            return Fn.buf.permute(0, 3, 1, 2)
+    for w, adopted in ((_krsc(8, 4, 3, 3), True), (nn.Parameter(torch.randn(8, 4, 3, 3)), False)):
+        Fn.apply(w).backward()
+        assert (w.grad.data_ptr() == Fn.buf.data_ptr()) == adopted
+        assert ops._is_leaf_weight(w) == adopted
+
+
+def test_shared_or_preloaded_weights_are_not_deferred():
+    w = _krsc(8, 4, 3, 3)
+    assert ops._note_weight_use(w) is w
+    assert ops._may_defer(w)
+    ops._note_weight_use(w)                           # a second site of the same graph: its gradient would be ADDED to the first
+    assert not ops._may_defer(w)
+    v = _krsc(8, 4, 3, 3)
+    ops._note_weight_use(v)
+    v.grad = torch.zeros_like(v)                      # zero_grad(set_to_none=False): autograd accumulates in place
+    assert not ops._may_defer(v)
+    u = _krsc(8, 4, 3, 3)
+    assert not ops._may_defer(u)                      # no recorded use (a flush between forward and backward)
+    with torch.no_grad():
+        assert ops._note_weight_use(_krsc(8, 4, 3, 3)) is None
+    assert not ops._may_defer(None)
+
+
+def test_flush_refuses_a_gradient_that_autograd_did_not_adopt(monkeypatch):
+    """the backstop: if the buffer being completed is not the parameter's .grad the step fails loudly instead of training on a
+    copy of the unreduced buffer"""
+    launched = []
+
+    class L:
+        @staticmethod
+        def semseg_reduce_slabs_multi(*a):
+            launched.append(a)
+            return 0
+    monkeypatch.setattr(ops._native, 'lib', lambda: L)
+    monkeypatch.setattr(ops, '_st', lambda: None)
+    w = _krsc(8, 4, 3, 3)
+    buf = torch.zeros(8, 3, 3, 4)
+    w.grad = buf.permute(0, 3, 1, 2).clone()          # a copy, as AccumulateGrad makes for a layout it does not adopt
+    ops._PENDING_SLABS.append((torch.zeros(16), buf, buf.numel(), 1, w))
+    with pytest.raises(RuntimeError, match='did not become its .grad'):
+        ops.flush_wgrad_reduces()
+    assert not launched and not ops._PENDING_SLABS
+    w.grad = buf.permute(0, 3, 1, 2)                  # adopted: the launch goes out
+    ops._PENDING_SLABS.append((torch.zeros(16), buf, buf.numel(), 1, w))
+    ops.flush_wgrad_reduces()
+    assert len(launched) == 1
+
+
+def test_a_failed_backward_launches_nothing_and_keeps_its_exception(monkeypatch):
+    monkeypatch.setattr(ops, 'flush_wgrad_reduces', lambda: pytest.fail('flush after a failed backward'))
+    with pytest.raises(ZeroDivisionError):
+        with ops.defer_wgrad_reduces():
+            ops._PENDING_SLABS.append('half-built')
+            ops._PENDING_WGRADS.append('half-built')
+            1 / 0
+    assert not ops._PENDING_SLABS and not ops._PENDING_WGRADS

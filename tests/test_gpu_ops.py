@@ -844,6 +844,47 @@ def test_deferred_wgrad_leaves_computed_weights_alone(monkeypatch):
     assert rel_err(grads[True, False], 2.0 * grads[True, True].cpu()) < 1e-5      # w = 2 p: products differ by an exact power of two only
 
 
+def test_deferred_wgrad_only_where_autograd_adopts_the_buffer(monkeypatch):
+    """round-4 advice: inside ops.defer_wgrad_reduces() a weight gradient is finished after backward only when the returned buffer
+    BECOMES the parameter's .grad.  A standard KCRS-contiguous nn.Parameter (autograd copies the view), a weight used at two sites
+    (autograd adds the second gradient to the first) and a parameter with a pre-existing .grad (in-place accumulation) must get the
+    same bits as without the deferral -- they used to get a copy of the unreduced buffer."""
+    from mit_semseg import ops, tuner
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    monkeypatch.setattr(tuner, 'ENABLED', False)
+    g = torch.Generator().manual_seed(6)
+    x = cl(torch.randn(2, 64, 16, 16, generator=g))
+    w0 = torch.randn(64, 64, 3, 3, generator=g) / 24
+    gy = cl(torch.randn(2, 64, 16, 16, generator=g))
+
+    def run(kind, defer):
+        if kind == 'kcrs':
+            p = torch.nn.Parameter(w0.clone().cuda())                    # plain contiguous [K, C, R, S]
+        else:
+            p = cl(w0.clone()).requires_grad_(True)
+        if kind == 'preloaded':
+            p.grad = torch.zeros_like(p)
+
+        def fb():
+            y = ops.conv2d(x, p, None, 1, 1, 1)
+            if kind == 'shared':
+                y = ops.conv2d(y, p, None, 1, 1, 1)
+            y.backward(gy)
+        ops._FWD_USES.clear()
+        if defer:
+            with ops.defer_wgrad_reduces():
+                fb()
+        else:
+            fb()
+        torch.cuda.synchronize()
+        assert not ops._PENDING_SLABS and not ops._PENDING_WGRADS
+        return p.grad.clone()
+    for kind in ('krsc', 'kcrs', 'shared', 'preloaded'):
+        a, b = run(kind, False), run(kind, True)
+        assert torch.isfinite(b).all(), kind
+        assert torch.equal(a.contiguous(), b.contiguous()), kind
+
+
 # (n, h, w, c, k, r, stride, pad, dil, split) -- ragged channel counts, strides, dilation, 1x1 and 3x3, with and without a split
 WGRAD_MULTI_GEOMS = [(2, 16, 16, 64, 64, 3, 1, 1, 1, 1), (2, 16, 16, 64, 64, 3, 1, 1, 1, 2), (1, 24, 20, 18, 36, 3, 1, 1, 1, 3),
                      (2, 17, 13, 48, 96, 3, 2, 1, 1, 1), (1, 32, 32, 144, 72, 1, 1, 0, 1, 4), (2, 16, 16, 32, 40, 3, 1, 2, 2, 2),
