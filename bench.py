@@ -474,6 +474,32 @@ def other_configs(skip, steps, warmup, budget_s=100):
         except Exception as e:                                    # never lose the headline to a side leg
             out[str(cid)] = {'workload': CONFIGS[cid]['yaml'], 'img_s': None, 'error': repr(e)[:200],
                              'leg_wall_s': round(time.perf_counter() - t0, 1)}
+        if CONFIGS[cid].get('variable') and out[str(cid)].get('img_s'):
+            # ... and the RAW stream of the same rule beside its steady state (round-4 review): 100 untimed + 300 timed steps in
+            # stream order, first sights (eager) and graph captures of new shapes INSIDE the timed region -- the first minutes of
+            # a training run, before the ~470 shapes of the ADE20K list have all been captured (tools/shape_stream_sim.py)
+            raw = [a for a in cmd]
+            i = raw.index('--shapes')
+            raw[i + 1] = '0'
+            raw[raw.index('--steps') + 1] = '300'
+            raw[raw.index('--warmup') + 1] = '100'
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run(raw, capture_output=True, text=True, timeout=budget_s + 140)
+                line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+                c = line['config']
+                ev = c['shape_events_timed']
+                out[str(cid)]['raw_stream'] = {
+                    'img_s': line['value'], 'ms_per_step': line['ms_per_step'], 'steps': line['steps'], 'warmup': line['warmup'],
+                    'fraction_of_steady_state': round(line['value'] / out[str(cid)]['img_s'], 3),
+                    'mean_px_per_image': c['mean_px_per_image'], 'distinct_shapes_timed': c['distinct_shapes_timed'],
+                    'events_timed': ev,
+                    'host_ms_per_capture': round(1e3 * ev['capture_host_s'] / max(1, ev['captured']), 1),
+                    'host_ms_per_first_sight': round(1e3 * ev['eager_host_s'] / max(1, ev['eager']), 1),
+                    'note': 'stream order, graph LRU 512; every new shape costs one eager step (first sight) and one capture '
+                            '(second sight), then replays', 'leg_wall_s': round(time.perf_counter() - t0, 1)}
+            except Exception as e:
+                out[str(cid)]['raw_stream'] = {'img_s': None, 'error': repr(e)[:200], 'leg_wall_s': round(time.perf_counter() - t0, 1)}
     return out
 
 
@@ -557,15 +583,13 @@ def scaling_model_block(step, sm, feed, t1_ms):
     backward end and at step end; three replays, the last one's timeline scaled to the measured step feeds
     mit_semseg/scaling_model.py.  MODEL, NOT MEASURED."""
     from mit_semseg import scaling_model as smod
-    from mit_semseg import ops
     enc, dec = sm.encoder, sm.decoder
     probe = smod.TimelineProbe(list(enc.parameters()) + list(dec.parameters()))
-    # the timeline of a RANK: under gradient buckets every weight gradient is complete when autograd accumulates it (no deferral,
-    # ops.defer_wgrad_reduces), so the markers are captured -- and the step is timed -- in that form
-    defer = ops.DEFER_WGRAD_REDUCE
+    # the timeline of a RANK: under gradient buckets the deferred / batched weight gradients are finished by the hook that completes
+    # a bucket, before its all-reduce (parallel.GradientBuckets._launch); the probe's bucket hooks flush the same way, so the markers
+    # are captured -- and the step is timed -- in the form a rank runs it (one flush per bucket instead of one after backward)
     t_rank_ms = None
     try:
-        ops.DEFER_WGRAD_REDUCE = False
         step.timeline = probe
         step._graphs.clear()
         for _ in range(4):                       # capture + three replays with the markers inside the graph
@@ -581,7 +605,6 @@ def scaling_model_block(step, sm, feed, t1_ms):
         torch.cuda.synchronize()
         t_rank_ms = e0.elapsed_time(e1) / reps
     finally:
-        ops.DEFER_WGRAD_REDUCE = defer
         step.timeline = None
         step._graphs.clear()
         probe.detach()
@@ -765,6 +788,7 @@ def main():
                        'train_gflop_per_image': round(gflop_img, 1),
                        'mean_px_per_image': round(sum(px) / len(px), 1),
                        'distinct_shapes_timed': len(set(shapes[args.warmup:])),
+                       'shape_events_timed': {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timed.items()},
                        'repeat_windows': ({'steps_per_window': max(args.steps, 50),
                                            'ms_per_step': [round(w, 3) for w in windows],
                                            'median_ms': round(sorted(windows)[len(windows) // 2], 3),

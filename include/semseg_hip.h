@@ -548,6 +548,7 @@ int semseg_comm_destroy(void* comm);
  *   its result with NaN and raises semseg_peer_status() (SEMSEG_ECOMM) instead of hanging. */
 int semseg_peer_max_world(void);
 int semseg_peer_create(int rank, int world, int max_doubles, double timeout_s, void** peer_out);
+int semseg_peer_set_timeout(void* peer, double timeout_s);   /* for exchanges launched from now on (self-test: short, run: long) */
 int semseg_peer_handle(void* peer, void* handle64);
 int semseg_peer_attach(void* peer, int src_rank, const void* handle64);
 int semseg_peer_attach_local(void* peer, int src_rank, void* other_peer);

@@ -2066,8 +2066,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFPara
 // per operand a whole 64-deep tile of a 128 x 128 block is 64 KiB, so the ring holds HALF tiles: entry j = the A rows (j even) or the
 // B rows (j odd) of tile j / 2, five entries of 32 KiB, 1.5 tiles in flight behind the tile being multiplied.
 // ------------------------------------------------------------------------------------------------
-template <int WGM, int WGN>
+// SCHED (round 5): bit 0 = the DMA pieces of a k-tile are issued in four groups BEHIND the four MFMA groups of the following tile
+// (first group right after the barrier that frees the slots) instead of all eight right after the barrier -- both waves of a SIMD
+// leave the barrier together, and eight back-to-back 60 - 185-cycle DMA issues per wave were a window in which neither feeds the
+// matrix pipe; bit 1 = s_setprio 1 around every MFMA group.
+template <int WGM, int WGN, int SCHED = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused64_kernel(const WFParams p) {
+    constexpr bool SPREAD = SCHED & 1, PRIO = SCHED & 2;
     constexpr int NP = 2, BM = 128, BN = 128, NENT = 5;
     typedef SchH2::frag frag;
     constexpr int NW = WGM * WGN;
@@ -2114,13 +2119,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused64_kernel(const WFPa
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
     int i_f = 0, i_c = 0, i_ent = 0, i_slot = 0;       // (frequency, 64-chunk) of the tile the next entry belongs to; entry index; its slot
-    auto issue_entry = [&]() {
+    // one ring entry in two halves (SPREAD issues them behind different MFMA groups): half h = the row groups [h GPW / 2, (h + 1) GPW / 2)
+    // of the entry; the second half closes the entry (advances the (frequency, chunk) walk, the entry index and the slot)
+    auto issue_half = [&](int h) {
         const bool live = i_ent < 2 * nk;               // wave-uniform
         const bool is_b = i_ent & 1;
         const uint32_t base = lds0 + (uint32_t)i_slot * ENT_BYTES;
         const uint32_t koff = (uint32_t)i_f * (is_b ? fb_b : fa_b) + 128u * (uint32_t)i_c;
+        constexpr int HG = GPW >= 2 ? GPW / 2 : 1;
 #pragma unroll
-        for (int i = 0; i < GPW; ++i)
+        for (int ii = 0; ii < HG; ++ii) {
+            const int i = (GPW >= 2 ? h * HG : 0) + ii;
+            if (GPW < 2 && h == 1) break;
 #pragma unroll
             for (int s = 0; s < NP; ++s) {
                 const uint32_t dst = base + (uint32_t)((s * BM + (wave + NW * i) * 8) * 128);
@@ -2132,11 +2142,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused64_kernel(const WFPa
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)dst, 16, vo, 0, 0, 0);
                 }
             }
-        if (is_b && live) {                             // the tile's B entry closes it: advance (frequency, chunk)
-            if (++i_c == chunks64) { i_c = 0; ++i_f; }
         }
-        ++i_ent;
-        i_slot = (i_slot == NENT - 1) ? 0 : i_slot + 1;
+        if (h == 1) {
+            if (is_b && live) {                         // the tile's B entry closes it: advance (frequency, chunk)
+                if (++i_c == chunks64) { i_c = 0; ++i_f; }
+            }
+            ++i_ent;
+            i_slot = (i_slot == NENT - 1) ? 0 : i_slot + 1;
+        }
+    };
+    auto issue_entry = [&]() {
+        issue_half(0);
+        issue_half(1);
     };
 
     f32x16 acc[FM][FN], y[4][FM][FN];
@@ -2172,10 +2189,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused64_kernel(const WFPa
         }
     };
     auto mma = [&](const frag (&av)[FM][NP], const frag (&bv)[FN][NP]) {
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) SchH2::mac(av[i], bv[j], acc[i][j]);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto fold = [&](int f) {
         const int a = f >> 2, b = f & 3;
@@ -2212,23 +2231,35 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused64_kernel(const WFPa
     for (int it = 0; it < nk; ++it) {
         read_frags(sa, sb, 1, a1, b1);
         mma(a0, b0);
+        if (SPREAD && it) issue_half(1);                      // second half of the B entry begun behind the last MFMA group of tile it - 1
         read_frags(sa, sb, 2, a0, b0);
         mma(a1, b1);
+        if (SPREAD && it) issue_half(0);                      // the A entry into the other slot tile it - 1 has freed
         read_frags(sa, sb, 3, a1, b1);
         mma(a0, b0);
+        if (SPREAD && it) issue_half(1);
         // my reads of this tile's two slots are done; the next tile's two entries (the oldest two of the three in flight) have landed
+        // (SPREAD: the newest PPE pieces are the A entry just issued, as in the burst form)
         wait_vm_barrier<1 * PPE>();
-        issue_entry();                                        // into slot sa
-        issue_entry();                                        // into slot sb
-        sa = (sb == NENT - 1) ? 0 : sb + 1;
-        sb = (sa == NENT - 1) ? 0 : sa + 1;
-        read_frags(sa, sb, 0, a0, b0);                        // past the last tile: zero tails, never multiplied
+        if (!SPREAD) {
+            issue_entry();                                    // into slot sa
+            issue_entry();                                    // into slot sb
+        }
+        const int na = (sb == NENT - 1) ? 0 : sb + 1;
+        const int nb = (na == NENT - 1) ? 0 : na + 1;
+        read_frags(na, nb, 0, a0, b0);                        // past the last tile: zero tails, never multiplied
         mma(a1, b1);
+        if (SPREAD) issue_half(0);                            // first half of the B entry that refills slot sa (i_slot == sa here)
+        sa = na;
+        sb = nb;
         if (++c_c == chunks64) {
             c_c = 0;
             fold(c_f);
             ++c_f;
         }
+    }
+    if (SPREAD) {                                             // close the entry left half issued (dead: past the last tile)
+        issue_half(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -2275,13 +2306,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused64_kernel(const WFPa
     }
 }
 
-template <int WGM, int WGN>
+template <int WGM, int WGN, int SCHED = 0>
 static int launch_wino_fused64(const WFParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)5 * 2 * 128 * 128;
     if (p.chunks & 1) return SEMSEG_EINVAL;                  // the reduction must be whole 64-channel tiles
     static SmemAttrCache attr_cache;
-    if (int e = ensure_smem_attr(attr_cache, (const void*)wino_fused64_kernel<WGM, WGN>, smem)) return e;
-    hipLaunchKernelGGL((wino_fused64_kernel<WGM, WGN>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), smem, st, p);
+    if (int e = ensure_smem_attr(attr_cache, (const void*)wino_fused64_kernel<WGM, WGN, SCHED>, smem)) return e;
+    hipLaunchKernelGGL((wino_fused64_kernel<WGM, WGN, SCHED>), dim3(p.tiles_m * p.tiles_n), dim3(64 * WGM * WGN), smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -2333,6 +2364,9 @@ extern "C" int semseg_winograd_gemm_output_h2(const void* v_planes, const void* 
         case 4: return launch_wino_fused<128, 128, 2, 2, 5>(p, st);
         case 5: return launch_wino_fused64<4, 2>(p, st);                       // 64-deep k-tiles, full-line DMA pieces, half-tile ring
         case 6: return launch_wino_fused64<2, 2>(p, st);
+        case 7: return launch_wino_fused64<4, 2, 1>(p, st);                    // form 5 with the DMA pieces spread behind the MFMA groups
+        case 8: return launch_wino_fused64<4, 2, 3>(p, st);                    // ... and s_setprio 1 around the MFMA groups
+        case 9: return launch_wino_fused64<4, 2, 2>(p, st);                    // form 5 with s_setprio alone
         case 100: return launch_wino_fused<128, 128, 4, 2, 5, 1>(p, st);      // probes of form 2 (garbage results)
         case 101: return launch_wino_fused<128, 128, 4, 2, 5, 2>(p, st);
         default: return SEMSEG_EINVAL;

@@ -65,6 +65,14 @@ bool semseg_peer::peer_args(void* peer, PeerArgs* out) {
 
 extern "C" int semseg_peer_max_world(void) { return kMaxWorld; }
 
+// the timeout of the exchanges launched FROM NOW ON (kernels take the context by value at launch; a captured graph keeps the
+// value of its capture): comm.peer_init runs its self-test on a short one and raises it for the training run
+extern "C" int semseg_peer_set_timeout(void* peer, double timeout_s) {
+    if (!peer || !(timeout_s > 0.0)) return SEMSEG_EINVAL;
+    static_cast<Peer*>(peer)->a.timeout_ticks = (long long)(timeout_s * 1e8);
+    return 0;
+}
+
 extern "C" int semseg_peer_create(int rank, int world, int max_doubles, double timeout_s, void** peer_out) {
     if (!peer_out || world < 1 || world > kMaxWorld || rank < 0 || rank >= world || max_doubles < 1 || !(timeout_s > 0.0))
         return SEMSEG_EINVAL;

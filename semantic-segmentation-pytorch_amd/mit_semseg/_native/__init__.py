@@ -164,6 +164,7 @@ SIGNATURES = {
     'semseg_comm_destroy': (c_int, [vp]),
     'semseg_peer_max_world': (c_int, []),
     'semseg_peer_create': (c_int, [c_int, c_int, c_int, ctypes.c_double, ctypes.POINTER(vp)]),
+    'semseg_peer_set_timeout': (c_int, [vp, ctypes.c_double]),
     'semseg_peer_handle': (c_int, [vp, vp]),
     'semseg_peer_attach': (c_int, [vp, c_int, vp]),
     'semseg_peer_attach_local': (c_int, [vp, c_int, vp]),

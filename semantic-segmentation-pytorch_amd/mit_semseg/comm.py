@@ -165,12 +165,12 @@ PEER_MAX_DOUBLES = 2 * 4096 + 1          # [sum, sum^2, n] of a 4096-channel BN
 
 
 def peer_enabled():
-    """SEMSEG_PEER=1 (read when the exchange would be built) turns the peer exchange on; the default leaves the SyncBN payloads
-    with RCCL / torch.distributed.  Opt-in because no run on more than one GPU has exercised it yet (IPC-mapped inboxes across
-    devices, xGMI store ordering): bench.py switches it on for its real run only after a child process per rank has trained a
-    small model through it (fused BN kernels exchanging inside hipGraph segments, bucket all-reduces beside them, bit-identical
-    replicas) -- tools/probes/ddp_graph_selftest.py; `train.py` users run that script once on their node and export SEMSEG_PEER=1."""
-    return os.environ.get('SEMSEG_PEER', '0') == '1'
+    """The peer exchange is built whenever it can be (one node, world <= semseg_peer_max_world()) and its collective bring-up
+    passes -- every rank mapped every inbox, the co-residency vote, and a known-sum self-test over more exchanges than the
+    protocol has slots, run on a SHORT timeout (SEMSEG_PEER_SELFTEST_TIMEOUT_S, 10 s) so that a node on which IPC-mapped inboxes
+    do not work falls back to RCCL / torch.distributed within seconds, unanimously, instead of training on the slow path by default
+    (rounds 2-4: opt-in, only bench.py turned it on; a train.py user got 122 small all-reduces per step).  SEMSEG_PEER=0 opts out."""
+    return os.environ.get('SEMSEG_PEER', '1') != '0'
 
 
 def peer_active(group=None):
@@ -207,8 +207,9 @@ def peer_init(group=None, max_doubles=PEER_MAX_DOUBLES, selftest=True):
     if world <= 1 or world > L.semseg_peer_max_world() or not _same_host(group):
         return False
     timeout_s = float(os.environ.get('SEMSEG_PEER_TIMEOUT_S', '120'))
+    selftest_timeout_s = min(timeout_s, float(os.environ.get('SEMSEG_PEER_SELFTEST_TIMEOUT_S', '10')))
     handle = ctypes.c_void_p()
-    ok = L.semseg_peer_create(rank, world, max_doubles, timeout_s, ctypes.byref(handle)) == 0
+    ok = L.semseg_peer_create(rank, world, max_doubles, selftest_timeout_s if selftest else timeout_s, ctypes.byref(handle)) == 0
     mine = (ctypes.c_ubyte * 64)()
     ok = ok and L.semseg_peer_handle(handle, mine) == 0
     handles = [None] * world
@@ -247,6 +248,8 @@ def peer_init(group=None, max_doubles=PEER_MAX_DOUBLES, selftest=True):
         if handle:
             L.semseg_peer_destroy(handle)
         return False
+    if selftest:
+        L.semseg_peer_set_timeout(handle, timeout_s)        # the training run waits longer for a straggler than the self-test did
     _PEERS[_key(group)] = dict(handle=handle, rank=rank, world=world, cap=max_doubles)
     return True
 

@@ -4,6 +4,7 @@ replayed (the whole step is capture-safe: no host sync, no allocation outside to
 learning rate lives in device memory)."""
 import collections
 import os
+import time
 
 import torch
 import torch.nn as nn
@@ -164,9 +165,13 @@ class TrainStep:
     tunes / assigns the conv launch plans of the new geometries and warms the allocator -- the second time it is captured
     (fwd + bwd + all-reduce + SGD), and from then on the batch is copied into the graph's static buffers and replayed.  The
     variable-size per-GPU batches of the multi-scale pipeline (BASELINE configs[3]: short side 300...600, long side <= 1000,
-    multiples of 8) therefore converge to replays of their most frequent shapes; at most `max_graphs` graphs are kept (least
-    recently used goes first) and they share ONE allocator pool, so their activation memory is the maximum over the shapes,
-    not the sum (each graph is self-contained: nothing but its (loss, acc) outputs outlives a replay)."""
+    multiples of 8) therefore converge to replays; at most `max_graphs` graphs are kept (least recently used goes first) and
+    they share ONE allocator pool, so their activation memory is the maximum over the shapes, not the sum (each graph is
+    self-contained: nothing but its (loss, acc) outputs outlives a replay).  `max_graphs` defaults to 512: the ADE20K size list
+    under the multi-scale rule yields 467 distinct batch shapes in 20 000 iterations (tools/shape_stream_sim.py), the five most
+    frequent cover 39 % of the stream, 16 cover 63 %, 256 cover 98 % -- an LRU of 16 (rounds 2-4) re-captured on HALF of all
+    steps, one of 512 never evicts.  What a graph costs beyond the shared pool is its kernel-node list and its static batch
+    (a few MB), against 288 GB of HBM."""
 
     def __init__(self, segmentation_module, lr_encoder=0.02, lr_decoder=0.02, momentum=0.9, weight_decay=1e-4,
                  lr_pow=0.9, max_iters=100000, graph=False, group=None, bucket_bytes=64 << 20, max_graphs=None):
@@ -192,14 +197,14 @@ class TrainStep:
         self._conv_weights = [m.weight for m in segmentation_module.modules() if type(m) is Conv2d]      # not the grouped ones
         self._weights_ready = False
         self.use_graph = graph
-        self.max_graphs = int(os.environ.get('SEMSEG_TRAIN_GRAPHS', max_graphs or 16))
+        self.max_graphs = int(os.environ.get('SEMSEG_TRAIN_GRAPHS', max_graphs or 512))
         self._graphs = collections.OrderedDict()      # feed_key -> (graph, static feed, (loss, acc))
         self._seen = {}                               # feed_key -> eager steps run at this shape
         self._pool = None
         self._graph = None                            # the graph of the most recent replay (bench.py reports the launch mode)
         self.warmup_eager = 2
         self.timeline = None                          # scaling_model.TimelineProbe: timestamp markers inside the (captured) step
-        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0}
+        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0, 'capture_host_s': 0.0, 'eager_host_s': 0.0}
 
     def adjust_learning_rate(self):
         """train.py:130-139 poly schedule"""
@@ -225,11 +230,10 @@ class TrainStep:
         if tl is not None:
             tl.mark('fwd_end')
             tl.arm()                          # its hooks mark each gradient bucket when backward completes it
-        if self.buckets is None:
-            # one rank: the split weight gradients of the whole backward pass are summed by ONE launch after it (ops.defer_wgrad_reduces)
-            with ops.defer_wgrad_reduces():
-                loss.backward()
-        else:
+        # the split weight gradients of the backward pass are summed, and the small ones computed, by batched launches: ONE flush after
+        # backward on a single rank, one per gradient bucket (from the hook that completes it, before its all-reduce) on a rank of
+        # a data-parallel job (ops.defer_wgrad_reduces)
+        with ops.defer_wgrad_reduces(flush_at_buckets=self.buckets is not None and self.buckets.flushes_deferred):
             loss.backward()
         if tl is not None:
             tl.armed = False
@@ -276,8 +280,13 @@ class TrainStep:
             if self.opt.steps < self.warmup_eager or seen < 1:
                 self._seen[key] = seen + 1
                 self.stats['eager'] += 1
-                return self._eager(feed)
+                t0 = time.perf_counter()
+                out = self._eager(feed)
+                self.stats['eager_host_s'] += time.perf_counter() - t0      # host time of issuing the step (no device sync)
+                return out
+            t0 = time.perf_counter()
             rec = self._capture(key, feed, mode)
+            self.stats['capture_host_s'] += time.perf_counter() - t0        # the capture pass + graph instantiation
         else:
             self._graphs.move_to_end(key)
         graph, static, out = rec

@@ -555,7 +555,7 @@ class Conv2dSplitFn(Function):
         ctx.geom = geom
         ctx.has_bias = bias is not None
         ctx.scheme = scheme
-        ctx.w_param = _note_weight_use(weight)
+        ctx.w_param = _note_weight_use(weight, ctx.needs_input_grad[1])
         return y
 
     @staticmethod
@@ -594,18 +594,19 @@ DEFER_WGRAD_REDUCE = os.environ.get('SEMSEG_DEFER_WGRAD_REDUCE', '1') != '0'
 # of the per-layer launches unchanged, bit-identical slabs).  SEMSEG_DEFER_WGRAD_LAUNCH=0 launches them where autograd reaches them.
 DEFER_WGRAD_LAUNCH = os.environ.get('SEMSEG_DEFER_WGRAD_LAUNCH', '1') != '0'
 _DEFER = [False]
-_PENDING_SLABS = []          # (slab tensor, gradient buffer, numel, splits, parameter)
-_PENDING_WGRADS = []         # (x planes, dy planes, slab tensor, gradient buffer, geometry, parameter)
+_PENDING_SLABS = []          # (slab tensor, gradient buffer, numel, splits, parameter, producing stream)
+_PENDING_WGRADS = []         # (x planes, dy planes, slab tensor, gradient buffer, geometry, parameter, producing stream)
 # forward uses of each leaf weight since the last flush, keyed by id(): a weight used at two sites of one graph has its second
 # gradient ADDED to the first by autograd -- which would read the first while it is still unreduced -- so only a weight with
 # exactly one recorded use is deferred (no record, e.g. a flush between forward and backward: not deferred either)
 _FWD_USES = {}
 
 
-def _note_weight_use(weight):
-    """called by the forward of every convolution node; returns the parameter to hand to backward when its gradient is one
-    autograd only accumulates (see _is_leaf_weight), else None"""
-    if not (torch.is_grad_enabled() and _is_leaf_weight(weight)):
+def _note_weight_use(weight, wanted=True):
+    """called by the forward of every convolution node (`wanted` = ctx.needs_input_grad of the weight: autograd runs forward()
+    with grad mode off, so that -- not torch.is_grad_enabled() -- says whether a backward will come); returns the parameter to
+    hand to backward when its gradient is one autograd only accumulates (see _is_leaf_weight), else None"""
+    if not (wanted and _is_leaf_weight(weight)):
         return None
     _FWD_USES[id(weight)] = _FWD_USES.get(id(weight), 0) + 1
     return weight
@@ -618,9 +619,16 @@ def _may_defer(param):
 
 
 class defer_wgrad_reduces:
+    """flush_at_buckets: the caller runs gradient buckets (parallel.GradientBuckets) that call flush_wgrad_reduces(mid_backward=True)
+    from the hook that completes a bucket, BEFORE the bucket is staged and its all-reduce launched -- so a rank gets the batched /
+    deferred weight gradients too, bucket by bucket, and no bucket ever travels with an unfinished gradient in it."""
+
+    def __init__(self, flush_at_buckets=False):
+        self.flush_at_buckets = flush_at_buckets
+
     def __enter__(self):
         self.prev = _DEFER[0]
-        _DEFER[0] = DEFER_WGRAD_REDUCE and CONV_MODE == 'h2' and not _sync_active()
+        _DEFER[0] = DEFER_WGRAD_REDUCE and CONV_MODE == 'h2' and (self.flush_at_buckets or not _sync_active())
         return self
 
     def __exit__(self, *exc):
@@ -634,28 +642,41 @@ class defer_wgrad_reduces:
         return False
 
 
-def flush_wgrad_reduces():
+def deferring():
+    return _DEFER[0]
+
+
+def flush_wgrad_reduces(mid_backward=False):
     """sum the slabs of every weight gradient deferred since the last flush, one launch per 64 tensors (on the current stream: after
-    backward() has returned autograd has made it wait for the streams the gradients were produced on)"""
+    backward() has returned autograd has made it wait for the streams the gradients were produced on).  mid_backward: called from a
+    gradient-bucket hook while backward is still running -- the current stream is first made to wait for every OTHER stream a pending
+    operand was produced on (the branch streams of run_branches), and the forward-use counts stay (the rest of the graph has not run)."""
+    cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+    if mid_backward and cur is not None:
+        for rec in list(_PENDING_WGRADS) + list(_PENDING_SLABS):
+            st = rec[-1]
+            if st is not None and st != cur:
+                cur.wait_stream(st)
     if _PENDING_WGRADS:
         probs, _PENDING_WGRADS[:] = list(_PENDING_WGRADS), []
         parr = (_native.WgradProblem * len(probs))()
-        cur = torch.cuda.current_stream() if probs[0][2].is_cuda else None
-        for i, (xs, dys, slabs, out, geom, _) in enumerate(probs):
+        on_dev = probs[0][2].is_cuda
+        for i, (xs, dys, slabs, out, geom, _, _) in enumerate(probs):
             q = parr[i]
             q.xs, q.dys, q.slabs, q.slabs_bytes = xs.data_ptr(), dys.data_ptr(), slabs.data_ptr(), slabs.numel() * 4
             q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.dil = geom
-            if cur is not None:              # planes produced on a branch stream, read on this one
+            if on_dev:                       # planes produced on a branch stream, read on this one
                 xs.record_stream(cur)
                 dys.record_stream(cur)
         _native.check(_native.lib().semseg_conv2d_wgrad_multi_h2(parr, len(probs), _st()), 'conv2d_wgrad_multi_h2')
-        for i, (xs, dys, slabs, out, geom, param) in enumerate(probs):
-            _PENDING_SLABS.append((slabs, out, geom[4] * geom[5] * geom[6] * geom[3], int(parr[i].splits), param))
-    _FWD_USES.clear()
+        for i, (xs, dys, slabs, out, geom, param, st) in enumerate(probs):
+            _PENDING_SLABS.append((slabs, out, geom[4] * geom[5] * geom[6] * geom[3], int(parr[i].splits), param, st))
+    if not mid_backward:
+        _FWD_USES.clear()
     if not _PENDING_SLABS:
         return
     items, _PENDING_SLABS[:] = list(_PENDING_SLABS), []
-    for slabs, out, numel, splits, param in items:
+    for slabs, out, numel, splits, param, _ in items:
         # the contract checked where it is cheap (once per eager step / capture pass): the buffer being completed below IS
         # the parameter's gradient.  Anything else -- autograd copied or accumulated the unreduced buffer -- is garbage already.
         if param is not None and (param.grad is None or param.grad.data_ptr() != out.data_ptr()):
@@ -663,10 +684,10 @@ def flush_wgrad_reduces():
                                'set SEMSEG_DEFER_WGRAD_REDUCE=0 or keep conv weights as KRSC leaves used once per step'
                                % (tuple(param.shape), param.stride(), 'missing' if param.grad is None else 'copied'))
     arr = (_native.SlabTensor * len(items))()
-    cur = torch.cuda.current_stream() if items[0][0].is_cuda else None
-    for i, (slabs, out, numel, splits, _) in enumerate(items):
+    on_dev = items[0][0].is_cuda
+    for i, (slabs, out, numel, splits, _, _) in enumerate(items):
         arr[i].slabs, arr[i].out, arr[i].numel, arr[i].splits = slabs.data_ptr(), out.data_ptr(), numel, splits
-        if cur is not None:                  # slabs / gradient allocated on a branch stream, summed on this one
+        if on_dev:                           # slabs / gradient allocated on a branch stream, summed on this one
             slabs.record_stream(cur)
             out.record_stream(cur)
     _native.check(_native.lib().semseg_reduce_slabs_multi(arr, len(items), _st()), 'reduce_slabs_multi')
@@ -682,6 +703,10 @@ def _is_leaf_weight(weight):
     # returned [K, C, R, S] view of the KRSC gradient buffer match the parameter's and AccumulateGrad adopts the buffer itself.
     # A KCRS-contiguous nn.Parameter would get a COPY, taken before the deferred launches have run.
     return bool(weight.dim() == 4 and weight.permute(0, 2, 3, 1).is_contiguous())
+
+
+def _producer_stream(t):
+    return torch.cuda.current_stream(t.device) if t.is_cuda else None
 
 
 def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, param=None):
@@ -703,12 +728,12 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, p
             nbytes = L.semseg_conv2d_wgrad_slabs_bytes(*geom)
             slabs = torch.empty((max(16, nbytes) + 3) // 4, device=dev, dtype=torch.float32)
             if DEFER_WGRAD_LAUNCH and L.semseg_conv2d_wgrad_tile_h2(*geom) == 1:
-                _PENDING_WGRADS.append((xs, dys, slabs, dwb, tuple(geom), param))
+                _PENDING_WGRADS.append((xs, dys, slabs, dwb, tuple(geom), param, _producer_stream(dwb)))
             else:
                 splits = ctypes.c_int(0)
                 _native.check(L.semseg_conv2d_wgrad_slabs_h2(_p(xs), _p(dys), _p(slabs), slabs.numel() * 4, ctypes.byref(splits),
                                                              *geom, _st()), 'conv2d_wgrad_slabs_h2')
-                _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value), param))
+                _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value), param, _producer_stream(dwb)))
         else:
             launch_w()
         dw = dwb.permute(0, 3, 1, 2)
@@ -1025,7 +1050,7 @@ def _winograd_wgrad(L, v, dzp, geom):
 # and read back by the unfused pair).  Which form runs is measured per geometry (tuner.choose); SEMSEG_WINOGRAD_FUSED=0 keeps
 # the batched GEMM + output transform everywhere.
 WINOGRAD_FUSED = os.environ.get('SEMSEG_WINOGRAD_FUSED', '1') != '0'
-WINOGRAD_FUSED_FORMS = 7          # library forms of the fused kernel: 32-deep k-tiles (8 waves on a 3- / 4- / 5-slot ring, 4 waves on 4 / 5
+WINOGRAD_FUSED_FORMS = 10         # library forms of the fused kernel: 32-deep k-tiles (8 waves on a 3- / 4- / 5-slot ring, 4 waves on 4 / 5
                                   # slots), 64-deep k-tiles with full-line DMA pieces on a half-tile ring (8 / 4 waves)
 
 
@@ -1213,7 +1238,7 @@ class ConvBNActFn(Function):
         ctx.save_for_backward(xp, w, wtp, z, y if keep_y else None, coef, g, stats, zmm, wino_v, gate, wut)
         ctx.geom = geom
         ctx.cfg = (bool(relu), residual is not None)
-        ctx.w_param = _note_weight_use(weight)
+        ctx.w_param = _note_weight_use(weight, ctx.needs_input_grad[1])
         box['planes'], box['absmax'] = yp, absmax
         return y
 

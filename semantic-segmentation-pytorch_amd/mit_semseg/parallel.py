@@ -101,12 +101,16 @@ class GradientBuckets:
         self._bucket_of = {}
         self._hooks = []
         self.armed = False
+        # weight gradients deferred by ops.defer_wgrad_reduces are completed by the hook that completes their bucket (_on_grad),
+        # which needs the hooks; without them (overlap=False / an old torch) every gradient is finished where it is produced
+        self.flushes_deferred = False
         for bi, b in enumerate(self.buckets):
             for p, _, _ in b['items']:
                 self._bucket_of[p] = bi
         if overlap and hasattr(torch.Tensor, 'register_post_accumulate_grad_hook'):
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            self.flushes_deferred = os.environ.get('SEMSEG_DEFER_WGRAD_BUCKETS', '1') != '0'
 
     def _make_bucket(self, items, total):
         dev = items[0][0].device
@@ -184,6 +188,10 @@ class GradientBuckets:
 
     def _launch(self, b):
         b['launched'] = True
+        if ops.deferring() or ops._PENDING_SLABS or ops._PENDING_WGRADS:
+            # every gradient of this bucket has been ACCUMULATED (the hooks counted them) but the deferred ones are still slabs /
+            # not yet launched: finish them before anything reads the bucket's gradients
+            ops.flush_wgrad_reduces(mid_backward=self.armed and ops.deferring())
         self._stage(b)
         if ops._SEGMENTS is not None:
             # segmented hipGraph capture (engine.SegmentedStep): the staging copies above belong to the segment being

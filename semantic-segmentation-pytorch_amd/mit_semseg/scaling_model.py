@@ -73,6 +73,9 @@ class TimelineProbe:
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
+            from . import ops
+            if ops.deferring():              # what GradientBuckets._launch does on a rank before a bucket travels
+                ops.flush_wgrad_reduces(mid_backward=True)
             self.mark('bucket%d' % bi)
 
     def detach(self):
@@ -153,8 +156,9 @@ def model_line(t1_ms, ticks, bucket_bytes, bn_channels, assumptions=None, t_rank
                    'all-reduce over one xGMI link per hop + per-exchange SyncBN cost; mit_semseg/scaling_model.py',
            'measured_1gpu_ms_per_step': round(t_ref, 3),
            'measured_rank_form_ms_per_step': round(t1_ms, 3),
-           'rank_form': 'the same step with every weight gradient launched and reduced where autograd reaches it (what a rank under '
-                        'gradient buckets runs; the single-GPU step batches them after backward), timed on this GPU',
+           'rank_form': 'the same step with the deferred / batched weight gradients finished once per gradient bucket, by the hook '
+                        'that completes the bucket (what a rank under gradient buckets runs; the single-GPU step finishes all of '
+                        'them in one go after backward), timed on this GPU',
            'timeline_ms': {k: round(v, 3) for k, v in marks.items()},
            'bucket_bytes': list(bucket_bytes), 'gradient_bytes': int(sum(bucket_bytes)),
            'syncbn_exchanges_per_step': 2 * len(bn_channels),

@@ -60,8 +60,7 @@ def test_shared_or_preloaded_weights_are_not_deferred():
     assert not ops._may_defer(v)
     u = _krsc(8, 4, 3, 3)
     assert not ops._may_defer(u)                      # no recorded use (a flush between forward and backward)
-    with torch.no_grad():
-        assert ops._note_weight_use(_krsc(8, 4, 3, 3)) is None
+    assert ops._note_weight_use(_krsc(8, 4, 3, 3), wanted=False) is None     # no backward will come (no_grad / frozen input)
     assert not ops._may_defer(None)
 
 
@@ -80,12 +79,12 @@ def test_flush_refuses_a_gradient_that_autograd_did_not_adopt(monkeypatch):
     w = _krsc(8, 4, 3, 3)
     buf = torch.zeros(8, 3, 3, 4)
     w.grad = buf.permute(0, 3, 1, 2).clone()          # a copy, as AccumulateGrad makes for a layout it does not adopt
-    ops._PENDING_SLABS.append((torch.zeros(16), buf, buf.numel(), 1, w))
+    ops._PENDING_SLABS.append((torch.zeros(16), buf, buf.numel(), 1, w, None))
     with pytest.raises(RuntimeError, match='did not become its .grad'):
         ops.flush_wgrad_reduces()
     assert not launched and not ops._PENDING_SLABS
     w.grad = buf.permute(0, 3, 1, 2)                  # adopted: the launch goes out
-    ops._PENDING_SLABS.append((torch.zeros(16), buf, buf.numel(), 1, w))
+    ops._PENDING_SLABS.append((torch.zeros(16), buf, buf.numel(), 1, w, None))
     ops.flush_wgrad_reduces()
     assert len(launched) == 1
 
@@ -98,3 +97,37 @@ def test_a_failed_backward_launches_nothing_and_keeps_its_exception(monkeypatch)
             ops._PENDING_WGRADS.append('half-built')
             1 / 0
     assert not ops._PENDING_SLABS and not ops._PENDING_WGRADS
+
+
+def test_a_gradient_bucket_flushes_the_deferred_gradients_before_it_is_staged(monkeypatch):
+    """data-parallel ranks keep the batched / deferred weight gradients (round-4 review, item 7): the hook that completes a bucket
+    finishes whatever is pending BEFORE the bucket's gradients are copied into the flat buffer and sent -- for every bucket, in
+    backward order, and never after a bucket has been staged"""
+    from mit_semseg import parallel
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 16), nn.ReLU(), nn.Linear(16, 4))
+    gb = parallel.GradientBuckets(net.parameters(), bucket_bytes=4 * 200, group=None, comm_stream=None, tail_bytes=4 * 40)
+    assert len(gb.buckets) >= 3 and gb.flushes_deferred
+    events = []
+    monkeypatch.setattr(ops, 'flush_wgrad_reduces', lambda mid_backward=False: events.append(('flush', mid_backward)))
+    real_stage = parallel.GradientBuckets._stage
+    monkeypatch.setattr(parallel.GradientBuckets, '_stage',
+                        lambda self, b: (events.append(('stage', self.buckets.index(b))), real_stage(self, b))[1])
+    monkeypatch.setattr(ops, 'CONV_MODE', 'h2')
+    gb.prepare()
+    with ops.defer_wgrad_reduces(flush_at_buckets=True):
+        assert ops.deferring()
+        net(torch.randn(3, 8)).sum().backward()
+        inside = list(events)
+    gb.finish()
+    staged = [e for e in events if e[0] == 'stage']
+    assert [i for _, i in staged] == list(range(len(gb.buckets)))             # every bucket once, in backward order
+    for k, e in enumerate(inside):
+        if e[0] == 'stage':
+            assert inside[k - 1] == ('flush', True), inside                   # mid-backward flush right before each staging
+    # without the bucket flushes a rank must not defer at all while SyncBN is active
+    monkeypatch.setattr(ops, '_sync_active', lambda: True)
+    with ops.defer_wgrad_reduces(flush_at_buckets=False):
+        assert not ops.deferring()
+    with ops.defer_wgrad_reduces(flush_at_buckets=True):
+        assert ops.deferring()

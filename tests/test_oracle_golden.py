@@ -41,14 +41,24 @@ def test_oracle_matches_reference(name):
             check_summary(sd[k], want[k], 1e-4, 1e-3, 'after-step ' + k)
 
 
-@pytest.mark.parametrize('case', ['cfg1_r50d_ppmds_512', 'cfg2_r50_upernet_512'])
-def test_oracle_matches_reference_at_full_size(case):
-    """BASELINE configs[1] / configs[2] at 2 x 512 x 512: the oracle's training-mode forward against the stored forward of the
-    unmodified reference (tests/golden/make_fullsize_golden.py) -- the oracle the 512 x 512 GPU parity test runs on the box is
-    pinned at that size too"""
+# forward of every full-size fixture; the backward too (every gradient tensor, the state after the step) where the CPU suite can
+# afford it: configs[1], the metric's config (SEMSEG_FULLSIZE_BACKWARD=all runs it for every case: ~10 min on 8 cores)
+_ALL_BWD = os.environ.get('SEMSEG_FULLSIZE_BACKWARD', '') == 'all'
+
+
+@pytest.mark.parametrize('case,backward', [('cfg1_r50d_ppmds_512', True), ('cfg2_r50_upernet_512', _ALL_BWD),
+                                           ('cfg3_r101d_ppmds_376x504', _ALL_BWD), ('cfg3_r101d_ppmds_456x680', _ALL_BWD),
+                                           ('cfg4_hrnetv2_c1_512', _ALL_BWD)])
+def test_oracle_matches_reference_at_full_size(case, backward):
+    """BASELINE configs[1..4] at full size (2 x 512 x 512; two variable-size shapes for configs[3]): the oracle's training step
+    against the stored step of the unmodified reference (tests/golden/make_fullsize_golden.py) -- forward: log-probabilities of the
+    pixel sample, the arg-max of every pixel, loss, accuracy; backward: EVERY gradient tensor and the state after the SGD step
+    against the float64 anchors in units of the reference's own fp32 band (the acceptance the GPU test applies to the HIP path,
+    here applied to the oracle, so the yardstick itself is pinned on the CPU)"""
     import json
     from oracle import semseg_oracle as O
-    from tests.util import load_fullsize_golden
+    from tests.util import (load_fullsize_golden, anchor_ratios, check_anchor_ratios, post_step_bands, post_step_record, is_head_tensor,
+                            scale_error, HEAD_SCALE_ERR)
     fx = load_fullsize_golden(case)
     assert fx is not None
     m = fx['meta']
@@ -59,15 +69,46 @@ def test_oracle_matches_reference_at_full_size(case):
     if m['arch_decoder'] == 'ppm_deepsup':
         drop['deepsup'] = O.synth_dropout_mask(2, m['fc_dim'] // 4, seed=m['seed_dropout'][1])
     img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=m['seed_batch'])
-    with torch.no_grad():
-        res = O.segmentation_forward(O.clone_sd(enc_sd, False), O.clone_sd(dec_sd, False), m['arch_encoder'], m['arch_decoder'], img, lab,
+    e, d = O.clone_sd(enc_sd, backward), O.clone_sd(dec_sd, backward)
+    with torch.set_grad_enabled(backward):
+        res = O.segmentation_forward(e, d, m['arch_encoder'], m['arch_decoder'], img, lab,
                                      training=True, dropout=drop, deep_sup_scale=m['deep_sup_scale'])
-    n, c, h, w = res['pred'].shape
-    rows = res['pred'].permute(0, 2, 3, 1).reshape(n * h * w, c)
+    pred = res['pred'].detach()
+    n, c, h, w = pred.shape
+    assert [n, c, h, w] == list(m['pred_shape'])
+    rows = pred.permute(0, 2, 3, 1).reshape(n * h * w, c)
     torch.testing.assert_close(rows[fx['pixels']], fx['logp'], atol=ATOL * 10, rtol=RTOL)
     assert torch.equal(rows.argmax(1).reshape(n, h, w), fx['argmax'].long())
-    torch.testing.assert_close(res['loss'], fx['loss'], atol=ATOL, rtol=RTOL)
+    torch.testing.assert_close(res['loss'].detach(), fx['loss'], atol=ATOL, rtol=RTOL)
     torch.testing.assert_close(res['acc'], fx['acc'], atol=0, rtol=0)
+    assert abs(fx['loss64'] - fx['loss'].item()) < 1e-4
+    for side in ('enc', 'dec'):
+        assert all(k.rsplit('.', 1)[-1] in ('running_mean', 'running_var') for k in fx['anchor_after_' + side])
+    if not backward:
+        return
+    res['loss'].backward()
+    lr = m['lr']
+    items, heads = [], []
+    for sd, side in ((e, 'enc'), (d, 'dec')):
+        want = fx['anchor_grads_' + side]
+        params = {k: v for k, v in sd.items() if v.requires_grad}
+        assert sorted(params) == sorted(want)
+        for k, v in params.items():
+            items.append((side + '.' + k, v.grad, want[k]))
+            if side == 'dec' and is_head_tensor(k, v):
+                heads.append((scale_error(v.grad, want[k]), k))
+    print(check_anchor_ratios(anchor_ratios(items), case + ' oracle gradients'))
+    assert heads and max(heads)[0] <= HEAD_SCALE_ERR, heads
+    items = []
+    for sd, sd0, side in ((e, enc_sd, 'enc'), (d, dec_sd, 'dec')):
+        params = {k: v for k, v in sd.items() if v.requires_grad}
+        O.sgd_step(params, {k: v.grad for k, v in params.items()}, {}, lr)
+        for k, v in params.items():
+            wd = 1e-4 if v.dim() == 4 else 0.0          # train.py:92-112: conv weights only
+            items.append((side + '.' + k, v, post_step_record(fx['anchor_grads_' + side][k], sd0[k], lr, wd)))
+        for k, rec in fx['anchor_after_' + side].items():
+            items.append((side + '.' + k, sd[k], rec))
+    print(check_anchor_ratios(anchor_ratios(items, post_step_bands(fx, lr)), case + ' oracle after-step state'))
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -172,6 +172,24 @@ def post_step_bands(g, lr):
     return out
 
 
+def post_step_record(rec, w0, lr, wd):
+    """anchor record of a PARAMETER after the first SGD step from the record of its gradient: w1 = w0 - lr (g + wd w0) (momentum
+    buffer = g on the first step, train.py:117-126), elementwise on the stored elements of the float64 gradient; the band of w1 is
+    lr x the band of g (tests/util.post_step_bands)"""
+    w = w0.detach().double().flatten()
+    out = dict(rec)
+    if 'full' in rec:
+        g = rec['full'].double().flatten()
+        out['full'] = (w - lr * (g + wd * w))
+    else:
+        g = rec['sample'].double()
+        ws = w[sample_index(rec['numel'])]
+        out['sample'] = (ws - lr * (g + wd * ws))
+    out['err_max'], out['err_l2'] = lr * rec['err_max'], lr * rec['err_l2']
+    out['absmax'] = w.abs().max().item()
+    return out
+
+
 def is_head_tensor(key, p, num_class=150):
     """decoder parameters with NO ReLU gate between them and the loss: the 1x1 classifier convs (models.py:456-465 conv_last[4] /
     conv_last_deepsup of the PPM heads, :540 conv_last[1] of UPerNet, :366 conv_last of C1 / C1DeepSup) -- recognised by their
