@@ -317,6 +317,22 @@ int semseg_bn_bwd_reduce_fused_peer(const float* dy, int dy_ld, const float* y, 
                                     int training, double* sums, float* dgamma, float* dbeta, void* blockbound,
                                     void* workspace, size_t workspace_bytes, void* stream, void* peer);
 
+/* semseg_bn_bwd_reduce_fused(_peer) / semseg_bn_bwd_apply_h2 with the incoming gradient given as TWO addends, dy + dy2: the two
+ * gradients that meet where the autograd graph forks (a block output feeds the next block's first conv AND its shortcut,
+ * resnet.py:72-92; an encoder map feeds two heads, models.py:253-268).  torch adds them with a kernel of its own before the BN
+ * backward reads the sum twice; here the sum is formed where it is consumed -- the same single fp32 add per element, so the results
+ * are those of the materialised sum bit for bit.  dy2: [P][dy2_ld], dy2_ld >= C; peer: NULL on a single rank. */
+int semseg_bn_bwd_reduce_fused_sum2(const float* dy, int dy_ld, const float* dy2, int dy2_ld, const float* y, int y_ld,
+                                    const float* z, const float* mean, const float* invstd, const float* gate_scale,
+                                    const float* gate_shift, int relu, int P, int C, const double* stats_count, const float* zmm,
+                                    const float* gamma, int training, double* sums, float* dgamma, float* dbeta, void* blockbound,
+                                    void* workspace, size_t workspace_bytes, void* stream, void* peer /* nullable */);
+int semseg_bn_bwd_apply_h2_sum2(const float* dy, int dy_ld, const float* dy2, int dy2_ld, const float* y, int y_ld, const float* z,
+                                const float* mean, const float* invstd, const float* gamma,
+                                const double* sums, const double* stats_count, int training, int relu,
+                                void* dz_planes, float* dres, int P, int C,
+                                const float* gate_scale, const float* gate_shift, const void* blockbound, void* stream);
+
 /* ---------------- elementwise helpers ------------------------------------------------------ */
 /* out = act(a + b) (hrnet.py:231-248 fuse sums); a,b,out [P,C] with their own ld */
 int semseg_add_act(const float* a, int a_ld, const float* b, int b_ld, int relu, float* out, int out_ld,

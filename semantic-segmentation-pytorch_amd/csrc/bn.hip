@@ -775,7 +775,11 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
                                                                 int cx, int py, int rows_per_block,
                                                                 double* __restrict__ partial, float* __restrict__ gm,
                                                                 const float* __restrict__ gscale,
-                                                                const float* __restrict__ gshift) {
+                                                                const float* __restrict__ gshift,
+                                                                const float* __restrict__ dy2, int dy2_ld) {
+    // dy2 != nullptr: the incoming gradient is the SUM dy + dy2 of the two gradients that meet at a fork (ops.ForkFn: block
+    // output -> next block's first conv + its shortcut), added here -- one fp32 add per element, the value the add kernel would
+    // have written -- instead of being materialised by a launch of its own and read back
     extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][4] floats
     float* redf = reinterpret_cast<float*>(red + (size_t)py * cx * 8);
     const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
@@ -823,13 +827,26 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
                 v[u] = *reinterpret_cast<const float4*>(z + (size_t)(p + u * py) * C + c);
                 yy[u] = gate_of(p + u * py);
             }
+            if (dy2) {                    // block-uniform
+                float4 h[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) h[u] = *reinterpret_cast<const float4*>(dy2 + (size_t)(p + u * py) * dy2_ld + c);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < U; ++u) { g[u].x += h[u].x; g[u].y += h[u].y; g[u].z += h[u].z; g[u].w += h[u].w; }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < U; ++u) acc(g[u], v[u], yy[u]);
         }
-        for (; p < row1; p += py)
-            acc(*reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c), *reinterpret_cast<const float4*>(z + (size_t)p * C + c),
-                gate_of(p));
+        for (; p < row1; p += py) {
+            float4 g1 = *reinterpret_cast<const float4*>(dy + (size_t)p * dy_ld + c);
+            if (dy2) {
+                const float4 h = *reinterpret_cast<const float4*>(dy2 + (size_t)p * dy2_ld + c);
+                g1.x += h.x; g1.y += h.y; g1.z += h.z; g1.w += h.w;
+            }
+            acc(g1, *reinterpret_cast<const float4*>(z + (size_t)p * C + c), gate_of(p));
+        }
     }
     if (ty < py) {
         double* r = red + ((size_t)ty * cx + tx) * 8;
@@ -904,10 +921,10 @@ extern "C" int semseg_bn_bwd_reduce_mm(const float* dy, int dy_ld, const float* 
     const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
     if (relu)
         hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<2>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
-                           relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr);
+                           relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr, nullptr, 0);
     else
         hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<0>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
-                           relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr);
+                           relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr, nullptr, 0);
     SEMSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_mm_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)partial,
                        (const float*)gm, g.gy, C, sums, gmax, dgamma, dbeta);
@@ -966,7 +983,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
                                                               int* __restrict__ hdr, float* __restrict__ dres, int P,
                                                               int C, int Cp, const float* __restrict__ gscale,
                                                               const float* __restrict__ gshift,
-                                                              const uint32_t* __restrict__ blockbound, int nbound) {
+                                                              const uint32_t* __restrict__ blockbound, int nbound,
+                                                              const float* __restrict__ dy2, int dy2_ld) {
+    // dy2 != nullptr: the incoming gradient is dy + dy2 (see bn_bwd_mm_partial_kernel)
     const int ex = h2_exponent_from(hdr, blockbound, nbound, nullptr);
     const float sc2 = pow2i(ex);
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
@@ -1027,7 +1046,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
         float g[8], v[8], yy[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 g4 = *reinterpret_cast<const float4*>(dy + p * dy_ld + c + 4 * h);
+            float4 g4 = *reinterpret_cast<const float4*>(dy + p * dy_ld + c + 4 * h);
+            if (dy2) {                    // grid-uniform
+                const float4 h4 = *reinterpret_cast<const float4*>(dy2 + p * dy2_ld + c + 4 * h);
+                g4.x += h4.x; g4.y += h4.y; g4.z += h4.z; g4.w += h4.w;
+            }
             g[4 * h] = g4.x; g[4 * h + 1] = g4.y; g[4 * h + 2] = g4.z; g[4 * h + 3] = g4.w;
             float4 v4 = f4zero();
             if (TRAIN || gate_z) v4 = *reinterpret_cast<const float4*>(z + p * C + c + 4 * h);
@@ -1067,11 +1090,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
     }
 }
 
-extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
-                                      const float* mean, const float* invstd, const float* gamma, const double* sums,
-                                      const double* stats_count, int training, int relu, void* dz_planes, float* dres, int P,
-                                      int C, const float* gate_scale, const float* gate_shift, const void* blockbound,
-                                      void* stream) {
+static int bn_bwd_apply_h2_impl(const float* dy, int dy_ld, const float* dy2, int dy2_ld, const float* y, int y_ld, const float* z,
+                                const float* mean, const float* invstd, const float* gamma, const double* sums,
+                                const double* stats_count, int training, int relu, void* dz_planes, float* dres, int P,
+                                int C, const float* gate_scale, const float* gate_shift, const void* blockbound,
+                                void* stream) {
+    if (dy2 && ((dy2_ld % 4) || dy2_ld < C || !aligned16(dy2))) return SEMSEG_EINVAL;
     if (!dy || !invstd || !gamma || !dz_planes || P <= 0 || C <= 0 || (C % 8) || (dy_ld % 4) || dy_ld < C ||
         !aligned16(dy) || !aligned16(dz_planes))
         return SEMSEG_EINVAL;
@@ -1089,7 +1113,7 @@ extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y
     const int target = quarter > 1024 ? quarter : 1024;
     if (blocks > target) blocks = target;
     const int nbound = ceil_div(C, 16);
-#define LAUNCH(T, R, D) hipLaunchKernelGGL((bn_bwd_apply_h2_kernel<T, R, D>), dim3(blocks), dim3(256), 0, st, dy, dy_ld, y, y_ld, z, mean, invstd, gamma, sums, stats_count, (uint16_t*)dz_planes, plane, pitch, hdr, dres, P, C, Cp, gate_scale, gate_shift, (const uint32_t*)blockbound, nbound)
+#define LAUNCH(T, R, D) hipLaunchKernelGGL((bn_bwd_apply_h2_kernel<T, R, D>), dim3(blocks), dim3(256), 0, st, dy, dy_ld, y, y_ld, z, mean, invstd, gamma, sums, stats_count, (uint16_t*)dz_planes, plane, pitch, hdr, dres, P, C, Cp, gate_scale, gate_shift, (const uint32_t*)blockbound, nbound, dy2, dy2_ld)
     const int key = (training ? 4 : 0) | (relu ? 2 : 0) | (dres ? 1 : 0);
     switch (key) {
         case 0: LAUNCH(false, false, false); break;
@@ -1104,6 +1128,26 @@ extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y
 #undef LAUNCH
     SEMSEG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int semseg_bn_bwd_apply_h2(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
+                                      const float* mean, const float* invstd, const float* gamma, const double* sums,
+                                      const double* stats_count, int training, int relu, void* dz_planes, float* dres, int P,
+                                      int C, const float* gate_scale, const float* gate_shift, const void* blockbound,
+                                      void* stream) {
+    return bn_bwd_apply_h2_impl(dy, dy_ld, nullptr, 0, y, y_ld, z, mean, invstd, gamma, sums, stats_count, training, relu, dz_planes,
+                                dres, P, C, gate_scale, gate_shift, blockbound, stream);
+}
+
+// ... with the incoming gradient as two addends, dy + dy2 (semseg_bn_bwd_reduce_fused_sum2)
+extern "C" int semseg_bn_bwd_apply_h2_sum2(const float* dy, int dy_ld, const float* dy2, int dy2_ld, const float* y, int y_ld,
+                                           const float* z, const float* mean, const float* invstd, const float* gamma,
+                                           const double* sums, const double* stats_count, int training, int relu, void* dz_planes,
+                                           float* dres, int P, int C, const float* gate_scale, const float* gate_shift,
+                                           const void* blockbound, void* stream) {
+    if (!dy2) return SEMSEG_EINVAL;
+    return bn_bwd_apply_h2_impl(dy, dy_ld, dy2, dy2_ld, y, y_ld, z, mean, invstd, gamma, sums, stats_count, training, relu, dz_planes,
+                                dres, P, C, gate_scale, gate_shift, blockbound, stream);
 }
 
 
@@ -1434,7 +1478,8 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
                                     const float* gate_shift, int relu, int P, int C, const double* stats_count,
                                     const float* zmm, const float* gamma, int training, double* sums, float* dgamma,
                                     float* dbeta, void* blockbound, void* workspace, size_t workspace_bytes,
-                                    void* stream, void* peer) {
+                                    void* stream, void* peer, const float* dy2 = nullptr, int dy2_ld = 0) {
+    if (dy2 && ((dy2_ld % 4) || dy2_ld < C || !aligned16(dy2))) return SEMSEG_EINVAL;
     semseg_peer::PeerArgs pa = {};
     if (peer && (!semseg_peer::peer_args(peer, &pa) || 2 * C > pa.cap)) return SEMSEG_EINVAL;
     if (peer && !exchange_grid_fits(bn_bwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;      // before any launch
@@ -1453,7 +1498,7 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
     const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
 #define LAUNCH_PARTIAL(GATE)                                                                                              \
     hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<GATE>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, \
-                       invstd, relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, gate_scale, gate_shift)
+                       invstd, relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, gate_scale, gate_shift, dy2, dy2_ld)
     if (!relu) LAUNCH_PARTIAL(0);
     else if (gate_scale) LAUNCH_PARTIAL(1);
     else if (y_ld == 0) LAUNCH_PARTIAL(3);          // `y` is the forward's ReLU bitmask
@@ -1491,6 +1536,20 @@ extern "C" int semseg_bn_bwd_reduce_fused_peer(const float* dy, int dy_ld, const
     if (!peer) return SEMSEG_EINVAL;
     return bn_bwd_reduce_fused_impl(dy, dy_ld, y, y_ld, z, mean, invstd, gate_scale, gate_shift, relu, P, C, stats_count, zmm, gamma,
                                     training, sums, dgamma, dbeta, blockbound, workspace, workspace_bytes, stream, peer);
+}
+
+// the same with the incoming gradient given as TWO addends (dy + dy2: the two gradients that meet at a fork of the autograd graph,
+// ops.ForkFn -- e.g. a block output that feeds the next block's first conv and its shortcut, resnet.py:84-92): the sum is formed
+// where it is consumed instead of by an add launch of its own.  peer may be NULL (single rank).
+extern "C" int semseg_bn_bwd_reduce_fused_sum2(const float* dy, int dy_ld, const float* dy2, int dy2_ld, const float* y, int y_ld,
+                                               const float* z, const float* mean, const float* invstd, const float* gate_scale,
+                                               const float* gate_shift, int relu, int P, int C, const double* stats_count,
+                                               const float* zmm, const float* gamma, int training, double* sums, float* dgamma,
+                                               float* dbeta, void* blockbound, void* workspace, size_t workspace_bytes,
+                                               void* stream, void* peer) {
+    if (!dy2) return SEMSEG_EINVAL;
+    return bn_bwd_reduce_fused_impl(dy, dy_ld, y, y_ld, z, mean, invstd, gate_scale, gate_shift, relu, P, C, stats_count, zmm, gamma,
+                                    training, sums, dgamma, dbeta, blockbound, workspace, workspace_bytes, stream, peer, dy2, dy2_ld);
 }
 
 // widest BN (channels) whose exchanging finish kernels -- ceil(C / 16) blocks that poll each other's peers inside the kernel -- are

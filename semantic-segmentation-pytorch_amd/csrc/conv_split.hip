@@ -103,7 +103,7 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
 // software-pipelined fragment reads (one barrier per k-tile), 10 = the 3-slot ring 4 with the same pipeline.  wgrad tiles: 0 = 128x128, 1 = 64x64 (register
 // staged); h2 only: 2 = 128x128 LDS-DMA 2-slot, 3 = 256x128 LDS-DMA 3-slot ring, 4 = 256x256 LDS-DMA 2-slot, 5 / 6 = 2 / 4 with
 // software-pipelined fragment reads.
-static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 10 : 1) : (sch == SchH2::ID ? 24 : 3); }
+static int max_tile(int sch, int pass) { return pass == 2 ? (sch == SchH2::ID ? 14 : 1) : (sch == SchH2::ID ? 26 : 3); }
 
 static inline bool tile_is_k64(int tile);
 // wgrad tile 10 (wgrad_taps_kernel) takes 3x3 stride-1 pad == dil convolutions whose output rows are whole 32-pixel chunks
@@ -124,7 +124,7 @@ static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R,
     // to 32 channels must be whole 64-channel chunks
     if ((pass == 0 || pass == 1 || pass == 3) && tile_is_k64(tile) && (((pass == 1 ? K : C) + 31) / 32) % 2) return SEMSEG_EINVAL;
     if (pass == 3 && tile >= 0 && (sch != SchH2::ID || split != 1 || !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 ||
-                                                                       tile == 10 || tile == 14 || tile == 22 || tile == 24)))
+                                                                       tile == 10 || tile == 14 || tile == 22 || tile == 24 || tile == 25 || tile == 26)))
         return SEMSEG_EINVAL;
     std::lock_guard<std::mutex> lk(g_plans_mu);
     const SKey key{sch, pass, N, H, W, C, K, R, S, stride, pad, dil};
@@ -879,9 +879,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     constexpr int LPT = NP * (AG + BG);                // DMA instructions per wave per tile
     constexpr int A_BYTES = NP * BM * 64, B_BYTES = NP * BN * 64, BUF_BYTES = A_BYTES + B_BYTES;
     static_assert(AG >= 1 && BG >= 1 && FM >= 1 && FN >= 1, "tile");
-    static_assert(NSLOT == 2 || NSLOT == 3 || (NSLOT >= 12 && NSLOT <= 15), "slots");     // 12 ... 15: 2 ... 5 slots, software-pipelined fragment reads
-    constexpr int RING = NSLOT >= 12 ? NSLOT - 10 : NSLOT;
+    // 12 ... 15: 2 ... 5 slots, software-pipelined fragment reads; 25 (round 5): ring of FIVE HALF tiles -- an entry is the A rows or
+    // the B rows of a k-tile, as in igemm_dma64_kernel -- with the DMA pieces spread behind the MFMA groups
+    static_assert(NSLOT == 2 || NSLOT == 3 || (NSLOT >= 12 && NSLOT <= 15) || NSLOT == 25, "slots");
+    constexpr int RING = NSLOT == 25 ? 3 : (NSLOT >= 12 ? NSLOT - 10 : NSLOT);
     static_assert((RING > 3 ? RING - 1 : 3) * LPT < 64, "vmcnt range");
+    static_assert(NSLOT != 25 || (BM == BN && NP == 2), "the half-tile ring takes square tiles of the h2 scheme");
 
     extern __shared__ __align__(16) uint4 smem4[];
     unsigned char* smem = reinterpret_cast<unsigned char*>(smem4);
@@ -1080,6 +1083,99 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
         }
     };
 
+    if constexpr (NSLOT == 25) {
+        // ---- ring of five half tiles (round 5) --------------------------------------------------------------------------------------
+        // The 256 x 256 block keeps two planes per operand: a 32-deep k-tile is 64 KiB, two whole slots are all the LDS holds, so
+        // tile it+2 could only be issued -- as one burst of LPT pieces per wave -- after the barrier that ends tile it, ONE tile
+        // before it is needed.  Entries of HALF a tile (the A rows, then the B rows: A_BYTES each) make the ring five deep in the
+        // same 160 KiB: tile it is multiplied from two slots, three entries (1.5 tiles) are in flight, and the two entries that
+        // refill the slots of tile it are issued behind DIFFERENT MFMA groups (the B rows of tile it+2 behind the second group of
+        // tile it, the A rows of tile it+3 behind the first group of tile it+1), not together right after the barrier
+        // (profiles/r6_*: the same change on the 64-deep kernels).  Same fragments, same MFMA order: bit-identical results.
+        constexpr int PPE = NP * AG;                       // pieces per wave per entry (AG == BG)
+        constexpr int NENT = 5;
+        static_assert(3 * PPE < 64, "vmcnt range");
+        int i_ent = 0, i_slot = 0;
+        auto issue_entry = [&]() {
+            const bool live = kt_begin + (i_ent >> 1) < kt_end;              // wave-uniform
+            const bool is_b = i_ent & 1;
+            const uint32_t base = lds0 + (uint32_t)i_slot * A_BYTES;
+            if (!is_b) {
+                uint32_t ka_b = 0;
+                if (live) {
+                    if (kw.dirty) {
+                        set_tap(kw.t, kw.r, kw.s);
+                        kw.dirty = false;
+                    }
+                    ka_b = 2u * 32u * (uint32_t)kw.cc;
+                }
+#pragma unroll
+                for (int i = 0; i < AG; ++i)
+#pragma unroll
+                    for (int s2 = 0; s2 < NP; ++s2) {
+                        const uint32_t vo = live ? a_src[i] + ((ka_b + s2 * a_plane_b) & a_msk[i]) : a_zero;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)(base + (s2 * BM + NW * i * 16) * 64), 16, vo,
+                                                                 0, 0, 0);
+                    }
+            } else {
+                uint32_t kb_b = 0;
+                if (live) {
+                    kb_b = 2u * ((uint32_t)kw.t * p.pitch + 32u * (uint32_t)kw.cc);
+                    kw.advance(p);                          // the tile's B entry closes it
+                }
+#pragma unroll
+                for (int i = 0; i < BG; ++i)
+#pragma unroll
+                    for (int s2 = 0; s2 < NP; ++s2) {
+                        const uint32_t vo = live ? b_src[i] + ((kb_b + s2 * b_plane_b) & b_msk[i]) : b_zero;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)(base + (s2 * BN + NW * i * 16) * 64), 16, vo,
+                                                                 0, 0, 0);
+                    }
+            }
+            ++i_ent;
+            i_slot = (i_slot == NENT - 1) ? 0 : i_slot + 1;
+        };
+        auto read_frags2 = [&](int sa, int sb, int ks, frag (&av)[FM][NP], frag (&bv)[FN][NP]) {
+            const uint4* As = reinterpret_cast<const uint4*>(smem + sa * A_BYTES);
+            const uint4* Bs = reinterpret_cast<const uint4*>(smem + sb * A_BYTES);
+            const int ch = 2 * ks + kb;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = wn * WN + j * 32 + frow;
+#pragma unroll
+                for (int s2 = 0; s2 < NP; ++s2) bv[j][s2] = *reinterpret_cast<const frag*>(&Bs[s2 * BN * 4 + s_slot(r, ch)]);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = wm * WM + i * 32 + frow;
+#pragma unroll
+                for (int s2 = 0; s2 < NP; ++s2) av[i][s2] = *reinterpret_cast<const frag*>(&As[s2 * BM * 4 + s_slot(r, ch)]);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < NENT; ++j) issue_entry();        // A(0) B(0) A(1) B(1) A(2)
+        frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+        wait_vm_barrier<3 * PPE>();                           // entries 0 and 1 have landed for every wave
+        int sa = 0, sb = 1;
+        read_frags2(sa, sb, 0, a0, b0);
+        for (int it = 0; it < nk; ++it) {
+            read_frags2(sa, sb, 1, a1, b1);
+            mma(a0, b0);
+            if (it) issue_entry();                            // A rows of tile it + 2 into the second slot tile it - 1 has freed
+            wait_vm_barrier<1 * PPE>();                       // my reads of tile it are done; tile it + 1 has landed (the A entry just issued may fly)
+            const int na = (sb == NENT - 1) ? 0 : sb + 1;
+            const int nb = (na == NENT - 1) ? 0 : na + 1;
+            read_frags2(na, nb, 0, a0, b0);                   // past the last tile: zero tails, never multiplied
+            mma(a1, b1);
+            issue_entry();                                    // B rows of tile it + 2 into slot sa (i_slot == sa here)
+            sa = na;
+            sb = nb;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        S_MFMA_DRAIN();
+        gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
+        return;
+    }
     // Every iteration issues exactly LPT DMA instructions per wave (dummy zero-tail fetches past the end), so "all but
     // the newest LPT have landed" == "tile `it` has landed" at the top of every iteration.
     issue(kt_begin, 0);
@@ -1158,7 +1254,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
 // 64-channel chunks (channels padded to 32 must be a multiple of 64); everything else -- tap algebra, split-K, batches, block order,
 // epilogue incl. the BN statistics -- is igemm_dma_kernel's.
 // ------------------------------------------------------------------------------------------------
-template <class SCH, int BM, int BN, int WGM, int WGN>
+// SPREAD (round 5, as wino_fused64_kernel's SCHED bit 0): the DMA pieces that refill a tile's two slots are issued in four groups
+// behind the four MFMA groups that follow the barrier, not as one burst right after it.
+template <class SCH, int BM, int BN, int WGM, int WGN, bool SPREAD = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma64_kernel(const SParams p) {
     constexpr int NP = SCH::NP, NENT = 5;
     typedef typename SCH::frag frag;
@@ -1273,44 +1371,56 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma64_kernel(const SPara
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
     int i_ent = 0, i_slot = 0;                         // ring entry to issue next (even: A rows of tile i_ent / 2, odd: its B rows)
-    auto issue_entry = [&]() {
-        const bool live = kt_begin + (i_ent >> 1) < kt_end;                 // wave-uniform
+    // one ring entry in two halves: half h = the row groups [h G8 / 2, (h + 1) G8 / 2) (all of them in half 0 when G8 == 1); the second
+    // half closes the entry
+    constexpr int HG = G8 >= 2 ? G8 / 2 : 1;
+    uint32_t ent_k = 0;                                // byte offset of the open entry's k position (set by its first half)
+    bool ent_live = false;
+    auto issue_half = [&](int h) {
         const bool is_b = i_ent & 1;
         const uint32_t base = lds0 + (uint32_t)i_slot * ENT_BYTES;
-        if (!is_b) {
-            uint32_t ka_b = 0;
-            if (live) {
-                if (kw.dirty) {
-                    set_tap(kw.t, kw.r, kw.s);
-                    kw.dirty = false;
+        if (h == 0) {
+            ent_live = kt_begin + (i_ent >> 1) < kt_end;                     // wave-uniform
+            ent_k = 0;
+            if (!is_b) {
+                if (ent_live) {
+                    if (kw.dirty) {
+                        set_tap(kw.t, kw.r, kw.s);
+                        kw.dirty = false;
+                    }
+                    ent_k = 2u * 64u * (uint32_t)kw.cc;
                 }
-                ka_b = 2u * 64u * (uint32_t)kw.cc;
-            }
-#pragma unroll
-            for (int i = 0; i < G8; ++i)
-#pragma unroll
-                for (int s = 0; s < NP; ++s) {
-                    const uint32_t vo = live ? a_src[i] + ((ka_b + s * a_plane_b) & a_msk[i]) : a_zero;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)(base + (s * BM + (wave + NW * i) * 8) * 128), 16,
-                                                             vo, 0, 0, 0);
-                }
-        } else {
-            uint32_t kb_b = 0;
-            if (live) {
-                kb_b = 2u * ((uint32_t)kw.t * p.pitch + 64u * (uint32_t)kw.cc);
+            } else if (ent_live) {
+                ent_k = 2u * ((uint32_t)kw.t * p.pitch + 64u * (uint32_t)kw.cc);
                 kw.advance(p);                          // the tile's B entry closes it
             }
+        }
+        if (!(G8 < 2 && h == 1)) {
 #pragma unroll
-            for (int i = 0; i < G8; ++i)
+            for (int ii = 0; ii < HG; ++ii) {
+                const int i = (G8 >= 2 ? h * HG : 0) + ii;
 #pragma unroll
                 for (int s = 0; s < NP; ++s) {
-                    const uint32_t vo = live ? b_src[i] + ((kb_b + s * b_plane_b) & b_msk[i]) : b_zero;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)(base + (s * BN + (wave + NW * i) * 8) * 128), 16,
-                                                             vo, 0, 0, 0);
+                    if (!is_b) {
+                        const uint32_t vo = ent_live ? a_src[i] + ((ent_k + s * a_plane_b) & a_msk[i]) : a_zero;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)(base + (s * BM + (wave + NW * i) * 8) * 128), 16,
+                                                                 vo, 0, 0, 0);
+                    } else {
+                        const uint32_t vo = ent_live ? b_src[i] + ((ent_k + s * b_plane_b) & b_msk[i]) : b_zero;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)(base + (s * BN + (wave + NW * i) * 8) * 128), 16,
+                                                                 vo, 0, 0, 0);
+                    }
                 }
+            }
         }
-        ++i_ent;
-        i_slot = (i_slot == NENT - 1) ? 0 : i_slot + 1;
+        if (h == 1) {
+            ++i_ent;
+            i_slot = (i_slot == NENT - 1) ? 0 : i_slot + 1;
+        }
+    };
+    auto issue_entry = [&]() {
+        issue_half(0);
+        issue_half(1);
     };
 
     f32x16 acc[FM][FN];
@@ -1358,36 +1468,54 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma64_kernel(const SPara
     for (int it = 0; it < nk; ++it) {
         read_frags(sa, sb, 1, a1, b1);
         mma(a0, b0);
+        if (SPREAD && it) issue_half(1);                      // closes the B entry begun behind the last MFMA group of tile it - 1
         read_frags(sa, sb, 2, a0, b0);
         mma(a1, b1);
+        if (SPREAD && it) issue_half(0);                      // the A entry into the other slot tile it - 1 has freed
         read_frags(sa, sb, 3, a1, b1);
         mma(a0, b0);
+        if (SPREAD && it) issue_half(1);
         wait_vm_barrier<1 * PPE>();                           // my reads of this tile are done, the next tile's two entries have landed
-        issue_entry();
-        issue_entry();
-        sa = (sb == NENT - 1) ? 0 : sb + 1;
-        sb = (sa == NENT - 1) ? 0 : sa + 1;
-        read_frags(sa, sb, 0, a0, b0);                        // past the last tile: zero tails, never multiplied
+        if (!SPREAD) {
+            issue_entry();
+            issue_entry();
+        }
+        const int na = (sb == NENT - 1) ? 0 : sb + 1;
+        const int nb = (na == NENT - 1) ? 0 : na + 1;
+        read_frags(na, nb, 0, a0, b0);                        // past the last tile: zero tails, never multiplied
         mma(a1, b1);
+        if (SPREAD) issue_half(0);                            // first half of the B entry that refills slot sa
+        sa = na;
+        sb = nb;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
     gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
 }
 
+static int dma64_spread() {          // SEMSEG_DMA64_SPREAD=0: the burst form (A/B switch of the round-5 measurement)
+    static const int v = [] { const char* e = getenv("SEMSEG_DMA64_SPREAD"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 template <class SCH, int BM, int BN, int WGM, int WGN>
 static int launch_dma64(const SParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)5 * SCH::NP * BM * 128;
     static_assert(smem <= 160 * 1024, "LDS");
-    static SmemAttrCache attr_cache;
-    if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_dma64_kernel<SCH, BM, BN, WGM, WGN>, smem)) return e;
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
-    hipLaunchKernelGGL((igemm_dma64_kernel<SCH, BM, BN, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, st, p);
+    if (dma64_spread()) {
+        static SmemAttrCache attr_cache;
+        if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_dma64_kernel<SCH, BM, BN, WGM, WGN, true>, smem)) return e;
+        hipLaunchKernelGGL((igemm_dma64_kernel<SCH, BM, BN, WGM, WGN, true>), grid, dim3(64 * WGM * WGN), smem, st, p);
+    } else {
+        static SmemAttrCache attr_cache;
+        if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_dma64_kernel<SCH, BM, BN, WGM, WGN, false>, smem)) return e;
+        hipLaunchKernelGGL((igemm_dma64_kernel<SCH, BM, BN, WGM, WGN, false>), grid, dim3(64 * WGM * WGN), smem, st, p);
+    }
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
 
-// out[m*out_ld + n] = bias[n] + sum_z partial[z][m*Cout + n]   (fixed order => deterministic)
 template <bool VEC>
 __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                          float* __restrict__ out, int out_ld,
@@ -1438,11 +1566,12 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static const int kTiles[25][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
+static const int kTiles[27][2] = {{128, 128}, {128, 64}, {64, 64}, {256, 128}, {256, 128}, {256, 256}, {128, 128},
                                    {256, 128}, {256, 256}, {128, 128}, {256, 128}, {256, 256}, {256, 128}, {256, 128},
                                    {256, 256}, {64, 64}, {128, 64}, {64, 64}, {128, 128},
                                    {64, 64}, {128, 128}, {128, 128},      // 19 ... 21: deep rings (round 4)
-                                   {128, 128}, {64, 64}, {128, 128}};     // 22 ... 24: 64-deep k-tiles (igemm_dma64_kernel)
+                                   {128, 128}, {64, 64}, {128, 128},      // 22 ... 24: 64-deep k-tiles (igemm_dma64_kernel)
+                                   {256, 256}, {256, 256}};               // 25 / 26: 256 x 256 on the ring of five half tiles (16 / 8 waves)
 static inline bool tile_is_k64(int tile) { return tile >= 22 && tile <= 24; }
 
 constexpr int kMaxEpilogueParts = 512;      // partial rows (= block row tiles) the BN finish kernel is asked to reduce; beyond
@@ -1511,7 +1640,8 @@ static int launch_rs(const SParams& p, hipStream_t st) {
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 static int launch_dma(const SParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)(NSLOT >= 12 ? NSLOT - 10 : NSLOT) * SCH::NP * (BM + BN) * 64;
+    constexpr size_t smem = NSLOT == 25 ? (size_t)5 * SCH::NP * BM * 64      // five half tiles
+                                        : (size_t)(NSLOT >= 12 ? NSLOT - 10 : NSLOT) * SCH::NP * (BM + BN) * 64;
     static_assert(smem <= 160 * 1024, "LDS");
     static SmemAttrCache attr_cache;
     if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>, smem)) return e;
@@ -1646,6 +1776,13 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
             break;
         case 24:
             if constexpr (SCH::NP == 2) rc = launch_dma64<SCH, 128, 128, 4, 4>(p, st);        // 16 waves (32 x 32 each), one block per CU
+            break;
+        // 256 x 256 on the ring of five half tiles with spread DMA issue (round 5): tiles 14 / 5 with 1.5 tiles in flight
+        case 25:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 256, 4, 4, 25>(p, st);      // 16 waves, 64 x 64 per wave
+            break;
+        case 26:
+            if constexpr (SCH::NP == 2) rc = launch_dma<SCH, 256, 256, 2, 4, 25>(p, st);      // 8 waves, 128 x 64 per wave
             break;
     }
     if (rc) return rc;
@@ -1803,6 +1940,8 @@ extern "C" int semseg_winograd_gemm_h2(const void* v_planes, const void* u_plane
         case 9: return launch_dma<SchH2, 128, 128, 4, 2, 12>(p, st);
         case 10: return launch_dma<SchH2, 256, 128, 4, 2, 13>(p, st);
         case 14: return launch_dma<SchH2, 256, 256, 4, 4, 12>(p, st);
+        case 25: return launch_dma<SchH2, 256, 256, 4, 4, 25>(p, st);
+        case 26: return launch_dma<SchH2, 256, 256, 2, 4, 25>(p, st);
         case 22:
         case 24:
             if (p.Cp % 64) return SEMSEG_EINVAL;
@@ -2861,7 +3000,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
     constexpr int A_BYTES = NP * CBA * 32 * 256, B_BYTES = NP * CBB * 32 * 256, BUF_BYTES = A_BYTES + B_BYTES;
     static_assert(BM % 128 == 0 && BN % 128 == 0 && (NW == 4 || NW == 8 || NW == 16) && FM >= 1 && FN >= 1, "tile");
     static_assert(!SPLIT_AB || CBA == CBB, "16 waves: equal operand widths");
-    static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3 || NSLOT == 12) && 2 * LPT < 64, "tile");
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && (NSLOT == 2 || NSLOT == 3 || NSLOT == 12 || NSLOT == 25) && 2 * LPT < 64, "tile");
+    static_assert(NSLOT != 25 || (CBA == CBB && NP == 2), "the half-tile ring takes square tiles of the h2 scheme");
 
     extern __shared__ __align__(16) unsigned char smem_w[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -3019,6 +3159,112 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
         }
     };
 
+    if constexpr (NSLOT == 25) {
+        // ---- ring of five half tiles with spread DMA issue (round 5; see igemm_dma_kernel NSLOT == 25) ---------------------------
+        // entry = the dy rows (even entries) or the x rows (odd) of a 32-pixel k-tile, A_BYTES each; tile it is multiplied from two
+        // slots while three entries fly; the x entry of tile it+2 is issued behind the second MFMA group of tile it, the dy entry
+        // of tile it+3 behind the first group of tile it+1.  16 waves: EVERY wave takes part in both entries (row group wave & 7,
+        // column block / plane wave >> 3), so the vmcnt accounting is the same for all of them.
+        constexpr int GPE = NW == 16 ? 1 : 8 / NW;                       // 4-row groups per wave and entry
+        constexpr int PPE = NW == 16 ? NP * CBA / 2 : GPE * NP * CBA;     // DMA pieces per wave and entry
+        constexpr int NENT = 5;
+        static_assert(PPE >= 1 && 3 * PPE < 64, "ring");
+        int i_ent = 0, i_slot = 0;
+        auto issue_entry = [&]() {
+            const int mt = m_begin + (i_ent >> 1) * 32;
+            const bool is_b = i_ent & 1;
+            const bool live = mt < m_end;                  // wave-uniform
+            const uint32_t base = lds0 + (uint32_t)i_slot * A_BYTES;
+#pragma unroll
+            for (int gi = 0; gi < GPE; ++gi) {
+                const int g = NW == 16 ? (wave & 7) : wave + NW * gi;
+                const int mr = mt + 4 * g + lrow;
+                const bool rowok = live && (mr < m_end);
+                const int m = min(mr, p.M - 1);
+                const uint32_t brow = (uint32_t)blockIdx.z * (uint32_t)p.batch_rows;
+                uint32_t off, msk;
+                if (!is_b) {
+                    msk = rowok ? 0xffffffffu : 0u;
+                    off = ((uint32_t)m + brow) * a_row_b + a_col_b;
+                } else {
+                    int n = (int)((float)m * inv_hwo);
+                    int rem = m - n * HWo;
+                    if (rem < 0) { --n; rem += HWo; } else if (rem >= HWo) { ++n; rem -= HWo; }
+                    int oh = (int)((float)rem * inv_ow);
+                    int ow = rem - oh * p.OW;
+                    if (ow < 0) { --oh; ow += p.OW; } else if (ow >= p.OW) { ++oh; ow -= p.OW; }
+                    const int ih = oh * p.stride - p.pad + r * p.dil;
+                    const int iw = ow * p.stride - p.pad + s * p.dil;
+                    const bool pixok = rowok & (ih >= 0) & (iw >= 0) & (ih < p.H) & (iw < p.W);
+                    msk = pixok ? 0xffffffffu : 0u;
+                    off = ((uint32_t)((n * p.H + ih) * p.W + iw) + brow) * b_row_b + b_col_b;
+                }
+#pragma unroll
+                for (int cb = 0; cb < CBA; ++cb) {
+                    if (NW == 16 && CBA == 2 && cb != (wave >> 3)) continue;           // wave-uniform
+#pragma unroll
+                    for (int h = 0; h < NP; ++h) {
+                        if (NW == 16 && CBA == 1 && h != (wave >> 3)) continue;        // wave-uniform
+                        const uint32_t dst = base + (uint32_t)(((h * CBA + cb) * 32 + 4 * g) * 256);
+                        if (!is_b) {
+                            const uint32_t ok = msk & a_cb_msk[cb];
+                            const uint32_t vo = ((off + cb * 256u + h * a_plane_b) & ok) | (a_zero & ~ok);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)dst, 16, vo, 0, 0, 0);
+                        } else {
+                            const uint32_t ok = msk & b_cb_msk[cb];
+                            const uint32_t vo = ((off + cb * 256u + h * b_plane_b) & ok) | (b_zero & ~ok);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)dst, 16, vo, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            ++i_ent;
+            i_slot = (i_slot == NENT - 1) ? 0 : i_slot + 1;
+        };
+        auto read_frags2 = [&](int sa, int sb, int ks, frag (&av)[FM][NP], frag (&bv)[FN][NP]) {
+            const unsigned char* As = smem_w + sa * A_BYTES;
+            const unsigned char* Bs = smem_w + sb * A_BYTES;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int h = 0; h < NP; ++h) {
+                    const unsigned char* q0 = As + a_foff[i] + (h * CBA * 32 + 16 * ks) * 256;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 256));
+                    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    av[i][h] = __builtin_bit_cast(frag, v);
+                }
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int h = 0; h < NP; ++h) {
+                    const unsigned char* q0 = Bs + b_foff[j] + (h * CBB * 32 + 16 * ks) * 256;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q0);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * 256));
+                    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bv[j][h] = __builtin_bit_cast(frag, v);
+                }
+        };
+#pragma unroll
+        for (int j = 0; j < NENT; ++j) issue_entry();        // dy(0) x(0) dy(1) x(1) dy(2)
+        frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+        wait_vm_barrier<3 * PPE>();                           // entries 0 and 1 have landed for every wave
+        int sa = 0, sb = 1;
+        read_frags2(sa, sb, 0, a0, b0);
+        for (int it = 0; it < nk; ++it) {
+            read_frags2(sa, sb, 1, a1, b1);
+            mma(a0, b0);
+            if (it) issue_entry();                            // dy rows of tile it + 2 into the second slot tile it - 1 has freed
+            wait_vm_barrier<1 * PPE>();                       // my reads of tile it are done; tile it + 1 has landed
+            const int na = (sb == NENT - 1) ? 0 : sb + 1;
+            const int nb = (na == NENT - 1) ? 0 : na + 1;
+            read_frags2(na, nb, 0, a0, b0);                   // past the last tile: zero tails, never multiplied
+            mma(a1, b1);
+            issue_entry();                                    // x rows of tile it + 2 into slot sa
+            sa = na;
+            sb = nb;
+        }
+    } else {
     issue(m_begin, 0);
     issue(m_begin + 32, 1);
     if constexpr (NSLOT == 12) {
@@ -3052,6 +3298,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
             slot = (slot == 2) ? 0 : slot + 1;
             fill = (fill == 2) ? 0 : fill + 1;
         }
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
@@ -3116,21 +3363,22 @@ struct WPlan {
 // 3 = 256x128 LDS-DMA 3-slot ring (8 waves), 4 = 256x256 LDS-DMA 2-slot (8 waves), 5 / 6 = 2 / 4 software pipelined -- chosen by
 // the tuner / overrides only
 // 10 = 64x64 with all nine taps of a 3x3 stride-1 conv in the block (wgrad_taps_kernel): tiles = tiles_k * tiles_c, not * T
-static const int kWTiles[11][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
-                                    {128, 128}, {128, 128}, {64, 64}};
+// 11 ... 14 (round 5): the LDS-DMA tiles on the ring of five half tiles with spread DMA issue: 256 x 256 on 16 / 8 waves, 128 x 128 on 8 / 4 waves
+static const int kWTiles[15][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
+                                    {128, 128}, {128, 128}, {64, 64}, {256, 256}, {256, 256}, {128, 128}, {128, 128}};
 constexpr int kWTileTaps = 10;
 
 // tuning overrides: SEMSEG_W3_TILE=0..3, SEMSEG_W3_SPLIT=n
 static WPlan plan_wgrad(int M, int K, int C, int T, int ov_tile = -1, int ov_split = 0) {
     WPlan pl;
     const int mtiles = ceil_div(M, 32);
-    const double tile_cost[11] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0, 1.0, 1.0, 2.9};
-    const int slots[11] = {512, 1024, 512, 256, 256, 512, 256, 256, 512, 512, 512};
+    const double tile_cost[15] = {1.0, 0.32, 1.0, 2.0, 4.0, 1.0, 4.0, 4.0, 1.0, 1.0, 2.9, 4.0, 4.0, 1.0, 1.0};
+    const int slots[15] = {512, 1024, 512, 256, 256, 512, 256, 256, 512, 512, 512, 256, 256, 512, 512};
     const int force_tile = ov_tile >= 0 ? ov_tile : env_int("SEMSEG_W3_TILE", -1);
     const int force_split = ov_split > 0 ? ov_split : env_int("SEMSEG_W3_SPLIT", 0);
     double best = 1e30;
     int best_t = 1, best_s = 1;
-    for (int t = 0; t < 11; ++t) {
+    for (int t = 0; t < 15; ++t) {
         if (force_tile >= 0 && t != force_tile) continue;
         if (force_tile < 0 && t >= 2) continue;
         if (t == 0 && (K < 128 || C < 128) && force_tile < 0) continue;
@@ -3179,7 +3427,8 @@ static int launch_wgrad(const WParams& p, hipStream_t st) {
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)(NSLOT == 12 ? 2 : NSLOT) * SCH::NP * (BM / 128 + BN / 128) * 32 * 256;
+    constexpr size_t smem = NSLOT == 25 ? (size_t)5 * SCH::NP * (BM / 128) * 32 * 256           // five half tiles
+                                        : (size_t)(NSLOT == 12 ? 2 : NSLOT) * SCH::NP * (BM / 128 + BN / 128) * 32 * 256;
     static_assert(smem <= 160 * 1024, "LDS");
     // 32-bit byte offsets in the buffer descriptors
     if ((size_t)2 * SCH::NP * p.x_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31) ||
@@ -3275,6 +3524,18 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
         case 9:
             if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 4, 12>(p, st);     // 16 waves, 32x32 per wave
             break;
+        case 11:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 256, 256, 4, 4, 25>(p, st);     // ring of five half tiles, 16 waves
+            break;
+        case 12:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 256, 256, 2, 4, 25>(p, st);     // ... 8 waves
+            break;
+        case 13:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 4, 2, 25>(p, st);     // 80 KiB: two blocks per CU
+            break;
+        case 14:
+            if constexpr (SCH::NP == 2) rc = launch_wgrad_dma<SCH, 128, 128, 2, 2, 25>(p, st);
+            break;
         case kWTileTaps: {
             if (!wtaps_eligible(R, S, stride, pad, dil, OW, p.M)) return SEMSEG_EINVAL;
             const size_t smem = wtaps_smem(SCH::NP, dil);
@@ -3335,7 +3596,13 @@ extern "C" int semseg_winograd_wgrad_gemm_h2(const void* v_planes, const void* d
         if (!workspace || workspace_bytes < (size_t)p.splits * slab * sizeof(float)) return SEMSEG_EWORKSPACE;
         p.partial = (float*)workspace;
     }
-    const int rc = big ? launch_wgrad_dma<SchH2, 256, 256, 2, 4, 2>(p, st) : launch_wgrad_dma<SchH2, 128, 128, 2, 2, 2>(p, st);
+    // form of the batched launch: 0 = the plain 2-slot loop of rounds 2-4; 1 / 2 = the ring of five half tiles on 8 / 16 waves (round 5)
+    static const int form = env_int("SEMSEG_WINO_WGRAD_FORM", 1);
+    int rc;
+    if (!big) rc = form ? launch_wgrad_dma<SchH2, 128, 128, 2, 2, 25>(p, st) : launch_wgrad_dma<SchH2, 128, 128, 2, 2, 2>(p, st);
+    else if (form == 2) rc = launch_wgrad_dma<SchH2, 256, 256, 4, 4, 25>(p, st);
+    else if (form == 1) rc = launch_wgrad_dma<SchH2, 256, 256, 2, 4, 25>(p, st);
+    else rc = launch_wgrad_dma<SchH2, 256, 256, 2, 4, 2>(p, st);
     if (rc) return rc;
     if (p.splits > 1) {
         const int blocks = (int)min((size_t)2048, ceil_div_sz(slab / 4, 256));

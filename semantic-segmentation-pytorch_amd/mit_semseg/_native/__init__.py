@@ -98,6 +98,10 @@ SIGNATURES = {
                                           vp, vp, vp, vp]),
     'semseg_bn_bwd_reduce_fused_peer': (c_int, [vp, c_int, vp, c_int, vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, c_int,
                                            vp, vp, vp, vp, vp, c_sz, vp] + [vp]),
+    'semseg_bn_bwd_reduce_fused_sum2': (c_int, [vp, c_int, vp, c_int, vp, c_int, vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, vp, c_int,
+                                                vp, vp, vp, vp, vp, c_sz, vp, vp]),
+    'semseg_bn_bwd_apply_h2_sum2': (c_int, [vp, c_int, vp, c_int, vp, c_int, vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int,
+                                            vp, vp, vp, vp]),
     'semseg_weights_prepare_h2': (c_int, [ctypes.POINTER(WPrepTensor), c_int, vp]),
     'semseg_add_act': (c_int, [vp, c_int, vp, c_int, c_int, vp, c_int, c_int, c_int, vp]),
     'semseg_relu_bwd': (c_int, [vp, c_int, vp, c_int, vp, c_int, c_int, c_int, vp]),

@@ -233,7 +233,8 @@ class TrainStep:
         # the split weight gradients of the backward pass are summed, and the small ones computed, by batched launches: ONE flush after
         # backward on a single rank, one per gradient bucket (from the hook that completes it, before its all-reduce) on a rank of
         # a data-parallel job (ops.defer_wgrad_reduces)
-        with ops.defer_wgrad_reduces(flush_at_buckets=self.buckets is not None and self.buckets.flushes_deferred):
+        with ops.defer_wgrad_reduces(flush_at_buckets=self.buckets is not None and self.buckets.flushes_deferred), \
+                ops.defer_fork_sums():        # ... and the gradient sums at the forks are formed by the BN kernels that consume them
             loss.backward()
         if tl is not None:
             tl.armed = False

@@ -156,6 +156,16 @@ class HighResolutionModule(nn.Module):
         return fused
 
 
+def _transition(layers, ys):
+    """hrnet.py:401-423: branch i of the next stage is `layers[i](ys[-1])` (a new, coarser branch made from the LAST branch) or
+    `ys[i]` itself (layers[i] is None).  The last branch then has two consumers -- and layer1's output both convs of transition1
+    --: they get their own aliases (ops.fork), so that the two gradients are summed by the native layer in one fixed order and a
+    sum the BN backward kernels form themselves (ops.defer_fork_sums) never meets autograd's own accumulation."""
+    src = [len(ys) - 1 if t is not None else i for i, t in enumerate(layers)]
+    alias = {j: list(ops.fork(ys[j], src.count(j))) for j in set(src)}
+    return [t(alias[j].pop()) if t is not None else alias[j].pop() for t, j in zip(layers, src)]
+
+
 class HRNetV2(nn.Module):
     """hrnet.py:258-437"""
 
@@ -216,12 +226,9 @@ class HRNetV2(nn.Module):
         x = conv_bn(self.conv1, self.bn1, x, relu=True)
         x = conv_bn(self.conv2, self.bn2, x, relu=True)
         x = self.layer1(x)
-        xs = [t(x) if t is not None else x for t in self.transition1]
-        ys = self.stage2(xs)
-        xs = [t(ys[-1]) if t is not None else ys[i] for i, t in enumerate(self.transition2)]
-        ys = self.stage3(xs)
-        xs = [t(ys[-1]) if t is not None else ys[i] for i, t in enumerate(self.transition3)]
-        ys = self.stage4(xs)
+        ys = self.stage2(_transition(self.transition1, [x]))
+        ys = self.stage3(_transition(self.transition2, ys))
+        ys = self.stage4(_transition(self.transition3, ys))
         size = ys[0].shape[2:]
         return [ops.concat([ys[0]] + [ops.interpolate_bilinear(t, size) for t in ys[1:]])]
 

@@ -212,7 +212,10 @@ class MobileNetV2Dilated(nn.Module):
         for i in range(self.total_idx):
             x = self.features[i](x)
             if i in self.down_idx:
-                conv_out.append(x)
+                # feeds the next block AND a decoder head: its own alias for each (as Resnet.forward; a fork output nobody uses
+                # costs nothing), so the native layer sums the two gradients
+                keep, x = ops.fork(x)
+                conv_out.append(keep)
         conv_out.append(x)
         return conv_out
 

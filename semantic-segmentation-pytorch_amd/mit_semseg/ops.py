@@ -207,6 +207,12 @@ def as_nhwc_of(x):
 
 def as_nhwc(x):
     """Returns (tensor, ld): `tensor` is logical NCHW over NHWC memory."""
+    if _ADDENDS:                               # a gradient whose second addend is still pending (defer_fork_sums): sum it now
+        x = _materialize_sum(x)
+    return _as_nhwc_plain(x)
+
+
+def _as_nhwc_plain(x):
     _require_cuda(x)
     if x.dtype != torch.float32:
         raise RuntimeError('native hot path computes in fp32, got %s' % x.dtype)
@@ -1254,7 +1260,17 @@ class ConvBNActFn(Function):
         oh, ow = conv_out_size(h, r, stride, pad, dil), conv_out_size(wd, s, stride, pad, dil)
         P = n * oh * ow
         dev = w.device
-        dy, dy_ld = as_nhwc(dy)
+        sync = _sync_active()
+        peer = _sync_peer(2 * k + 1) if sync else None
+        # the gradient may arrive as TWO addends (a fork's sum left to its consumer, defer_fork_sums): the fused BN backward kernels
+        # add them where they read them; the unfused SyncBN path below reads dy through entry points without a second pointer
+        dy2 = _take_addend(dy) if (k % 8 == 0 and (not sync or peer is not None)) else None
+        dy2_ld = 0
+        if dy2 is not None:
+            dy, dy_ld = _as_nhwc_plain(dy)                # the pair is formed by the kernels below
+            dy2, dy2_ld = _as_nhwc_plain(dy2)
+        else:
+            dy, dy_ld = as_nhwc(dy)
         sums = torch.empty((2 * k,), device=dev, dtype=torch.float64)
         gmax = torch.empty((k,), device=dev, dtype=torch.float32)
         dgamma = torch.empty((k,), device=dev, dtype=torch.float32)
@@ -1265,14 +1281,15 @@ class ConvBNActFn(Function):
         dres = empty_nhwc(n, k, oh, ow, dev) if (has_res and ctx.needs_input_grad[4]) else None
         gate = relu and not has_res                       # ReLU gate from z (forward's own fmaf), y was not saved
         gsc, gsh = (coef[2], coef[3]) if gate else (None, None)
-        sync = _sync_active()
-        peer = _sync_peer(2 * k + 1) if sync else None
         y_arg, y_ld = (_p(gate_bits), 0) if gate_bits is not None else (_p(y), k)      # y_ld 0: the forward's ReLU bitmask
         if not sync or peer is not None:
             bb = torch.empty(((k + 15) // 16,), device=dev, dtype=torch.int32)
             args = (_p(dy), dy_ld, y_arg, y_ld, _p(z), _p(coef[0]), _p(coef[1]), _p(gsc), _p(gsh), int(relu), P, k, _p(count),
                     _p(zmm), _p(gamma), 1, _p(sums), _p(dgamma), _p(dbeta), _p(bb), _p(ws), ws.numel(), _st())
-            if peer is None:
+            if dy2 is not None:
+                _native.check(L.semseg_bn_bwd_reduce_fused_sum2(_p(dy), dy_ld, _p(dy2), dy2_ld, *args[2:], peer),
+                              'bn_bwd_reduce_fused_sum2')
+            elif peer is None:
                 _native.check(L.semseg_bn_bwd_reduce_fused(*args), 'bn_bwd_reduce_fused')
             else:
                 _native.check(L.semseg_bn_bwd_reduce_fused_peer(*args, peer), 'bn_bwd_reduce_fused_peer')
@@ -1290,9 +1307,14 @@ class ConvBNActFn(Function):
             _maybe_allreduce(sums)
             _native.check(L.semseg_bn_bwd_bound(_p(sums), _p(count), _p(gmax), _p(zmm), _p(coef[0]), _p(coef[1]), _p(gamma),
                                                 k, 1, _p(dzp), P, _st()), 'bn_bwd_bound')
-        _native.check(L.semseg_bn_bwd_apply_h2(_p(dy), dy_ld, y_arg, y_ld, _p(z), _p(coef[0]), _p(coef[1]), _p(gamma),
-                                               _p(sums), _p(count), 1, int(relu), _p(dzp), _p(dres), P, k, _p(gsc), _p(gsh),
-                                               _p(bb), _st()), 'bn_bwd_apply_h2')
+        if dy2 is not None:
+            _native.check(L.semseg_bn_bwd_apply_h2_sum2(_p(dy), dy_ld, _p(dy2), dy2_ld, y_arg, y_ld, _p(z), _p(coef[0]), _p(coef[1]),
+                                                        _p(gamma), _p(sums), _p(count), 1, int(relu), _p(dzp), _p(dres), P, k,
+                                                        _p(gsc), _p(gsh), _p(bb), _st()), 'bn_bwd_apply_h2_sum2')
+        else:
+            _native.check(L.semseg_bn_bwd_apply_h2(_p(dy), dy_ld, y_arg, y_ld, _p(z), _p(coef[0]), _p(coef[1]), _p(gamma),
+                                                   _p(sums), _p(count), 1, int(relu), _p(dzp), _p(dres), P, k, _p(gsc), _p(gsh),
+                                                   _p(bb), _st()), 'bn_bwd_apply_h2')
         need_dw = ctx.needs_input_grad[1]
         dw_wino = None
         if wino_v is not None and need_dw:
@@ -1431,6 +1453,65 @@ def clamp_max(x, cap):
     return ClampMaxFn.apply(x, float(cap))
 
 
+# The two gradients that meet at a fork are not added by a launch of their own when the consumer of the sum can read two addends:
+# inside `defer_fork_sums()` (TrainStep, around backward) ForkFn.backward hands back its FIRST gradient and records the second in
+# _ADDENDS; ConvBNActFn.backward -- the producer of every forked tensor of the ResNet / HRNet blocks -- takes the pair and passes both
+# to the BN backward kernels (semseg_bn_bwd_*_sum2: the same fp32 add per element, bit-identical to the materialised sum).  Every
+# other native consumer reaches its gradient through as_nhwc(), which adds a pending pair on the spot; a pair that NOBODY took by
+# the end of backward (a torch-side consumer saw the first addend alone) raises in __exit__.  SEMSEG_DEFER_FORK_SUMS=0 disables.
+DEFER_FORK_SUMS = os.environ.get('SEMSEG_DEFER_FORK_SUMS', '1') != '0'
+_FORK_DEFER = [False]
+_ADDENDS = {}                # data_ptr of the first addend -> (first, second, [some consumer formed the sum])
+
+
+class defer_fork_sums:
+    def __enter__(self):
+        self.prev = _FORK_DEFER[0]
+        _FORK_DEFER[0] = DEFER_FORK_SUMS and CONV_MODE == 'h2' and FUSE
+        return self
+
+    def __exit__(self, *exc):
+        _FORK_DEFER[0] = self.prev
+        left = [tuple(rec[0].shape) for rec in _ADDENDS.values() if not rec[2][0]]
+        _ADDENDS.clear()
+        if left and not (exc and exc[0] is not None):
+            raise RuntimeError('%d gradient sum(s) deferred at a fork were never formed (shapes %s): a consumer outside the native '
+                               'layer read the first addend alone; set SEMSEG_DEFER_FORK_SUMS=0' % (len(left), left[:4]))
+        return False
+
+
+def _take_addend(g):
+    """the second addend of gradient `g` if ForkFn left one pending (the caller then forms g + addend where it reads g), else None.
+    The record stays until backward has ended -- a backward that hands its incoming gradient on unchanged (an identity, or the same
+    tensor to two producers) leads several consumers to the same pair, and each of them must see the whole sum."""
+    if not _ADDENDS or g is None:
+        return None
+    rec = _ADDENDS.get(g.data_ptr())
+    if rec is None or rec[0].shape != g.shape or rec[0].stride() != g.stride():
+        return None
+    rec[2][0] = True
+    return rec[1]
+
+
+def _add_nhwc(ga, gb):
+    L = _native.lib()
+    ga, a_ld = _as_nhwc_plain(ga)              # plain: the pair being summed stays on record (its first addend would resolve again)
+    gb, b_ld = _as_nhwc_plain(gb)
+    n, c, h, w = ga.shape
+    out = empty_nhwc(n, c, h, w, ga.device)
+    if c % 4 == 0 and a_ld % 4 == 0 and b_ld % 4 == 0:
+        _native.check(L.semseg_add_act(_p(ga), a_ld, _p(gb), b_ld, 0, _p(out), c, n * h * w, c, _st()), 'add_act')
+    else:
+        _native.check(L.semseg_copy2d(_p(ga), a_ld, _p(out), c, n * h * w, c, 0, _st()), 'copy2d')
+        _native.check(L.semseg_copy2d(_p(gb), b_ld, _p(out), c, n * h * w, c, 1, _st()), 'copy2d')
+    return out
+
+
+def _materialize_sum(g):
+    other = _take_addend(g) if torch.is_tensor(g) else None
+    return g if other is None else _add_nhwc(g, other)
+
+
 class ForkFn(Function):
     """A tensor with TWO consumers (block input -> first conv + shortcut, encoder map -> two heads): returns two aliases of
     it; backward adds the two gradients with the native add kernel -- otherwise autograd's own accumulation does that sum with
@@ -1449,17 +1530,17 @@ class ForkFn(Function):
     def backward(ctx, ga, gb):
         if ga is None or gb is None:
             return gb if ga is None else ga
-        L = _native.lib()
-        ga, a_ld = as_nhwc(ga)
-        gb, b_ld = as_nhwc(gb)
-        n, c, h, w = ga.shape
-        out = empty_nhwc(n, c, h, w, ga.device)
-        if c % 4 == 0 and a_ld % 4 == 0 and b_ld % 4 == 0:
-            _native.check(L.semseg_add_act(_p(ga), a_ld, _p(gb), b_ld, 0, _p(out), c, n * h * w, c, _st()), 'add_act')
-        else:
-            _native.check(L.semseg_copy2d(_p(ga), a_ld, _p(out), c, n * h * w, c, 0, _st()), 'copy2d')
-            _native.check(L.semseg_copy2d(_p(gb), b_ld, _p(out), c, n * h * w, c, 1, _st()), 'copy2d')
-        return out
+        if _ADDENDS:                                    # a pending pair of an inner fork is summed here: one level is deferred
+            ga, gb = _materialize_sum(ga), _materialize_sum(gb)
+        if _FORK_DEFER[0] and ga.dtype == torch.float32 and gb.dtype == torch.float32 and ga.shape == gb.shape:
+            ga, a_ld = _as_nhwc_plain(ga)
+            gb, b_ld = _as_nhwc_plain(gb)
+            c = ga.shape[1]
+            if c % 8 == 0 and a_ld % 4 == 0 and b_ld % 4 == 0 and ga.data_ptr() % 16 == 0 and gb.data_ptr() % 16 == 0 and \
+                    ga.data_ptr() not in _ADDENDS:
+                _ADDENDS[ga.data_ptr()] = (ga, gb, [False])
+                return ga
+        return _add_nhwc(ga, gb)
 
 
 def fork(x, n=2):

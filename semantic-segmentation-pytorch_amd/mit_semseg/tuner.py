@@ -67,6 +67,8 @@ def _load_cache():
             parts = k.split(',')
             key = (parts[0],) + tuple(int(t) for t in parts[1:])
             if key[1] == 4:                   # a choice between launch forms (choose()), not a library plan
+                if counter == 'from_perfdb' and os.environ.get('SEMSEG_TUNE_RECHOOSE', '0') == '1':
+                    continue                  # tools/rechoose_forms.sh: new launch forms exist, every choice is timed afresh
                 _done[key] = tuple(v)
                 stats_db[counter] += 1
                 continue
@@ -93,9 +95,9 @@ _WSPLITS = _SPLITS
 # fwd/dgrad tile ids per scheme (csrc/conv_split.hip): 0..2 register staged, 3 = 256x128 LDS-DMA, h2 only: 4 = 256x128
 # 3-slot ring, 5 = 256x256, 6..10 their software-pipelined / 128x128 forms, 11..13 = 4-wave forms (256x256, 256x128 2- and 3-slot),
 # 14 = 256x256 on 16 waves, 15..17 = 64x64 / 128x64 on the LDS-DMA ring (4 waves).  SEMSEG_TUNE_TILES=0,1,2,3 restricts the candidates (e.g. to bisect a suspect kernel).
-_TILES = {'s3': (0, 1, 2, 3), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24)}      # 19..21: 4- / 5-slot rings on the small tiles; 22..24: 64-deep k-tiles
+_TILES = {'s3': (0, 1, 2, 3), 'h2': tuple(range(27))}      # 19..21: 4- / 5-slot rings on the small tiles; 22..24: 64-deep k-tiles; 25 / 26: 256 x 256 on the ring of five half tiles
 # weight-gradient tile ids: 0 = 128x128, 1 = 64x64 register staged; h2 only: 2 = 128x128 LDS-DMA, 3 = 256x128 LDS-DMA ring
-_WTILES = {'s3': (0, 1), 'h2': (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)}      # 10: all nine taps of a 3x3 stride-1 conv in one block
+_WTILES = {'s3': (0, 1), 'h2': tuple(range(15))}      # 10: all nine taps of a 3x3 stride-1 conv in one block; 11 ... 14: ring of five half tiles
 _ALLOW = os.environ.get('SEMSEG_TUNE_TILES', '')
 if _ALLOW:
     _allow = tuple(int(t) for t in _ALLOW.split(','))
@@ -140,7 +142,7 @@ def timing():
     return _TIMING[0]
 
 
-WINO_TILES = (6, 7, 8, 9, 10, 14, 22, 24)       # tile forms the batched Winograd forward GEMM can run on (csrc/conv_split.hip, plan pass 3)
+WINO_TILES = (6, 7, 8, 9, 10, 14, 22, 24, 25, 26)       # tile forms the batched Winograd forward GEMM can run on (csrc/conv_split.hip, plan pass 3)
 
 
 def ensure_winograd_gemm(tiles, c, k, launch):

@@ -356,6 +356,46 @@ def test_hrnet_branch_streams_equal_one_stream(monkeypatch):
 
 # every environment switch of the product that survives in the code base, with the golden case(s) that exercise what it changes:
 # the parity suite must hold on BOTH sides of each switch (they are read at import time, hence one child process per switch)
+@pytest.mark.parametrize('name', ['r50d_ppmds_64_train', 'hrnetv2_c1_128_train'])
+def test_deferred_fork_sums_are_bit_identical(name, monkeypatch):
+    """the gradient sums at the forks (block output -> next block's first conv + its shortcut; HRNet's branch outputs -> every row of
+    the exchange) formed inside the BN backward kernels that consume them (ops.defer_fork_sums, semseg_bn_bwd_*_sum2) give the same
+    bits as the add launches they replace: one fp32 add per element either way; state after two steps compared with torch.equal"""
+    from mit_semseg import ops, tuner
+    from mit_semseg.engine import TrainStep
+    monkeypatch.setattr(tuner, 'ENABLED', False)          # heuristic plans: both runs launch the same plans
+    g = load_golden(name)
+    m = g['meta']
+    dev = torch.device('cuda:0')
+    img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=304 + m['seed'])
+    feed = {'img_data': img.to(dev), 'seg_label': lab.to(dev)}
+    taken = []
+    real = ops._take_addend
+
+    def counting(t):
+        r = real(t)
+        if r is not None:
+            taken.append(tuple(t.shape))
+        return r
+    monkeypatch.setattr(ops, '_take_addend', counting)
+    states = []
+    for defer in (True, False):
+        monkeypatch.setattr(ops, 'DEFER_FORK_SUMS', defer)
+        sm, _, _ = build_native(g, dev)
+        ts = TrainStep(sm, lr_encoder=m['lr'], lr_decoder=m['lr'], max_iters=10 ** 9)
+        del taken[:]
+        for _ in range(2):
+            loss, _ = ts.step(feed)
+        torch.cuda.synchronize()
+        assert not ops._ADDENDS
+        assert (len(taken) >= 8) == defer, (defer, len(taken))          # the path under test ran
+        states.append(({k: v.clone() for k, v in sm.state_dict().items()}, loss.clone()))
+    (a, la), (b, lb) = states
+    assert torch.equal(la, lb)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 SWITCH_CASES = [
     ('SEMSEG_CONV=s3', 'r18d_ppmds_64_train'),               # 3-way bf16 split family end to end
     ('SEMSEG_CONV=f32', 'r18d_ppmds_64_train'),              # exact-fp32 MFMA family end to end
@@ -376,6 +416,10 @@ SWITCH_CASES = [
     ('SEMSEG_TUNE_DB=0', 'r18d_ppmds_64_train'),
     ('SEMSEG_DEFER_WGRAD_REDUCE=0', 'r50d_ppmds_64_train'),  # one reduce launch per split weight gradient instead of ONE per step             # no shipped launch plans: every geometry timed in the process
     ('SEMSEG_DEFER_WGRAD_LAUNCH=0', 'hrnetv2_c1_128_train'), # every small weight gradient its own launch instead of 24 per launch
+    ('SEMSEG_DEFER_FORK_SUMS=0', 'r50d_ppmds_64_train'),     # the gradient sums at the forks by add launches instead of inside the BN backward kernels
+    ('SEMSEG_DEFER_FORK_SUMS=0', 'hrnetv2_c1_128_train'),
+    ('SEMSEG_DMA64_SPREAD=0', 'r50d_ppmds_64_train'),        # the 64-deep GEMM tiles with their DMA pieces in one burst per k-tile
+    ('SEMSEG_WINO_WGRAD_FORM=0', 'r50d_ppmds_64_train'),     # the batched Winograd weight-gradient GEMM on the plain 2-slot loop
     ('SEMSEG_DEPTHWISE_DIRECT=0', 'mnv2d_c1ds_64_train'),
     ('SEMSEG_GROUPED_DIRECT=0', 'resnext101_upernet_128_eval'),
 ]

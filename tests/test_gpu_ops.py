@@ -747,7 +747,7 @@ PLAN_CASES = [
 
 
 @pytest.mark.parametrize('case', PLAN_CASES, ids=str)
-@pytest.mark.parametrize('pass_id,tile', [(0, t) for t in range(25)] + [(1, t) for t in range(25)] + [(2, t) for t in range(10)])
+@pytest.mark.parametrize('pass_id,tile', [(0, t) for t in range(27)] + [(1, t) for t in range(27)] + [(2, t) for t in list(range(10)) + [11, 12, 13, 14]])
 @pytest.mark.parametrize('split', [1, 3])
 def test_h2_conv_every_tile_pinned(case, pass_id, tile, split, monkeypatch):
     from mit_semseg import ops, _native, tuner
@@ -947,7 +947,7 @@ def test_h2_wgrad_many_problems_in_one_launch(count):
 
 
 @pytest.mark.parametrize('case', PLAN_CASES + [(2, 64, 40, 40, 64, 3, 1, 1, 1), (2, 1024, 8, 8, 48, 1, 1, 0, 1)], ids=str)
-@pytest.mark.parametrize('tile', list(range(25)))
+@pytest.mark.parametrize('tile', list(range(27)))
 def test_conv_epilogue_statistics_match_the_sweep(case, tile):
     """semseg_conv2d_fwd_stats_h2 (BN statistics of the conv result gathered per wave row in the GEMM epilogue) +
     semseg_bn_fwd_finish_fused against the statistics sweep over the same result (semseg_bn_fwd_stats_fused), for EVERY tile

@@ -55,8 +55,9 @@ def test_set_plan_refuses_tiles_a_geometry_cannot_take(L):
             unpin(L, 0, even)
     # tiles beyond the tables, unknown passes
     geom = (2, 16, 16, 64, 64, 3, 3, 1, 1, 1)
-    assert L.semseg_conv2d_h2_set_plan(0, *geom, 25, 1) != 0
-    assert L.semseg_conv2d_h2_set_plan(2, *geom, 11, 1) != 0
+    assert L.semseg_conv2d_h2_set_plan(0, *geom, 26, 1) == 0 and L.semseg_conv2d_h2_set_plan(0, *geom, -1, 0) == 0
+    assert L.semseg_conv2d_h2_set_plan(0, *geom, 27, 1) != 0
+    assert L.semseg_conv2d_h2_set_plan(2, *geom, 15, 1) != 0
     assert L.semseg_conv2d_h2_set_plan(7, *geom, 0, 1) != 0
 
 

@@ -117,6 +117,8 @@ def main():
     ap.add_argument('--split', type=int, default=0, help="force this split-K / split-M factor for the 'default' configuration")
     ap.add_argument('--verify', action='store_true',
                     help='compare every configuration with the exact-fp32 MFMA kernel on the same (seeded) inputs: max|err|/rms')
+    ap.add_argument('--tiles', default='', help='--sweep: only these tile ids (comma separated)')
+    ap.add_argument('--splits', default='1,2,4,8,16', help='--sweep: these split factors')
     args = ap.parse_args()
     L = _native.lib()
     ws = torch.empty(1 << 30, dtype=torch.uint8, device='cuda:0')
@@ -133,17 +135,22 @@ def main():
                 forced[('SEMSEG_W3' if split_mode else 'SEMSEG_WGRAD') + '_SPLIT' if which == 'wgrad' else
                        ('SEMSEG_S3' if split_mode else 'SEMSEG_IGEMM') + '_SPLITK'] = str(args.split)
             cfgs = [('default', forced)]
+            splits = tuple(int(v) for v in args.splits.split(','))
             if args.sweep:
                 pre = 'SEMSEG_W3' if split_mode else 'SEMSEG_WGRAD'
                 pre2 = 'SEMSEG_S3' if split_mode else 'SEMSEG_IGEMM'
                 if which == 'wgrad':
-                    wtiles = tuple(range(11)) if args.mode == 'h2' else (0, 1)
+                    wtiles = tuple(range(15)) if args.mode == 'h2' else (0, 1)
+                    if args.tiles:
+                        wtiles = tuple(int(t) for t in args.tiles.split(','))
                     cfgs += [('t%d_s%d' % (t, sp), {pre + '_TILE': str(t), pre + '_SPLIT': str(sp)})
-                             for t in wtiles for sp in ((32, 64, 128, 256, 512) if t == 10 else (1, 2, 4, 8, 16))]
+                             for t in wtiles for sp in ((32, 64, 128, 256, 512) if t == 10 else splits)]
                 elif which != 'split':
-                    tiles = tuple(range(25)) if args.mode == 'h2' else (0, 1, 2, 3)
+                    tiles = tuple(range(27)) if args.mode == 'h2' else (0, 1, 2, 3)
+                    if args.tiles:
+                        tiles = tuple(int(t) for t in args.tiles.split(','))
                     cfgs += [('t%d_s%d' % (t, sp), {pre2 + '_TILE': str(t), pre2 + '_SPLITK': str(sp)})
-                             for t in tiles for sp in (1, 2, 4, 8, 16)]
+                             for t in tiles for sp in splits]
             ref = None
             if args.verify and which != 'split':
                 for kk in list(os.environ):

@@ -15,7 +15,7 @@
 #   prof             rocprofv3 --kernel-trace --stats of the quick bench -> kernel_stats*.csv, trace_gaps.txt
 #   prof:N           the same for bench.py --config N
 #   conv:ARGS        tools/conv_bench.py ARGS (comma -> space), e.g. conv:--mode,h2,--layers,layer4_d4,--sweep
-#   py:PATH          python PATH (a probe under tools/probes)
+#   py:PATH+ARG+...  python PATH ARG ... (a probe under tools/probes; '+' separates the arguments)
 TAG=${1:-run}; shift; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; ROOT=$PWD
 python __graft_entry__.py > $OUT/build.log 2>&1 || { echo BUILD FAILED; tail -20 $OUT/build.log; exit 1; }
 export SEMSEG_TUNE_CACHE=${SEMSEG_TUNE_CACHE:-/tmp/semseg_plans_h2.json}
@@ -56,7 +56,7 @@ for stage in "$@"; do
     prof) profile cfg1 ;;
     prof:*) profile cfg${stage#prof:} --config ${stage#prof:} ;;
     conv:*) args=${stage#conv:}; timeout 900 python tools/conv_bench.py ${args//,/ } > $OUT/conv_$n.txt 2>&1; echo "rc=$?"; tail -40 $OUT/conv_$n.txt | cut -c1-250 ;;
-    py:*) timeout 900 python ${stage#py:} > $OUT/py_$n.txt 2>&1; echo "rc=$?"; tail -40 $OUT/py_$n.txt | cut -c1-250 ;;
+    py:*) a=${stage#py:}; timeout 900 python ${a//+/ } > $OUT/py_$n.txt 2>&1; echo "rc=$?"; tail -40 $OUT/py_$n.txt | cut -c1-250 ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
