@@ -326,9 +326,29 @@ def cpu_baseline(cfg, steps=3):
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
-        return json.loads(line)
+        out = json.loads(line)
     except Exception as e:                                    # never lose the GPU line to the CPU leg
         return {'value': None, 'unit': 'images/sec', 'cores': threads, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
+    # BASELINE.md 3 says torch.set_num_threads(os.cpu_count()): that run too, so the recipe is visibly followed -- one timed step after
+    # one warm-up step, under a time limit (a 256-thread host needs minutes per step: the line then says so instead of a number)
+    if host > threads:
+        limit = float(os.environ.get('SEMSEG_CPU_BASELINE_ALL_CORES_S', '60'))
+        t0 = time.perf_counter()
+        try:
+            cmd2 = [a for a in cmd]
+            cmd2[cmd2.index('--threads') + 1] = str(host)
+            cmd2[cmd2.index('--steps') + 1] = '1'
+            r = subprocess.run(cmd2, capture_output=True, text=True, timeout=limit)
+            l2 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+            out['all_cores'] = {'cores': host, 'value': l2['value'], 'unit': l2['unit'], 'sample': l2.get('sample')}
+        except subprocess.TimeoutExpired:
+            out['all_cores'] = {'cores': host, 'value': None,
+                                'sample': 'did not finish 1 warm-up + 1 timed step within %.0f s (torch CPU convolutions thrash at this '
+                                          'thread count: 203 s per step measured at 256 threads in round 2)' % limit}
+        except Exception as e:
+            out['all_cores'] = {'cores': host, 'value': None, 'sample': 'failed: %r' % (e,)}
+        out['all_cores']['wall_s'] = round(time.perf_counter() - t0, 1)
+    return out
 
 
 STAGES = ('comm', 'peer', 'segmented', 'graph')
@@ -478,11 +498,8 @@ def other_configs(skip, steps, warmup, budget_s=100):
             # ... and the RAW stream of the same rule beside its steady state (round-4 review): 100 untimed + 300 timed steps in
             # stream order, first sights (eager) and graph captures of new shapes INSIDE the timed region -- the first minutes of
             # a training run, before the ~470 shapes of the ADE20K list have all been captured (tools/shape_stream_sim.py)
-            raw = [a for a in cmd]
-            i = raw.index('--shapes')
-            raw[i + 1] = '0'
-            raw[raw.index('--steps') + 1] = '300'
-            raw[raw.index('--warmup') + 1] = '100'
+            raw = [sys.executable, os.path.abspath(__file__), '--config', str(cid), '--gpus', '1', '--shapes', '0', '--steps', '300',
+                   '--warmup', '100', '--no-cpu-baseline', '--no-other-configs', '--repeats', '0', '--no-box', '--no-scaling-model']
             t0 = time.perf_counter()
             try:
                 r = subprocess.run(raw, capture_output=True, text=True, timeout=budget_s + 140)
@@ -495,6 +512,7 @@ def other_configs(skip, steps, warmup, budget_s=100):
                     'mean_px_per_image': c['mean_px_per_image'], 'distinct_shapes_timed': c['distinct_shapes_timed'],
                     'events_timed': ev,
                     'host_ms_per_capture': round(1e3 * ev['capture_host_s'] / max(1, ev['captured']), 1),
+                    'of_which_instantiate_ms': round(1e3 * ev.get('instantiate_host_s', 0.0) / max(1, ev['captured']), 1),
                     'host_ms_per_first_sight': round(1e3 * ev['eager_host_s'] / max(1, ev['eager']), 1),
                     'note': 'stream order, graph LRU 512; every new shape costs one eager step (first sight) and one capture '
                             '(second sight), then replays', 'leg_wall_s': round(time.perf_counter() - t0, 1)}

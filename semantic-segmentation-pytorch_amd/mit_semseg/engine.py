@@ -157,6 +157,17 @@ def feed_key(feed):
     return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(feed.items()) if torch.is_tensor(v))
 
 
+class _TimedGraph(torch.cuda.CUDAGraph):
+    """a CUDAGraph that remembers how long ending the capture took (the graph is instantiated there): what a new batch shape costs
+    beyond the Python pass that records it"""
+    end_s = 0.0
+
+    def capture_end(self):
+        t0 = time.perf_counter()
+        super().capture_end()
+        self.end_s = time.perf_counter() - t0
+
+
 class TrainStep:
     """One training iteration of train.py:34-48 for a SegmentationModule.
 
@@ -204,7 +215,7 @@ class TrainStep:
         self._graph = None                            # the graph of the most recent replay (bench.py reports the launch mode)
         self.warmup_eager = 2
         self.timeline = None                          # scaling_model.TimelineProbe: timestamp markers inside the (captured) step
-        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0, 'capture_host_s': 0.0, 'eager_host_s': 0.0}
+        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0, 'capture_host_s': 0.0, 'instantiate_host_s': 0.0, 'eager_host_s': 0.0}
 
     def adjust_learning_rate(self):
         """train.py:130-139 poly schedule"""
@@ -310,9 +321,10 @@ class TrainStep:
             graph = SegmentedStep()
             out = graph.capture(lambda: self._eager(static), self._pool)
         else:
-            graph = torch.cuda.CUDAGraph()
+            graph = _TimedGraph()
             with torch.cuda.graph(graph, pool=self._pool):
                 out = self._eager(static)
+            self.stats['instantiate_host_s'] += graph.end_s    # of capture_host_s: hipStreamEndCapture + hipGraphInstantiate
         rec = self._graphs[key] = (graph, static, out)
         self.stats['captured'] += 1
         return rec
