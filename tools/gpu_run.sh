@@ -37,6 +37,8 @@ profile() { name=$1; shift
   python tools/rocprof_summary.py $src $OUT/kernel_stats_$name.csv
   python tools/rocprof_summary.py $src $OUT/kernel_stats_by_grid_$name.csv --by-grid
   python tools/trace_gaps.py $src 0.6 > $OUT/trace_gaps_$name.txt; head -3 $OUT/trace_gaps_$name.txt
+  ( cd tools && python trace_concurrency.py $ROOT/$src 8 > $ROOT/$OUT/trace_concurrency_$name.txt 2>&1 ); head -34 $OUT/trace_concurrency_$name.txt
+  ( cd tools && python trace_context.py $ROOT/$src copyBuffer 0.5 > $ROOT/$OUT/trace_context_copybuffer_$name.txt 2>&1 ); head -14 $OUT/trace_context_copybuffer_$name.txt
   rm -rf $OUT/prof_$name; }
 n=0
 for stage in "$@"; do
