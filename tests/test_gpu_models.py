@@ -363,6 +363,8 @@ def test_deferred_fork_sums_are_bit_identical(name, monkeypatch):
     bits as the add launches they replace: one fp32 add per element either way; state after two steps compared with torch.equal"""
     from mit_semseg import ops, tuner
     from mit_semseg.engine import TrainStep
+    if not (ops.FUSE and ops.CONV_MODE == 'h2'):
+        pytest.skip('the sums are only deferred on the fused h2 path (this process runs with a switch that turns it off)')
     monkeypatch.setattr(tuner, 'ENABLED', False)          # heuristic plans: both runs launch the same plans
     g = load_golden(name)
     m = g['meta']
