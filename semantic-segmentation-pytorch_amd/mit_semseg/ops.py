@@ -1057,7 +1057,8 @@ def _winograd_wgrad(L, v, dzp, geom):
 # the batched GEMM + output transform everywhere.
 WINOGRAD_FUSED = os.environ.get('SEMSEG_WINOGRAD_FUSED', '1') != '0'
 WINOGRAD_FUSED_FORMS = 10         # library forms of the fused kernel: 32-deep k-tiles (8 waves on a 3- / 4- / 5-slot ring, 4 waves on 4 / 5
-                                  # slots), 64-deep k-tiles with full-line DMA pieces on a half-tile ring (8 / 4 waves)
+                                  # slots), 64-deep k-tiles with full-line DMA pieces on a half-tile ring (8 / 4 waves: 5 / 6), round 5: 7 =
+                                  # form 5 with its DMA pieces spread behind the MFMA groups, 8 / 9 = 7 / 5 with s_setprio (form 6 spread: measured, never chosen, removed)
 
 
 def _winograd_dgrad(L, dzp, ut_planes, geom, form=None):

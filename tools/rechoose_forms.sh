@@ -11,7 +11,7 @@ for c in 1 2 3; do
       > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err
   echo "cfg$c rc=$?"
 done
-timeout 600 python -m pytest tests/test_gpu_models.py -m gpu -q -x -p no:cacheprovider -k "full_size" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
+timeout 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "full_size or winograd_dgrad" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
 python - <<'PY'
 import json, os
 out = os.path.join('gpurun_out', 'rechoose')
