@@ -48,6 +48,32 @@ def _bucket_key(scheme, pass_id, geom):
     return (scheme, pass_id, c, k, r, s, stride, pad, dil, int(round(2.0 * math.log2(m))))
 
 
+def _bucket_lookup(bkey):
+    """the plan of bucket `bkey`, else of the NEAREST half-octave of the same layer (up to two octaves away): a plan measured for the
+    same layer at a neighbouring size beats timing ~200 candidates inside a training step -- the variable-size stream of BASELINE
+    configs[3] keeps meeting new pixel counts (81 geometries were timed inside 400 steps of the raw stream before this, gpurun r6N)"""
+    rec = _bucket_plans.get(bkey)
+    if rec is not None:
+        return rec
+    for d in (1, -1, 2, -2, 3, -3, 4, -4):
+        rec = _bucket_plans.get(bkey[:-1] + (bkey[-1] + d,))
+        if rec is not None:
+            return rec
+    return None
+
+
+def _bucket_key_wino(pass_id, geom):
+    """pass 3 (tile of the batched Winograd GEMM, geom = (tiles, 1, 1, C, K, ...)) and pass 4 (launch form, geom = (tiles, n, dil, C, K,
+    ...)): the same layer in the same half-octave of Winograd tiles.  Without it every new batch shape of the variable-size stream
+    (BASELINE configs[3]) timed ~10 GEMM tiles and ~10 fused forms of conv_last / cbr_deepsup / layer4 on its first sight: 0.3 - 0.5 s
+    per shape (bench.py raw_stream leg, gpurun r6M)."""
+    import math
+    tiles = max(1, int(geom[0]))
+    if pass_id == 3:
+        return ('w3', int(geom[3]), int(geom[4]), int(round(2.0 * math.log2(tiles))))
+    return ('w4', int(geom[2]), int(geom[3]), int(geom[4]), int(round(2.0 * math.log2(tiles))))
+
+
 def _load_cache():
     """perf database first (read-only), then the read-write cache of SEMSEG_TUNE_CACHE on top of it"""
     global _cache_loaded
@@ -71,11 +97,18 @@ def _load_cache():
                     continue                  # tools/rechoose_forms.sh: new launch forms exist, every choice is timed afresh
                 _done[key] = tuple(v)
                 stats_db[counter] += 1
+                bk = _bucket_key_wino(4, key[2:])
+                if counter == 'from_cache' or bk not in _bucket_plans:
+                    _bucket_plans[bk] = (int(v[0]), int(v[1]))
                 continue
             if v[0] >= 0 and _set_plan(L, key[0])(key[1], *key[2:], int(v[0]), int(v[1])) != 0:
                 continue                      # a plan this build of the library does not know: the geometry is timed afresh
             _done[key] = tuple(v)
             stats_db[counter] += 1
+            if key[1] == 3:
+                bk = _bucket_key_wino(3, key[2:])
+                if counter == 'from_cache' or bk not in _bucket_plans:
+                    _bucket_plans[bk] = (int(v[0]), int(v[1]))
             if key[1] in (0, 1, 2):
                 bk = _bucket_key(key[0], key[1], key[2:])
                 if counter == 'from_cache' or bk not in _bucket_plans:      # the later source (the user's cache) wins, as for _done;
@@ -156,10 +189,17 @@ def ensure_winograd_gemm(tiles, c, k, launch):
         _load_cache()
     if not ENABLED or key in _done:
         return
-    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
-        return
     L = _native.lib()
     set_plan = _set_plan(L, 'h2')
+    bkey = _bucket_key_wino(3, geom)
+    if BUCKETS and _bucket_lookup(bkey) is not None:
+        tile, _ = _bucket_lookup(bkey)
+        if tile < 0 or set_plan(3, *geom, tile, 1) == 0:
+            _done[key] = (tile, 1 if tile >= 0 else 0, None)
+            stats['inherited'] += 1
+            return
+    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return
     stats['timed'] += 1
     best = None
     _TIMING[0] = True
@@ -183,6 +223,8 @@ def ensure_winograd_gemm(tiles, c, k, launch):
         else:
             set_plan(3, *geom, best[0], 1)
     _done[key] = best
+    if best is not None:
+        _bucket_plans.setdefault(bkey, (int(best[0]), int(best[1])))
     _save_cache()
 
 
@@ -197,6 +239,12 @@ def choose(geom, candidates, default=0):
     rec = _done.get(key)
     if rec is not None:
         return int(rec[0]) if 0 <= int(rec[0]) < len(candidates) else default
+    bkey = _bucket_key_wino(4, key[2:])
+    near = _bucket_lookup(bkey) if (ENABLED and BUCKETS) else None
+    if near is not None and 0 <= near[0] < len(candidates):
+        _done[key] = (near[0], 1, None)          # the form measured for the same layer at a neighbouring size
+        stats['inherited'] += 1
+        return near[0]
     if not ENABLED or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
         return default
     stats['timed'] += 1
@@ -212,6 +260,7 @@ def choose(geom, candidates, default=0):
     if best is None:
         return default
     _done[key] = best
+    _bucket_plans.setdefault(bkey, (int(best[0]), 1))
     _save_cache()
     return best[0]
 
@@ -224,8 +273,8 @@ def ensure(scheme, pass_id, geom, launch):
         _load_cache()
     if not ENABLED or key in _done:
         return
-    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
-        return                                  # host-logic dry runs (CPU, stubbed ABI) and graph capture: never time
+    if not torch.cuda.is_available():
+        return                                  # host-logic dry runs (CPU, stubbed ABI): never time
     L = _native.lib()
     n, h, w, c, k, r, s, stride, pad, dil = geom
     oh = (h + 2 * pad - dil * (r - 1) - 1) // stride + 1
@@ -240,8 +289,8 @@ def ensure(scheme, pass_id, geom, launch):
     tiles = _WTILES[scheme] if pass_id == 2 else _TILES[scheme]
     set_plan = _set_plan(L, scheme)
     bkey = _bucket_key(scheme, pass_id, geom)
-    if BUCKETS and bkey in _bucket_plans:
-        tile, split = _bucket_plans[bkey]
+    if BUCKETS and _bucket_lookup(bkey) is not None:
+        tile, split = _bucket_lookup(bkey)
         ok = True
         if tile >= 0:
             while split > 1 and kt // split < 4:              # the same validity rule as the sweep below
@@ -251,6 +300,8 @@ def ensure(scheme, pass_id, geom, launch):
             _done[key] = (tile, split if tile >= 0 else 0, None)
             stats['inherited'] += 1
             return
+    if torch.cuda.is_current_stream_capturing():
+        return                                  # graph capture: a plan may be inherited (above), never timed
     stats['timed'] += 1
     best = None
     ranked = []                                     # (ms, tile, split) of every candidate that ran

@@ -1,5 +1,9 @@
-export TMPDIR=/tmp
-bash tools/gpu_run.sh r6M bench "test:env_switch_keeps_model_parity and FUSE" 2>&1 | tail -12
-bash tools/gpu_pmc_wino.sh r6M_pmc_fused --form,8 2>&1 | tail -40
-bash tools/gpu_pmc_wino.sh r6M_pmc_l4fwd --mode,fwd,--geom,2:64:64:512:512:4,--tile,14 2>&1 | tail -60
-bash tools/gpu_run.sh r6M_prof prof prof:4 2>&1 | grep -v "^wrote" | tail -80
+OUT=gpurun_out/r6N; mkdir -p $OUT; export TMPDIR=/tmp
+python __graft_entry__.py > $OUT/build.log 2>&1 || { echo BUILD FAILED; exit 1; }
+timeout 600 python bench.py --config 3 --shapes 0 --steps 300 --warmup 100 --no-cpu-baseline --no-other-configs --repeats 0 --no-box --no-scaling-model > $OUT/raw.json 2> $OUT/raw.err
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r6N/raw.json') if l.startswith('{')][-1])
+print(d['value'], d['ms_per_step'], d['config']['shape_events_timed'], d['config']['launch_plans'])
+PY
+tail -3 $OUT/raw.err
