@@ -2128,6 +2128,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFPara
         if (live) {
             if (++i_c == p.chunks) { i_c = 0; ++i_f; }
         }
+        if (PROBE == 4) {
+            // hybrid: the A pieces by LDS-DMA, the B pieces by plain loads (consumed one call later): do the two paths add up?
+#pragma unroll
+            for (int i = 0; i < BG * NP; ++i) {
+                dummy.x ^= hold[i].x; dummy.y ^= hold[i].y; dummy.z ^= hold[i].z; dummy.w ^= hold[i].w;
+            }
+#pragma unroll
+            for (int i = 0; i < AG; ++i)
+#pragma unroll
+                for (int s = 0; s < NP; ++s) {
+                    const uint32_t vo = live ? a_src[i] + ((ka + s * a_plane_b) & a_msk[i]) : a_zero;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)(abuf + (s * BM + NW * i * 16) * 64), 16, vo, 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < BG; ++i)
+#pragma unroll
+                for (int s = 0; s < NP; ++s) {
+                    const uint32_t vo = live ? b_src[i] + ((kb + s * b_plane_b) & b_msk[i]) : b_zero;
+                    hold[i * NP + s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, vo, 0, 0));
+                }
+            return;
+        }
         if (PROBE == 3) {
             // the OLDEST of the PD k-tiles in flight is consumed, the others shift down (register moves the compiler renames away
             // in the unrolled loop body), the new tile's loads take the last place
@@ -2236,20 +2258,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFPara
 #pragma unroll
     for (int t = 0; t < NSLOT; ++t) issue(t, t);
     frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
-    if (PROBE != 3) wait_vm_barrier<(NSLOT - 1) * LPT>();     // tile 0 has landed for every wave
+    if (PROBE < 3) wait_vm_barrier<(NSLOT - 1) * LPT>();      // tile 0 has landed for every wave
     read_frags(0, 0, a0, b0);
     int slot = 0, c_c = 0, c_f = 0;                            // (frequency, chunk) of the tile being MULTIPLIED
     for (int it = 0; it < nk; ++it) {
         const int next = (slot == NSLOT - 1) ? 0 : slot + 1;
-        if (PROBE != 1 && PROBE != 3) {
+        if (PROBE != 1 && PROBE < 3) {
             read_frags(slot, 1, a1, b1);
             mma(a0, b0);
         }
         if (PROBE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (PROBE == 3) __builtin_amdgcn_s_barrier();
+        else if (PROBE >= 3) __builtin_amdgcn_s_barrier();
         else wait_vm_barrier<(NSLOT - 2) * LPT>();            // my reads of `slot` are done, tile it+1 has landed
         issue(it + NSLOT, slot);
-        if (PROBE != 1 && PROBE != 3) {
+        if (PROBE != 1 && PROBE < 3) {
             read_frags(next, 0, a0, b0);                      // past the last tile: zero tail, never multiplied
             mma(a1, b1);
         }
@@ -2261,7 +2283,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wino_fused_kernel(const WFPara
         slot = next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (PROBE == 3) {
+    if (PROBE >= 3) {
 #pragma unroll
         for (int i = 0; i < PD * LPT; ++i) { dummy.x ^= hold[i].x; dummy.y ^= hold[i].y; dummy.z ^= hold[i].z; dummy.w ^= hold[i].w; }
         if ((dummy.x ^ dummy.y ^ dummy.z ^ dummy.w) == 0x9e3779b9u) p.out[0] = 1.f;      // keeps the loads alive
@@ -2624,6 +2646,7 @@ extern "C" int semseg_winograd_gemm_output_h2(const void* v_planes, const void* 
         case 100: return launch_wino_fused<128, 128, 4, 2, 5, 1>(p, st);      // probes of form 2 (garbage results)
         case 101: return launch_wino_fused<128, 128, 4, 2, 5, 2>(p, st);
         case 102: return launch_wino_fused<128, 128, 4, 2, 5, 3>(p, st);      // the piece stream by plain loads into registers
+        case 103: return launch_wino_fused<128, 128, 4, 2, 5, 4>(p, st);      // A pieces by LDS-DMA, B pieces by plain loads
         default: return SEMSEG_EINVAL;
     }
 }

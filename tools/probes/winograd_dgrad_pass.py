@@ -56,7 +56,7 @@ def main():
     _native.check(L.semseg_conv2d_h2_set_plan(3, tiles, 1, 1, k, c, 3, 3, 1, 1, 1, args.tile, 1), 'set_plan')
     if args.time:
         gflop = 2.0 * n * h * w * c * k * 9 * 1e-9
-        forms = list(range(1 + ops.WINOGRAD_FUSED_FORMS)) + ([101, 102, 103] if args.probes else [])
+        forms = list(range(1 + ops.WINOGRAD_FUSED_FORMS)) + ([101, 102, 103, 104] if args.probes else [])
         for form in forms:
             if form > 100:      # 101 = the fused kernel's DMA stream alone, 102 = its fragment reads + MFMAs alone (garbage results)
                 tiles = L.semseg_winograd_tiles(n, h, w, dil)
@@ -75,7 +75,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 what = {101: 'DMA stream only', 102: 'fragment reads + MFMAs only',
-                        103: 'the piece stream by plain 16-byte loads into registers, no LDS'}[form]
+                        103: 'the piece stream by plain 16-byte loads into registers, no LDS',
+                        104: 'A pieces by LDS-DMA, B pieces by plain loads into registers'}[form]
                 print('geom %s probe %d (%s): %.4f ms per launch' % (args.geom, form, what, e0.elapsed_time(e1) / args.iters))
                 continue
             for _ in range(3):
