@@ -590,6 +590,10 @@ int semseg_probe_timestamp(void* slot, void* stream);
 int semseg_probe_mfma_f16(void* sink, int blocks, int iters, void* cycles, void* stream);
 int semseg_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
 int semseg_probe_empty(void* stream);
+/* operand ingest of a CU: `blocks` x 4 waves gather `steps` x 32 KiB each from a rows x pitch byte matrix in pieces of
+ * (1024 / seg_bytes) rows x seg_bytes -- by LDS-DMA (dma != 0) or by plain 16-byte loads into registers; tools/probes/gather_ingest.py */
+int semseg_probe_gather(const void* src, unsigned rows, unsigned pitch, int seg_bytes, int dma, int blocks, int steps, void* sink,
+                        void* stream);
 
 #ifdef __cplusplus
 }

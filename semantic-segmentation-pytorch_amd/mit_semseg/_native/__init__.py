@@ -180,6 +180,7 @@ SIGNATURES = {
     'semseg_probe_mfma_f16': (c_int, [vp, c_int, c_int, vp, vp]),
     'semseg_probe_copy': (c_int, [vp, vp, c_sz, vp]),
     'semseg_probe_empty': (c_int, [vp]),
+    'semseg_probe_gather': (c_int, [vp, ctypes.c_uint, ctypes.c_uint, c_int, c_int, c_int, c_int, vp, vp]),
 }
 
 
