@@ -172,9 +172,10 @@ class TrainStep:
     """One training iteration of train.py:34-48 for a SegmentationModule.
 
     step(feed) -> (loss, acc) device scalars.  With `graph=True` the step is captured into a hipGraph PER FEED SHAPE: the
-    first time a shape is seen (and during the first `warmup_eager` steps) the step runs eagerly -- that sizes the workspace,
-    tunes / assigns the conv launch plans of the new geometries and warms the allocator -- the second time it is captured
-    (fwd + bwd + all-reduce + SGD), and from then on the batch is copied into the graph's static buffers and replayed.  The
+    first `warmup_eager` steps run eagerly -- that sizes the workspace, tunes the conv launch plans and warms the allocator --,
+    after them a shape is recorded (fwd + bwd + all-reduce + SGD) the first time it is seen (`capture_first_sight`; its launch
+    plans are inherited from the same layers at neighbouring sizes, tuner._bucket_lookup) and from then on the batch is copied
+    into the graph's static buffers and replayed.  The
     variable-size per-GPU batches of the multi-scale pipeline (BASELINE configs[3]: short side 300...600, long side <= 1000,
     multiples of 8) therefore converge to replays; at most `max_graphs` graphs are kept (least recently used goes first) and
     they share ONE allocator pool, so their activation memory is the maximum over the shapes, not the sum (each graph is
@@ -211,11 +212,20 @@ class TrainStep:
         self.max_graphs = int(os.environ.get('SEMSEG_TRAIN_GRAPHS', max_graphs or 512))
         self._graphs = collections.OrderedDict()      # feed_key -> (graph, static feed, (loss, acc))
         self._seen = {}                               # feed_key -> eager steps run at this shape
+        self._provisional = {}                        # feed_key -> a first-sight graph captured without all its launch plans (see below)
         self._pool = None
+        self._capture_stream = None
         self._graph = None                            # the graph of the most recent replay (bench.py reports the launch mode)
         self.warmup_eager = 2
+        # a NEW batch shape is captured the first time it is seen (after the warm-up steps), not run eagerly once and captured at its
+        # second sight: the Python pass that records the step costs about what the eager pass costs, so a shape that comes back (most do:
+        # TrainStep docstring) pays one pass instead of two.  A capture cannot time launch plans: a geometry met inside it without a plan to
+        # inherit (tuner.stats['missed_capturing']) makes the graph provisional -- replayed this once, then the old order (eager pass
+        # that times the plans, capture at the next sight).  SEMSEG_CAPTURE_FIRST_SIGHT=0: the old order for every shape.
+        self.capture_first_sight = os.environ.get('SEMSEG_CAPTURE_FIRST_SIGHT', '1') != '0'
         self.timeline = None                          # scaling_model.TimelineProbe: timestamp markers inside the (captured) step
-        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0, 'capture_host_s': 0.0, 'instantiate_host_s': 0.0, 'eager_host_s': 0.0}
+        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0, 'provisional': 0, 'capture_host_s': 0.0, 'instantiate_host_s': 0.0,
+                      'eager_host_s': 0.0}
 
     def adjust_learning_rate(self):
         """train.py:130-139 poly schedule"""
@@ -289,16 +299,26 @@ class TrainStep:
         rec = self._graphs.get(key)
         if rec is None:
             seen = self._seen.get(key, 0)
-            if self.opt.steps < self.warmup_eager or seen < 1:
+            first_sight = seen < 1 and self.capture_first_sight and mode == 'graph' and key not in self._provisional
+            if self.opt.steps < self.warmup_eager or (seen < 1 and not first_sight):
                 self._seen[key] = seen + 1
                 self.stats['eager'] += 1
                 t0 = time.perf_counter()
                 out = self._eager(feed)
                 self.stats['eager_host_s'] += time.perf_counter() - t0      # host time of issuing the step (no device sync)
                 return out
+            from . import tuner
+            missed = tuner.stats['missed_capturing']
             t0 = time.perf_counter()
             rec = self._capture(key, feed, mode)
             self.stats['capture_host_s'] += time.perf_counter() - t0        # the capture pass + graph instantiation
+            if first_sight and tuner.stats['missed_capturing'] != missed:
+                # provisional: replayed this once; the next sight runs eagerly (times the missing plans), the one after captures for good.
+                # The graph object outlives its replay (it is dropped when the shape is captured again, many steps later)
+                self._provisional[key] = self._graphs.pop(key)
+                self.stats['provisional'] += 1
+            else:
+                self._provisional.pop(key, None)
         else:
             self._graphs.move_to_end(key)
         graph, static, out = rec
@@ -321,9 +341,23 @@ class TrainStep:
             graph = SegmentedStep()
             out = graph.capture(lambda: self._eager(static), self._pool)
         else:
+            # NOT `with torch.cuda.graph(...)`: its __enter__ is torch.cuda.synchronize() + empty_cache(), which drains the queue of
+            # replays the host has run ahead of and leaves the device idle for the whole recording pass -- on the variable-size stream
+            # (a new shape every few steps at the start of a run) that serialises ~40 ms of host work per new shape with the device.
+            # Recording executes nothing: the capture stream only has to be ordered after the work already issued (an event wait, no
+            # host sync), and the replay goes to the current stream as before.  The graphs' private pool needs no room made for it.
             graph = _TimedGraph()
-            with torch.cuda.graph(graph, pool=self._pool):
-                out = self._eager(static)
+            if self._capture_stream is None:
+                self._capture_stream = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self._capture_stream.wait_stream(cur)
+            with torch.cuda.stream(self._capture_stream):
+                graph.capture_begin(pool=self._pool)
+                try:
+                    out = self._eager(static)
+                finally:
+                    graph.capture_end()
+            cur.wait_stream(self._capture_stream)
             self.stats['instantiate_host_s'] += graph.end_s    # of capture_host_s: hipStreamEndCapture + hipGraphInstantiate
         rec = self._graphs[key] = (graph, static, out)
         self.stats['captured'] += 1

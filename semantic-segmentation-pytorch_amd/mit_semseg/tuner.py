@@ -36,7 +36,7 @@ stats_db = {'from_perfdb': 0, 'from_cache': 0}
 # SEMSEG_TUNE_BUCKETS=0: time every geometry.
 BUCKETS = os.environ.get('SEMSEG_TUNE_BUCKETS', '1') != '0'
 _bucket_plans = {}  # (scheme, pass, C, K, R, S, stride, pad, dil, bucket) -> (tile, split)
-stats = {'timed': 0, 'inherited': 0}
+stats = {'timed': 0, 'inherited': 0, 'missed_capturing': 0}   # missed_capturing: geometries met inside a graph capture with no plan to inherit
 
 
 def _bucket_key(scheme, pass_id, geom):
@@ -198,7 +198,10 @@ def ensure_winograd_gemm(tiles, c, k, launch):
             _done[key] = (tile, 1 if tile >= 0 else 0, None)
             stats['inherited'] += 1
             return
-    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+    if not torch.cuda.is_available():
+        return
+    if torch.cuda.is_current_stream_capturing():
+        stats['missed_capturing'] += 1          # runs on the library's default; engine.TrainStep re-captures after an eager (timing) pass
         return
     stats['timed'] += 1
     best = None
@@ -245,7 +248,10 @@ def choose(geom, candidates, default=0):
         _done[key] = (near[0], 1, None)          # the form measured for the same layer at a neighbouring size
         stats['inherited'] += 1
         return near[0]
-    if not ENABLED or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+    if not ENABLED or not torch.cuda.is_available():
+        return default
+    if torch.cuda.is_current_stream_capturing():
+        stats['missed_capturing'] += 1
         return default
     stats['timed'] += 1
     best = None
@@ -301,6 +307,7 @@ def ensure(scheme, pass_id, geom, launch):
             stats['inherited'] += 1
             return
     if torch.cuda.is_current_stream_capturing():
+        stats['missed_capturing'] += 1
         return                                  # graph capture: a plan may be inherited (above), never timed
     stats['timed'] += 1
     best = None
