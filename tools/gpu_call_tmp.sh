@@ -1,13 +1,11 @@
-OUT=gpurun_out/r6X; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=gpurun_out/r6Y; mkdir -p $OUT; export TMPDIR=/tmp
 python __graft_entry__.py > $OUT/build.log 2>&1 || { echo BUILD FAILED; exit 1; }
-timeout 400 python -m pytest tests/test_gpu_ddp.py tests/test_gpu_probes.py tests/test_gpu_models.py -q -x -k "per_shape_train_graphs or timeline or probe or graph or replay" 2>&1 | grep -v amdgpu.ids | tail -8
-for fs in 1; do
-SEMSEG_CAPTURE_FIRST_SIGHT=$fs timeout 600 python bench.py --config 3 --shapes 0 --steps 300 --warmup 100 --no-cpu-baseline --no-other-configs --repeats 0 --no-box --no-scaling-model > $OUT/raw$fs.json 2> $OUT/raw$fs.err
-python - $fs <<'PY'
-import json, sys
-fs = sys.argv[1]
-d=json.loads([l for l in open('gpurun_out/r6X/raw%s.json' % fs) if l.startswith('{')][-1])
-print('first_sight=%s' % fs, d['value'], d['ms_per_step'], d['config']['shape_events_timed'], d['config']['launch_plans'], d['config']['final_loss'])
+( time timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2>&1 | grep real
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r6Y/bench.json') if l.startswith('{')][-1])
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('traffic'), d['cpu_baseline']['value'])
+for k,v in d['config']['other_configs'].items():
+    print(k, v.get('img_s'), v.get('ms_per_step'), {kk: vv for kk, vv in (v.get('raw_stream') or {}).items() if kk in ('img_s','fraction_of_steady_state','events_timed','host_ms_per_capture')})
 PY
-tail -2 $OUT/raw$fs.err
-done
+tail -2 $OUT/bench.err
