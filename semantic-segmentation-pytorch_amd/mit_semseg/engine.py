@@ -109,10 +109,9 @@ class SegmentedStep:
 
     def capture(self, run, pool):
         """`run()` executes one eager step on static buffers; returns what it returns"""
-        import gc
         self.pool = pool
-        gc.collect()
-        torch.cuda.synchronize()
+        # no device synchronize, no gc.collect() (TrainStep._capture): recording executes nothing, the capture stream is ordered after the
+        # work already issued by the event wait below
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         prev = ops._SEGMENTS
@@ -166,6 +165,25 @@ class _TimedGraph(torch.cuda.CUDAGraph):
         t0 = time.perf_counter()
         super().capture_end()
         self.end_s = time.perf_counter() - t0
+
+
+def record_graph(graph, run, stream, pool=None):
+    """record `run()` into `graph` on `stream` (not the current one) WITHOUT a device synchronize: what `with torch.cuda.graph(...)` does
+    minus its torch.cuda.synchronize() + empty_cache().  Recording executes nothing, so the capture stream only has to be ordered after
+    the work already issued (an event wait); the replay goes to whatever stream is current then.  Returns what run() returns."""
+    cur = torch.cuda.current_stream()
+    stream.wait_stream(cur)
+    with torch.cuda.stream(stream):
+        if pool is None:
+            graph.capture_begin()
+        else:
+            graph.capture_begin(pool=pool)
+        try:
+            out = run()
+        finally:
+            graph.capture_end()
+    cur.wait_stream(stream)
+    return out
 
 
 class TrainStep:
@@ -299,7 +317,7 @@ class TrainStep:
         rec = self._graphs.get(key)
         if rec is None:
             seen = self._seen.get(key, 0)
-            first_sight = seen < 1 and self.capture_first_sight and mode == 'graph' and key not in self._provisional
+            first_sight = seen < 1 and self.capture_first_sight and key not in self._provisional
             if self.opt.steps < self.warmup_eager or (seen < 1 and not first_sight):
                 self._seen[key] = seen + 1
                 self.stats['eager'] += 1
@@ -349,15 +367,7 @@ class TrainStep:
             graph = _TimedGraph()
             if self._capture_stream is None:
                 self._capture_stream = torch.cuda.Stream()
-            cur = torch.cuda.current_stream()
-            self._capture_stream.wait_stream(cur)
-            with torch.cuda.stream(self._capture_stream):
-                graph.capture_begin(pool=self._pool)
-                try:
-                    out = self._eager(static)
-                finally:
-                    graph.capture_end()
-            cur.wait_stream(self._capture_stream)
+            out = record_graph(graph, lambda: self._eager(static), self._capture_stream, self._pool)
             self.stats['instantiate_host_s'] += graph.end_s    # of capture_host_s: hipStreamEndCapture + hipGraphInstantiate
         rec = self._graphs[key] = (graph, static, out)
         self.stats['captured'] += 1
@@ -385,6 +395,7 @@ class InferenceGraph:
         self.max_graphs = max_graphs
         self._graphs = {}           # (img shape, segSize, accumulate, weight) -> (graph, static image, output)
         self._scores = {}           # (N, segSize) -> score buffer of multi_scale
+        self._capture_stream = None
 
     def _eager(self, img, segSize, head=None):
         with torch.no_grad():
@@ -406,8 +417,9 @@ class InferenceGraph:
                 head[0].copy_(keep)
             static = img.clone()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._eager(static, segSize, head)
+            if self._capture_stream is None:
+                self._capture_stream = torch.cuda.Stream()
+            out = record_graph(graph, lambda: self._eager(static, segSize, head), self._capture_stream)
             rec = self._graphs[key] = (graph, static, out)
         graph, static, out = rec
         static.copy_(img)
