@@ -864,9 +864,26 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// -DSEMSEG_STAMPS (tools/probes/gemm_phase_stamps.py builds such a library beside the product one): wave 0 of every block of
+// igemm_dma_kernel leaves four wall-clock stamps -- entry, first tile landed, k loop done, epilogue done -- in a device table
+#ifdef SEMSEG_STAMPS
+__device__ unsigned long long semseg_dbg_stamps[4 * 16384];
+#define SEMSEG_STAMP(i)                                                                                                          \
+    do {                                                                                                                          \
+        if (threadIdx.x == 0)                                                                                                     \
+            semseg_dbg_stamps[((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 16383) * 4 + (i)] = wall_clock64(); \
+    } while (0)
+extern "C" int semseg_debug_stamps(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(semseg_dbg_stamps), n * sizeof(unsigned long long));
+}
+#else
+#define SEMSEG_STAMP(i)
+#endif
+
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
 __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams p) {
     constexpr int NP = SCH::NP;
+    SEMSEG_STAMP(0);
     typedef typename SCH::frag frag;
     // waves: 8 (4x2 / 2x4) for the round-1 tiles; 4 (2x2: 128x128 / 128x64 per wave -- a third less LDS read traffic per MFMA, one
     // wave per SIMD with up to 512 registers) and 16 (4x4: 64x64 per wave, four waves per SIMD to hide the waits) since round 2
@@ -997,6 +1014,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem + (uint32_t)wave * 1024u;   // this wave's first 16-row group
     // issue the DMA of k-tile `kt` into LDS slot `slot` (every lane fetches the zero tail when kt is out of range)
     auto issue = [&](int kt, int slot) {
+#ifdef SEMSEG_PROBE_NODMA
+        return;                                  // timing probe (tools/probes/gemm_phase_stamps.py): the loop without its DMA
+#endif
         const uint32_t abuf = lds0 + (uint32_t)slot * BUF_BYTES;
         const uint32_t bbuf = abuf + A_BYTES;
         if (kt < kt_end) {                  // wave-uniform; tiles are issued in k order: the counters advance here
@@ -1053,6 +1073,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
 
     // fragments of k-step `ks` (16 of the 32 channels of the k-tile) of the tile in `slot`
     auto read_frags = [&](int slot, int ks, frag (&av)[FM][NP], frag (&bv)[FN][NP]) {
+#ifdef SEMSEG_PROBE_NOREAD
+        return;                                  // timing probe: no fragment reads
+#endif
         const uint4* As = reinterpret_cast<const uint4*>(smem + slot * BUF_BYTES);
         const uint4* Bs = reinterpret_cast<const uint4*>(smem + slot * BUF_BYTES + A_BYTES);
         const int ch = 2 * ks + kb;
@@ -1070,6 +1093,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
         }
     };
     auto mma = [&](const frag (&av)[FM][NP], const frag (&bv)[FN][NP]) {
+#ifdef SEMSEG_PROBE_NOMMA                                 // timing probe: the fragments are read and dropped
+#ifndef SEMSEG_PROBE_NOREAD
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(av[i][s]));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bv[j][s]));
+        }
+#endif
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -1278,6 +1313,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
         //       DMA tile it+2 -> the slot just read | read ks=0 of tile it+1 | MMA ks=1
         frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
         wait_vm_barrier<LPT>();                               // tile 0 has landed for every wave
+        SEMSEG_STAMP(1);
         read_frags(0, 0, a0, b0);
         for (int it = 0; it < nk; ++it) {
             const int slot = it & 1;
@@ -1308,7 +1344,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
+    SEMSEG_STAMP(2);
     gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
+    SEMSEG_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------

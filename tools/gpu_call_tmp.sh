@@ -1,3 +1,3 @@
-OUT=gpurun_out/r6Z; mkdir -p $OUT; export TMPDIR=/tmp
-python __graft_entry__.py > $OUT/build.log 2>&1 || { echo BUILD FAILED; exit 1; }
-timeout 800 python -m pytest tests/test_gpu_ddp.py tests/test_gpu_probes.py tests/test_gpu_eval_loop.py tests/test_gpu_drivers.py -q -x 2>&1 | grep -v amdgpu.ids | tail -8
+for layer in l4_conv2_d4 conv_last; do for v in "" _nomma _nodma _dmaonly _mmaonly; do
+echo "== $layer variant '$v'"; python tools/probes/gemm_phase_stamps.py --layer $layer --variant "$v" 2>&1 | grep -v "amdgpu.ids\|Warning\|_warn_once\|blocks with stamp" | tail -8
+done; done
