@@ -47,6 +47,7 @@ def main():
     ap.add_argument('--build', action='store_true')
     ap.add_argument('--layer', default='l4_conv2_d4')
     ap.add_argument('--variant', default='', choices=sorted(VARIANTS))
+    ap.add_argument('--wino-tile', type=int, default=-1, help='pin this tile for the batched Winograd GEMM (plan pass 3) instead of the tuned one')
     a = ap.parse_args()
     if a.build:
         return build()
@@ -78,6 +79,13 @@ def main():
     ops.prepare_conv_weights([w0])
     x = ops.conv_bn_act(x, w0, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, bn0.num_batches_tracked, None, 1, 0, 1,
                         training=True, relu=True)
+
+    if a.wino_tile >= 0:
+        from mit_semseg import tuner
+        tiles = n * ((h + 1) // 2) * ((w + 1) // 2)
+        geom = (tiles, 1, 1, c, k, 3, 3, 1, 1, 1)
+        tuner._done[('h2', 3) + geom] = (a.wino_tile, 1, None)
+        print('pinned wino GEMM tile %d: rc %d' % (a.wino_tile, L.semseg_conv2d_h2_set_plan(3, *geom, a.wino_tile, 1)))
 
     def run():
         # the fused conv -> BN -> ReLU node is the caller of the Winograd forward in the product
