@@ -242,7 +242,7 @@ class TrainStep:
         # that times the plans, capture at the next sight).  SEMSEG_CAPTURE_FIRST_SIGHT=0: the old order for every shape.
         self.capture_first_sight = os.environ.get('SEMSEG_CAPTURE_FIRST_SIGHT', '1') != '0'
         self.timeline = None                          # scaling_model.TimelineProbe: timestamp markers inside the (captured) step
-        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0, 'provisional': 0, 'capture_host_s': 0.0, 'instantiate_host_s': 0.0,
+        self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0, 'provisional': 0, 'capture_failed': 0, 'capture_host_s': 0.0, 'instantiate_host_s': 0.0,
                       'eager_host_s': 0.0}
 
     def adjust_learning_rate(self):
@@ -328,7 +328,19 @@ class TrainStep:
             from . import tuner
             missed = tuner.stats['missed_capturing']
             t0 = time.perf_counter()
-            rec = self._capture(key, feed, mode)
+            try:
+                rec = self._capture(key, feed, mode)
+            except RuntimeError:
+                if not first_sight:
+                    raise
+                # something on this shape's path cannot be recorded before it has run once (the old order would have run it eagerly
+                # first): nothing of a recording executes, so the step is still to be done -- eagerly, and the shape keeps the old order
+                self._graphs.pop(key, None)
+                self._provisional[key] = None
+                self.stats['capture_failed'] += 1
+                self._seen[key] = 1
+                self.stats['eager'] += 1
+                return self._eager(feed)
             self.stats['capture_host_s'] += time.perf_counter() - t0        # the capture pass + graph instantiation
             if first_sight and tuner.stats['missed_capturing'] != missed:
                 # provisional: replayed this once; the next sight runs eagerly (times the missing plans), the one after captures for good.

@@ -14,7 +14,7 @@ class _Graph:
         self.log.append(('replay', self.key))
 
 
-def _step(monkeypatch, first_sight, missing=()):
+def _step(monkeypatch, first_sight, missing=(), unrecordable=()):
     """a TrainStep whose capture / eager passes only write to a log; capturing a shape in `missing` meets a geometry without a launch plan"""
     monkeypatch.setenv('SEMSEG_CAPTURE_FIRST_SIGHT', '1' if first_sight else '0')
     net = nn.Module()
@@ -31,6 +31,8 @@ def _step(monkeypatch, first_sight, missing=()):
     def capture(key, feed, mode='graph'):
         shape = tuple(feed['x'].shape)
         log.append(('capture', shape))
+        if shape in unrecordable and shape not in timed:
+            raise RuntimeError('operation not permitted when stream is capturing')
         if shape in missing and shape not in timed:
             tuner.stats['missed_capturing'] += 1
         rec = ts._graphs[key] = (_Graph(log, shape), {}, (torch.zeros(()), torch.zeros(())))
@@ -88,3 +90,11 @@ def test_a_capture_that_met_an_unplanned_geometry_is_provisional(monkeypatch):
                    ('capture', C), ('replay', C),                    # for good
                    ('replay', C)]
     assert ts.stats['provisional'] == 1 and not ts._provisional
+
+
+def test_a_shape_that_cannot_be_recorded_at_first_sight_falls_back_to_the_old_order(monkeypatch):
+    """a failed first-sight recording executes nothing: the step runs eagerly instead, and the shape is recorded at its next sight"""
+    ts, log = _step(monkeypatch, True, unrecordable={C})
+    _run(ts, log, [A, B, C, C, C])
+    assert log == [('eager', A), ('eager', B), ('capture', C), ('eager', C), ('capture', C), ('replay', C), ('replay', C)]
+    assert ts.stats['capture_failed'] == 1 and ts.stats['captured'] == 1
