@@ -1,3 +1,7 @@
-for layer in conv_last l4_conv2_d4; do for t in 25 26; do for v in "" _dmaonly _mmaonly; do
-echo "== $layer tile $t variant '$v'"; python tools/probes/gemm_phase_stamps.py --layer $layer --variant "$v" --wino-tile $t 2>&1 | grep "pinned\|   kernel void igemm"
-done; done; done
+OUT=gpurun_out/r7B; mkdir -p $OUT; export TMPDIR=/tmp
+python __graft_entry__.py > $OUT/build.log 2>&1 || { echo BUILD FAILED; exit 1; }
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_ddp.py -q -x -k "every_tile_pinned or epilogue_statistics or per_shape_train_graphs or winograd" 2>&1 | grep -v amdgpu.ids | tail -4
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"
