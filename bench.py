@@ -717,9 +717,9 @@ def main():
                      graph=not args.no_graph)      # world > 1: eager unless SEMSEG_DDP_GRAPH=1 (TrainStep)
 
     if cfg.get('variable') and args.shapes:
-        # steady state of the variable-size path: every shape of the run has been seen (first sight = eager step + launch-plan
-        # assignment, second sight = capture) before the warm-up / timed steps, as in a long training run; `--shapes 0` times
-        # the cold path instead (first sights and captures inside the timed region)
+        # steady state of the variable-size path: every shape of the run has been seen and recorded into its hipGraph (TrainStep: at its
+        # first sight after the two eager warm-up steps) before the warm-up / timed steps, as in a long training run; `--shapes 0`
+        # times the cold path instead (the recording passes of new shapes inside the timed region)
         for _ in range(2):
             for hw in pool:
                 step.step(pool[hw])
@@ -790,14 +790,14 @@ def main():
                                         'px/img = %.0f^2, %d distinct shapes in the timed steps%s'
                                         % (sum(px) / len(px), (sum(px) / len(px)) ** 0.5, len(set(shapes[args.warmup:])),
                                            ', all seen before the timed region (steady state)' if args.shapes else ' (cold path '
-                                           'included: first sights and graph captures are timed)'))
+                                           'included: the recording passes of new shapes are timed)'))
                                        if cfg.get('variable') else '512x512x3', cfg['rate']),
                        'global_batch': 2 * world, 'parallelism': 'dp%d' % world,
                        'launch': (('segmented hipGraphs (%s)' % step._graph.counts() if type(step._graph).__name__ == 'SegmentedStep'
                                    else 'hipGraph replay') if timed['replayed'] == args.steps else
                                   'eager' if timed['replayed'] == 0 else
                                   'per-shape hipGraphs: %(replayed)d of the timed steps replayed (%(captured)d captured in the '
-                                  'timed region), %(eager)d eager (first sight of a shape)' % timed),
+                                  'timed region), %(eager)d eager passes' % timed),
                        'ddp_graph_selftest': selftest_ok,
                        'collectives': collectives_used(world),
                        'conv_path': ops_mode(),

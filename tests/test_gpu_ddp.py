@@ -253,7 +253,7 @@ def test_two_ranks_segmented_graphs_equal_eager(peer):
 
 def test_per_shape_train_graphs_equal_eager_and_evict():
     """BASELINE configs[3] (variable-size per-GPU batches, dataset.py:121-142): TrainStep keeps one hipGraph per batch shape.
-    A sequence that alternates between three shapes (first sight eager, second sight captured, then replays; `max_graphs=2`
+    A sequence that alternates between three shapes (two eager warm-up steps, then every shape recorded when it is next seen, then replays; `max_graphs=2`
     forces an eviction and a re-capture) ends in exactly the weights / BN statistics / losses of the same sequence launched
     eagerly."""
     from mit_semseg.models import ModelBuilder, SegmentationModule

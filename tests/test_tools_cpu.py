@@ -65,3 +65,25 @@ def test_abi_call_trace_lists_every_convolution_of_the_step():
     assert count('conv2d_wgrad_h2') + count('conv2d_wgrad_slabs_h2') + batched + wino_wgrad == convs
     stem = [l for l in lines if l[0] == 'conv2d_fwd_stats_h2'][0]
     assert stem[2:12] == ['2', '512', '512', '3', '64', '3', '3', '2', '1', '1']           # after y_ld: N H W C K R S stride pad dil
+
+
+def test_shape_stream_simulator_two_clocks():
+    """tools/shape_stream_sim.simulate on a hand-made stream: the host issues, the device executes; a recording pass behind a device
+    synchronize is exposed, one without it hides behind the replays already queued; the LRU evicts and re-records"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import shape_stream_sim as S
+    A, B, C = (2, 64, 64), (2, 72, 104), (2, 96, 64)
+    costs = dict(replay_ms=10.0, eager_ms=20.0, capture_ms=30.0, host_replay_ms=0.0)
+    # A is known; B appears in the window after three replays of A: 3 x 10 ms of device work are queued when its recording starts
+    stream = [A, A, A, A, B, B]
+    v_sync, ev = S.simulate(stream, 1, 5, cap=8, first_sight=True, sync_capture=True, **costs)
+    v_free, ev2 = S.simulate(stream, 1, 5, cap=8, first_sight=True, sync_capture=False, **costs)
+    assert ev == ev2 == {'replayed': 4, 'captured': 1}
+    assert abs(2e3 * 5 / v_sync - (3 * 10 + 30 + 2 * 10)) < 1e-6        # recording starts when the device has drained, then two steps
+    assert abs(2e3 * 5 / v_free - (5 * 10)) < 1e-6                      # 30 ms of recording behind 30 ms of queued replays: hidden
+    # second sight: the warm-up step ran A eagerly, so A is recorded inside the window too; B costs an eager pass and a recording
+    v_old, ev3 = S.simulate(stream, 1, 5, cap=8, first_sight=False, sync_capture=True, **costs)
+    assert ev3 == {'replayed': 2, 'eager': 1, 'captured': 2} and v_old < v_sync
+    # an LRU of one graph re-records on every change of shape
+    _, ev4 = S.simulate([A, B, A, B, A, B], 0, 6, cap=1, first_sight=True, sync_capture=False, **costs)
+    assert ev4['captured'] == 6 and ev4['evicted'] == 5
