@@ -205,7 +205,28 @@ def lib():
     return _lib
 
 
+class NativeError(RuntimeError):
+    """a C-ABI entry point returned a non-zero code; `.code` is that code (SEMSEG_E* < 0, else a hipError_t)"""
+
+    def __init__(self, what, code):
+        self.what, self.code = what, int(code)
+        super().__init__('%s failed with code %d (%s)' % (
+            what, code, {-1: 'SEMSEG_EINVAL', -2: 'SEMSEG_EWORKSPACE'}.get(code, 'hipError_t')))
+
+
+def is_capture_error(exc):
+    """True if `exc` says that an operation was refused BECAUSE a stream capture is under way (hipErrorStreamCapture* = 900 ... 908
+    from an entry point, or torch's own 'operation not permitted when stream is capturing' family) -- the one kind of failure
+    after which running the same step eagerly is the right answer.  Never an out-of-memory error."""
+    if isinstance(exc, torch.cuda.OutOfMemoryError):
+        return False
+    code = getattr(exc, 'code', None)
+    if isinstance(code, int) and 900 <= code <= 908:
+        return True
+    msg = str(exc).lower()
+    return 'captur' in msg and 'out of memory' not in msg
+
+
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError('%s failed with code %d (%s)' % (
-            what, rc, {-1: 'SEMSEG_EINVAL', -2: 'SEMSEG_EWORKSPACE'}.get(rc, 'hipError_t')))
+        raise NativeError(what, rc)

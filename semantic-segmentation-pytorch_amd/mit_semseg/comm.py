@@ -242,6 +242,17 @@ def peer_init(group=None, max_doubles=PEER_MAX_DOUBLES, selftest=True):
                 first = first + 1.0 / (r + 1)
             ok = ok and rc == 0 and L.semseg_peer_status(handle) == 0 and bool((a[1:] == want).all()) and float(a[0].item()) == first
         ok = _unanimous(ok, group)
+        if ok:
+            # ... and the kernels a training step really exchanges in: the fused BN finish kernels (forward statistics, backward
+            # sums, the two-addend form) and one of them inside a captured + replayed hipGraph -- still on the short timeout, so a
+            # node where the in-kernel exchange does not work falls back within seconds instead of failing inside a step
+            try:
+                ok = _peer_selftest_fused(L, handle, rank, world, dev)
+            except Exception as e:                                     # noqa: BLE001 -- any failure means "not on this node"
+                import sys
+                print('mit_semseg.comm: peer self-test (fused BN kernels) raised %r on rank %d' % (e, rank), file=sys.stderr)
+                ok = False
+            ok = _unanimous(ok, group)
     if not ok:                       # the same verdict on every rank (_unanimous): everybody takes this branch together
         torch.cuda.synchronize()
         dist.barrier(group=group)    # nobody unmaps an inbox while a peer's self-test kernel may still store into it
@@ -252,6 +263,102 @@ def peer_init(group=None, max_doubles=PEER_MAX_DOUBLES, selftest=True):
         L.semseg_peer_set_timeout(handle, timeout_s)        # the training run waits longer for a straggler than the self-test did
     _PEERS[_key(group)] = dict(handle=handle, rank=rank, world=world, cap=max_doubles)
     return True
+
+
+def _selftest_rows(rank, P, C, device, dtype=torch.float32):
+    """rank's [P, C] matrix of small integers (pixel % 3 + channel % 5 + rank + 1): every sum of them -- and of their squares and
+    products -- is exact in fp64 whatever the order, so the exchanged totals have ONE right answer"""
+    pix = torch.arange(P, device=device, dtype=dtype).remainder(3)
+    ch = torch.arange(C, device=device, dtype=dtype).remainder(5)
+    return (pix[:, None] + ch[None, :] + float(rank + 1)).contiguous()
+
+
+def _peer_selftest_fused(L, handle, rank, world, dev, P=96, C=48):
+    """The SyncBN kernels of the training step on a known problem, through THIS exchange: semseg_bn_fwd_stats_fused_peer (twice
+    eagerly, then captured into a hipGraph and replayed twice), semseg_bn_bwd_reduce_fused_peer and semseg_bn_bwd_reduce_fused_sum2.
+    Every rank launches every exchange whatever its verdict so far (the peers wait for its payload).  True iff every total is the
+    known one."""
+    vp = ctypes.c_void_p
+
+    def p(t):
+        return vp(t.data_ptr()) if t is not None else vp(0)
+    f32 = dict(device=dev, dtype=torch.float32)
+    z = _selftest_rows(rank, P, C, dev)
+    dy = _selftest_rows(rank, P, C, dev) + 2.0
+    dy2 = _selftest_rows(world - 1 - rank, P, C, dev)
+    zs = [_selftest_rows(r, P, C, 'cpu', torch.float64) for r in range(world)]
+    want_sum = sum(t.sum(0) for t in zs)
+    want_sq = sum((t * t).sum(0) for t in zs)
+    want_dy = sum((t + 2.0).sum(0) for t in zs)
+    want_dy12 = want_dy + want_sum                               # sum over ranks of dy2 = sum over ranks of z (the ranks mirrored)
+    gamma, beta = torch.ones(C, **f32), torch.zeros(C, **f32)
+    coef = torch.empty((4, C), **f32)
+    zmm = torch.empty((2 * C,), **f32)
+    bb = torch.empty(((C + 15) // 16,), device=dev, dtype=torch.int32)
+    ws = torch.empty(int(L.semseg_bn_mm_workspace_bytes(P, C)), device=dev, dtype=torch.uint8)
+    stats = torch.zeros((2 * C + 1,), device=dev, dtype=torch.float64)
+    sums = torch.zeros((2 * C,), device=dev, dtype=torch.float64)
+    dgamma, dbeta = torch.empty(C, **f32), torch.empty(C, **f32)
+    ok = [True]
+
+    def fwd():
+        st = vp(torch.cuda.current_stream().cuda_stream)
+        rc = L.semseg_bn_fwd_stats_fused_peer(p(z), P, C, p(stats), p(zmm), p(gamma), p(beta), vp(0), vp(0), vp(0), 0.1, 1e-5, 0,
+                                              vp(0), p(coef[0]), p(coef[1]), p(coef[2]), p(coef[3]), p(bb), p(ws), ws.numel(), st,
+                                              handle, vp(0))
+        ok[0] = ok[0] and rc == 0
+
+    def fwd_good():
+        torch.cuda.synchronize()
+        s = stats.cpu()
+        mean = (want_sum / float(world * P)).float()
+        good = L.semseg_peer_status(handle) == 0 and torch.equal(s[:C], want_sum) and torch.equal(s[C:2 * C], want_sq) and \
+            float(s[2 * C]) == float(world * P) and torch.equal(coef[0].cpu(), mean)
+        stats.zero_()
+        coef.zero_()
+        return good
+
+    for _ in range(2):
+        fwd()
+        ok[0] = fwd_good() and ok[0]
+    # the same exchange recorded into a hipGraph and replayed: how TrainStep / SegmentedStep issue it (the kernel reads the
+    # exchange's sequence number from device memory when it RUNS, so a replay takes the next slot like an eager launch)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        try:
+            fwd()
+        finally:
+            graph.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):
+        graph.replay()
+        ok[0] = fwd_good() and ok[0]
+    # backward sums on the statistics of a last eager forward (mean / invstd / count as a step has them)
+    fwd()
+    torch.cuda.synchronize()
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    count = stats[2 * C:]
+    xhat = [(t - (want_sum / float(world * P))[None, :]) for t in zs]
+
+    def bwd_good(want_first, addend):
+        torch.cuda.synchronize()
+        s = sums.cpu()
+        var = want_sq / float(world * P) - (want_sum / float(world * P)) ** 2
+        second = sum(((t + 2.0 + (a if addend else 0.0)) * x).sum(0) for t, a, x in zip(zs, reversed(zs), xhat)) / (var + 1e-5).sqrt()
+        good = L.semseg_peer_status(handle) == 0 and torch.equal(s[:C], want_first) and \
+            bool(((s[C:] - second).abs() <= 1e-4 * (1.0 + second.abs())).all())
+        sums.zero_()
+        return good
+    rc = L.semseg_bn_bwd_reduce_fused_peer(p(dy), C, vp(0), C, p(z), p(coef[0]), p(coef[1]), vp(0), vp(0), 0, P, C, p(count), p(zmm),
+                                           p(gamma), 1, p(sums), p(dgamma), p(dbeta), p(bb), p(ws), ws.numel(), st, handle)
+    ok[0] = bwd_good(want_dy, False) and rc == 0 and ok[0]
+    rc = L.semseg_bn_bwd_reduce_fused_sum2(p(dy), C, p(dy2), C, vp(0), C, p(z), p(coef[0]), p(coef[1]), vp(0), vp(0), 0, P, C, p(count),
+                                           p(zmm), p(gamma), 1, p(sums), p(dgamma), p(dbeta), p(bb), p(ws), ws.numel(), st, handle)
+    ok[0] = bwd_good(want_dy12, True) and rc == 0 and ok[0]
+    return bool(ok[0])
 
 
 def _unanimous(ok, group):

@@ -242,6 +242,7 @@ class TrainStep:
         # that times the plans, capture at the next sight).  SEMSEG_CAPTURE_FIRST_SIGHT=0: the old order for every shape.
         self.capture_first_sight = os.environ.get('SEMSEG_CAPTURE_FIRST_SIGHT', '1') != '0'
         self.timeline = None                          # scaling_model.TimelineProbe: timestamp markers inside the (captured) step
+        self._capture_errors = {}                     # feed_key -> repr of the capture refusal that sent the shape to the old order (logged once)
         self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0, 'provisional': 0, 'capture_failed': 0, 'capture_host_s': 0.0, 'instantiate_host_s': 0.0,
                       'eager_host_s': 0.0}
 
@@ -288,6 +289,34 @@ class TrainStep:
             tl.mark('step_end')
         return loss.detach(), acc.detach()
 
+    def _host_state(self):
+        """what a recording pass changes on the HOST (it executes nothing on the device): restored before the eager retry of a
+        refused first-sight recording, so that the retry is the step the caller asked for, not the one after it"""
+        from . import tuner
+        return dict(opt_steps=self.opt.steps, opt_state=set(self.opt.state.keys()), weights_ready=self._weights_ready,
+                    wplanes=dict(ops._WPLANES), dropout=dict(ops._DROPOUT_STATE), tuner_stats=dict(tuner.stats),
+                    captured=self.stats['captured'], evicted=self.stats['evicted'])
+
+    def _restore_host_state(self, host):
+        from . import tuner
+        self.opt.steps = host['opt_steps']
+        for p in [p for p in self.opt.state if p not in host['opt_state']]:
+            del self.opt.state[p]                     # a momentum buffer created inside the refused recording lives in its pool
+        self._weights_ready = host['weights_ready']
+        ops._WPLANES.clear()
+        ops._WPLANES.update(host['wplanes'])          # plane buffers first allocated inside the recording went with its pool
+        ops._DROPOUT_STATE.clear()
+        ops._DROPOUT_STATE.update(host['dropout'])
+        ops._PENDING_WGRADS[:] = []
+        ops._PENDING_SLABS[:] = []
+        ops._FWD_USES.clear()
+        ops._ADDENDS.clear()
+        tuner.stats.clear()
+        tuner.stats.update(host['tuner_stats'])
+        self.stats['captured'] = host['captured']
+        if self.buckets is not None:
+            self.buckets.armed = False
+
     def launch_mode(self):
         """'eager' | 'graph' (the whole step is ONE hipGraph) | 'segmented' (SegmentedStep: graphs between the collectives).
         world > 1: the RCCL all-reduces can be captured with the rest of the step -- a world-1 RCCL all-reduce survives capture +
@@ -328,13 +357,24 @@ class TrainStep:
             from . import tuner
             missed = tuner.stats['missed_capturing']
             t0 = time.perf_counter()
+            host = self._host_state()
             try:
                 rec = self._capture(key, feed, mode)
-            except RuntimeError:
-                if not first_sight:
+            except RuntimeError as e:
+                # ONLY a refusal that is about the capture itself (something on this shape's path cannot be recorded before it has run
+                # once) is answered by the old order; an out-of-memory error, a kernel or argument error from _native.check, anything
+                # else propagates -- the eager pass would hit it again, or worse, would not
+                from . import _native
+                if not first_sight or not _native.is_capture_error(e):
                     raise
-                # something on this shape's path cannot be recorded before it has run once (the old order would have run it eagerly
-                # first): nothing of a recording executes, so the step is still to be done -- eagerly, and the shape keeps the old order
+                if key not in self._capture_errors:
+                    import sys
+                    self._capture_errors[key] = repr(e)
+                    print('mit_semseg.engine: recording the step at first sight failed for batch shape %s (%r); this shape runs '
+                          'eagerly once and is recorded at its next sight' % (key, e), file=sys.stderr)
+                # nothing of a recording executes, so the step is still to be done -- eagerly, from the host state the recording
+                # pass started with (it has advanced the optimiser's step count, created records, armed the buckets)
+                self._restore_host_state(host)
                 self._graphs.pop(key, None)
                 self._provisional[key] = None
                 self.stats['capture_failed'] += 1

@@ -682,6 +682,17 @@ def flush_wgrad_reduces(mid_backward=False):
     if not _PENDING_SLABS:
         return
     items, _PENDING_SLABS[:] = list(_PENDING_SLABS), []
+    if mid_backward:
+        # called from the hook that completed ONE gradient bucket: autograd orders a weight's AccumulateGrad against those of its
+        # sibling BN parameters only by an unspecified tie-break, so an entry whose parameter has not received its gradient yet
+        # belongs to a bucket that is still open -- it stays pending for the flush of that bucket (or the final one), instead
+        # of failing the adoption check below before autograd had its chance
+        later = [it for it in items if it[4] is not None and it[4].grad is None]
+        if later:
+            items = [it for it in items if not (it[4] is not None and it[4].grad is None)]
+            _PENDING_SLABS.extend(later)
+            if not items:
+                return
     for slabs, out, numel, splits, param, _ in items:
         # the contract checked where it is cheap (once per eager step / capture pass): the buffer being completed below IS
         # the parameter's gradient.  Anything else -- autograd copied or accumulated the unreduced buffer -- is garbage already.

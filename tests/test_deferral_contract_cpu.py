@@ -131,3 +131,35 @@ def test_a_gradient_bucket_flushes_the_deferred_gradients_before_it_is_staged(mo
         assert not ops.deferring()
     with ops.defer_wgrad_reduces(flush_at_buckets=True):
         assert ops.deferring()
+
+
+def test_a_mid_backward_flush_leaves_gradients_autograd_has_not_accumulated_yet(monkeypatch):
+    """a bucket boundary may fall between a BN's gamma / beta and the conv weight of the next bucket, and autograd does not specify
+    which AccumulateGrad of equal priority runs first: the flush from the bucket hook completes what HAS been adopted and leaves a
+    weight whose .grad is still empty for the flush of its own bucket; the final flush still refuses it loudly"""
+    launched = []
+
+    class L:
+        @staticmethod
+        def semseg_reduce_slabs_multi(arr, n, st):
+            launched.append(n)
+            return 0
+    monkeypatch.setattr(ops._native, 'lib', lambda: L)
+    monkeypatch.setattr(ops, '_st', lambda: None)
+    done, open_ = _krsc(8, 4, 3, 3), _krsc(8, 4, 3, 3)
+    b1, b2 = torch.zeros(8, 3, 3, 4), torch.zeros(8, 3, 3, 4)
+    done.grad = b1.permute(0, 3, 1, 2)                # adopted already
+    ops._PENDING_SLABS.append((torch.zeros(16), b1, b1.numel(), 1, done, None))
+    ops._PENDING_SLABS.append((torch.zeros(16), b2, b2.numel(), 1, open_, None))      # AccumulateGrad has not run yet
+    ops._FWD_USES[id(open_)] = 1
+    ops.flush_wgrad_reduces(mid_backward=True)
+    assert launched == [1] and len(ops._PENDING_SLABS) == 1 and ops._PENDING_SLABS[0][4] is open_
+    assert ops._FWD_USES                               # the rest of the graph has not run: the use counts stay
+    ops.flush_wgrad_reduces(mid_backward=True)         # nothing ready: nothing launched, the entry keeps waiting
+    assert launched == [1] and len(ops._PENDING_SLABS) == 1
+    open_.grad = b2.permute(0, 3, 1, 2)
+    ops.flush_wgrad_reduces(mid_backward=True)
+    assert launched == [1, 1] and not ops._PENDING_SLABS
+    ops._PENDING_SLABS.append((torch.zeros(16), b2, b2.numel(), 1, _krsc(8, 4, 3, 3), None))
+    with pytest.raises(RuntimeError, match='did not become its .grad'):
+        ops.flush_wgrad_reduces()                      # after backward: an empty .grad is an error, as before

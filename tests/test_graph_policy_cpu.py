@@ -98,3 +98,42 @@ def test_a_shape_that_cannot_be_recorded_at_first_sight_falls_back_to_the_old_or
     _run(ts, log, [A, B, C, C, C])
     assert log == [('eager', A), ('eager', B), ('capture', C), ('eager', C), ('capture', C), ('replay', C), ('replay', C)]
     assert ts.stats['capture_failed'] == 1 and ts.stats['captured'] == 1
+
+
+def test_only_capture_refusals_fall_back_other_errors_propagate(monkeypatch):
+    """an out-of-memory error or a kernel / argument error met while recording is NOT answered by an eager rerun (the
+    rerun hid real bugs until the shape was seen a second time): it propagates, and the host state of the refused recording
+    (optimiser step count) is put back before a legitimate eager retry"""
+    import pytest
+    from mit_semseg import _native
+    assert _native.is_capture_error(RuntimeError('operation not permitted when stream is capturing'))
+    assert _native.is_capture_error(_native.NativeError('conv2d_fwd_h2', 900))
+    assert not _native.is_capture_error(_native.NativeError('conv2d_fwd_h2', -1))
+    assert not _native.is_capture_error(torch.cuda.OutOfMemoryError('HIP out of memory while capturing'))
+    for exc in (torch.cuda.OutOfMemoryError('HIP out of memory'), _native.NativeError('bn_apply_h2', -1), RuntimeError('shape mismatch')):
+        ts, log = _step(monkeypatch, True)
+        _run(ts, log, [A, B])
+
+        def capture(key, feed, mode='graph', exc=exc):
+            raise exc
+        monkeypatch.setattr(ts, '_capture', capture)
+        with pytest.raises(type(exc)):
+            ts.step({'x': torch.zeros(C)})
+        assert ts.stats['capture_failed'] == 0 and ts.stats['eager'] == 2
+    # a refusal: the recording pass had advanced the optimiser's step count; the eager retry starts from the count before it
+    ts, log = _step(monkeypatch, True)
+    _run(ts, log, [A, B])
+    seen = []
+
+    def capture(key, feed, mode='graph'):
+        ts.opt.steps += 1                           # what _eager does inside the recording
+        raise RuntimeError('hipErrorStreamCaptureUnsupported: operation not permitted when stream is capturing')
+    orig = ts._eager
+
+    def eager(feed):
+        seen.append(ts.opt.steps)
+        return orig(feed)
+    monkeypatch.setattr(ts, '_capture', capture)
+    monkeypatch.setattr(ts, '_eager', eager)
+    ts.step({'x': torch.zeros(C)})
+    assert seen == [2] and ts.opt.steps == 3 and ts.stats['capture_failed'] == 1
