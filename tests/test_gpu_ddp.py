@@ -447,3 +447,26 @@ def test_peer_exchange_world8_in_one_process():
     assert r.returncode == 0, r.stderr[-3000:]
     for marker in ('WORLD8_EXCHANGE_OK', 'WORLD8_FUSED_BN_OK', 'WORLD8_TIMEOUT_OK'):
         assert marker in r.stdout, marker
+
+
+def test_bench_two_ranks_on_one_gpu_prints_a_line():
+    """The N > 1 path of bench.py END TO END on the one GPU of the test box (round-5 review, item 7a; until now a builder script
+    stage, tools/gpu_run.sh `ddp2`): `bench.py --gpus 2` launches itself as two ranks (SEMSEG_BENCH_DEVICE=0: both on device 0,
+    gloo as the rendezvous), SyncBN goes over the peer exchange INSIDE the fused BN kernels, the gradient buckets are reduced
+    between the hipGraph segments, and rank 0 prints the contract's JSON line."""
+    import subprocess
+    env = dict(os.environ, SEMSEG_BENCH_DEVICE='0', GPU_MAX_HW_QUEUES='2', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3',
+                        '--no-cpu-baseline', '--no-other-configs'], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 2 and d['steps'] == 6 and d['warmup'] == 3 and d['value'] > 0
+    col = d['config']['collectives']
+    assert col['peer_world'] == 2, col                                   # SyncBN payloads over the peer exchange (csrc/peer.hip)
+    assert 'segmented' in str(d['config']['launch']), d['config']['launch']
+    from tests.util import parity_line
+    parity_line('bench.py --gpus 2 on one GPU (gloo rendezvous, peer exchange): %.1f img/s, %.2f ms/step, launch %s, collectives %s'
+                % (d['value'], d['ms_per_step'], d['config']['launch'], col))

@@ -10,8 +10,8 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.util import (parity_line, load_fullsize_golden, check_fullsize_golden, golden_cases, load_golden, anchor_ratios, check_anchor_ratios, is_head_tensor, scale_error, post_step_bands, post_step_record,
-                        HEAD_SCALE_ERR, HEURISTIC_PLAN_GOLDEN, KNIFE_EDGE_GOLDEN, KNIFE_EDGE_SCALE_ERR, KNIFE_EDGE_MEDIAN_SCALE_ERR)
+from tests.util import (parity_line, check_directions, load_fullsize_golden, check_fullsize_golden, golden_cases, load_golden, anchor_ratios, check_anchor_ratios, is_head_tensor, scale_error, post_step_bands, post_step_record,
+                        HEAD_SCALE_ERR, HEURISTIC_PLAN_GOLDEN, KNIFE_EDGE_GOLDEN, KNIFE_EDGE_SCALE_ERR, KNIFE_EDGE_MEDIAN_SCALE_ERR, KNIFE_EDGE_COSINE_MIN)
 from oracle import semseg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -138,6 +138,7 @@ def test_native_gradients_vs_reference_anchor(name, monkeypatch):
             if side == 'dec.' and is_head_tensor(k, p):
                 heads.append((scale_error(p.grad, want[k]), side + k))
     parity_line(check_anchor_ratios(anchor_ratios(items), name + ' gradients'))
+    parity_line(check_directions(items, name + ' gradients'))                 # the well-conditioned twin: cosine / dot product per tensor
     # the classifier convs: no ReLU gate between them and the loss, so their gradients agree elementwise at roundoff level
     # (measured 2e-6 ... 1.2e-5 of the tensor's scale on every case, h2 and exact-fp32 alike)
     assert heads, 'no classifier tensors found'
@@ -218,6 +219,7 @@ def test_full_size_vs_oracle(case):
             if side == 'dec.' and is_head_tensor(k, p):
                 heads.append((scale_error(p.grad, want[k]), side + k))
     parity_line(check_anchor_ratios(anchor_ratios(items), case + ' gradients'))
+    parity_line(check_directions(items, case + ' gradients'))
     assert heads, 'no classifier tensors found'
     parity_line('%s classifier gradients: max |err| / scale %.2e (%s)' % ((case,) + max(heads)))
     assert max(heads)[0] <= HEAD_SCALE_ERR, heads
@@ -247,10 +249,11 @@ def test_knife_edge_case_gradients_stay_within_a_loose_elementwise_limit(name):
     cent across the board, or breaks the 2 x 2 BN path in backward, fails here."""
     g = load_golden(name)
     sm = _native_grads(g, torch.device('cuda:0'))
-    worst, heads, errs = (0.0, ''), [], []
+    worst, heads, errs, items = (0.0, ''), [], [], []
     for mod, want, side in ((sm.encoder, g['anchor_grads_enc'], 'enc.'), (sm.decoder, g['anchor_grads_dec'], 'dec.')):
         for k, p in mod.named_parameters():
             assert torch.isfinite(p.grad).all(), side + k
+            items.append((side + k, p.grad, want[k]))
             e = scale_error(p.grad, want[k])
             errs.append(e)
             worst = max(worst, (e, side + k))
@@ -261,6 +264,9 @@ def test_knife_edge_case_gradients_stay_within_a_loose_elementwise_limit(name):
         name, median, worst[0], worst[1], max(heads)[0]))
     assert median <= KNIFE_EDGE_MEDIAN_SCALE_ERR, median
     assert worst[0] <= KNIFE_EDGE_SCALE_ERR, worst
+    # ... and to the direction check of every other case (round-5 review): a knife edge resolving the other way moves single
+    # elements of the 2 x 2 branch, not the direction of the tensors
+    parity_line(check_directions(items, name + ' gradients (knife-edge case)', min_cos=KNIFE_EDGE_COSINE_MIN))
     assert max(heads)[0] <= HEAD_SCALE_ERR, heads
 
 

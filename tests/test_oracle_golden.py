@@ -39,6 +39,12 @@ def test_oracle_matches_reference(name):
             if k.rsplit('.', 1)[-1] in ('_tmp_running_mean', '_tmp_running_var', '_running_iter'):
                 continue   # fork-only DP buffers, untouched on the single-device path (batchnorm.py:50-52)
             check_summary(sd[k], want[k], 1e-4, 1e-3, 'after-step ' + k)
+    if 'anchor_grads_enc' in g:
+        # the well-conditioned acceptance of the GPU tests (tests/util.check_directions: cosine / dot product per gradient tensor
+        # against the float64 anchor) applied to the reference's own fp32 arithmetic: pins the yardstick and its calibration on the CPU
+        from tests.util import check_directions
+        items = [(side + '.' + k, gr[k], g['anchor_grads_' + side][k]) for side, gr in (('enc', grads[0]), ('dec', grads[1])) for k in gr]
+        print(check_directions(items, name + ' oracle gradients'))
 
 
 # forward of every full-size fixture; the backward too (every gradient tensor, the state after the step) where the CPU suite can
@@ -98,6 +104,8 @@ def test_oracle_matches_reference_at_full_size(case, backward):
             if side == 'dec' and is_head_tensor(k, v):
                 heads.append((scale_error(v.grad, want[k]), k))
     print(check_anchor_ratios(anchor_ratios(items), case + ' oracle gradients'))
+    from tests.util import check_directions
+    print(check_directions(items, case + ' oracle gradients'))
     assert heads and max(heads)[0] <= HEAD_SCALE_ERR, heads
     items = []
     for sd, sd0, side in ((e, enc_sd, 'enc'), (d, dec_sd, 'dec')):

@@ -50,7 +50,7 @@ for stage in "$@"; do
     ab:*) spec=${stage#ab:}; name=${spec%%:*}; kv=${spec#*:}; IFS=, read -ra kvs <<< "$kv"; q ${name}_$n "${kvs[@]}" ;;
     lib:*) q lib_$n SEMSEG_NATIVE_LIB=$ROOT/${stage#lib:} ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
-    tests) timeout 2400 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log | cut -c1-300; grep -a "FAILED\|Error" $OUT/pytest_gpu.log | cut -c1-300 | head -20 ;;
+    tests) timeout 2400 python -m pytest tests -m gpu -q -s --durations=80 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log | cut -c1-300; grep -a "FAILED\|Error" $OUT/pytest_gpu.log | cut -c1-300 | head -20 ;;
     tests-fast) timeout 1200 python -m pytest tests -m gpu -q -x -k "not every_tile_pinned" > $OUT/pytest_gpu_fast.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest_gpu_fast.log | cut -c1-300; grep -a "FAILED\|Error" $OUT/pytest_gpu_fast.log | cut -c1-300 | head -20 ;;
     test:*) timeout 1200 python -m pytest tests -m gpu -q -s -k "${stage#test:}" > $OUT/pytest_k_$n.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_k_$n.log | cut -c1-300 ;;
     ddp2) SEMSEG_BENCH_DEVICE=0 GPU_MAX_HW_QUEUES=2 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 > $OUT/bench_ddp2.json 2> $OUT/bench_ddp2.err; echo "rc=$?"; cut -c1-600 $OUT/bench_ddp2.json; tail -3 $OUT/bench_ddp2.err | cut -c1-300 ;;

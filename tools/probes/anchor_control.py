@@ -51,6 +51,11 @@ def worker():
         med, p95, mx, worst, n = summarize(util.anchor_ratios(items))
         raw = max(util.anchor_ratio(t, rec, k) for k, t, rec in items)          # without the case-wide lower limit of the band
         worst_scale = max(util.scale_error(t, rec) for k, t, rec in items)
+        try:
+            direction = util.check_directions(items, name, min_cos=-2.0, median_cos=-2.0, median_dot=float('inf'))
+        except AssertionError as e:
+            direction = 'FAILED: %s' % (e,)
+        print('DIRECTION %s %s' % (ops.CONV_MODE, direction), flush=True)
         rows.append(dict(case=name, what='gradients', n=n, median=med, p95=p95, max=mx, worst=worst, raw_max=raw,
                          rel_band=util.case_rel_band([rec for _, _, rec in items]), worst_scale_err=worst_scale,
                          head_rel_err_max=max(h[0] for h in heads) if heads else None))
@@ -90,6 +95,7 @@ def main():
     out_dir = os.path.join(ROOT, 'gpurun_out', 'anchor_control')
     os.makedirs(out_dir, exist_ok=True)
     tables = {}
+    directions = []            # tests/util.check_directions per (mode, case): the well-conditioned twin of the band statistics
     for spec in args.modes:
         conv, _, envs = spec.partition(':')
         env = dict(os.environ, SEMSEG_CONV=conv, ANCHOR_CONTROL_WORKER='1', ANCHOR_CONTROL_CASES=','.join(args.cases))
@@ -97,6 +103,7 @@ def main():
             k, _, v = kv.partition('=')
             env[k] = v
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=1500)
+        directions.extend(ln[len('DIRECTION '):] for ln in r.stdout.splitlines() if ln.startswith('DIRECTION '))
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('ANCHOR_TABLE ')]
         if not line:
             print('mode %s failed:\n%s\n%s' % (spec, r.stdout[-1500:], r.stderr[-3000:]))
@@ -113,6 +120,10 @@ def main():
             r = rows[i]
             lines.append('    %-36s %s   %s%s' % (spec, fmt(r), r['worst'],
                                                  ('   classifier |err|/scale %.1e' % r['head_rel_err_max']) if r['head_rel_err_max'] is not None else ''))
+    if directions:
+        lines.append('')
+        lines.append('direction of every gradient tensor against the float64 anchor (tests/util.check_directions), `mode case: ...`')
+        lines.extend(directions)
     text = '\n'.join(lines)
     print(text)
     with open(os.path.join(out_dir, args.tag + '.txt'), 'w') as fh:
