@@ -595,6 +595,29 @@ int semseg_probe_empty(void* stream);
 int semseg_probe_gather(const void* src, unsigned rows, unsigned pitch, int seg_bytes, int dma, int blocks, int steps, void* sink,
                         void* stream);
 
+/* ---------------- side-by-side launches of independent sub-networks (csrc/batch.h, csrc/batch.hip) -----------------------------
+ * HRNetV2's parallel branches (reference hrnet.py:225-227: `for i in range(self.num_branches): x[i] = self.branches[i](x[i])`)
+ * run the same sequence of conv / BN launches on four geometries; the reference leaves them to four sequential cuDNN / ATen call
+ * chains.  Between begin and end the launches of the converted kernel families are RECORDED per branch (every entry point still
+ * does its host work -- plans, out-parameters -- at call time) and end() issues the records that sit at the same position of every
+ * branch as ONE launch whose blocks find their problem in a table in the kernel arguments: same blocks, same arithmetic, same
+ * order inside a branch -- bit-identical to the sequential launches.  One scope per process at a time.
+ *   begin(branches, stream): open a scope of 1 ... 8 branches whose launches ALL leave on `stream` (whatever stream argument the
+ *   calls inside carry -- the host runs every branch under a stream context of its own so that the caching allocator keeps the
+ *   branches' temporaries apart); branch(i): the calls that follow belong to branch i; next_op(): the host has finished one C-ABI
+ *   call of the current branch (launches pair up only under the same ordinal); flush(): issue what has been recorded, keep the
+ *   scope; end(): flush + close, returns the first launch error of the scope; abort(): drop everything (a failed forward / backward);
+ *   active(): 1 inside a scope; stats(out[4]): scopes opened, launches recorded, launches issued through the recorder's launch
+ *   path, problems they carried. */
+int semseg_batch_begin(int branches, void* stream);
+int semseg_batch_branch(int index);
+int semseg_batch_next_op(void);
+int semseg_batch_flush(void);
+int semseg_batch_end(void);
+int semseg_batch_abort(void);
+int semseg_batch_active(void);
+int semseg_batch_stats(long long* out4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'mit_semseg', '_native')
 LIB = os.path.join(OUT_DIR, 'libsemseg_hip.so')
-SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'conv_split.hip', 'weights_prep.hip', 'winograd.hip', 'bn.hip', 'pool_resize.hip', 'head.hip', 'input_pipeline.hip', 'depthwise.hip', 'grouped.hip', 'comm.hip', 'peer.hip', 'probe.hip', 'api.hip']
+SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'conv_split.hip', 'weights_prep.hip', 'winograd.hip', 'bn.hip', 'pool_resize.hip', 'head.hip', 'input_pipeline.hip', 'depthwise.hip', 'grouped.hip', 'comm.hip', 'peer.hip', 'probe.hip', 'batch.hip', 'api.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC,
          '-Wno-unused-result']

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "peer_dev.h"
 #include "split_layout.h"
+#include "batch.h"
 #include <stdlib.h>
 
 // block = 256 threads arranged as cx channel-quads x py row lanes; grid = (quad groups, row chunks)
@@ -197,7 +198,10 @@ extern "C" int semseg_bn_eval_coeffs(const float* gamma, const float* beta, cons
 
 // y = act(z*scale + shift (+res)); one float4 per thread-iteration, grid-stride over P*C/4 quads
 template <bool RES, bool RELU>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+struct bn_apply_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ z, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
                                                        int res_ld, float* __restrict__ y, int y_ld, int P, int C) {
     const int qpr = C / 4;
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         }
         *reinterpret_cast<float4*>(y + (size_t)p * y_ld + c) = o;
     }
-}
+    }
+};
 
 static inline int stream_blocks(size_t items) {
     size_t b = ceil_div_sz(items, 256);
@@ -236,7 +241,7 @@ extern "C" int semseg_bn_apply(const float* z, const float* scale, const float* 
     if (residual && ((res_ld % 4) || res_ld < C || !aligned16(residual))) return SEMSEG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = stream_blocks((size_t)P * (C / 4));
-#define LAUNCH(R, A) hipLaunchKernelGGL((bn_apply_kernel<R, A>), dim3(blocks), dim3(256), 0, st, z, scale, shift, residual, res_ld, y, y_ld, P, C)
+#define LAUNCH(R, A) SEMSEG_LAUNCH_BODY((bn_apply_kernel_body<R, A>), dim3(blocks), 0, st, z, scale, shift, residual, res_ld, y, y_ld, P, C)
     if (residual) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
     else          { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -426,7 +431,10 @@ extern "C" size_t semseg_bn_mm_workspace_bytes(int P, int C) {
 
 // as bn_stats_partial_kernel + per-channel min / max of z:  mm[by][0][c] = min, mm[by][1][c] = max
 constexpr int ROWS_IN_FLIGHT = 8;
-__global__ __launch_bounds__(256) void bn_stats_mm_partial_kernel(const float* __restrict__ z, int P, int C, int cx, int py,
+struct bn_stats_mm_partial_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ z, int P, int C, int cx, int py,
                                                                   int rows_per_block, double* __restrict__ partial,
                                                                   float* __restrict__ mm, float* __restrict__ zero_word) {
     extern __shared__ double red[];   // [py][cx][8] doubles, then [py][cx][8] floats
@@ -495,7 +503,8 @@ __global__ __launch_bounds__(256) void bn_stats_mm_partial_kernel(const float* _
             of[C + c + e] = mx[e];
         }
     }
-}
+    }
+};
 
 // column sums of the fp64 partials (as colsum_finish_kernel) + column min (j < C) / max (j >= C) of the float partials
 __global__ __launch_bounds__(256) void bn_stats_mm_finish_kernel(const double* __restrict__ partial,
@@ -540,7 +549,7 @@ extern "C" int semseg_bn_stats_mm(const float* z, int P, int C, double* stats, f
     double* partial = (double*)workspace;
     float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
-    hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
+    SEMSEG_LAUNCH_BODY((bn_stats_mm_partial_kernel_body), dim3(g.gx, g.gy), smem, st, z, P, C, g.cx, g.py,
                        g.rows_per_block, partial, mm, (float*)nullptr);
     SEMSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_mm_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)partial,
@@ -560,7 +569,7 @@ extern "C" int semseg_bn_stats_mm_partial(const float* z, int P, int C, void* wo
     double* partial = (double*)workspace;
     float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
-    hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, (hipStream_t)stream, z, P, C, g.cx, g.py,
+    SEMSEG_LAUNCH_BODY((bn_stats_mm_partial_kernel_body), dim3(g.gx, g.gy), smem, (hipStream_t)stream, z, P, C, g.cx, g.py,
                        g.rows_per_block, partial, mm, (float*)nullptr);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -632,13 +641,13 @@ extern "C" int semseg_bn_finalize_mm(const double* stats, const float* zmm, int 
 // merged finish kernel left in `blockbound` (bit patterns; every block redoes this <= 1 KB reduction, block 0 publishes
 // the exponent word and the bound itself).
 __device__ __forceinline__ int h2_exponent_from(int* __restrict__ hdr, const uint32_t* __restrict__ blockbound, int nbound,
-                                                float* __restrict__ absmax_out) {
+                                                float* __restrict__ absmax_out, const bool first_block) {
     if (!blockbound) return hdr[0];
     uint32_t m = 0;
     for (int i = threadIdx.x; i < nbound; i += blockDim.x) m = max(m, blockbound[i]);
     m = block_max_u32(m);
     const int ex = h2_exponent(m);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (first_block && threadIdx.x == 0) {
         hdr[0] = ex;
         if (absmax_out) absmax_out[0] = __uint_as_float(m);
     }
@@ -648,13 +657,16 @@ __device__ __forceinline__ int h2_exponent_from(int* __restrict__ hdr, const uin
 // y = act(z*scale + shift (+res)) written as fp32 AND as h2 split planes (exponent from the header, set by
 // bn_finalize_mm).  One thread = 8 channels of one pixel: 2 x 16 B fp32 stores + 2 x 16 B plane stores.
 template <bool RES, bool RELU>
-__global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+struct bn_apply_h2_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ z, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ res,
                                                           int res_ld, float* __restrict__ y, uint16_t* __restrict__ planes,
                                                           size_t plane, int pitch, int* __restrict__ hdr, int P, int C,
                                                           int Cp, const uint32_t* __restrict__ blockbound, int nbound,
                                                           float* __restrict__ absmax_out, uint8_t* __restrict__ gate) {
-    const int ex = h2_exponent_from(hdr, blockbound, nbound, absmax_out);
+    const int ex = h2_exponent_from(hdr, blockbound, nbound, absmax_out, blockIdx.x == 0);
     const float sc2 = pow2i(ex);
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
         reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
@@ -718,7 +730,8 @@ __global__ __launch_bounds__(256) void bn_apply_h2_kernel(const float* __restric
         *reinterpret_cast<f16x8*>(planes + po) = p0;
         *reinterpret_cast<f16x8*>(planes + plane + po) = p1;
     }
-}
+    }
+};
 
 static int bn_apply_h2_impl(const float* z, const float* scale, const float* shift, const float* residual, int res_ld,
                             int relu, float* y, void* y_planes, int P, int C, const void* blockbound, float* absmax_out,
@@ -740,7 +753,7 @@ static int bn_apply_h2_impl(const float* z, const float* scale, const float* shi
         if (blocks > target) blocks = target;
     }
     const int nbound = ceil_div(C, 16);
-#define LAUNCH(R, A) hipLaunchKernelGGL((bn_apply_h2_kernel<R, A>), dim3(blocks), dim3(256), 0, st, z, scale, shift, residual, res_ld, y, (uint16_t*)y_planes, plane, pitch, hdr, P, C, Cp, (const uint32_t*)blockbound, nbound, absmax_out, gate)
+#define LAUNCH(R, A) SEMSEG_LAUNCH_BODY((bn_apply_h2_kernel_body<R, A>), dim3(blocks), 0, st, z, scale, shift, residual, res_ld, y, (uint16_t*)y_planes, plane, pitch, hdr, P, C, Cp, (const uint32_t*)blockbound, nbound, absmax_out, gate)
     if (residual) { if (relu) LAUNCH(true, true); else LAUNCH(true, false); }
     else          { if (relu) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -768,7 +781,10 @@ extern "C" int semseg_bn_apply_h2_gate(const float* z, const float* scale, const
 // GATE: 0 = no ReLU, 1 = ReLU gate recomputed from z (gscale/gshift), 2 = ReLU gate read from y, 3 = from the forward's bitmask
 // (`y` then points to P x C/8 bytes, semseg_bn_apply_h2_gate)
 template <int GATE>
-__global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __restrict__ dy, int dy_ld,
+struct bn_bwd_mm_partial_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ dy, int dy_ld,
                                                                 const float* __restrict__ y, int y_ld,
                                                                 const float* __restrict__ z, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, int relu, int P, int C,
@@ -876,7 +892,8 @@ __global__ __launch_bounds__(256) void bn_bwd_mm_partial_kernel(const float* __r
             of[c + e] = __uint_as_float(m[e]);
         }
     }
-}
+    }
+};
 
 __global__ __launch_bounds__(256) void bn_bwd_mm_finish_kernel(const double* __restrict__ partial, const float* __restrict__ gm,
                                                                int nparts, int C, double* __restrict__ sums,
@@ -920,10 +937,10 @@ extern "C" int semseg_bn_bwd_reduce_mm(const float* dy, int dy_ld, const float* 
     float* gm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
     if (relu)
-        hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<2>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
+        SEMSEG_LAUNCH_BODY((bn_bwd_mm_partial_kernel_body<2>), dim3(g.gx, g.gy), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
                            relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr, nullptr, 0);
     else
-        hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<0>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
+        SEMSEG_LAUNCH_BODY((bn_bwd_mm_partial_kernel_body<0>), dim3(g.gx, g.gy), smem, st, dy, dy_ld, y, y_ld, z, mean, invstd,
                            relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, (const float*)nullptr, (const float*)nullptr, nullptr, 0);
     SEMSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_mm_finish_kernel, dim3(ceil_div(2 * C, 16)), dim3(256), 0, st, (const double*)partial,
@@ -972,7 +989,10 @@ extern "C" int semseg_bn_bwd_bound(const double* sums, const double* stats_count
 
 // bn_bwd_apply_kernel writing the h2 split planes of dz instead of fp32 dz (dres stays fp32)
 template <bool TRAIN, bool RELU, bool DRES>
-__global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __restrict__ dy, int dy_ld,
+struct bn_bwd_apply_h2_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ dy, int dy_ld,
                                                               const float* __restrict__ y, int y_ld,
                                                               const float* __restrict__ z, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd,
@@ -986,7 +1006,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
                                                               const uint32_t* __restrict__ blockbound, int nbound,
                                                               const float* __restrict__ dy2, int dy2_ld) {
     // dy2 != nullptr: the incoming gradient is dy + dy2 (see bn_bwd_mm_partial_kernel)
-    const int ex = h2_exponent_from(hdr, blockbound, nbound, nullptr);
+    const int ex = h2_exponent_from(hdr, blockbound, nbound, nullptr, blockIdx.x == 0);
     const float sc2 = pow2i(ex);
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
         reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
@@ -1088,7 +1108,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
         *reinterpret_cast<f16x8*>(planes + po) = p0;
         *reinterpret_cast<f16x8*>(planes + plane + po) = p1;
     }
-}
+    }
+};
 
 static int bn_bwd_apply_h2_impl(const float* dy, int dy_ld, const float* dy2, int dy2_ld, const float* y, int y_ld, const float* z,
                                 const float* mean, const float* invstd, const float* gamma, const double* sums,
@@ -1113,7 +1134,7 @@ static int bn_bwd_apply_h2_impl(const float* dy, int dy_ld, const float* dy2, in
     const int target = quarter > 1024 ? quarter : 1024;
     if (blocks > target) blocks = target;
     const int nbound = ceil_div(C, 16);
-#define LAUNCH(T, R, D) hipLaunchKernelGGL((bn_bwd_apply_h2_kernel<T, R, D>), dim3(blocks), dim3(256), 0, st, dy, dy_ld, y, y_ld, z, mean, invstd, gamma, sums, stats_count, (uint16_t*)dz_planes, plane, pitch, hdr, dres, P, C, Cp, gate_scale, gate_shift, (const uint32_t*)blockbound, nbound, dy2, dy2_ld)
+#define LAUNCH(T, R, D) SEMSEG_LAUNCH_BODY((bn_bwd_apply_h2_kernel_body<T, R, D>), dim3(blocks), 0, st, dy, dy_ld, y, y_ld, z, mean, invstd, gamma, sums, stats_count, (uint16_t*)dz_planes, plane, pitch, hdr, dres, P, C, Cp, gate_scale, gate_shift, (const uint32_t*)blockbound, nbound, dy2, dy2_ld)
     const int key = (training ? 4 : 0) | (relu ? 2 : 0) | (dres ? 1 : 0);
     switch (key) {
         case 0: LAUNCH(false, false, false); break;
@@ -1160,8 +1181,10 @@ extern "C" int semseg_bn_bwd_apply_h2_sum2(const float* dy, int dy_ld, const flo
 // peers' inboxes as soon as the block has them and come back summed over the ranks -- the all-reduce of batchnorm.py:98-117
 // INSIDE the finish kernel; min / max and the bounds stay rank-local (they only choose an exponent).
 template <bool PEER>
-__global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
-    const double* __restrict__ partial, const float* __restrict__ mm, int nparts, int C, double count,
+struct bn_fwd_finish_fused_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const double* __restrict__ partial, const float* __restrict__ mm, int nparts, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, int relu, const float* __restrict__ res_absmax,
     double* __restrict__ stats, float* __restrict__ zmm, float* __restrict__ mean, float* __restrict__ invstd,
@@ -1266,6 +1289,12 @@ __global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel(
         }
         if (PEER) semseg_peer::advance(pa, s_q, gridDim.x);
     }
+    }
+};
+// the PEER form as a kernel of its own: it waits for the other ranks inside the kernel, so it is never recorded, and the
+// co-residency query (exchange_capacity) needs its symbol
+__global__ __launch_bounds__(256) void bn_fwd_finish_fused_kernel_peer(const double* __restrict__ partial, const float* __restrict__ mm, int nparts, int C, double count, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps, int relu, const float* __restrict__ res_absmax, double* __restrict__ stats, float* __restrict__ zmm, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int64_t* __restrict__ num_batches_tracked, uint32_t* __restrict__ blockbound, float* __restrict__ absmax_out, semseg_peer::PeerArgs pa) {
+    bn_fwd_finish_fused_kernel_body<true>::run(semseg_batch::U3{blockIdx.x, blockIdx.y, blockIdx.z}, semseg_batch::U3{gridDim.x, gridDim.y, gridDim.z}, partial, mm, nparts, C, count, gamma, beta, running_mean, running_var, momentum, eps, relu, res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, blockbound, absmax_out, pa);
 }
 
 // Co-residency guard of the kernels that exchange with their peers while they run (csrc/peer_dev.h): block b of a rank spins
@@ -1308,7 +1337,7 @@ static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, 
     if (peer && (!semseg_peer::peer_args(peer, &pa) || 2 * C + 1 > pa.cap)) return SEMSEG_EINVAL;
     // BEFORE anything is launched: a rank that cannot co-schedule the exchanging grid leaves with nothing in flight (and the ranks
     // have agreed on semseg_bn_peer_channel_capacity() when the exchange was built, comm.peer_init -- this is the backstop)
-    if (peer && !exchange_grid_fits(bn_fwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;
+    if (peer && !exchange_grid_fits(bn_fwd_finish_fused_kernel_peer, ceil_div(C, 16))) return SEMSEG_EINVAL;
     if ((!z && pre_parts <= 0) || !stats || !zmm || !gamma || !beta || !mean || !invstd || !scale || !shift || !blockbound ||
         P <= 0 || C <= 0 || (C % 4) || (z && !aligned16(z)))
         return SEMSEG_EINVAL;
@@ -1321,17 +1350,17 @@ static int bn_fwd_stats_fused_impl(const float* z, int P, int C, double* stats, 
     float* mm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     if (pre_parts <= 0) {
         const size_t smem = (size_t)g.py * g.cx * 8 * (sizeof(double) + sizeof(float));
-        hipLaunchKernelGGL(bn_stats_mm_partial_kernel, dim3(g.gx, g.gy), dim3(256), smem, st, z, P, C, g.cx, g.py,
+        SEMSEG_LAUNCH_BODY((bn_stats_mm_partial_kernel_body), dim3(g.gx, g.gy), smem, st, z, P, C, g.cx, g.py,
                            g.rows_per_block, partial, mm, absmax_out);
         SEMSEG_LAUNCH_CHECK();
     }
     if (peer)
-        hipLaunchKernelGGL(bn_fwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+        hipLaunchKernelGGL(bn_fwd_finish_fused_kernel_peer, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
                            (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
                            res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound,
                            absmax_out, pa);
     else
-        hipLaunchKernelGGL(bn_fwd_finish_fused_kernel<false>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+        SEMSEG_LAUNCH_BODY((bn_fwd_finish_fused_kernel_body<false>), dim3(ceil_div(C, 16)), 0, st, (const double*)partial,
                            (const float*)mm, g.gy, C, (double)P, gamma, beta, running_mean, running_var, momentum, eps, relu,
                            res_absmax, stats, zmm, mean, invstd, scale, shift, num_batches_tracked, (uint32_t*)blockbound,
                            absmax_out, pa);
@@ -1390,8 +1419,10 @@ extern "C" int semseg_bn_fwd_finish_fused(const void* partials, size_t partials_
 // PEER: as bn_fwd_finish_fused_kernel -- [sum g, sum g xhat] summed over the ranks inside the kernel; dgamma / dbeta stay the
 // rank's own sums (parameter gradients are reduced with the gradient buckets), max|g| stays rank-local.
 template <bool PEER>
-__global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
-    const double* __restrict__ partial, const float* __restrict__ gm, int nparts, int C, const double* __restrict__ count,
+struct bn_bwd_finish_fused_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const double* __restrict__ partial, const float* __restrict__ gm, int nparts, int C, const double* __restrict__ count,
     const float* __restrict__ zmm, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, int training, double* __restrict__ sums, float* __restrict__ dgamma,
     float* __restrict__ dbeta, uint32_t* __restrict__ blockbound, semseg_peer::PeerArgs pa) {
@@ -1471,6 +1502,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel(
         blockbound[blockIdx.x] = bits;
         if (PEER) semseg_peer::advance(pa, s_q, gridDim.x);
     }
+    }
+};
+// the PEER form as a kernel of its own: it waits for the other ranks inside the kernel, so it is never recorded, and the
+// co-residency query (exchange_capacity) needs its symbol
+__global__ __launch_bounds__(256) void bn_bwd_finish_fused_kernel_peer(const double* __restrict__ partial, const float* __restrict__ gm, int nparts, int C, const double* __restrict__ count, const float* __restrict__ zmm, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma, int training, double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, uint32_t* __restrict__ blockbound, semseg_peer::PeerArgs pa) {
+    bn_bwd_finish_fused_kernel_body<true>::run(semseg_batch::U3{blockIdx.x, blockIdx.y, blockIdx.z}, semseg_batch::U3{gridDim.x, gridDim.y, gridDim.z}, partial, gm, nparts, C, count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta, blockbound, pa);
 }
 
 static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, int y_ld, const float* z,
@@ -1482,7 +1519,7 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
     if (dy2 && ((dy2_ld % 4) || dy2_ld < C || !aligned16(dy2))) return SEMSEG_EINVAL;
     semseg_peer::PeerArgs pa = {};
     if (peer && (!semseg_peer::peer_args(peer, &pa) || 2 * C > pa.cap)) return SEMSEG_EINVAL;
-    if (peer && !exchange_grid_fits(bn_bwd_finish_fused_kernel<true>, ceil_div(C, 16))) return SEMSEG_EINVAL;      // before any launch
+    if (peer && !exchange_grid_fits(bn_bwd_finish_fused_kernel_peer, ceil_div(C, 16))) return SEMSEG_EINVAL;      // before any launch
     if (!dy || !z || !mean || !invstd || !sums || !gamma || !blockbound || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) ||
         dy_ld < C)
         return SEMSEG_EINVAL;
@@ -1497,7 +1534,7 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
     float* gm = reinterpret_cast<float*>(partial + (size_t)g.gy * 2 * C);
     const size_t smem = (size_t)g.py * g.cx * (8 * sizeof(double) + 4 * sizeof(float));
 #define LAUNCH_PARTIAL(GATE)                                                                                              \
-    hipLaunchKernelGGL(bn_bwd_mm_partial_kernel<GATE>, dim3(g.gx, g.gy), dim3(256), smem, st, dy, dy_ld, y, y_ld, z, mean, \
+    SEMSEG_LAUNCH_BODY((bn_bwd_mm_partial_kernel_body<GATE>), dim3(g.gx, g.gy), smem, st, dy, dy_ld, y, y_ld, z, mean, \
                        invstd, relu, P, C, g.cx, g.py, g.rows_per_block, partial, gm, gate_scale, gate_shift, dy2, dy2_ld)
     if (!relu) LAUNCH_PARTIAL(0);
     else if (gate_scale) LAUNCH_PARTIAL(1);
@@ -1506,11 +1543,11 @@ static int bn_bwd_reduce_fused_impl(const float* dy, int dy_ld, const float* y, 
 #undef LAUNCH_PARTIAL
     SEMSEG_LAUNCH_CHECK();
     if (peer)
-        hipLaunchKernelGGL(bn_bwd_finish_fused_kernel<true>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+        hipLaunchKernelGGL(bn_bwd_finish_fused_kernel_peer, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
                            (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
                            (uint32_t*)blockbound, pa);
     else
-        hipLaunchKernelGGL(bn_bwd_finish_fused_kernel<false>, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const double*)partial,
+        SEMSEG_LAUNCH_BODY((bn_bwd_finish_fused_kernel_body<false>), dim3(ceil_div(C, 16)), 0, st, (const double*)partial,
                            (const float*)gm, g.gy, C, stats_count, zmm, mean, invstd, gamma, training, sums, dgamma, dbeta,
                            (uint32_t*)blockbound, pa);
     SEMSEG_LAUNCH_CHECK();
@@ -1557,7 +1594,7 @@ extern "C" int semseg_bn_bwd_reduce_fused_sum2(const float* dy, int dy_ld, const
 // exchange is built and keeps the peer exchange only if every rank can hold the widest payload it was created for (round-3 advice:
 // a rank that failed the check inside a step left its peers spinning until the timeout).
 extern "C" int semseg_bn_peer_channel_capacity(void) {
-    const int a = exchange_capacity(bn_fwd_finish_fused_kernel<true>), b = exchange_capacity(bn_bwd_finish_fused_kernel<true>);
+    const int a = exchange_capacity(bn_fwd_finish_fused_kernel_peer), b = exchange_capacity(bn_bwd_finish_fused_kernel_peer);
     const int blocks = a < b ? a : b;
     return blocks > 0 ? (blocks > (1 << 26) ? (1 << 30) : blocks * 16) : 0;
 }

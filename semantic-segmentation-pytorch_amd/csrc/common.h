@@ -7,6 +7,22 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// While the host has a side-by-side scope open (csrc/batch.h) the launches of the converted kernel families are recorded, not
+// issued.  Every OTHER launch of the library must not overtake them: it first issues whatever has been recorded (correct for any
+// kernel; only the converted ones are batched) and leaves on the scope's stream -- the stream the recorded launches will be issued on,
+// whatever stream the host had current when it made the call.  One load of a bool when no scope is open.
+namespace semseg_batch {
+bool recording();
+hipStream_t direct_stream(hipStream_t requested);      // no scope: `requested`; else: flush what is recorded, then the scope's stream
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                  \
+    do {                                                                                                                   \
+        hipStream_t st__ = (hipStream_t)(streamId);                                                                        \
+        if (semseg_batch::recording()) st__ = semseg_batch::direct_stream(st__);                                           \
+        kernelName<<<(numBlocks), (numThreads), (memPerBlock), st__>>>(__VA_ARGS__);                                       \
+    } while (0)
+
 #define SEMSEG_LAUNCH_CHECK()                       \
     do {                                            \
         hipError_t e__ = hipGetLastError();         \

@@ -37,6 +37,7 @@
 // hrnet.py:26-29,188-205,316-338 and its autograd backward.
 #include "common.h"
 #include "split_layout.h"
+#include "batch.h"
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
@@ -329,7 +330,10 @@ struct SplitBounds {
     int n;
 };
 template <bool VEC>
-__global__ __launch_bounds__(256) void split_h2_bounds_kernel(const float* __restrict__ x, int x_ld, uint16_t* __restrict__ out,
+struct split_h2_bounds_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ x, int x_ld, uint16_t* __restrict__ out,
                                                               int rows, int C, int Cp, int pitch, size_t plane, SplitBounds b,
                                                               int* __restrict__ hdr) {
     float bound = 0.f;
@@ -372,7 +376,8 @@ __global__ __launch_bounds__(256) void split_h2_bounds_kernel(const float* __res
         *reinterpret_cast<f16x8*>(out + o) = p0;
         *reinterpret_cast<f16x8*>(out + plane + o) = p1;
     }
-}
+    }
+};
 
 extern "C" int semseg_split_h2_bounds(const float* x, int x_ld, void* xs, int rows, int C, const float* const* bounds_host,
                                       int nbounds, void* stream) {
@@ -389,10 +394,10 @@ extern "C" int semseg_split_h2_bounds(const float* x, int x_ld, void* xs, int ro
     const size_t total = (size_t)rows * (Cp >> 3);
     const int blocks = (int)min((size_t)16384, ceil_div_sz(total, 256));
     if (vec)
-        hipLaunchKernelGGL(split_h2_bounds_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs, rows,
+        SEMSEG_LAUNCH_BODY((split_h2_bounds_kernel_body<true>), dim3(blocks), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs, rows,
                            C, Cp, pitch, plane, b, hdr);
     else
-        hipLaunchKernelGGL(split_h2_bounds_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs,
+        SEMSEG_LAUNCH_BODY((split_h2_bounds_kernel_body<false>), dim3(blocks), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)xs,
                            rows, C, Cp, pitch, plane, b, hdr);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -636,7 +641,12 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
 }
 
 template <class SCH, int BM, int BN>
-__global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
+struct igemm_rs_kernel_body {
+    static constexpr int THREADS = 256;
+    // the many-problem form only where small problems meet (HRNetV2 branches): h2 scheme, tiles up to 128 x 128
+    static constexpr bool MULTI = std::is_same<SCH, SchH2>::value && BM <= 128 && BN <= 128;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const SParams p) {
     constexpr int NP = SCH::NP;
     typedef typename SCH::frag frag;
     constexpr int RPP = 64;                 // rows per load pass (256 threads x 16 B = 64 rows x 64 B)
@@ -841,7 +851,8 @@ __global__ __launch_bounds__(256) void igemm_rs_kernel(const SParams p) {
     if (kt_begin < kt_end) compute_tile();
     S_MFMA_DRAIN();
     gemm_epilogue<SCH, FM, FN, 2, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem4);
-}
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // LDS-DMA variant for the large layers: BM x BN x 32 block tile, 8 waves (WGM x WGN), NSLOT LDS buffers filled by
@@ -881,7 +892,12 @@ extern "C" int semseg_debug_stamps(unsigned long long* host, size_t n) {
 #endif
 
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
-__global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams p) {
+struct igemm_dma_kernel_body {
+    static constexpr int THREADS = WGM * WGN * 64;
+    // the many-problem form only where small problems meet (HRNetV2 branches): h2 scheme, tiles up to 128 x 128
+    static constexpr bool MULTI = std::is_same<SCH, SchH2>::value && BM <= 128 && BN <= 128;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const SParams p) {
     constexpr int NP = SCH::NP;
     SEMSEG_STAMP(0);
     typedef typename SCH::frag frag;
@@ -1347,7 +1363,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
     SEMSEG_STAMP(2);
     gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
     SEMSEG_STAMP(3);
-}
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // igemm_dma_kernel on 64-deep k-tiles (round 4; tiles 22 / 23).  What the 32-deep loop leaves on the table was measured on the fused
@@ -1364,7 +1381,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma_kernel(const SParams
 // SPREAD (round 5, as wino_fused64_kernel's SCHED bit 0): the DMA pieces that refill a tile's two slots are issued in four groups
 // behind the four MFMA groups that follow the barrier, not as one burst right after it.
 template <class SCH, int BM, int BN, int WGM, int WGN, bool SPREAD = false>
-__global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma64_kernel(const SParams p) {
+struct igemm_dma64_kernel_body {
+    static constexpr int THREADS = WGM * WGN * 64;
+    // the many-problem form only where small problems meet (HRNetV2 branches): h2 scheme, tiles up to 128 x 128
+    static constexpr bool MULTI = std::is_same<SCH, SchH2>::value && BM <= 128 && BN <= 128;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const SParams p) {
     constexpr int NP = SCH::NP, NENT = 5;
     typedef typename SCH::frag frag;
     constexpr int NW = WGM * WGN;
@@ -1598,7 +1620,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_dma64_kernel(const SPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
     gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
-}
+    }
+};
 
 static int dma64_spread() {          // SEMSEG_DMA64_SPREAD=0: the burst form (A/B switch of the round-5 measurement)
     static const int v = [] { const char* e = getenv("SEMSEG_DMA64_SPREAD"); return e ? atoi(e) : 1; }();
@@ -1611,20 +1634,19 @@ static int launch_dma64(const SParams& p, hipStream_t st) {
     static_assert(smem <= 160 * 1024, "LDS");
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
     if (dma64_spread()) {
-        static SmemAttrCache attr_cache;
-        if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_dma64_kernel<SCH, BM, BN, WGM, WGN, true>, smem)) return e;
-        hipLaunchKernelGGL((igemm_dma64_kernel<SCH, BM, BN, WGM, WGN, true>), grid, dim3(64 * WGM * WGN), smem, st, p);
+            SEMSEG_LAUNCH_BODY((igemm_dma64_kernel_body<SCH, BM, BN, WGM, WGN, true>), grid, smem, st, p);
     } else {
-        static SmemAttrCache attr_cache;
-        if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_dma64_kernel<SCH, BM, BN, WGM, WGN, false>, smem)) return e;
-        hipLaunchKernelGGL((igemm_dma64_kernel<SCH, BM, BN, WGM, WGN, false>), grid, dim3(64 * WGM * WGN), smem, st, p);
+            SEMSEG_LAUNCH_BODY((igemm_dma64_kernel_body<SCH, BM, BN, WGM, WGN, false>), grid, smem, st, p);
     }
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
 
 template <bool VEC>
-__global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+struct split_gemm_reduce_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ partial, const float* __restrict__ bias,
                                          float* __restrict__ out, int out_ld,
                                          int M, int Cout, int splits) {
     const size_t total = (size_t)M * Cout;
@@ -1661,7 +1683,8 @@ __global__ void split_gemm_reduce_kernel(const float* __restrict__ partial, cons
         if (bias) s += bias[n];
         out[(size_t)m * out_ld + n] = s;
     }
-}
+    }
+};
 
 struct SPlan {
     int tile, BM, BN;
@@ -1737,10 +1760,8 @@ static SPlan plan_gemm(int sch, int M, int Cout, int Cp, int T, int ov_tile = -1
 template <class SCH, int BM, int BN>
 static int launch_rs(const SParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)SCH::NP * (BM + BN) * 64;
-    static SmemAttrCache attr_cache;
-    if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_rs_kernel<SCH, BM, BN>, smem)) return e;
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
-    hipLaunchKernelGGL((igemm_rs_kernel<SCH, BM, BN>), grid, dim3(256), smem, st, p);
+    SEMSEG_LAUNCH_BODY((igemm_rs_kernel_body<SCH, BM, BN>), grid, smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -1750,10 +1771,8 @@ static int launch_dma(const SParams& p, hipStream_t st) {
     constexpr size_t smem = NSLOT == 25 ? (size_t)5 * SCH::NP * BM * 64      // five half tiles
                                         : (size_t)(NSLOT >= 33 ? NSLOT - 30 : (NSLOT >= 12 ? NSLOT - 10 : NSLOT)) * SCH::NP * (BM + BN) * 64;
     static_assert(smem <= 160 * 1024, "LDS");
-    static SmemAttrCache attr_cache;
-    if (int e = ensure_smem_attr(attr_cache, (const void*)igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>, smem)) return e;
     dim3 grid(p.tiles_m * p.tiles_n, p.splits, p.batches > 0 ? p.batches : 1);
-    hipLaunchKernelGGL((igemm_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(64 * WGM * WGN), smem, st, p);
+    SEMSEG_LAUNCH_BODY((igemm_dma_kernel_body<SCH, BM, BN, WGM, WGN, NSLOT>), grid, smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -1907,10 +1926,10 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
                          (!p.bias || aligned16(p.bias));
         const int blocks = (int)min((size_t)2048, ceil_div_sz(vec ? total / 4 : total, 256));
         if (vec)
-            hipLaunchKernelGGL(split_gemm_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.out, p.out_ld,
+            SEMSEG_LAUNCH_BODY((split_gemm_reduce_kernel_body<true>), dim3(blocks), 0, st, p.partial, p.bias, p.out, p.out_ld,
                                p.M, p.Cout, pl.splits);
         else
-            hipLaunchKernelGGL(split_gemm_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias, p.out, p.out_ld,
+            SEMSEG_LAUNCH_BODY((split_gemm_reduce_kernel_body<false>), dim3(blocks), 0, st, p.partial, p.bias, p.out, p.out_ld,
                                p.M, p.Cout, pl.splits);
         SEMSEG_LAUNCH_CHECK();
     }

@@ -176,6 +176,14 @@ SIGNATURES = {
     'semseg_peer_status': (c_int, [vp]),
     'semseg_peer_destroy': (c_int, [vp]),
     'semseg_bn_peer_channel_capacity': (c_int, []),
+    'semseg_batch_begin': (c_int, [c_int, vp]),
+    'semseg_batch_branch': (c_int, [c_int]),
+    'semseg_batch_next_op': (c_int, []),
+    'semseg_batch_flush': (c_int, []),
+    'semseg_batch_end': (c_int, []),
+    'semseg_batch_abort': (c_int, []),
+    'semseg_batch_active': (c_int, []),
+    'semseg_batch_stats': (c_int, [ctypes.POINTER(ctypes.c_longlong)]),
     'semseg_probe_timestamp': (c_int, [vp, vp]),
     'semseg_probe_mfma_f16': (c_int, [vp, c_int, c_int, vp, vp]),
     'semseg_probe_copy': (c_int, [vp, vp, c_sz, vp]),
@@ -227,6 +235,11 @@ def is_capture_error(exc):
     return 'captur' in msg and 'out of memory' not in msg
 
 
+RECORDING = [False]        # ops.BranchesFn: a side-by-side scope (semseg_batch_begin) is open -- every checked C-ABI call is one ordinal
+
+
 def check(rc, what):
     if rc != 0:
         raise NativeError(what, rc)
+    if RECORDING[0]:
+        _lib.semseg_batch_next_op()

@@ -257,7 +257,16 @@ class TrainStep:
             ops.prepare_conv_weights(self._conv_weights)
             self._weights_ready = True
 
-    def _eager(self, feed):
+    def _eager(self, feed, recording=False):
+        """one step issued on the current stream.  recording: this pass is being RECORDED into a hipGraph (it cannot time launch
+        plans anyway), so independent sub-networks may go out as side-by-side launches (ops.batch_branches); an eager pass of a
+        graph-mode step is where the tuner times new geometries and keeps the plain launches; without graphs every pass after the
+        first is batched"""
+        batched = recording or (not self.use_graph and self.opt.steps >= 1)
+        with ops.batch_branches(batched):
+            return self._eager_pass(feed)
+
+    def _eager_pass(self, feed):
         if not self._weights_ready:
             self._prepare_weights()
         tl = self.timeline
@@ -409,7 +418,7 @@ class TrainStep:
             self._pool = torch.cuda.graph_pool_handle()
         if mode == 'segmented':
             graph = SegmentedStep()
-            out = graph.capture(lambda: self._eager(static), self._pool)
+            out = graph.capture(lambda: self._eager(static, recording=True), self._pool)
         else:
             # NOT `with torch.cuda.graph(...)`: its __enter__ is torch.cuda.synchronize() + empty_cache(), which drains the queue of
             # replays the host has run ahead of and leaves the device idle for the whole recording pass -- on the variable-size stream
@@ -419,7 +428,7 @@ class TrainStep:
             graph = _TimedGraph()
             if self._capture_stream is None:
                 self._capture_stream = torch.cuda.Stream()
-            out = record_graph(graph, lambda: self._eager(static), self._capture_stream, self._pool)
+            out = record_graph(graph, lambda: self._eager(static, recording=True), self._capture_stream, self._pool)
             self.stats['instantiate_host_s'] += graph.end_s    # of capture_host_s: hipStreamEndCapture + hipGraphInstantiate
         rec = self._graphs[key] = (graph, static, out)
         self.stats['captured'] += 1

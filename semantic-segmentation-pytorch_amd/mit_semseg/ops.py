@@ -70,10 +70,192 @@ def _branch_streams(device, count):
     return pool[:count]
 
 
+# Independent sub-networks as SIDE-BY-SIDE launches (round 6; csrc/batch.h): the branches run the same sequence of conv / BN
+# launches on different geometries, each a few blocks and ~10 us long, so the step is their number (2 726 per HRNetV2 step) whatever
+# stream they sit on.  Inside `batch_branches()` (TrainStep, around forward + backward of a pass that does not time launch plans)
+# run_branches executes the Python of every branch with the library RECORDING its launches, and the records at the same position of
+# every branch leave as ONE launch (semseg_batch_end) -- in forward and, through ONE autograd node for all branches (BranchesFn),
+# in backward.  Same kernels, same order inside a branch: bit-identical.  SEMSEG_BATCH_BRANCHES=0 disables.
+BATCH_BRANCHES = os.environ.get('SEMSEG_BATCH_BRANCHES', '1') != '0'
+_BATCH = [False]
+
+
+class batch_branches:
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _BATCH[0]
+        _BATCH[0] = self.enabled and BATCH_BRANCHES and CONV_MODE == 'h2' and FUSE
+        return self
+
+    def __exit__(self, *exc):
+        _BATCH[0] = self.prev
+        return False
+
+
+_TENSOR_RECORDS = ('_semseg_planes', '_semseg_absmax', '_semseg_planes_only')
+
+
+def _copy_records(src, dst):
+    """the split planes / bound scalars / planes-only mark that travel with tensor `src`, for its alias `dst` (same storage)"""
+    for name in _TENSOR_RECORDS:
+        rec = getattr(src, name, None)
+        if rec is None:
+            continue
+        if name == '_semseg_planes':
+            if rec[4] == src._version and rec[5] == src.data_ptr() == dst.data_ptr():
+                attach_planes(dst, rec[0], rec[1], rec[2], rec[3])
+        elif name == '_semseg_absmax':
+            if rec[1] == src._version and rec[2] == src.data_ptr() == dst.data_ptr():
+                attach_absmax(dst, rec[0])
+        else:
+            dst._semseg_planes_only = rec
+
+
+def _fork_streams(main, streams):
+    """the branch streams carry no launch of a batched scope -- everything leaves on `main` -- but the Python of branch i runs with
+    streams[i] current so that the caching allocator keeps the branches' temporaries in pools of their own (a block freed by one
+    branch must not be handed to another while both are only RECORDED: inside a branch the recorded order is the issue order, across
+    branches it is not); forked from / joined to `main` like the side streams of the old form so that a graph capture covers them"""
+    fork = torch.cuda.Event()
+    fork.record(main)
+    for st in streams:
+        st.wait_event(fork)
+
+
+def _join_streams(main, streams):
+    for st in streams:
+        done = torch.cuda.Event()
+        done.record(st)
+        main.wait_event(done)
+
+
+class _Recording:
+    """the library records the launches of the C-ABI calls made inside (semseg_batch_begin ... _end on `main`)"""
+
+    def __init__(self, n, main, streams):
+        self.n, self.main, self.streams = n, main, streams
+
+    def __enter__(self):
+        L = _native.lib()
+        _fork_streams(self.main, self.streams)
+        _native.check(L.semseg_batch_begin(self.n, vp(self.main.cuda_stream)), 'batch_begin')
+        _native.RECORDING[0] = True
+        self.prev_timing = tuner.NO_TIMING[0]
+        tuner.NO_TIMING[0] = True
+        return self
+
+    def branch(self, i):
+        _native.lib().semseg_batch_branch(i)
+        return torch.cuda.stream(self.streams[i])
+
+    def __exit__(self, et, ev, tb):
+        L = _native.lib()
+        _native.RECORDING[0] = False
+        tuner.NO_TIMING[0] = self.prev_timing
+        if et is not None:
+            L.semseg_batch_abort()
+            _join_streams(self.main, self.streams)
+            return False
+        rc = L.semseg_batch_end()
+        _join_streams(self.main, self.streams)
+        _native.check(rc, 'batch_end')
+        return False
+
+
+class BranchesFn(Function):
+    """[f(x) for f, x in zip(fns, xs)] for independent sub-networks as ONE autograd node whose forward and backward record the
+    launches of all branches and issue them position by position (see BATCH_BRANCHES above).  The branches' own autograd graphs
+    live inside the node: forward builds them on detached inputs, backward runs them one after the other (torch.autograd.grad on the
+    calling thread) while the library records."""
+
+    @staticmethod
+    def forward(ctx, holder, *xs):
+        fns = holder['fns']
+        n = len(fns)
+        dev = xs[0].device
+        main = torch.cuda.current_stream(dev)
+        streams = _branch_streams(dev, n)
+        ctx.set_materialize_grads(False)
+        inner_x, inner_y = [], []
+        with _Recording(n, main, streams) as rec:
+            for i in range(n):
+                with rec.branch(i), torch.enable_grad():
+                    xi = xs[i].detach()
+                    _copy_records(xs[i], xi)
+                    xi.requires_grad_(bool(ctx.needs_input_grad[i + 1]))
+                    yi = fns[i](xi)
+                inner_x.append(xi)
+                inner_y.append(yi)
+        ctx.inner = (fns, inner_x, inner_y, streams)
+        holder['outs'] = inner_y
+        return tuple(y.detach() for y in inner_y)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gys):
+        fns, inner_x, inner_y, streams = ctx.inner
+        ctx.inner = None
+        n = len(fns)
+        dev = inner_y[0].device
+        main = torch.cuda.current_stream(dev)
+        gxs = [None] * n
+        param_grads = []
+        with _Recording(n, main, streams) as rec:
+            for i in range(n):
+                if gys[i] is None or not inner_y[i].requires_grad:
+                    continue
+                params = [p for p in fns[i].parameters() if p.requires_grad]
+                inputs = ([inner_x[i]] if inner_x[i].requires_grad else []) + params
+                if not inputs:
+                    continue
+                with rec.branch(i):
+                    grads = torch.autograd.grad([inner_y[i]], inputs, [gys[i]], allow_unused=True)
+                if inner_x[i].requires_grad:
+                    gxs[i], grads = grads[0], grads[1:]
+                param_grads.extend((p, g) for p, g in zip(params, grads) if g is not None)
+        # what AccumulateGrad does, after the scope has closed (an accumulation into an existing gradient is a torch kernel): the
+        # returned buffer BECOMES .grad -- the adoption the deferred weight gradients rely on (_may_defer / flush_wgrad_reduces)
+        for p, g in param_grads:
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad = p.grad + g
+        return (None,) + tuple(gxs)
+
+
+def _run_branches_batched(fns, args):
+    holder = {'fns': list(fns)}
+    outs = BranchesFn.apply(holder, *args)
+    for o, y in zip(outs, holder.pop('outs')):
+        _copy_records(y, o)                             # the planes / bound the last BN of the branch left on its output
+    return list(outs)
+
+
+def _batchable(fns, args):
+    if not (_BATCH[0] and torch.is_grad_enabled() and 1 < len(fns) <= 8 and len(fns) == len(args)):
+        return False
+    dev = None
+    for f, a in zip(fns, args):
+        if not (isinstance(f, torch.nn.Module) and torch.is_tensor(a) and a.is_cuda and a.dim() == 4 and a.dtype == torch.float32):
+            return False
+        if dev is not None and a.device != dev:
+            return False
+        dev = a.device
+    if not any(a.requires_grad or any(p.requires_grad for p in f.parameters()) for f, a in zip(fns, args)):
+        return False
+    if _sync_active() or _SEGMENTS is not None or _native.lib().semseg_batch_active():
+        return False                                    # SyncBN exchanges keep ONE issue order; a scope inside a scope stays sequential
+    return torch.cuda.current_stream(dev).cuda_stream not in _BRANCH_TAG
+
+
 def run_branches(fns, args):
-    """[f(a) for f, a in zip(fns, args)] with f_1 ... f_n-1 on side streams (f_0, the largest, stays on the current stream);
-    joined before returning.  Off when SyncBN is active (the ranks must issue their exchanges in ONE order) and during a
-    segmented capture."""
+    """[f(a) for f, a in zip(fns, args)] for independent sub-networks: as side-by-side launches inside `batch_branches()`
+    (BranchesFn), else with f_1 ... f_n-1 on side streams (f_0, the largest, stays on the current stream), joined before
+    returning.  Off when SyncBN is active (the ranks must issue their exchanges in ONE order) and during a segmented capture."""
+    if _batchable(fns, args):
+        return _run_branches_batched(fns, args)
     x0 = args[0]
     while isinstance(x0, (list, tuple)):                  # an argument may be a list of tensors (every branch reads all of them)
         x0 = x0[0]

@@ -37,6 +37,13 @@ stats_db = {'from_perfdb': 0, 'from_cache': 0}
 BUCKETS = os.environ.get('SEMSEG_TUNE_BUCKETS', '1') != '0'
 _bucket_plans = {}  # (scheme, pass, C, K, R, S, stride, pad, dil, bucket) -> (tile, split)
 stats = {'timed': 0, 'inherited': 0, 'missed_capturing': 0}   # missed_capturing: geometries met inside a graph capture with no plan to inherit
+# launches are being RECORDED, not issued (ops.BranchesFn: side-by-side launches of independent sub-networks, csrc/batch.h): nothing
+# can be timed -- treated like a graph capture (a plan may be inherited, a geometry without one runs on the library's default)
+NO_TIMING = [False]
+
+
+def _cannot_time():
+    return NO_TIMING[0] or torch.cuda.is_current_stream_capturing()
 
 
 def _bucket_key(scheme, pass_id, geom):
@@ -200,7 +207,7 @@ def ensure_winograd_gemm(tiles, c, k, launch):
             return
     if not torch.cuda.is_available():
         return
-    if torch.cuda.is_current_stream_capturing():
+    if _cannot_time():
         stats['missed_capturing'] += 1          # runs on the library's default; engine.TrainStep re-captures after an eager (timing) pass
         return
     stats['timed'] += 1
@@ -250,7 +257,7 @@ def choose(geom, candidates, default=0):
         return near[0]
     if not ENABLED or not torch.cuda.is_available():
         return default
-    if torch.cuda.is_current_stream_capturing():
+    if _cannot_time():
         stats['missed_capturing'] += 1
         return default
     stats['timed'] += 1
@@ -306,7 +313,7 @@ def ensure(scheme, pass_id, geom, launch):
             _done[key] = (tile, split if tile >= 0 else 0, None)
             stats['inherited'] += 1
             return
-    if torch.cuda.is_current_stream_capturing():
+    if _cannot_time():
         stats['missed_capturing'] += 1
         return                                  # graph capture: a plan may be inherited (above), never timed
     stats['timed'] += 1

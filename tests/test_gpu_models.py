@@ -433,18 +433,38 @@ SWITCH_CASES = [
 ]
 
 
-@pytest.mark.parametrize('switch,case', SWITCH_CASES, ids=[s for s, _ in SWITCH_CASES])
-def test_env_switch_keeps_model_parity(switch, case):
-    """the golden tests of `case` (forward bounds, post-step state and, where stored, every gradient against the float64
-    anchors) in a child process with `switch` set"""
+_SWITCH_FARM = {}
+
+
+def _switch_child(switch, case):
     import subprocess
     import sys
-    if os.environ.get('SEMSEG_SWITCH_CHILD'):
-        pytest.skip('already inside a switch child')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     k, v = switch.split('=')
     env = dict(os.environ, SEMSEG_SWITCH_CHILD='1', **{k: v})
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_models.py'), '-q', '-x', '-m', 'gpu',
                         '-k', '%s and not switch' % case], env=env, capture_output=True, text=True, timeout=900, cwd=root)
-    tail = r.stdout[-1500:]
-    assert r.returncode == 0 and ' passed' in tail, '%s: %s\n%s' % (switch, tail, r.stderr[-1500:])
+    return r.returncode, r.stdout[-1500:], r.stderr[-1500:]
+
+
+def _switch_result(switch, case):
+    """the children of ALL switch cases are started when the first of them is asked for, SWITCH_WORKERS at a time: a child spends
+    most of its ~14 s importing torch and loading the library, not on the GPU, and 24 of them one after the other were 360 of the
+    suite's 580 s (round-5 review, item 7c: the suite has to stay well inside the driver's 1 200 s)"""
+    if not _SWITCH_FARM:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=int(os.environ.get('SEMSEG_SWITCH_WORKERS', '6')))
+        for sw, cs in SWITCH_CASES:
+            _SWITCH_FARM[(sw, cs)] = pool.submit(_switch_child, sw, cs)
+        pool.shutdown(wait=False)
+    return _SWITCH_FARM[(switch, case)].result()
+
+
+@pytest.mark.parametrize('switch,case', SWITCH_CASES, ids=[s for s, _ in SWITCH_CASES])
+def test_env_switch_keeps_model_parity(switch, case):
+    """the golden tests of `case` (forward bounds, post-step state and, where stored, every gradient against the float64
+    anchors) in a child process with `switch` set"""
+    if os.environ.get('SEMSEG_SWITCH_CHILD'):
+        pytest.skip('already inside a switch child')
+    rc, tail, err = _switch_result(switch, case)
+    assert rc == 0 and ' passed' in tail, '%s: %s\n%s' % (switch, tail, err)
