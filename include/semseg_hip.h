@@ -602,21 +602,27 @@ int semseg_probe_gather(const void* src, unsigned rows, unsigned pitch, int seg_
  * does its host work -- plans, out-parameters -- at call time) and end() issues the records that sit at the same position of every
  * branch as ONE launch whose blocks find their problem in a table in the kernel arguments: same blocks, same arithmetic, same
  * order inside a branch -- bit-identical to the sequential launches.  One scope per process at a time.
- *   begin(branches, stream): open a scope of 1 ... 8 branches whose launches ALL leave on `stream` (whatever stream argument the
+ *   begin(branches, stream): open a scope of 1 ... 16 branches whose launches ALL leave on `stream` (whatever stream argument the
  *   calls inside carry -- the host runs every branch under a stream context of its own so that the caching allocator keeps the
  *   branches' temporaries apart); branch(i): the calls that follow belong to branch i; next_op(): the host has finished one C-ABI
  *   call of the current branch (launches pair up only under the same ordinal); flush(): issue what has been recorded, keep the
  *   scope; end(): flush + close, returns the first launch error of the scope; abort(): drop everything (a failed forward / backward);
- *   active(): 1 inside a scope; stats(out[4]): scopes opened, launches recorded, launches issued through the recorder's launch
- *   path, problems they carried. */
+ *   active(): 1 inside a scope; stats(out[4]): scopes opened, launches recorded, launches the zip issued for them, direct launches
+ *   inside a scope (each forced a flush: an unconverted kernel on a branch's path). */
 int semseg_batch_begin(int branches, void* stream);
 int semseg_batch_branch(int index);
 int semseg_batch_next_op(void);
+int semseg_batch_next_unit(void);   /* the next unit of the branch (one conv -> BN node, forward or backward): ordinals restart at a multiple of 256 */
 int semseg_batch_flush(void);
 int semseg_batch_end(void);
 int semseg_batch_abort(void);
 int semseg_batch_active(void);
 int semseg_batch_stats(long long* out4);
+/* launch plan of the forward / data-gradient GEMMs recorded inside a scope (csrc/conv_split.hip batch_plan): ONE tile form without
+ * split-K for every problem of at most max_tiles 64 x 64 tiles, so that the branches' GEMMs are the same kernel instantiation and
+ * pair up; tile -1: the per-geometry plans (what the sequential launches run: bit-identical results); max_tiles <= 0: unchanged.
+ * Defaults: SEMSEG_BATCH_TILE (-1: measured best on HRNetV2, csrc/conv_split.hip), SEMSEG_BATCH_MAX_TILES (1024).  Returns the previous tile. */
+int semseg_batch_plan(int tile, int max_tiles);
 
 #ifdef __cplusplus
 }

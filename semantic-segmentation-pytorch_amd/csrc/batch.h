@@ -27,7 +27,7 @@
 
 namespace semseg_batch {
 
-constexpr int kMaxBranches = 8;      // branches of one scope
+constexpr int kMaxBranches = 16;     // branches of one scope (HRNetV2's stage-4 exchange: 12 independent conv chains)
 constexpr int kMaxGroup = 4;         // problems of one many_kernel launch (4 argument blocks stay far below the 4 KB argument segment)
 constexpr int kMaxArgBytes = 480;    // argument block of one record
 
@@ -41,6 +41,10 @@ typedef int (*GroupLaunch)(const Record* const* recs, int n, hipStream_t st);
 struct Record {
     GroupLaunch launch;              // issues n >= 1 records of this kernel instantiation as one launch; identifies the instantiation
     int op;                          // ordinal of the C-ABI call inside its branch (semseg_batch_next_op)
+    int max_group;                   // 1: this instantiation has no many-problem form (BODY::MULTI == false): recorded, issued alone
+    const char* name;                // __PRETTY_FUNCTION__ of the issuing function: names the body in SEMSEG_BATCH_DEBUG traces
+    int cost;                        // how long ONE block of this launch runs, in the launch site's own unit (hint_cost; 0: unknown):
+                                     // the problems of a group are laid out longest blocks first (the hardware starts blocks in order)
     U3 grid;
     unsigned smem;
     alignas(16) unsigned char args[kMaxArgBytes];
@@ -50,8 +54,9 @@ struct Record {
 bool recording();                                // a scope is open in this process
 Record* new_record();                            // appended to the current branch
 int flush_recorded();                            // everything recorded so far leaves on the scope's stream; the scope stays open
-hipStream_t direct_stream(hipStream_t requested);   // for a launch that is NOT recorded: flush, then the scope's stream (no scope: `requested`)
+hipStream_t direct_stream(hipStream_t requested, const char* what = nullptr);   // for a launch that is NOT recorded: flush, then the scope's stream (no scope: `requested`)
 void count_launch(int problems);                 // statistics (semseg_batch_stats)
+void hint_cost(int cost);                        // for the NEXT launch_body of this thread's current branch (a GEMM: k-tiles per block)
 
 // ---- argument blocks ---------------------------------------------------------------------------------------------------------
 template <class... A>
@@ -126,6 +131,15 @@ struct SmemAttr {
     }
 };
 
+template <class BODY>
+struct body_multi {      // a body may opt out of the many-problem form (`static constexpr bool MULTI = false`): it then flushes and launches alone
+    template <class B>
+    static constexpr auto test(int) -> decltype(B::MULTI) { return B::MULTI; }
+    template <class B>
+    static constexpr bool test(...) { return true; }
+    static constexpr bool value = test<BODY>(0);
+};
+
 template <class BODY, class... A>
 struct Issue {
     // peel the pack back into a parameter list
@@ -152,38 +166,34 @@ struct Issue {
             memcpy(&p, recs[0]->args, sizeof(P));
             return one(dim3(recs[0]->grid.x, recs[0]->grid.y, recs[0]->grid.z), recs[0]->smem, st, p);
         }
-        if (n > kMaxGroup) return -1;
-        Table<P> t;
-        memset(&t, 0, sizeof(t));
-        t.n = n;
-        long blocks = 0;
-        size_t smem = 0;
-        for (int i = 0; i < n; ++i) {
-            memcpy(&t.p[i], recs[i]->args, sizeof(P));
-            t.grid[i] = recs[i]->grid;
-            t.first[i] = (int)blocks;
-            blocks += (long)recs[i]->grid.x * recs[i]->grid.y * recs[i]->grid.z;
-            blocks = (blocks + 7) & ~7L;
-            if (recs[i]->smem > smem) smem = recs[i]->smem;
+        if constexpr (body_multi<BODY>::value) {
+            if (n > kMaxGroup) return -1;
+            Table<P> t;
+            memset(&t, 0, sizeof(t));
+            t.n = n;
+            long blocks = 0;
+            size_t smem = 0;
+            for (int i = 0; i < n; ++i) {
+                memcpy(&t.p[i], recs[i]->args, sizeof(P));
+                t.grid[i] = recs[i]->grid;
+                t.first[i] = (int)blocks;
+                blocks += (long)recs[i]->grid.x * recs[i]->grid.y * recs[i]->grid.z;
+                blocks = (blocks + 7) & ~7L;
+                if (recs[i]->smem > smem) smem = recs[i]->smem;
+            }
+            if (blocks >= (1L << 31)) return -1;
+            t.first[n] = (int)blocks;
+            static SmemAttr attr;
+            if (int e = attr.ensure((const void*)many_kernel<BODY, A...>, smem)) return e;
+            many_kernel<BODY, A...><<<dim3((unsigned)blocks), dim3(BODY::THREADS), smem, st>>>(t);
+            const hipError_t e = hipGetLastError();
+            count_launch(n);
+            return e == hipSuccess ? 0 : (int)e;
+        } else {
+            return -1;               // the zip never groups records of max_group 1
         }
-        if (blocks >= (1L << 31)) return -1;
-        t.first[n] = (int)blocks;
-        static SmemAttr attr;
-        if (int e = attr.ensure((const void*)many_kernel<BODY, A...>, smem)) return e;
-        many_kernel<BODY, A...><<<dim3((unsigned)blocks), dim3(BODY::THREADS), smem, st>>>(t);
-        const hipError_t e = hipGetLastError();
-        count_launch(n);
-        return e == hipSuccess ? 0 : (int)e;
     }
-};
-
-template <class BODY>
-struct body_multi {      // a body may opt out of the many-problem form (`static constexpr bool MULTI = false`): it then flushes and launches alone
-    template <class B>
-    static constexpr auto test(int) -> decltype(B::MULTI) { return B::MULTI; }
-    template <class B>
-    static constexpr bool test(...) { return true; }
-    static constexpr bool value = test<BODY>(0);
+    static const char* name() { return __PRETTY_FUNCTION__; }
 };
 
 // The launch of a kernel written as a BODY: recorded while a scope is open, issued at once otherwise.  Returns 0 or a hipError_t.
@@ -191,10 +201,12 @@ template <class BODY, class... A>
 static inline int launch_body(dim3 grid, size_t smem, hipStream_t st, A... a) {
     typedef Pack<A...> P;
     if (recording()) {
-        if constexpr (body_multi<BODY>::value && sizeof(P) <= kMaxArgBytes) {
+        if constexpr (sizeof(P) <= kMaxArgBytes) {
             Record* r = new_record();
             if (r) {
                 r->launch = &Issue<BODY, A...>::group;
+                r->max_group = body_multi<BODY>::value ? kMaxGroup : 1;
+                r->name = Issue<BODY, A...>::name();
                 r->grid = U3{grid.x, grid.y, grid.z};
                 r->smem = (unsigned)smem;
                 const P p = P::make(a...);
@@ -202,7 +214,7 @@ static inline int launch_body(dim3 grid, size_t smem, hipStream_t st, A... a) {
                 return 0;
             }
         }
-        st = direct_stream(st);
+        st = direct_stream(st, Issue<BODY, A...>::name());
     }
     return Issue<BODY, A...>::one(grid, smem, st, P::make(a...));
 }

@@ -13,13 +13,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // whatever stream the host had current when it made the call.  One load of a bool when no scope is open.
 namespace semseg_batch {
 bool recording();
-hipStream_t direct_stream(hipStream_t requested);      // no scope: `requested`; else: flush what is recorded, then the scope's stream
+hipStream_t direct_stream(hipStream_t requested, const char* what);      // no scope: `requested`; else: flush what is recorded, then the scope's stream
 }
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                  \
     do {                                                                                                                   \
         hipStream_t st__ = (hipStream_t)(streamId);                                                                        \
-        if (semseg_batch::recording()) st__ = semseg_batch::direct_stream(st__);                                           \
+        if (semseg_batch::recording()) st__ = semseg_batch::direct_stream(st__, "BODY = " #kernelName "]");                                      \
         kernelName<<<(numBlocks), (numThreads), (memPerBlock), st__>>>(__VA_ARGS__);                                       \
     } while (0)
 

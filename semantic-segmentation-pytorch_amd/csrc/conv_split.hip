@@ -87,8 +87,44 @@ typedef std::array<int, 12> SKey;     // scheme, pass, N, H, W, C, K, R, S, stri
 static std::map<SKey, std::pair<int, int>> g_plans;
 static std::mutex g_plans_mu;
 
+// Plans of launches that are being RECORDED for a side-by-side launch (csrc/batch.h; HRNetV2's branches): the per-geometry plans
+// were timed with the chip to one problem -- every geometry its own tile form, small ones split along K to reach 256 CUs -- but
+// records pair up only under ONE kernel instantiation, and in a launch of four problems the others fill the chip.  So inside a
+// scope the forward / data-gradient GEMMs of small problems CAN run on ONE tile form without a split: SEMSEG_BATCH_TILE (15 / 17 / 19:
+// the 64 x 64 tiles on the LDS-DMA rings, which take every channel count; 23 = the 64-deep form where the reduction is whole
+// 64-channel chunks, else 17), up to SEMSEG_BATCH_MAX_TILES 64 x 64 tiles per problem (default 1024; larger problems keep their own
+// plan).  Measured on HRNetV2 at 2 x 512 x 512 (gpurun r8e, ms per step): no scope 25.27; per-geometry plans inside the scopes 22.32;
+// tile 15: 22.58, 19: 22.63, 17: 23.81, 23: 24.51, 2: 24.95 -- a GEMM of four problems on one tile form is bound by the chip's block
+// slots (80 KiB of LDS per 64-deep block: two per CU), not by its launches, and the per-geometry tiles are each the fastest for
+// their problem.  Default -1: the per-geometry plans (the GEMMs of a position pair up where their plans name the same kernel).
+static int g_batch_tile = [] { const char* e = getenv("SEMSEG_BATCH_TILE"); return e ? atoi(e) : -1; }();
+static int g_batch_max_tiles = [] { const char* e = getenv("SEMSEG_BATCH_MAX_TILES"); return e ? atoi(e) : 1024; }();
+// the same two knobs at run time (tests compare the side-by-side launches bit for bit with the sequential ones on the per-geometry
+// plans: tile -1); returns the previous tile
+extern "C" int semseg_batch_plan(int tile, int max_tiles) {
+    const int prev = g_batch_tile;
+    g_batch_tile = tile;
+    if (max_tiles > 0) g_batch_max_tiles = max_tiles;
+    return prev;
+}
+static bool batch_plan(int pass, int M, int Cout, int Cred, int* tile, int* split) {
+    if (pass > 1 || !semseg_batch::recording()) return false;
+    const int want = g_batch_tile, max_tiles = g_batch_max_tiles;
+    if (want < 0) return false;
+    if ((long)((M + 63) / 64) * ((Cout + 63) / 64) > max_tiles) return false;
+    int t = want;
+    if (t >= 22 && t <= 24 && (((Cred + 31) / 32) % 2)) t = 17;
+    *tile = t;
+    *split = 1;
+    return true;
+}
+
 static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                         int* tile, int* split) {
+    if (sch == 1 /* SchH2::ID */ && pass <= 1) {
+        const int OH = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, OW = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+        if (pass == 0 ? batch_plan(0, N * OH * OW, K, C, tile, split) : batch_plan(1, N * H * W, C, K, tile, split)) return true;
+    }
     std::lock_guard<std::mutex> lk(g_plans_mu);
     if (g_plans.empty()) return false;
     auto it = g_plans.find(SKey{sch, pass, N, H, W, C, K, R, S, stride, pad, dil});
@@ -543,7 +579,9 @@ __device__ __forceinline__ int s_slot(int row, int q) { return row * 4 + (q ^ ((
 // so that ONE partial row per block row tile reaches memory (tiles_m rows for the BN finish kernel instead of tiles_m x WGM).
 template <class SCH, int FM, int FN, int WGM, int BN>
 __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM][FN], int row0, int col0, int z, int bz, int lane,
-                                              int tm, int wm, int wcol, void* smem) {
+                                              int tm, int wm, int wcol, void* smem, const bool first_block) {
+    // first_block: this is block (0, 0) of ITS launch's grid -- a parameter, not the built-in index: inside a side-by-side launch
+    // (csrc/batch.h) a problem's first block sits anywhere in the combined grid
     float* dst;
     int dst_ld;
     const bool direct = p.splits == 1;
@@ -559,7 +597,7 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
     const int col_l = lane & 31;
     const int row_l = 4 * (lane >> 5);
     const bool stats = direct && p.st_sum != nullptr;            // uniform over the block
-    if (stats && p.st_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.st_zero[0] = 0.f;
+    if (stats && p.st_zero && first_block && threadIdx.x == 0) p.st_zero[0] = 0.f;
     double su[FN], sq[FN];
     float mn[FN], mx[FN];
 #pragma unroll
@@ -850,7 +888,7 @@ struct igemm_rs_kernel_body {
     }
     if (kt_begin < kt_end) compute_tile();
     S_MFMA_DRAIN();
-    gemm_epilogue<SCH, FM, FN, 2, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem4);
+    gemm_epilogue<SCH, FM, FN, 2, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem4, blockIdx.x == 0 && blockIdx.y == 0);
     }
 };
 
@@ -1225,7 +1263,7 @@ struct igemm_dma_kernel_body {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         S_MFMA_DRAIN();
-        gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
+        gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0);
         return;
     }
     // Every iteration issues exactly LPT DMA instructions per wave (dummy zero-tail fetches past the end), so "all but
@@ -1295,7 +1333,7 @@ struct igemm_dma_kernel_body {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         S_MFMA_DRAIN();
-        gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
+        gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0);
         return;
     }
     issue(kt_begin, 0);
@@ -1361,7 +1399,7 @@ struct igemm_dma_kernel_body {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
     SEMSEG_STAMP(2);
-    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
+    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0);
     SEMSEG_STAMP(3);
     }
 };
@@ -1619,7 +1657,7 @@ struct igemm_dma64_kernel_body {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
-    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem);
+    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0);
     }
 };
 
@@ -1835,6 +1873,7 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
         }
     }
     int rc = SEMSEG_EINVAL;
+    semseg_batch::hint_cost(p.kt_per_split);       // a recorded launch: blocks with the longest k loop go first in a side-by-side launch
     switch (pl.tile) {
         case 0: rc = launch_rs<SCH, 128, 128>(p, st); break;
         case 1: rc = launch_rs<SCH, 128, 64>(p, st); break;
@@ -2975,9 +3014,14 @@ __device__ __forceinline__ void wgrad_block_body(const WParams& p, int lin, int 
 }
 
 template <class SCH, int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WParams p) {
+struct wgrad_kernel_body {
+    static constexpr int THREADS = 256;
+    static constexpr bool MULTI = std::is_same<SCH, SchH2>::value && BM <= 128 && BN <= 128;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const WParams p) {
     wgrad_block_body<SCH, BM, BN>(p, blockIdx.x + gridDim.x * blockIdx.y, gridDim.y);
-}
+    }
+};
 
 // MANY weight gradients in one launch (semseg_conv2d_wgrad_multi_h2): the weight gradients of a backward pass are read by the
 // optimizer only, so the host may hold the small ones back (their operands stay alive) and run their blocks side by side -- HRNet's
@@ -3180,7 +3224,11 @@ static bool wtaps_eligible(int R, int S, int stride, int pad, int dil, int OW, i
 //   NSLOT == 3: wait(tile it) | barrier | issue tile it+2 | multiply                (8 waves, one barrier per k-tile)
 // ------------------------------------------------------------------------------------------------
 template <class SCH, int BM, int BN, int WGM, int WGN, int NSLOT>
-__global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams p) {
+struct wgrad_dma_kernel_body {
+    static constexpr int THREADS = WGM * WGN * 64;
+    static constexpr bool MULTI = std::is_same<SCH, SchH2>::value && BM <= 128 && BN <= 128;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const WParams p) {
     constexpr int NP = SCH::NP;
     typedef typename SCH::frag frag;
     constexpr int NW = WGM * WGN;
@@ -3520,9 +3568,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_dma_kernel(const WParams
             }
         }
     }
-}
+    }
+};
 
-__global__ void split_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t total, int splits) {
+struct split_wgrad_reduce_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ partial, float* __restrict__ dw, size_t total, int splits) {
     // float4 lanes (the slabs are 16-byte aligned and total % 4 == 0 is checked by the launcher; scalar tail otherwise)
     const size_t quads = total >> 2;
     const float4* p4 = reinterpret_cast<const float4*>(partial);
@@ -3540,16 +3592,21 @@ __global__ void split_wgrad_reduce_kernel(const float* __restrict__ partial, flo
         }
         o4[i] = s;
     }
-}
+    }
+};
 
-__global__ void split_wgrad_reduce_scalar_kernel(const float* __restrict__ partial, float* __restrict__ dw, size_t total,
+struct split_wgrad_reduce_scalar_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ partial, float* __restrict__ dw, size_t total,
                                                  int splits) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         float s = partial[i];
         for (int z = 1; z < splits; ++z) s += partial[(size_t)z * total + i];
         dw[i] = s;
     }
-}
+    }
+};
 
 struct WPlan {
     int tile, BM, BN, tiles_k, tiles_c, splits, m_per_split;
@@ -3614,9 +3671,8 @@ template <class SCH, int BT>
 static int launch_wgrad(const WParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)2 * WTile<SCH::NP, BT>::BYTES;
     static SmemAttrCache attr_cache;
-    if (int e = ensure_smem_attr(attr_cache, (const void*)wgrad_kernel<SCH, BT, BT>, smem)) return e;
     dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits);
-    hipLaunchKernelGGL((wgrad_kernel<SCH, BT, BT>), grid, dim3(256), smem, st, p);
+    SEMSEG_LAUNCH_BODY((wgrad_kernel_body<SCH, BT, BT>), grid, smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -3631,9 +3687,8 @@ static int launch_wgrad_dma(const WParams& p, hipStream_t st) {
         (size_t)2 * SCH::NP * p.dy_plane + SPLIT_ZERO_TAIL_BYTES >= ((size_t)1 << 31))
         return SEMSEG_EINVAL;
     static SmemAttrCache attr_cache;
-    if (int e = ensure_smem_attr(attr_cache, (const void*)wgrad_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>, smem)) return e;
     dim3 grid(p.tiles_k * p.tiles_c * p.T, p.splits, p.batches > 0 ? p.batches : 1);
-    hipLaunchKernelGGL((wgrad_dma_kernel<SCH, BM, BN, WGM, WGN, NSLOT>), grid, dim3(WGM * WGN * 64), smem, st, p);
+    SEMSEG_LAUNCH_BODY((wgrad_dma_kernel_body<SCH, BM, BN, WGM, WGN, NSLOT>), grid, smem, st, p);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -3748,10 +3803,10 @@ static int conv_wgrad(const void* xs, const void* dys, float* dw,
         const size_t total = (size_t)K * p.T * C;
         if (total % 4 == 0 && aligned16(p.partial) && aligned16(dw)) {
             const int blocks = (int)min((size_t)2048, ceil_div_sz(total / 4, 256));
-            hipLaunchKernelGGL(split_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, total, pl.splits);
+            SEMSEG_LAUNCH_BODY((split_wgrad_reduce_kernel_body), dim3(blocks), 0, st, p.partial, dw, total, pl.splits);
         } else {
             const int blocks = (int)min((size_t)2048, ceil_div_sz(total, 256));
-            hipLaunchKernelGGL(split_wgrad_reduce_scalar_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, total, pl.splits);
+            SEMSEG_LAUNCH_BODY((split_wgrad_reduce_scalar_kernel_body), dim3(blocks), 0, st, p.partial, dw, total, pl.splits);
         }
         SEMSEG_LAUNCH_CHECK();
     }
@@ -3802,7 +3857,7 @@ extern "C" int semseg_winograd_wgrad_gemm_h2(const void* v_planes, const void* d
     if (rc) return rc;
     if (p.splits > 1) {
         const int blocks = (int)min((size_t)2048, ceil_div_sz(slab / 4, 256));
-        hipLaunchKernelGGL(split_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dU, slab, p.splits);
+        SEMSEG_LAUNCH_BODY((split_wgrad_reduce_kernel_body), dim3(blocks), 0, st, p.partial, dU, slab, p.splits);
         SEMSEG_LAUNCH_CHECK();
     }
     return 0;

@@ -179,11 +179,13 @@ SIGNATURES = {
     'semseg_batch_begin': (c_int, [c_int, vp]),
     'semseg_batch_branch': (c_int, [c_int]),
     'semseg_batch_next_op': (c_int, []),
+    'semseg_batch_next_unit': (c_int, []),
     'semseg_batch_flush': (c_int, []),
     'semseg_batch_end': (c_int, []),
     'semseg_batch_abort': (c_int, []),
     'semseg_batch_active': (c_int, []),
     'semseg_batch_stats': (c_int, [ctypes.POINTER(ctypes.c_longlong)]),
+    'semseg_batch_plan': (c_int, [c_int, c_int]),
     'semseg_probe_timestamp': (c_int, [vp, vp]),
     'semseg_probe_mfma_f16': (c_int, [vp, c_int, c_int, vp, vp]),
     'semseg_probe_copy': (c_int, [vp, vp, c_sz, vp]),
@@ -236,6 +238,12 @@ def is_capture_error(exc):
 
 
 RECORDING = [False]        # ops.BranchesFn: a side-by-side scope (semseg_batch_begin) is open -- every checked C-ABI call is one ordinal
+
+
+def next_unit():
+    """ops: the current branch of an open side-by-side scope enters its next conv -> BN unit (semseg_batch_next_unit)"""
+    if RECORDING[0]:
+        _lib.semseg_batch_next_unit()
 
 
 def check(rc, what):

@@ -242,6 +242,7 @@ class TrainStep:
         # that times the plans, capture at the next sight).  SEMSEG_CAPTURE_FIRST_SIGHT=0: the old order for every shape.
         self.capture_first_sight = os.environ.get('SEMSEG_CAPTURE_FIRST_SIGHT', '1') != '0'
         self.timeline = None                          # scaling_model.TimelineProbe: timestamp markers inside the (captured) step
+        self._time_next_pass = False                  # graph=False: the next eager pass keeps the plain launches and times the plans a batched pass missed
         self._capture_errors = {}                     # feed_key -> repr of the capture refusal that sent the shape to the old order (logged once)
         self.stats = {'eager': 0, 'captured': 0, 'replayed': 0, 'evicted': 0, 'provisional': 0, 'capture_failed': 0, 'capture_host_s': 0.0, 'instantiate_host_s': 0.0,
                       'eager_host_s': 0.0}
@@ -259,12 +260,18 @@ class TrainStep:
 
     def _eager(self, feed, recording=False):
         """one step issued on the current stream.  recording: this pass is being RECORDED into a hipGraph (it cannot time launch
-        plans anyway), so independent sub-networks may go out as side-by-side launches (ops.batch_branches); an eager pass of a
-        graph-mode step is where the tuner times new geometries and keeps the plain launches; without graphs every pass after the
-        first is batched"""
-        batched = recording or (not self.use_graph and self.opt.steps >= 1)
+        plans anyway), so independent sub-networks go out as side-by-side launches (ops.batch_branches).  An eager pass of a
+        graph-mode step is where the tuner times new geometries: it keeps the plain launches.  Without graphs every pass is batched,
+        except the one after a batched pass that met a geometry without a launch plan (nothing can be timed while launches are only
+        recorded): that one runs the plain launches and times them -- the provisional rule of the graph path."""
+        from . import tuner
+        batched = recording or (not self.use_graph and not self._time_next_pass)
+        missed = tuner.stats['missed_capturing']
         with ops.batch_branches(batched):
-            return self._eager_pass(feed)
+            out = self._eager_pass(feed)
+        if not recording:
+            self._time_next_pass = batched and tuner.stats['missed_capturing'] != missed
+        return out
 
     def _eager_pass(self, feed):
         if not self._weights_ready:

@@ -134,14 +134,21 @@ class HighResolutionModule(nn.Module):
         # every branch output feeds every row of the exchange: `rows` consumers.  ops.fork hands each row its own alias, so the
         # gradients of the rows are summed by the native add kernel in one fixed order instead of autograd's own accumulation
         xs = [ops.fork(t, rows) for t in x]
+        # the conv chains of the exchange -- fuse_layers[i][j] on branch j's output for every row i != j, 12 of them in stage 4 --
+        # are independent of each other: inside a side-by-side scope (ops.batch_branches) their launches pair up unit by unit like
+        # those of the branches above; otherwise they run one after the other on the current stream, as before (forked onto side
+        # streams they made hipStreamEndCapture crash on this ROCm, gpurun r3x)
+        pairs = [(i, j) for i in range(rows) for j in range(self.num_branches) if j != i]
+        term = dict(zip(pairs, ops.run_branches([self.fuse_layers[i][j] for i, j in pairs], [xs[j][i] for i, j in pairs],
+                                                side_streams=False)))
         for i in range(rows):
             # same left-to-right summation order as hrnet.py:232-248
-            y = xs[0][i] if i == 0 else self.fuse_layers[i][0](xs[0][i])
+            y = xs[0][i] if i == 0 else term[(i, 0)]
             bounds = [ops.absmax_of(y)]                     # |sum| <= sum of the terms' bounds (up-sampling is a convex combination)
             last = self.num_branches - 1
             for j in range(1, self.num_branches):
                 relu = j == last                            # the final ReLU (hrnet.py:248) rides on the last add
-                t = xs[j][i] if j == i else self.fuse_layers[i][j](xs[j][i])
+                t = xs[j][i] if j == i else term[(i, j)]
                 bounds.append(ops.absmax_of(t))
                 if j > i:
                     y = ops.interpolate_bilinear(t, x[i].shape[2:], base=y, relu=relu)

@@ -234,7 +234,7 @@ def _run_branches_batched(fns, args):
 
 
 def _batchable(fns, args):
-    if not (_BATCH[0] and torch.is_grad_enabled() and 1 < len(fns) <= 8 and len(fns) == len(args)):
+    if not (_BATCH[0] and torch.is_grad_enabled() and 1 < len(fns) <= 16 and len(fns) == len(args)):
         return False
     dev = None
     for f, a in zip(fns, args):
@@ -250,12 +250,15 @@ def _batchable(fns, args):
     return torch.cuda.current_stream(dev).cuda_stream not in _BRANCH_TAG
 
 
-def run_branches(fns, args):
+def run_branches(fns, args, side_streams=True):
     """[f(a) for f, a in zip(fns, args)] for independent sub-networks: as side-by-side launches inside `batch_branches()`
     (BranchesFn), else with f_1 ... f_n-1 on side streams (f_0, the largest, stays on the current stream), joined before
-    returning.  Off when SyncBN is active (the ranks must issue their exchanges in ONE order) and during a segmented capture."""
+    returning (side_streams=False: one after the other on the current stream).  Off when SyncBN is active (the ranks must issue
+    their exchanges in ONE order) and during a segmented capture."""
     if _batchable(fns, args):
         return _run_branches_batched(fns, args)
+    if not side_streams:
+        return [f(a) for f, a in zip(fns, args)]
     x0 = args[0]
     while isinstance(x0, (list, tuple)):                  # an argument may be a list of tensors (every branch reads all of them)
         x0 = x0[0]
@@ -1308,6 +1311,7 @@ class ConvBNActFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, xp, wp, wtp, res_absmax, running_mean, running_var, nbt, cfg, box):
         wut = box.get('wino_t')             # U' planes of the Winograd data gradient (None: direct kernel)
+        _native.next_unit()                 # inside a side-by-side scope: the branches pair up their launches unit by unit
         stride, pad, dil, momentum, eps, relu, emit = cfg[:7]
         planes_only = len(cfg) > 7 and cfg[7]
         box['planes_only'] = False
@@ -1446,6 +1450,7 @@ class ConvBNActFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         L = _native.lib()
+        _native.next_unit()
         sch = SCHEMES['h2']
         xp, w, wtp, z, y, coef, gamma, stats, zmm, wino_v, gate_bits, wut = ctx.saved_tensors
         relu, has_res = ctx.cfg

@@ -329,32 +329,64 @@ def test_inference_graph_replay_equals_eager():
 
 
 
+def _batch_stats():
+    import ctypes
+    from mit_semseg import _native
+    out = (ctypes.c_longlong * 4)()
+    _native.check(_native.lib().semseg_batch_stats(out), 'batch_stats')
+    return dict(scopes=out[0], recorded=out[1], issued=out[2], forced=out[3])
+
+
 def test_hrnet_branch_streams_equal_one_stream(monkeypatch):
-    """ops.run_branches: HRNetV2's parallel branches on side HIP streams (hrnet.py:225-227) train to exactly the weights of the
-    one-stream step -- same kernels, same order inside every branch -- with eager launches and as a captured hipGraph whose
-    branches are parallel chains; the scratch of the branch streams is their own."""
+    """ops.run_branches: HRNetV2's parallel branches (hrnet.py:225-227) train to exactly the weights of the one-stream step
+      * on side HIP streams (the form of rounds 2-5), with eager launches and as a captured hipGraph whose branches are parallel chains;
+      * as SIDE-BY-SIDE launches (round 6, csrc/batch.h: the launches of all branches recorded and issued position by position through
+        the many-problem trampoline, forward and -- ops.BranchesFn -- backward), eagerly and inside a captured hipGraph
+    -- same kernels, same order inside every branch, so the state after four steps is compared with torch.equal."""
     from mit_semseg import ops, tuner
     from mit_semseg.engine import TrainStep
     monkeypatch.setattr(tuner, 'ENABLED', False)          # heuristic launch plans: the runs must sum in the same order
+    from mit_semseg import _native
+    prev_tile = _native.lib().semseg_batch_plan(-1, 0)    # ... inside the scopes too (their own tile form changes the summation order)
+    try:
+        _hrnet_branch_forms(monkeypatch, ops, TrainStep)
+    finally:
+        _native.lib().semseg_batch_plan(prev_tile, 0)
+
+
+def _hrnet_branch_forms(monkeypatch, ops, TrainStep):
     g = load_golden('hrnetv2_c1_64_train')
     m = g['meta']
     dev = torch.device('cuda:0')
     img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=m['seed'] + 2)
     feed = {'img_data': img.to(dev), 'seg_label': lab.to(dev)}
     res = {}
-    for streams, graph in ((False, False), (True, False), (True, True)):
+    for streams, graph, batch in ((False, False, False), (True, False, False), (True, True, False), (True, False, True), (True, True, True)):
         monkeypatch.setattr(ops, 'BRANCH_STREAMS', streams)
+        monkeypatch.setattr(ops, 'BATCH_BRANCHES', batch)
         sm, _, _ = build_native(g, dev)
         ts = TrainStep(sm, max_iters=1000, graph=graph)
+        before = _batch_stats()
         for _ in range(4):
             loss, acc = ts.step(feed)
         torch.cuda.synchronize()
+        after = _batch_stats()
         if graph:
             assert ts.stats['replayed'] >= 2
-        res[(streams, graph)] = ({k: v.detach().clone() for k, v in sm.state_dict().items()}, loss.item())
+        if batch:
+            # the path under test ran: scopes were opened (forward + backward of every HighResolutionModule with > 1 branch) and
+            # their launches carried several problems each
+            scopes, recorded, issued, forced = (after[k] - before[k] for k in ('scopes', 'recorded', 'issued', 'forced'))
+            assert scopes >= 16 and recorded >= 1.5 * issued and forced == 0, (before, after)
+            parity_line('hrnetv2_c1_64_train side-by-side launches (%s): %d scopes, %d recorded launches left as %d (%.2f problems per '
+                        'launch), %d direct launches inside a scope' % ('graph capture' if graph else 'eager', scopes, recorded, issued,
+                                                                       recorded / max(1, issued), forced))
+        else:
+            assert after['scopes'] == before['scopes']
+        res[(streams, graph, batch)] = ({k: v.detach().clone() for k, v in sm.state_dict().items()}, loss.item())
     assert ops._BRANCH_POOL and any(k[2].startswith('branch') for k in ops._WS)       # the branch streams really ran, on their own scratch
-    base = res[(False, False)]
-    for key in ((True, False), (True, True)):
+    base = res[(False, False, False)]
+    for key in res:
         assert res[key][1] == base[1], (key, res[key][1], base[1])
         for k, v in base[0].items():
             assert torch.equal(res[key][0][k], v), (key, k)
@@ -419,6 +451,7 @@ SWITCH_CASES = [
     ('SEMSEG_TUNE_BUCKETS=0', 'r18d_ppmds_64_train'),
     ('SEMSEG_FORCE_SYNC_PATH=1', 'r18d_ppmds_64_train'),     # the unfused SyncBN kernel sequence on one rank
     ('SEMSEG_BRANCH_STREAMS=0', 'hrnetv2_c1_128_train'),
+    ('SEMSEG_BATCH_BRANCHES=0', 'hrnetv2_c1_128_train'),    # the branches on side streams (rounds 2-5) instead of side-by-side launches
     ('SEMSEG_PLANES_ONLY=0', 'r50d_ppmds_64_train'),         # every BN output also as fp32 (round 4: bn1 / bn2 of a block are planes only)
     ('SEMSEG_WINOGRAD_FUSED=0', 'r50d_ppmds_64_train'),      # Winograd data gradients as batched GEMM + output transform
     ('SEMSEG_TUNE_DB=0', 'r18d_ppmds_64_train'),

@@ -6,6 +6,7 @@
 #   quick            bench.py --steps 40 --warmup 6 --no-cpu-baseline --no-other-configs (twice: a, b)
 #   cfg:N            bench.py --config N --steps 40 --warmup 8 --no-cpu-baseline
 #   ab:NAME:K=V,...  quick bench with the given environment (A/B inside one box; repeat the stage for interleaved runs)
+#   abc:N:NAME:K=V,...  the same for bench.py --config N
 #   lib:PATH         quick bench against another build of the library (SEMSEG_NATIVE_LIB)
 #   smoke            __graft_entry__.smoke()
 #   tests            pytest -m gpu (whole suite)        tests-fast: without the tile-pinned sweep
@@ -47,6 +48,7 @@ for stage in "$@"; do
     bench) ( unset SEMSEG_TUNE_CACHE; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err ); echo "rc=$?: $(show $OUT/bench.json)"; cut -c1-400 $OUT/bench.json; tail -3 $OUT/bench.err | cut -c1-300 ;;
     quick) q a X=1; q b X=1; cp $SEMSEG_TUNE_CACHE $OUT/plans_h2.json 2>/dev/null ;;
     cfg:*) c=${stage#cfg:}; timeout 900 python bench.py --config $c --steps 40 --warmup 8 --no-cpu-baseline > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; echo "rc=$?: $(show $OUT/bench_cfg$c.json)"; tail -2 $OUT/bench_cfg$c.err | cut -c1-300 ;;
+    abc:*) spec=${stage#abc:}; c=${spec%%:*}; spec=${spec#*:}; name=${spec%%:*}; kv=${spec#*:}; IFS=, read -ra kvs <<< "$kv"; env "${kvs[@]}" timeout 600 python bench.py --config $c --steps 40 --warmup 8 --no-cpu-baseline --no-other-configs --no-box --no-scaling-model > $OUT/bench_cfg${c}_${name}_$n.json 2> $OUT/bench_cfg${c}_${name}_$n.err; echo "cfg$c $name rc=$?: $(show $OUT/bench_cfg${c}_${name}_$n.json)"; tail -1 $OUT/bench_cfg${c}_${name}_$n.err | cut -c1-200 ;;
     ab:*) spec=${stage#ab:}; name=${spec%%:*}; kv=${spec#*:}; IFS=, read -ra kvs <<< "$kv"; q ${name}_$n "${kvs[@]}" ;;
     lib:*) q lib_$n SEMSEG_NATIVE_LIB=$ROOT/${stage#lib:} ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;

@@ -14,6 +14,9 @@ from trace_gaps import load
 
 def family(name):
     n = name.replace('void ', '')
+    m = re.match(r'semseg_batch::(one|many)_kernel<(\w+?)_body\b', n)
+    if m:                                   # the generic kernels of csrc/batch.h: name the body they run ("+": many problems per launch)
+        return m.group(2) + ('+' if m.group(1) == 'many' else '')
     n = re.sub(r'\(.*', '', n)
     n = re.sub(r'<.*', '', n)
     return n.split('::')[-1]
