@@ -97,7 +97,7 @@ static std::mutex g_plans_mu;
 // tile 15: 22.58, 19: 22.63, 17: 23.81, 23: 24.51, 2: 24.95 -- a GEMM of four problems on one tile form is bound by the chip's block
 // slots (80 KiB of LDS per 64-deep block: two per CU), not by its launches, and the per-geometry tiles are each the fastest for
 // their problem.  Default -1: the per-geometry plans (the GEMMs of a position pair up where their plans name the same kernel).
-static int g_batch_tile = [] { const char* e = getenv("SEMSEG_BATCH_TILE"); return e ? atoi(e) : -1; }();
+static int g_batch_tile = [] { const char* e = getenv("SEMSEG_BATCH_TILE"); return e ? atoi(e) : -2; }();
 static int g_batch_max_tiles = [] { const char* e = getenv("SEMSEG_BATCH_MAX_TILES"); return e ? atoi(e) : 1024; }();
 // the same two knobs at run time (tests compare the side-by-side launches bit for bit with the sequential ones on the per-geometry
 // plans: tile -1); returns the previous tile
@@ -112,9 +112,7 @@ static bool batch_plan(int pass, int M, int Cout, int Cred, int* tile, int* spli
     const int want = g_batch_tile, max_tiles = g_batch_max_tiles;
     if (want < 0) return false;
     if ((long)((M + 63) / 64) * ((Cout + 63) / 64) > max_tiles) return false;
-    int t = want;
-    if (t >= 22 && t <= 24 && (((Cred + 31) / 32) % 2)) t = 17;
-    *tile = t;
+    *tile = want;
     *split = 1;
     return true;
 }
@@ -131,6 +129,12 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
     if (it == g_plans.end()) return false;
     *tile = it->second.first;
     *split = it->second.second;
+    // SEMSEG_BATCH_TILE=-2 (default): inside a side-by-side scope every 64 x 64 form of the per-geometry plans (register staged,
+    // 2- / 3- / 5-slot rings) becomes THE 64-deep form, split kept -- the branches' plans then name one kernel where they differed
+    // only in the ring (the 96-channel branch could not take the 64-deep kernel when the plans were timed) and their GEMMs pair up
+    if (sch == 1 && pass <= 1 && g_batch_tile == -2 && semseg_batch::recording() &&
+        (*tile == 2 || *tile == 15 || *tile == 17 || *tile == 19))
+        *tile = 23;
     return true;
 }
 
@@ -157,9 +161,9 @@ static int set_plan(int sch, int pass, int N, int H, int W, int C, int K, int R,
     // a plan is refused where its kernel does not take the geometry (the tuner then skips the candidate; a plan inherited from
     // another image size of the same layer -- mit_semseg/tuner.py buckets -- is re-timed instead of failing at launch)
     if (pass == 2 && tile == 10 && !wtaps_geometry_ok(N, H, W, R, S, stride, pad, dil)) return SEMSEG_EINVAL;
-    // tiles 22 ... 24 (64-deep k-tiles): the reduction -- C forward and in the batched Winograd GEMM, K in the data gradient -- padded
-    // to 32 channels must be whole 64-channel chunks
-    if ((pass == 0 || pass == 1 || pass == 3) && tile_is_k64(tile) && (((pass == 1 ? K : C) + 31) / 32) % 2) return SEMSEG_EINVAL;
+    // tiles 22 ... 24 (64-deep k-tiles) in the batched Winograd GEMM: the reduction C padded to 32 channels must be whole 64-channel chunks
+    // (round 6: the forward / data-gradient kernel takes an odd count too -- the missing half chunk is fetched as zeros)
+    if (pass == 3 && tile_is_k64(tile) && ((C + 31) / 32) % 2) return SEMSEG_EINVAL;
     if (pass == 3 && tile >= 0 && (sch != SchH2::ID || split != 1 || !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 ||
                                                                        tile == 10 || tile == 14 || tile == 22 || tile == 24 || tile == 25 || tile == 26)))
         return SEMSEG_EINVAL;
@@ -442,7 +446,10 @@ extern "C" int semseg_split_h2_bounds(const float* x, int x_ld, void* xs, int ro
 // out[0] = sum of `n` (<= 8) non-negative device scalars: the bound of |a + b + ...| from the bounds of the terms (the exchange
 // sums of hrnet.py:231-248, whose result feeds the residual branch of the next module's blocks: without a bound of it the BN
 // kernels of those blocks cannot bound their own outputs and every conv of the branch falls back to absmax + split passes)
-__global__ void bound_sum_kernel(SplitBounds b, float* __restrict__ out) {
+struct bound_sum_kernel_body {
+    static constexpr int THREADS = 1;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               SplitBounds b, float* __restrict__ out) {
     float s = 0.f;
     bool bad = false;
     for (int i = 0; i < b.n; ++i) {
@@ -451,7 +458,8 @@ __global__ void bound_sum_kernel(SplitBounds b, float* __restrict__ out) {
         s += v;
     }
     out[0] = bad ? __uint_as_float(0x7fc00000u) : s * 1.0000005f;      // rounded up: stays an upper bound of the exact sum
-}
+    }
+};
 
 extern "C" int semseg_bound_sum(const float* const* bounds_host, int nbounds, float* out, void* stream) {
     if (!bounds_host || !out || nbounds <= 0 || nbounds > 8) return SEMSEG_EINVAL;
@@ -460,7 +468,7 @@ extern "C" int semseg_bound_sum(const float* const* bounds_host, int nbounds, fl
     for (int i = 0; i < 8; ++i) b.p[i] = i < nbounds ? bounds_host[i] : nullptr;
     for (int i = 0; i < nbounds; ++i)
         if (!b.p[i]) return SEMSEG_EINVAL;
-    hipLaunchKernelGGL(bound_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, b, out);
+    SEMSEG_LAUNCH_BODY((bound_sum_kernel_body), dim3(1), 0, (hipStream_t)stream, b, out);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -514,6 +522,8 @@ struct SParams {
     int tiles_m, tiles_n, splits;
     int batches;                                       // 0 / 1: plain; > 1: gridDim.z batches (splits must be 1)
     int tn_fast;                                        // block order inside an XCD: column tiles fastest (run_gemm)
+    int k64_tail;                                       // 64-deep k-tiles on a reduction of an ODD number of 32-channel chunks: the upper half of the
+                                                        // last 64-channel chunk of every tap does not exist and is fetched as zeros (igemm_dma64_kernel)
     int batch_in_rows, batch_w_rows, batch_out_rows;   // batched GEMM (one batch per grid z): row offsets per batch of the
                                                        // activation planes, of the weight planes (in units of T rows) and of `out`
     // BN statistics of the result gathered in the epilogue (forward convs that a BatchNorm follows, splits == 1 only): every
@@ -1543,12 +1553,18 @@ struct igemm_dma64_kernel_body {
     constexpr int HG = G8 >= 2 ? G8 / 2 : 1;
     uint32_t ent_k = 0;                                // byte offset of the open entry's k position (set by its first half)
     bool ent_live = false;
+    // a reduction of an odd number of 32-channel chunks (96 channels: HRNetV2's second branch): the last 64-channel chunk of a tap
+    // has only its lower half; the lanes that would fetch the upper half (logical 16-byte chunks 4 ... 7 of the 128-byte row) read
+    // the zero tail instead -- for BOTH operands, so the products are 0 x 0 whatever lies behind the row
+    const bool upper_half_lane = q >= 4;
+    bool ent_tail = false;                             // wave-uniform: the open entry is such a last chunk
     auto issue_half = [&](int h) {
         const bool is_b = i_ent & 1;
         const uint32_t base = lds0 + (uint32_t)i_slot * ENT_BYTES;
         if (h == 0) {
             ent_live = kt_begin + (i_ent >> 1) < kt_end;                     // wave-uniform
             ent_k = 0;
+            ent_tail = false;
             if (!is_b) {
                 if (ent_live) {
                     if (kw.dirty) {
@@ -1556,12 +1572,15 @@ struct igemm_dma64_kernel_body {
                         kw.dirty = false;
                     }
                     ent_k = 2u * 64u * (uint32_t)kw.cc;
+                    ent_tail = p.k64_tail && kw.cc == p.chunks - 1;
                 }
             } else if (ent_live) {
                 ent_k = 2u * ((uint32_t)kw.t * p.pitch + 64u * (uint32_t)kw.cc);
+                ent_tail = p.k64_tail && kw.cc == p.chunks - 1;
                 kw.advance(p);                          // the tile's B entry closes it
             }
         }
+        const bool fetch = ent_live && !(ent_tail && upper_half_lane);
         if (!(G8 < 2 && h == 1)) {
 #pragma unroll
             for (int ii = 0; ii < HG; ++ii) {
@@ -1569,11 +1588,11 @@ struct igemm_dma64_kernel_body {
 #pragma unroll
                 for (int s = 0; s < NP; ++s) {
                     if (!is_b) {
-                        const uint32_t vo = ent_live ? a_src[i] + ((ent_k + s * a_plane_b) & a_msk[i]) : a_zero;
+                        const uint32_t vo = fetch ? a_src[i] + ((ent_k + s * a_plane_b) & a_msk[i]) : a_zero;
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(uintptr_t)(base + (s * BM + (wave + NW * i) * 8) * 128), 16,
                                                                  vo, 0, 0, 0);
                     } else {
-                        const uint32_t vo = ent_live ? b_src[i] + ((ent_k + s * b_plane_b) & b_msk[i]) : b_zero;
+                        const uint32_t vo = fetch ? b_src[i] + ((ent_k + s * b_plane_b) & b_msk[i]) : b_zero;
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(uintptr_t)(base + (s * BN + (wave + NW * i) * 8) * 128), 16,
                                                                  vo, 0, 0, 0);
                     }
@@ -1835,8 +1854,9 @@ static int run_gemm(SParams p, size_t in_rows, int ov_tile, int ov_split, void* 
     SPlan pl = plan_gemm(SCH::ID, p.M, p.Cout, p.Cp, p.T, ov_tile, ov_split);
     if (tile_is_k64(pl.tile)) {
         // 64-deep k-tiles: the reduction is counted in 64-channel chunks; the split of the plan is kept (never more slabs than planned)
-        if (p.Cp % 64) return SEMSEG_EINVAL;
-        pl.chunks = p.Cp / 64;
+        if (p.batches > 1 && (p.Cp % 64)) return SEMSEG_EINVAL;     // the batched Winograd GEMM keeps whole chunks
+        p.k64_tail = (p.Cp % 64) ? 1 : 0;
+        pl.chunks = (p.Cp + 63) / 64;
         pl.ktiles = p.T * pl.chunks;
         pl.kt_per_split = ceil_div(pl.ktiles, pl.splits);
         pl.splits = ceil_div(pl.ktiles, pl.kt_per_split);

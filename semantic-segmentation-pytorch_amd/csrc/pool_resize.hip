@@ -4,6 +4,7 @@
 // backward is written in GATHER form (each output element owned by exactly one thread, fixed
 // summation order) so results are deterministic without atomics.
 #include "common.h"
+#include "batch.h"
 #include <stdlib.h>
 
 static inline int stream_blocks(size_t items) {
@@ -17,7 +18,10 @@ static inline int stream_blocks(size_t items) {
 
 // ------------------------------------------------------------------ elementwise -----------------
 template <bool RELU>
-__global__ void add_act_kernel(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld,
+struct add_act_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld,
                                float* __restrict__ out, int out_ld, int P, int C) {
     const int qpr = C / 4;
     const size_t total = (size_t)P * qpr;
@@ -30,19 +34,23 @@ __global__ void add_act_kernel(const float* __restrict__ a, int a_ld, const floa
         if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         *reinterpret_cast<float4*>(out + (size_t)p * out_ld + c) = o;
     }
-}
+    }
+};
 
 extern "C" int semseg_add_act(const float* a, int a_ld, const float* b, int b_ld, int relu, float* out, int out_ld,
                               int P, int C, void* stream) {
     if (!a || !b || !out || P <= 0 || C <= 0 || (C % 4) || (a_ld % 4) || (b_ld % 4) || (out_ld % 4)) return SEMSEG_EINVAL;
     const int blocks = stream_blocks((size_t)P * (C / 4));
-    if (relu) hipLaunchKernelGGL(add_act_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, a_ld, b, b_ld, out, out_ld, P, C);
-    else      hipLaunchKernelGGL(add_act_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, a_ld, b, b_ld, out, out_ld, P, C);
+    if (relu) SEMSEG_LAUNCH_BODY((add_act_kernel_body<true>), dim3(blocks), 0, (hipStream_t)stream, a, a_ld, b, b_ld, out, out_ld, P, C);
+    else      SEMSEG_LAUNCH_BODY((add_act_kernel_body<false>), dim3(blocks), 0, (hipStream_t)stream, a, a_ld, b, b_ld, out, out_ld, P, C);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
 
-__global__ void relu_bwd_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ y, int y_ld,
+struct relu_bwd_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ dy, int dy_ld, const float* __restrict__ y, int y_ld,
                                 float* __restrict__ dx, int dx_ld, int P, int C) {
     const int qpr = C / 4;
     const size_t total = (size_t)P * qpr;
@@ -54,12 +62,13 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, int dy_ld, const f
         const float4 o = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
         *reinterpret_cast<float4*>(dx + (size_t)p * dx_ld + c) = o;
     }
-}
+    }
+};
 
 extern "C" int semseg_relu_bwd(const float* dy, int dy_ld, const float* y, int y_ld, float* dx, int dx_ld, int P, int C,
                                void* stream) {
     if (!dy || !y || !dx || P <= 0 || C <= 0 || (C % 4) || (dy_ld % 4) || (y_ld % 4) || (dx_ld % 4)) return SEMSEG_EINVAL;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_blocks((size_t)P * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
+    SEMSEG_LAUNCH_BODY((relu_bwd_kernel_body), dim3(stream_blocks((size_t)P * (C / 4))), 0, (hipStream_t)stream, dy, dy_ld,
                        y, y_ld, dx, dx_ld, P, C);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -142,7 +151,10 @@ extern "C" int semseg_dropout_mask(float* mask, int n, float p, void* state, voi
 }
 
 template <bool ACC, bool VEC>
-__global__ void copy2d_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld, int P, int C) {
+struct copy2d_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ src, int src_ld, float* __restrict__ dst, int dst_ld, int P, int C) {
     if (VEC) {
         const int qpr = C / 4;
         const size_t total = (size_t)P * qpr;
@@ -165,7 +177,8 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int src_ld, float* 
             *d = v;
         }
     }
-}
+    }
+};
 
 extern "C" int semseg_copy2d(const float* src, int src_ld, float* dst, int dst_ld, int P, int C, int accumulate,
                              void* stream) {
@@ -173,7 +186,7 @@ extern "C" int semseg_copy2d(const float* src, int src_ld, float* dst, int dst_l
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (C % 4 == 0) && (src_ld % 4 == 0) && (dst_ld % 4 == 0) && aligned16(src) && aligned16(dst);
     const int blocks = stream_blocks(vec ? (size_t)P * (C / 4) : (size_t)P * C);
-#define LAUNCH(A, V) hipLaunchKernelGGL((copy2d_kernel<A, V>), dim3(blocks), dim3(256), 0, st, src, src_ld, dst, dst_ld, P, C)
+#define LAUNCH(A, V) SEMSEG_LAUNCH_BODY((copy2d_kernel_body<A, V>), dim3(blocks), 0, st, src, src_ld, dst, dst_ld, P, C)
     if (accumulate) { if (vec) LAUNCH(true, true); else LAUNCH(true, false); }
     else            { if (vec) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -684,7 +697,10 @@ template <> struct VecT<1> { typedef float type; };
 
 // V = floats per lane (4 when C % 4 == 0; 2 / 1 for the 150-class logits of the inference branch)
 template <bool ACC, bool RELU, int V>
-__global__ void bilinear_fwd_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ y, int y_ld, int N, int IH,
+struct bilinear_fwd_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ x, int x_ld, float* __restrict__ y, int y_ld, int N, int IH,
                                     int IW, int OH, int OW, int C, float sh, float sw) {
     typedef typename VecT<V>::type vec;
     const int qpr = C / V;
@@ -720,7 +736,8 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int x_ld, float
         }
         *d = o;
     }
-}
+    }
+};
 
 extern "C" int semseg_bilinear_fwd(const float* x, int x_ld, float* y, int y_ld, int accumulate, int relu, int N, int IH, int IW,
                                    int OH, int OW, int C, void* stream) {
@@ -730,7 +747,7 @@ extern "C" int semseg_bilinear_fwd(const float* x, int x_ld, float* y, int y_ld,
     if (C % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && aligned16(x) && aligned16(y)) V = 4;
     else if (C % 2 == 0 && x_ld % 2 == 0 && y_ld % 2 == 0 && (((uintptr_t)x | (uintptr_t)y) & 7) == 0) V = 2;
     const int blocks = stream_blocks((size_t)N * OH * OW * (C / V));
-#define LAUNCH(A, R, VV) hipLaunchKernelGGL((bilinear_fwd_kernel<A, R, VV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, y, y_ld, N, IH, IW, OH, OW, C, sh, sw)
+#define LAUNCH(A, R, VV) SEMSEG_LAUNCH_BODY((bilinear_fwd_kernel_body<A, R, VV>), dim3(blocks), 0, (hipStream_t)stream, x, x_ld, y, y_ld, N, IH, IW, OH, OW, C, sh, sw)
 #define LAUNCH_V(A, R) do { if (V == 4) LAUNCH(A, R, 4); else if (V == 2) LAUNCH(A, R, 2); else LAUNCH(A, R, 1); } while (0)
     if (accumulate) { if (relu) LAUNCH_V(true, true); else LAUNCH_V(true, false); }
     else            { if (relu) LAUNCH_V(false, true); else LAUNCH_V(false, false); }
@@ -827,7 +844,10 @@ extern "C" int semseg_upsample_softmax(const float* logits, int x_ld, float* out
 // lanes) for ordinary maps; ql = 4 (16 channels, 64 pixel lanes) when the input map is tiny and every input pixel
 // gathers from thousands of output pixels (PPM: 1x1 .. 6x6 -> 64x64 took 85 us per scale with 16 lanes).
 template <bool ACC>
-__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int dy_ld, float* __restrict__ dx,
+struct bilinear_bwd_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ dy, int dy_ld, float* __restrict__ dx,
                                                            int dx_ld, int N, int IH, int IW, int OH, int OW, int C, float sh,
                                                            float sw, int ql) {
     __shared__ float4 red[256];
@@ -888,7 +908,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
         if (ACC) { const float4 o = *d; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
         *d = a;
     }
-}
+    }
+};
 
 extern "C" int semseg_bilinear_bwd(const float* dy, int dy_ld, float* dx, int dx_ld, int accumulate, int N, int IH, int IW,
                                    int OH, int OW, int C, void* stream) {
@@ -898,8 +919,8 @@ extern "C" int semseg_bilinear_bwd(const float* dy, int dy_ld, float* dx, int dx
     // tiny input maps: few blocks, huge gather windows -> more pixel lanes per block and more (narrower) blocks
     const int ql = ((long)N * IH * IW * ceil_div(C, 64) < 512 && (long)OH * OW >= 16L * IH * IW) ? 4 : 16;
     dim3 grid(N * IH * IW, ceil_div(C, 4 * ql));
-    if (accumulate) hipLaunchKernelGGL(bilinear_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw, ql);
-    else            hipLaunchKernelGGL(bilinear_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw, ql);
+    if (accumulate) SEMSEG_LAUNCH_BODY((bilinear_bwd_kernel_body<true>), grid, 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw, ql);
+    else            SEMSEG_LAUNCH_BODY((bilinear_bwd_kernel_body<false>), grid, 0, (hipStream_t)stream, dy, dy_ld, dx, dx_ld, N, IH, IW, OH, OW, C, sh, sw, ql);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -125,11 +125,7 @@ class HighResolutionModule(nn.Module):
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        x = ops.run_branches(list(self.branches), x)      # independent until the exchange below: side streams (ops.run_branches)
-        # The accumulation chains of the exchange are independent of each other as well, but a step whose capture forks them onto
-        # the branch streams too makes hipStreamEndCapture crash on this ROCm (gpurun r3x; eager launches are fine): they stay
-        # on the current stream.
-        fused = []
+        x = ops.run_branches(list(self.branches), x)      # independent until the exchange below (ops.run_branches)
         rows = len(self.fuse_layers)
         # every branch output feeds every row of the exchange: `rows` consumers.  ops.fork hands each row its own alias, so the
         # gradients of the rows are summed by the native add kernel in one fixed order instead of autograd's own accumulation
@@ -141,25 +137,33 @@ class HighResolutionModule(nn.Module):
         pairs = [(i, j) for i in range(rows) for j in range(self.num_branches) if j != i]
         term = dict(zip(pairs, ops.run_branches([self.fuse_layers[i][j] for i, j in pairs], [xs[j][i] for i, j in pairs],
                                                 side_streams=False)))
-        for i in range(rows):
-            # same left-to-right summation order as hrnet.py:232-248
-            y = xs[0][i] if i == 0 else term[(i, 0)]
-            bounds = [ops.absmax_of(y)]                     # |sum| <= sum of the terms' bounds (up-sampling is a convex combination)
-            last = self.num_branches - 1
-            for j in range(1, self.num_branches):
-                relu = j == last                            # the final ReLU (hrnet.py:248) rides on the last add
-                t = xs[j][i] if j == i else term[(i, j)]
-                bounds.append(ops.absmax_of(t))
-                if j > i:
-                    y = ops.interpolate_bilinear(t, x[i].shape[2:], base=y, relu=relu)
-                else:
-                    y = ops.add_act(y, t, relu=relu)
-            if all(b is not None for b in bounds):
-                # the exchange output feeds the residual branch of the next module's blocks: with a bound of it their BN kernels
-                # can bound (and emit the split planes of) their own outputs -- without, every conv of the next branch pays an
-                # absmax + split pass over its input (115 such pairs per HRNetV2 step before round 3)
-                ops.attach_absmax(y, ops.bound_sum(bounds))
-            fused.append(y)
+        # ... and so are the accumulation chains of the rows: row i sums, left to right as hrnet.py:232-248, branch i's own output and
+        # the terms of the other branches (up-sampled where they come from a coarser one); one branch of a scope per row
+        sizes = [t.shape[2:] for t in x]
+        last = self.num_branches - 1
+
+        def row(i):
+            def run(ts):
+                y = ts[0]
+                bounds = [ops.absmax_of(y)]                 # |sum| <= sum of the terms' bounds (up-sampling is a convex combination)
+                for j in range(1, self.num_branches):
+                    ops.batch_unit()                        # the rows pair up their launches step by step
+                    relu = j == last                        # the final ReLU (hrnet.py:248) rides on the last add
+                    bounds.append(ops.absmax_of(ts[j]))
+                    if j > i:
+                        y = ops.interpolate_bilinear(ts[j], sizes[i], base=y, relu=relu)
+                    else:
+                        y = ops.add_act(y, ts[j], relu=relu)
+                if all(b is not None for b in bounds):
+                    # the exchange output feeds the residual branch of the next module's blocks: with a bound of it their BN kernels
+                    # can bound (and emit the split planes of) their own outputs -- without, every conv of the next branch pays an
+                    # absmax + split pass over its input (115 such pairs per HRNetV2 step before round 3)
+                    ops.attach_absmax(y, ops.bound_sum(bounds))
+                return y
+            return ops.Branch(run)
+        fused = ops.run_branches([row(i) for i in range(rows)],
+                                 [[xs[j][i] if j == i else term[(i, j)] for j in range(self.num_branches)] for i in range(rows)],
+                                 side_streams=False)
         return fused
 
 

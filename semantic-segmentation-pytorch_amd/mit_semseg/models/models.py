@@ -312,8 +312,10 @@ class PPM(nn.Module):
         # all pyramid scales pooled in one pass over conv5 (ops.adaptive_avg_pool_multi)
         conv5, c5 = ops.fork(conv5)                  # two consumers: the pyramid pooling and the concat
         pooled = ops.adaptive_avg_pool_multi(c5, [b._modules['0'].output_size for b in self.ppm])
-        fns = [lambda p, b=b: ops.interpolate_bilinear(b.after_pool(p), size) for b in self.ppm]
-        return ops.concat([conv5] + [f(p) for f, p in zip(fns, pooled)])
+        # the four pyramid branches (1x1 conv -> BN -> ReLU on an s x s map, then up-sampling) are independent: inside a side-by-side
+        # scope (ops.batch_branches) their launches pair up; else one after the other, as before
+        fns = [ops.Branch(lambda p, b=b: ops.interpolate_bilinear(b.after_pool(p), size), [b]) for b in self.ppm]
+        return ops.concat([conv5] + ops.run_branches(fns, list(pooled), side_streams=False))
 
     def forward(self, conv_out, segSize=None):
         x = self.conv_last(self._pyramid(conv_out[-1]))
@@ -361,18 +363,27 @@ class UPerNet(nn.Module):
         conv5, c5 = ops.fork(conv_out[-1])            # two consumers: the pyramid pooling and the concat
         size = conv5.shape[2:]
         pooled = ops.adaptive_avg_pool_multi(c5, [pool.output_size for pool in self.ppm_pooling])    # one pass over conv5
-        ppm_out = [conv5] + [conv(ops.interpolate_bilinear(p, size)) for p, conv in zip(pooled, self.ppm_conv)]
+        # the pyramid branches, and below the lateral 1x1 convs and the 3x3 output convs of the FPN levels, are independent of each
+        # other: side-by-side launches inside ops.batch_branches(), one after the other otherwise
+        ppm_out = [conv5] + ops.run_branches(
+            [ops.Branch(lambda p, conv=conv: conv(ops.interpolate_bilinear(p, size)), [conv]) for conv in self.ppm_conv],
+            list(pooled), side_streams=False)
         f = self.ppm_last_conv(ops.concat(ppm_out))
         fpn_feature_list = [f]
-        for i in reversed(range(len(conv_out) - 1)):
-            lateral = self.fpn_in[i](conv_out[i])
+        levels = list(range(len(conv_out) - 1))
+        laterals = ops.run_branches([self.fpn_in[i] for i in levels], [conv_out[i] for i in levels], side_streams=False)
+        tops = {}
+        for i in reversed(levels):
+            lateral = laterals[i]
             bounds = (ops.absmax_of(lateral), ops.absmax_of(f))
             f = ops.interpolate_bilinear(f, lateral.shape[2:], base=lateral)     # top-down: lateral + up(f)
             if bounds[0] is not None and bounds[1] is not None:
                 # |lateral + up(f)| <= bound(lateral) + bound(f): the 3x3 conv that follows then needs no absmax pass over the sum
                 # (and may take the Winograd forward, which scales its input transform by a bound)
                 ops.attach_absmax(f, ops.bound_sum(bounds))
-            fpn_feature_list.append(self.fpn_out[i](f))
+            tops[i] = f
+        outs = ops.run_branches([self.fpn_out[i] for i in levels], [tops[i] for i in levels], side_streams=False)
+        fpn_feature_list += [outs[i] for i in reversed(levels)]
         fpn_feature_list.reverse()                                               # [P2 - P5]
         out_size = fpn_feature_list[0].shape[2:]
         fusion = ops.concat([fpn_feature_list[0]] +

@@ -164,28 +164,54 @@ class _Recording:
         return False
 
 
+class Branch:
+    """a branch of run_branches that is not an nn.Module: `fn(x)` plus the modules whose parameters it uses (their gradients are
+    produced inside the branches' node, BranchesFn.backward)"""
+
+    def __init__(self, fn, modules=()):
+        self.fn, self.modules = fn, tuple(modules)
+
+    def __call__(self, x):
+        return self.fn(x)
+
+    def parameters(self):
+        for m in self.modules:
+            yield from m.parameters()
+
+
+def _branch_params(f):
+    get = getattr(f, 'parameters', None)
+    return [p for p in get() if p.requires_grad] if get is not None else []
+
+
 class BranchesFn(Function):
     """[f(x) for f, x in zip(fns, xs)] for independent sub-networks as ONE autograd node whose forward and backward record the
     launches of all branches and issue them position by position (see BATCH_BRANCHES above).  The branches' own autograd graphs
     live inside the node: forward builds them on detached inputs, backward runs them one after the other (torch.autograd.grad on the
-    calling thread) while the library records."""
+    calling thread) while the library records.  A branch takes one tensor or a list of tensors (holder['counts'])."""
 
     @staticmethod
-    def forward(ctx, holder, *xs):
-        fns = holder['fns']
+    def forward(ctx, holder, *flat):
+        fns, counts = holder['fns'], holder['counts']
         n = len(fns)
-        dev = xs[0].device
+        dev = flat[0].device
         main = torch.cuda.current_stream(dev)
         streams = _branch_streams(dev, n)
         ctx.set_materialize_grads(False)
         inner_x, inner_y = [], []
         with _Recording(n, main, streams) as rec:
+            k = 0
             for i in range(n):
+                m = counts[i] if counts[i] is not None else 1
                 with rec.branch(i), torch.enable_grad():
-                    xi = xs[i].detach()
-                    _copy_records(xs[i], xi)
-                    xi.requires_grad_(bool(ctx.needs_input_grad[i + 1]))
-                    yi = fns[i](xi)
+                    xi = []
+                    for t, need in zip(flat[k:k + m], ctx.needs_input_grad[1 + k:1 + k + m]):
+                        d = t.detach()
+                        _copy_records(t, d)
+                        d.requires_grad_(bool(need))
+                        xi.append(d)
+                    yi = fns[i](xi if counts[i] is not None else xi[0])
+                k += m
                 inner_x.append(xi)
                 inner_y.append(yi)
         ctx.inner = (fns, inner_x, inner_y, streams)
@@ -200,21 +226,22 @@ class BranchesFn(Function):
         n = len(fns)
         dev = inner_y[0].device
         main = torch.cuda.current_stream(dev)
-        gxs = [None] * n
+        gxs = [[None] * len(xi) for xi in inner_x]
         param_grads = []
         with _Recording(n, main, streams) as rec:
             for i in range(n):
                 if gys[i] is None or not inner_y[i].requires_grad:
                     continue
-                params = [p for p in fns[i].parameters() if p.requires_grad]
-                inputs = ([inner_x[i]] if inner_x[i].requires_grad else []) + params
+                params = _branch_params(fns[i])
+                wanted = [k for k, t in enumerate(inner_x[i]) if t.requires_grad]
+                inputs = [inner_x[i][k] for k in wanted] + params
                 if not inputs:
                     continue
                 with rec.branch(i):
                     grads = torch.autograd.grad([inner_y[i]], inputs, [gys[i]], allow_unused=True)
-                if inner_x[i].requires_grad:
-                    gxs[i], grads = grads[0], grads[1:]
-                param_grads.extend((p, g) for p, g in zip(params, grads) if g is not None)
+                for k, g in zip(wanted, grads):
+                    gxs[i][k] = g
+                param_grads.extend((p, g) for p, g in zip(params, grads[len(wanted):]) if g is not None)
         # what AccumulateGrad does, after the scope has closed (an accumulation into an existing gradient is a torch kernel): the
         # returned buffer BECOMES .grad -- the adoption the deferred weight gradients rely on (_may_defer / flush_wgrad_reduces)
         for p, g in param_grads:
@@ -222,32 +249,48 @@ class BranchesFn(Function):
                 p.grad = g
             else:
                 p.grad = p.grad + g
-        return (None,) + tuple(gxs)
+        return (None,) + tuple(g for row in gxs for g in row)
 
 
 def _run_branches_batched(fns, args):
-    holder = {'fns': list(fns)}
-    outs = BranchesFn.apply(holder, *args)
+    counts = [len(a) if isinstance(a, (list, tuple)) else None for a in args]
+    flat = [t for a in args for t in (a if isinstance(a, (list, tuple)) else (a,))]
+    holder = {'fns': list(fns), 'counts': counts}
+    outs = BranchesFn.apply(holder, *flat)
     for o, y in zip(outs, holder.pop('outs')):
-        _copy_records(y, o)                             # the planes / bound the last BN of the branch left on its output
+        _copy_records(y, o)                             # the planes / bound the last op of the branch left on its output
     return list(outs)
 
 
 def _batchable(fns, args):
     if not (_BATCH[0] and torch.is_grad_enabled() and 1 < len(fns) <= 16 and len(fns) == len(args)):
         return False
-    dev = None
+    dev, any_grad = None, False
     for f, a in zip(fns, args):
-        if not (isinstance(f, torch.nn.Module) and torch.is_tensor(a) and a.is_cuda and a.dim() == 4 and a.dtype == torch.float32):
+        if not callable(f):
             return False
-        if dev is not None and a.device != dev:
+        ts = a if isinstance(a, (list, tuple)) else (a,)
+        if not ts:
             return False
-        dev = a.device
-    if not any(a.requires_grad or any(p.requires_grad for p in f.parameters()) for f, a in zip(fns, args)):
+        for t in ts:
+            if not (torch.is_tensor(t) and t.is_cuda and t.dim() == 4 and t.dtype == torch.float32):
+                return False
+            if dev is not None and t.device != dev:
+                return False
+            dev = t.device
+            any_grad = any_grad or t.requires_grad
+        any_grad = any_grad or bool(_branch_params(f))
+    if not any_grad:
         return False
     if _sync_active() or _SEGMENTS is not None or _native.lib().semseg_batch_active():
         return False                                    # SyncBN exchanges keep ONE issue order; a scope inside a scope stays sequential
     return torch.cuda.current_stream(dev).cuda_stream not in _BRANCH_TAG
+
+
+def batch_unit():
+    """the current branch of an open side-by-side scope enters its next unit: launches of different branches pair up unit by unit
+    (ConvBNActFn does this itself; a branch made of other operators marks its steps with it)"""
+    _native.next_unit()
 
 
 def run_branches(fns, args, side_streams=True):
@@ -1606,6 +1649,7 @@ class AddActFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
+        _native.next_unit()
         if not ctx.relu:
             return dy, dy, None
         (out,) = ctx.saved_tensors
@@ -2003,6 +2047,7 @@ class BilinearFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         L = _native.lib()
+        _native.next_unit()
         n, c, h, w, oh, ow = ctx.shape
         dy, ld = as_nhwc(dy)
         if ctx.relu:
