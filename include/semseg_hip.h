@@ -421,6 +421,11 @@ typedef struct {
                      (f, c), channels K: semseg_split_h2_bytes(16*C, K) bytes; NULL = not wanted */
 } semseg_wprep_tensor;
 int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host, int n, void* stream);
+/* the partial-maximum slots of a conv weight's KRSC plane buffer (device address inside `krsc_planes`), for semseg_sgd_step_fused;
+ * and the preparation that trusts them (have_absmax != 0: EVERY tensor of the call had its slots filled by the fused SGD kernel
+ * since its weights last changed; 0: as semseg_weights_prepare_h2) */
+void* semseg_weights_absmax_slots(void* krsc_planes, int K, int T, int C);
+int semseg_weights_prepare_h2_after_sgd(const semseg_wprep_tensor* tensors_host, int n, int have_absmax, void* stream);
 
 /* ---------------- evaluation metrics (eval.py:74-84, utils.py:128-156) -----------------------
  * pred[p] = argmax_c scores[p, c] (first maximum, as torch.max) on [P, C] rows with pixel stride ld; with `label`
@@ -535,6 +540,19 @@ typedef struct {
  * (buf = g on first_step); p -= lr*buf. */
 int semseg_sgd_step(const semseg_sgd_tensor* tensors_host, int n, const float* lr, float momentum,
                     float grad_scale, void* stream);
+/* The same update (train.py:115-127) as ONE pass over the weights where the step made three (round 6): a tensor may name
+ *  - slabs / splits: its gradient still lies as `splits` partial sums of numel floats each (semseg_conv2d_wgrad_slabs_h2 /
+ *    _wgrad_multi_h2): the kernel adds them in slab order 0, 1, 2, ... -- the bits semseg_reduce_slabs_multi would produce --
+ *    writes the sum to `grad` and uses it; slabs == NULL: `grad` is read as before;
+ *  - absmax_slots: 512 uint32 slots (semseg_weights_absmax_slots) that receive the block maxima of |w| of the UPDATED weights
+ *    (bit patterns; unused slots zero): semseg_weights_prepare_h2_after_sgd(have_absmax = 1) then derives the exponent of
+ *    the weight planes from them without a pass of its own over the weights.  NULL: not wanted. */
+typedef struct {
+    float* param; float* grad; float* momentum_buf; int64_t numel; float weight_decay; int first_step;
+    const float* slabs; int splits; void* absmax_slots;
+} semseg_sgd_tensor2;
+int semseg_sgd_step_fused(const semseg_sgd_tensor2* tensors_host, int n, const float* lr, float momentum,
+                          float grad_scale, void* stream);
 
 /* ---------------- collectives over RCCL / xGMI ------------------------------------
  * Replace the reference's single-process thread rendezvous: lib/nn/modules/comm.py:46-131 (SyncMaster / SlavePipe queues),

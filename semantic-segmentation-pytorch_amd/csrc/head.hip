@@ -261,6 +261,124 @@ extern "C" int semseg_sgd_step(const semseg_sgd_tensor* tensors_host, int n, con
     return 0;
 }
 
+// ---- round 6: ONE pass over the weights where there were three -------------------------------------------------------------------
+// After backward the step read every weight gradient three times: reduce_slabs_multi_kernel summed the deferred split weight
+// gradients into .grad, sgd_kernel read .grad back, and wprep_absmax_kernel read every updated conv weight again for the exponent of
+// its h2 planes.  sgd_fused_kernel (i) sums the slabs of a deferred gradient itself -- slab order 0, 1, 2, ... as the reduce kernel:
+// the same bits -- and leaves the sum in .grad for whoever looks at it afterwards, (ii) leaves, per block, the maximum |w| of the
+// UPDATED weights it wrote in the 512 partial slots the weight preparation reduces (a maximum is order-independent: the exponent
+// is the one wprep_absmax_kernel finds).  train.py:115-127 semantics unchanged.
+constexpr int SGD2_MAX_TENSORS = 48;
+constexpr int SGD2_SLOTS = 512;           // partial maxima per tensor (csrc/weights_prep.hip reads as many when told so)
+struct Sgd2Batch {
+    semseg_sgd_tensor2 t[SGD2_MAX_TENSORS];
+    int n;
+};
+static_assert(sizeof(Sgd2Batch) <= 4000, "kernel arguments");
+
+__device__ __forceinline__ uint32_t sgd_absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+__global__ __launch_bounds__(256) void sgd_fused_kernel(const Sgd2Batch b, const float* __restrict__ lr_ptr, float momentum,
+                                                        float grad_scale) {
+    __shared__ uint32_t red[4];
+    const semseg_sgd_tensor2 t = b.t[blockIdx.y];
+    const float lr = lr_ptr[0];
+    const int64_t n = t.numel;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t mx = 0;
+    auto upd = [&](float w, float gr, float mb, float& m_out, float& w_out) {
+        const float g = fmaf(t.weight_decay, w, gr * grad_scale);
+        const float m = t.first_step ? g : fmaf(momentum, mb, g);
+        m_out = m;
+        w_out = w - lr * m;
+        mx = max(mx, sgd_absbits(w_out));
+    };
+    const bool vec = ((reinterpret_cast<uintptr_t>(t.param) | reinterpret_cast<uintptr_t>(t.grad) |
+                       reinterpret_cast<uintptr_t>(t.momentum_buf) | reinterpret_cast<uintptr_t>(t.slabs)) & 15) == 0 &&
+                     (!t.slabs || (n & 3) == 0);
+    int64_t done = 0;
+    if (vec) {
+        const int64_t quads = n >> 2;
+        float4* p4 = reinterpret_cast<float4*>(t.param);
+        float4* m4 = reinterpret_cast<float4*>(t.momentum_buf);
+        float4* g4 = reinterpret_cast<float4*>(t.grad);
+        const float4* s4 = reinterpret_cast<const float4*>(t.slabs);
+        for (int64_t i = tid; i < quads; i += stride) {
+            const float4 w = p4[i];
+            const float4 mb = t.first_step ? f4zero() : m4[i];
+            float4 gr;
+            if (s4) {
+                gr = s4[i];
+                for (int z = 1; z < t.splits; z += 4) {       // 4 loads in flight, additions in slab order (reduce_slabs_multi_kernel)
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (z + u < t.splits) v[u] = s4[(int64_t)(z + u) * quads + i];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (z + u < t.splits) { gr.x += v[u].x; gr.y += v[u].y; gr.z += v[u].z; gr.w += v[u].w; }
+                }
+                g4[i] = gr;
+            } else {
+                gr = g4[i];
+            }
+            float4 m, wn;
+            upd(w.x, gr.x, mb.x, m.x, wn.x); upd(w.y, gr.y, mb.y, m.y, wn.y);
+            upd(w.z, gr.z, mb.z, m.z, wn.z); upd(w.w, gr.w, mb.w, m.w, wn.w);
+            m4[i] = m;
+            p4[i] = wn;
+        }
+        done = quads << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += stride) {
+        float gr;
+        if (t.slabs) {
+            gr = t.slabs[i];
+            for (int z = 1; z < t.splits; ++z) gr += t.slabs[(int64_t)z * n + i];
+            t.grad[i] = gr;
+        } else {
+            gr = t.grad[i];
+        }
+        float m, wn;
+        upd(t.param[i], gr, t.first_step ? 0.f : t.momentum_buf[i], m, wn);
+        t.momentum_buf[i] = m;
+        t.param[i] = wn;
+    }
+    uint32_t* slots = reinterpret_cast<uint32_t*>(t.absmax_slots);
+    if (slots) {                                              // block-uniform
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) slots[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (blockIdx.x == 0)
+            for (int i = gridDim.x + threadIdx.x; i < SGD2_SLOTS; i += blockDim.x) slots[i] = 0u;
+    }
+}
+
+extern "C" int semseg_sgd_step_fused(const semseg_sgd_tensor2* tensors_host, int n, const float* lr, float momentum, float grad_scale,
+                                     void* stream) {
+    if (!tensors_host || n < 0 || !lr) return SEMSEG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += SGD2_MAX_TENSORS) {
+        Sgd2Batch b;
+        b.n = min(SGD2_MAX_TENSORS, n - base);
+        int64_t maxn = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.t[i] = tensors_host[base + i];
+            if (!b.t[i].param || !b.t[i].grad || !b.t[i].momentum_buf || (b.t[i].slabs && b.t[i].splits < 1)) return SEMSEG_EINVAL;
+            if (b.t[i].numel > maxn) maxn = b.t[i].numel;
+        }
+        int gx = (int)((maxn + 256 * 8 - 1) / (256 * 8));
+        if (gx < 1) gx = 1;
+        if (gx > SGD2_SLOTS) gx = SGD2_SLOTS;
+        hipLaunchKernelGGL(sgd_fused_kernel, dim3(gx, b.n), dim3(256), 0, st, b, lr, momentum, grad_scale);
+        SEMSEG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 extern "C" int semseg_abi_version(void) { return 1; }
 
 // ---------------------------------------------------------------- evaluation metrics --------------

@@ -11,6 +11,8 @@
 
 constexpr int WPREP_MAX_TENSORS = 48;      // 48 x 72 B of descriptors stay below the 4 KiB kernel-argument limit
 constexpr int WPREP_CHUNKS = 256;          // absmax partial blocks per tensor (<= H2_MAX_PARTIALS)
+constexpr int WPREP_SLOTS = 512;           // partial slots the split kernel reduces: 256 from wprep_absmax_kernel (the rest zero) or up to 512
+                                           // from the fused SGD kernel (csrc/head.hip sgd_fused_kernel)
 
 struct WPrepTensor {
     const float* w;        // [K][T][C] fp32
@@ -28,7 +30,7 @@ struct WPrepBatch {
     int n;
 };
 
-__device__ __forceinline__ uint32_t* wprep_partials(const WPrepTensor& t, size_t krsc_plane) {
+__host__ __device__ __forceinline__ uint32_t* wprep_partials(const WPrepTensor& t, size_t krsc_plane) {
     unsigned char* base = reinterpret_cast<unsigned char*>(t.krsc) + (size_t)H2_NP * krsc_plane * 2 + SPLIT_ZERO_TAIL_BYTES;
     return reinterpret_cast<uint32_t*>(base) + 64;      // 256 B after the exponent word
 }
@@ -47,7 +49,11 @@ __global__ __launch_bounds__(256) void wprep_absmax_kernel(const WPrepBatch b, i
     m = block_max_u32(m);
     const int Cp = (t.C + 31) & ~31;
     const int pitch = ((Cp * 2) % 2048 == 0) ? Cp + pitch_pad : Cp;
-    if (threadIdx.x == 0) wprep_partials(t, (size_t)t.K * t.T * pitch)[blockIdx.x] = m;
+    if (threadIdx.x == 0) {
+        uint32_t* slots = wprep_partials(t, (size_t)t.K * t.T * pitch);
+        slots[blockIdx.x] = m;
+        slots[WPREP_CHUNKS + blockIdx.x] = 0u;      // the upper half of the WPREP_SLOTS slots (only the fused SGD kernel fills it)
+    }
 }
 
 // one block = one 64(k) x 64(c) tile of one tap of one tensor
@@ -72,8 +78,8 @@ __global__ __launch_bounds__(256) void wprep_split_kernel(const WPrepBatch b, in
 
     // exponent from the partial maxima of wprep_absmax_kernel
     const uint32_t* partial = wprep_partials(t, plane_krsc);
-    static_assert(WPREP_CHUNKS <= 256 && WPREP_CHUNKS <= H2_MAX_PARTIALS, "one partial per thread");
-    uint32_t m = threadIdx.x < WPREP_CHUNKS ? partial[threadIdx.x] : 0u;
+    static_assert(WPREP_SLOTS == 2 * WPREP_CHUNKS && WPREP_CHUNKS == 256 && WPREP_SLOTS <= H2_MAX_PARTIALS, "two partials per thread");
+    uint32_t m = max(partial[threadIdx.x], partial[WPREP_CHUNKS + threadIdx.x]);
     m = block_max_u32(m);
     const int ex = h2_exponent(m);
     const float sc = pow2i(ex);
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void wprep_wino_kernel(const WPrepBatch b, int
     const size_t plane_krsc = (size_t)K * t.T * pitch;
     const size_t plane = (size_t)16 * K * pitch;
     const uint32_t* partial = wprep_partials(t, plane_krsc);
-    uint32_t m = threadIdx.x < WPREP_CHUNKS ? partial[threadIdx.x] : 0u;
+    uint32_t m = max(partial[threadIdx.x], partial[WPREP_CHUNKS + threadIdx.x]);       // WPREP_SLOTS slots, two per thread
     m = block_max_u32(m);
     const float bound = 2.25f * __uint_as_float(m);
     const int ex = h2_exponent((m >> 23) == 255 ? m : __float_as_uint(bound));
@@ -293,7 +299,24 @@ __global__ __launch_bounds__(256) void wprep_wino_t_kernel(const WPrepBatch b, i
     }
 }
 
+// device address of the WPREP_SLOTS partial-maximum slots of a conv weight's KRSC plane buffer (what the fused SGD kernel fills)
+extern "C" void* semseg_weights_absmax_slots(void* krsc_planes, int K, int T, int C) {
+    if (!krsc_planes || K <= 0 || T <= 0 || C <= 0) return nullptr;
+    WPrepTensor t = {};
+    t.krsc = (uint16_t*)krsc_planes;
+    return wprep_partials(t, (size_t)K * T * split_pitch(C));
+}
+
+static int weights_prepare(const semseg_wprep_tensor* tensors_host, int n, int have_absmax, void* stream);
 extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host, int n, void* stream) {
+    return weights_prepare(tensors_host, n, 0, stream);
+}
+// have_absmax != 0: the partial maxima of EVERY tensor are in place already (semseg_sgd_step_fused wrote them while it updated the
+// weights): the pass over the weights that only finds their maximum is not launched
+extern "C" int semseg_weights_prepare_h2_after_sgd(const semseg_wprep_tensor* tensors_host, int n, int have_absmax, void* stream) {
+    return weights_prepare(tensors_host, n, have_absmax, stream);
+}
+static int weights_prepare(const semseg_wprep_tensor* tensors_host, int n, int have_absmax, void* stream) {
     if (!tensors_host || n < 0) return SEMSEG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int pitch_pad = split_pitch(1024) - 1024;      // the skew split_layout.h applies to power-of-two pitches
@@ -329,8 +352,10 @@ extern "C" int semseg_weights_prepare_h2(const semseg_wprep_tensor* tensors_host
             }
         }
         if (b.n == 0) break;
-        hipLaunchKernelGGL(wprep_absmax_kernel, dim3(WPREP_CHUNKS, b.n), dim3(256), 0, st, b, pitch_pad);
-        SEMSEG_LAUNCH_CHECK();
+        if (!have_absmax) {
+            hipLaunchKernelGGL(wprep_absmax_kernel, dim3(WPREP_CHUNKS, b.n), dim3(256), 0, st, b, pitch_pad);
+            SEMSEG_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(wprep_split_kernel, dim3(tiles), dim3(256), 0, st, b, pitch_pad);
         SEMSEG_LAUNCH_CHECK();
         if (wino_blocks > 0) {

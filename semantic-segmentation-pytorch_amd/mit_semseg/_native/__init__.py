@@ -21,6 +21,11 @@ class SgdTensor(ctypes.Structure):
                 ('weight_decay', c_f), ('first_step', c_int)]
 
 
+class SgdTensor2(ctypes.Structure):
+    _fields_ = [('param', vp), ('grad', vp), ('momentum_buf', vp), ('numel', ctypes.c_int64), ('weight_decay', c_f),
+                ('first_step', c_int), ('slabs', vp), ('splits', c_int), ('absmax_slots', vp)]
+
+
 class SlabTensor(ctypes.Structure):
     _fields_ = [('slabs', vp), ('out', vp), ('numel', ctypes.c_int64), ('splits', c_int)]
 
@@ -157,6 +162,9 @@ SIGNATURES = {
     'semseg_input_resample_v_normalize': (c_int, [vp, c_int, c_int, vp, vp, c_int, c_int, vp, vp, c_int, vp]),
     'semseg_input_label_gather': (c_int, [vp, c_int, vp, vp, c_int, c_int, vp, c_int, vp]),
     'semseg_sgd_step': (c_int, [ctypes.POINTER(SgdTensor), c_int, vp, c_f, c_f, vp]),
+    'semseg_sgd_step_fused': (c_int, [ctypes.POINTER(SgdTensor2), c_int, vp, c_f, c_f, vp]),
+    'semseg_weights_absmax_slots': (vp, [vp, c_int, c_int, c_int]),
+    'semseg_weights_prepare_h2_after_sgd': (c_int, [ctypes.POINTER(WPrepTensor), c_int, c_int, vp]),
     'semseg_comm_available': (c_int, []),
     'semseg_comm_version': (c_int, []),
     'semseg_comm_unique_id': (c_int, [vp]),

@@ -289,7 +289,8 @@ class TrainStep:
         # the split weight gradients of the backward pass are summed, and the small ones computed, by batched launches: ONE flush after
         # backward on a single rank, one per gradient bucket (from the hook that completes it, before its all-reduce) on a rank of
         # a data-parallel job (ops.defer_wgrad_reduces)
-        with ops.defer_wgrad_reduces(flush_at_buckets=self.buckets is not None and self.buckets.flushes_deferred), \
+        with ops.defer_wgrad_reduces(flush_at_buckets=self.buckets is not None and self.buckets.flushes_deferred,
+                                     into_sgd=self.buckets is None), \
                 ops.defer_fork_sums():        # ... and the gradient sums at the forks are formed by the BN kernels that consume them
             loss.backward()
         if tl is not None:
@@ -299,7 +300,8 @@ class TrainStep:
         if self.buckets is not None:
             self.buckets.finish()
             scale = 1.0 / self.world          # loss.mean() over replicas (train.py:42)
-        self.opt.step(grad_scale=scale)
+        self.opt.step(grad_scale=scale)           # one pass: sums the deferred gradient slabs, updates, leaves max|w| for the planes
+        ops.finish_leftover_slabs()
         self._prepare_weights()               # planes of the UPDATED weights, for the next step
         if tl is not None:
             tl.mark('step_end')
@@ -327,6 +329,8 @@ class TrainStep:
         ops._PENDING_SLABS[:] = []
         ops._FWD_USES.clear()
         ops._ADDENDS.clear()
+        ops._SLABS_FOR_SGD.clear()                    # the recorded SGD kernel that would have summed / flagged them never ran
+        ops._ABSMAX_FRESH.clear()
         tuner.stats.clear()
         tuner.stats.update(host['tuner_stats'])
         self.stats['captured'] = host['captured']

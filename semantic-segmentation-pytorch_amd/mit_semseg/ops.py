@@ -698,6 +698,7 @@ def prepare_conv_weights(weights):
             utb = torch.empty(L.semseg_split_h2_bytes(16 * c, k), dtype=torch.uint8, device=w.device) \
                 if (_wino_eligible(k, c, r, s) and _wino_dgrad_eligible(k)) else None
             rec = (weakref.ref(w), w._version, w.data_ptr(), kb, cb, ub, utb)
+            _ABSMAX_FRESH.pop(id(w), None)               # new plane buffers: their slots have not been written
         else:
             rec = (rec[0], w._version, rec[2], rec[3], rec[4], rec[5], rec[6])
         _WPLANES[id(w)] = rec
@@ -711,7 +712,12 @@ def prepare_conv_weights(weights):
         arr[i].K, arr[i].T, arr[i].C = k, r * s, c
         arr[i].wino = rec[5].data_ptr() if rec[5] is not None else None
         arr[i].wino_t = rec[6].data_ptr() if rec[6] is not None else None
-    _native.check(L.semseg_weights_prepare_h2(arr, len(todo), _st()), 'weights_prepare_h2')
+    # every tensor's partial |w| maxima are in place (the fused SGD kernel wrote them with the update): no absmax pass
+    # (and nothing touched the weight through torch since: the version counter the flag was taken at)
+    have = SGD_FUSED and all(_ABSMAX_FRESH.get(id(w), None) == w._version for w, _ in todo)
+    for w, _ in todo:
+        _ABSMAX_FRESH.pop(id(w), None)
+    _native.check(L.semseg_weights_prepare_h2_after_sgd(arr, len(todo), 1 if have else 0, _st()), 'weights_prepare_h2')
     return len(todo)
 
 
@@ -827,6 +833,12 @@ DEFER_WGRAD_REDUCE = os.environ.get('SEMSEG_DEFER_WGRAD_REDUCE', '1') != '0'
 # and flush_wgrad_reduces runs the blocks of up to 24 of them side by side in one launch (semseg_conv2d_wgrad_multi_h2: the blocks
 # of the per-layer launches unchanged, bit-identical slabs).  SEMSEG_DEFER_WGRAD_LAUNCH=0 launches them where autograd reaches them.
 DEFER_WGRAD_LAUNCH = os.environ.get('SEMSEG_DEFER_WGRAD_LAUNCH', '1') != '0'
+# ONE pass over the weights after backward (round 6): the fused SGD kernel sums the slabs of the deferred weight gradients itself and
+# leaves the maxima of the updated weights for the weight preparation (csrc/head.hip sgd_fused_kernel).  SEMSEG_SGD_FUSED=0: the
+# reduce launch, the plain SGD kernel and the absmax pass of the weight preparation, as before.
+SGD_FUSED = os.environ.get('SEMSEG_SGD_FUSED', '1') != '0'
+_SLABS_FOR_SGD = {}          # id(parameter) -> (slab tensor, gradient buffer, numel, splits, parameter): summed by sgd_step
+_ABSMAX_FRESH = {}           # id(conv weight) -> its torch version when the fused SGD kernel wrote the partial |w| maxima of its planes
 _DEFER = [False]
 _PENDING_SLABS = []          # (slab tensor, gradient buffer, numel, splits, parameter, producing stream)
 _PENDING_WGRADS = []         # (x planes, dy planes, slab tensor, gradient buffer, geometry, parameter, producing stream)
@@ -857,8 +869,13 @@ class defer_wgrad_reduces:
     from the hook that completes a bucket, BEFORE the bucket is staged and its all-reduce launched -- so a rank gets the batched /
     deferred weight gradients too, bucket by bucket, and no bucket ever travels with an unfinished gradient in it."""
 
-    def __init__(self, flush_at_buckets=False):
+    def __init__(self, flush_at_buckets=False, into_sgd=False):
+        """into_sgd: the caller runs ops.sgd_step on every parameter right after backward and nothing reads a gradient in between
+        (TrainStep on one rank): the slabs of a deferred gradient are then summed by the SGD kernel itself (semseg_sgd_step_fused:
+        same slab order, same bits, the sum left in .grad) instead of by a reduce launch of their own; whatever sgd_step did not
+        take is reduced by finish_leftover_slabs()."""
         self.flush_at_buckets = flush_at_buckets
+        self.into_sgd = bool(into_sgd) and SGD_FUSED and not flush_at_buckets
 
     def __enter__(self):
         self.prev = _DEFER[0]
@@ -872,7 +889,10 @@ class defer_wgrad_reduces:
             _PENDING_SLABS[:] = []
             _FWD_USES.clear()
             return False
-        flush_wgrad_reduces()
+        if self.into_sgd:
+            flush_wgrad_reduces(into_sgd=True)
+        else:
+            flush_wgrad_reduces()
         return False
 
 
@@ -880,7 +900,7 @@ def deferring():
     return _DEFER[0]
 
 
-def flush_wgrad_reduces(mid_backward=False):
+def flush_wgrad_reduces(mid_backward=False, into_sgd=False):
     """sum the slabs of every weight gradient deferred since the last flush, one launch per 64 tensors (on the current stream: after
     backward() has returned autograd has made it wait for the streams the gradients were produced on).  mid_backward: called from a
     gradient-bucket hook while backward is still running -- the current stream is first made to wait for every OTHER stream a pending
@@ -928,6 +948,14 @@ def flush_wgrad_reduces(mid_backward=False):
             raise RuntimeError('deferred weight gradient of a %s parameter did not become its .grad (layout %s, grad %s): '
                                'set SEMSEG_DEFER_WGRAD_REDUCE=0 or keep conv weights as KRSC leaves used once per step'
                                % (tuple(param.shape), param.stride(), 'missing' if param.grad is None else 'copied'))
+    if into_sgd and not mid_backward:
+        # the gradients of leaf parameters wait for the SGD kernel (sgd_step); a buffer without a parameter behind it is summed now
+        for it in items:
+            if it[4] is not None:
+                _SLABS_FOR_SGD[id(it[4])] = it[:5]
+        items = [it for it in items if it[4] is None]
+        if not items:
+            return
     arr = (_native.SlabTensor * len(items))()
     on_dev = items[0][0].is_cuda
     for i, (slabs, out, numel, splits, _, _) in enumerate(items):
@@ -2211,7 +2239,10 @@ def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum
     if isinstance(first_step, (bool, int)):
         first_step = [first_step] * len(params)
     n = len(params)
-    arr = (_native.SgdTensor * n)()
+    L = _native.lib()
+    fused = SGD_FUSED and CONV_MODE == 'h2'
+    arr = ((_native.SgdTensor2 if fused else _native.SgdTensor) * n)()
+    keep = []
     for i, (p, g, b) in enumerate(zip(params, grads, bufs)):
         if p.stride() != g.stride() or p.stride() != b.stride():
             raise RuntimeError('sgd_step: param/grad/momentum strides differ')
@@ -2221,11 +2252,40 @@ def sgd_step(params, grads, bufs, first_step, weight_decays, lr_tensor, momentum
         arr[i].numel = p.numel()
         arr[i].weight_decay = float(weight_decays[i])
         arr[i].first_step = 1 if first_step[i] else 0
-    _native.check(_native.lib().semseg_sgd_step(arr, n, _p(lr_tensor), float(momentum), float(grad_scale), _st()),
-                  'sgd_step')
+        if not fused:
+            continue
+        rec = _SLABS_FOR_SGD.pop(id(p), None)
+        if rec is not None:
+            slabs, out, numel, splits, _ = rec
+            if out.data_ptr() != g.data_ptr() or numel != p.numel():
+                raise RuntimeError('sgd_step: the deferred gradient of a %s parameter is not the gradient handed to the optimiser'
+                                   % (tuple(p.shape),))
+            arr[i].slabs, arr[i].splits = slabs.data_ptr(), splits
+            keep.append(slabs)
+        wrec = _WPLANES.get(id(p)) if FUSE else None
+        if wrec is not None and wrec[0]() is p and wrec[2] == p.data_ptr():
+            k, c, r, s2 = p.shape
+            arr[i].absmax_slots = L.semseg_weights_absmax_slots(vp(wrec[3].data_ptr()), k, r * s2, c)
+            _ABSMAX_FRESH[id(p)] = p._version
+    if fused:
+        _native.check(L.semseg_sgd_step_fused(arr, n, _p(lr_tensor), float(momentum), float(grad_scale), _st()), 'sgd_step_fused')
+    else:
+        _native.check(L.semseg_sgd_step(arr, n, _p(lr_tensor), float(momentum), float(grad_scale), _st()), 'sgd_step')
     # the kernel updates the parameters behind torch's back (no version bump): prepared weight planes are stale until
     # prepare_conv_weights runs again (TrainStep does, right after this call)
     for p in params:
         rec = _WPLANES.get(id(p))
         if rec is not None:
             _WPLANES[id(p)] = (rec[0], -1, rec[2], rec[3], rec[4], rec[5], rec[6])
+
+
+def finish_leftover_slabs():
+    """deferred gradients that no sgd_step took (a parameter outside the optimiser's groups): summed by the reduce launch after all"""
+    if not _SLABS_FOR_SGD:
+        return
+    items = list(_SLABS_FOR_SGD.values())
+    _SLABS_FOR_SGD.clear()
+    arr = (_native.SlabTensor * len(items))()
+    for i, (slabs, out, numel, splits, _) in enumerate(items):
+        arr[i].slabs, arr[i].out, arr[i].numel, arr[i].splits = slabs.data_ptr(), out.data_ptr(), numel, splits
+    _native.check(_native.lib().semseg_reduce_slabs_multi(arr, len(items), _st()), 'reduce_slabs_multi')

@@ -461,6 +461,7 @@ SWITCH_CASES = [
     ('SEMSEG_DEFER_FORK_SUMS=0', 'hrnetv2_c1_128_train'),
     ('SEMSEG_DMA64_SPREAD=0', 'r50d_ppmds_64_train'),        # the 64-deep GEMM tiles with their DMA pieces in one burst per k-tile
     ('SEMSEG_WINO_WGRAD_FORM=0', 'r50d_ppmds_64_train'),     # the batched Winograd weight-gradient GEMM on the plain 2-slot loop
+    ('SEMSEG_SGD_FUSED=0', 'r50d_ppmds_64_train'),           # reduce launch + plain SGD kernel + absmax pass instead of the one fused pass over the weights
     ('SEMSEG_DEPTHWISE_DIRECT=0', 'mnv2d_c1ds_64_train'),
     ('SEMSEG_GROUPED_DIRECT=0', 'resnext101_upernet_128_eval'),
 ]

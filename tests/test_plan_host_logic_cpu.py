@@ -44,15 +44,22 @@ def test_set_plan_refuses_tiles_a_geometry_cannot_take(L):
         assert L.semseg_conv2d_h2_set_plan(2, *ok, 10, 1) == 0
     finally:
         unpin(L, 2, ok)
-    # 64-deep k-tiles (22 - 24): the reduction, padded to 32 channels, must be whole 64-channel chunks
+    # 64-deep k-tiles (22 - 24): forward / data gradient take any reduction since round 6 (an odd count of 32-channel chunks: the
+    # missing half of the last 64-channel chunk is fetched as zeros, igemm_dma64_kernel); the batched Winograd GEMM (pass 3)
+    # still wants whole 64-channel chunks
     for tile in (22, 23, 24):
-        odd = (2, 16, 16, 96, 64, 1, 1, 1, 0, 1)            # C = 96: one and a half chunks
-        assert L.semseg_conv2d_h2_set_plan(0, *odd, tile, 1) != 0, tile
-        even = (2, 16, 16, 128, 64, 1, 1, 1, 0, 1)
-        try:
-            assert L.semseg_conv2d_h2_set_plan(0, *even, tile, 1) == 0, tile
-        finally:
-            unpin(L, 0, even)
+        for geom in ((2, 16, 16, 96, 64, 1, 1, 1, 0, 1), (2, 16, 16, 128, 64, 1, 1, 1, 0, 1)):      # C = 96: one and a half chunks
+            for pass_id in (0, 1):
+                try:
+                    assert L.semseg_conv2d_h2_set_plan(pass_id, *geom, tile, 1) == 0, (tile, geom)
+                finally:
+                    unpin(L, pass_id, geom)
+    wino_odd, wino_even = (128, 1, 1, 96, 64, 3, 3, 1, 1, 1), (128, 1, 1, 128, 64, 3, 3, 1, 1, 1)
+    assert L.semseg_conv2d_h2_set_plan(3, *wino_odd, 22, 1) != 0
+    try:
+        assert L.semseg_conv2d_h2_set_plan(3, *wino_even, 22, 1) == 0
+    finally:
+        unpin(L, 3, wino_even)
     # tiles beyond the tables, unknown passes
     geom = (2, 16, 16, 64, 64, 3, 3, 1, 1, 1)
     assert L.semseg_conv2d_h2_set_plan(0, *geom, 26, 1) == 0 and L.semseg_conv2d_h2_set_plan(0, *geom, -1, 0) == 0
