@@ -249,6 +249,12 @@ class BranchesFn(Function):
                 p.grad = g
             else:
                 p.grad = p.grad + g
+            # ... and then runs the parameter's post-accumulate-grad hooks (gradient buckets, the timeline probe of bench.py's
+            # scaling model: they mark when a parameter's gradient is complete)
+            hooks = getattr(p, '_post_accumulate_grad_hooks', None)
+            if hooks:
+                for hook in list(hooks.values()):
+                    hook(p)
         return (None,) + tuple(g for row in gxs for g in row)
 
 

@@ -286,9 +286,9 @@ def test_deferred_wgrad_reduce_is_bit_identical(monkeypatch):
     batched = []
     real = ops.flush_wgrad_reduces
 
-    def counting():
+    def counting(*a, **kw):
         batched.append(len(ops._PENDING_WGRADS))
-        return real()
+        return real(*a, **kw)
     monkeypatch.setattr(ops, 'flush_wgrad_reduces', counting)
     states = []
     for defer, launch in ((True, True), (True, False), (False, False)):
@@ -300,7 +300,7 @@ def test_deferred_wgrad_reduce_is_bit_identical(monkeypatch):
         for _ in range(2):
             loss, _ = ts.step(feed)
         torch.cuda.synchronize()
-        assert not ops._PENDING_SLABS and not ops._PENDING_WGRADS
+        assert not ops._PENDING_SLABS and not ops._PENDING_WGRADS and not ops._SLABS_FOR_SGD
         assert (max(batched) >= 8) == (defer and launch), batched      # the path under test ran (r18: more than 8 small layers)
         states.append(({k: v.clone() for k, v in sm.state_dict().items()}, loss.clone()))
     for (b, lb) in states[1:]:
@@ -482,12 +482,13 @@ def _switch_child(switch, case):
 
 
 def _switch_result(switch, case):
-    """the children of ALL switch cases are started when the first of them is asked for, SWITCH_WORKERS at a time: a child spends
-    most of its ~14 s importing torch and loading the library, not on the GPU, and 24 of them one after the other were 360 of the
-    suite's 580 s (round-5 review, item 7c: the suite has to stay well inside the driver's 1 200 s)"""
+    """the children of ALL switch cases are started when the first of them is asked for, SEMSEG_SWITCH_WORKERS (2) at a time: a child
+    spends most of its ~14 s importing torch and loading the library, not on the GPU, and 24 of them one after the other were 360 of
+    the suite's 580 s (round-5 review, item 7c).  Two, not more: six at a time made the children that time launch plans crawl
+    (processes time-slicing one GPU: 820 s for one child, gpurun r8l)"""
     if not _SWITCH_FARM:
         from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=int(os.environ.get('SEMSEG_SWITCH_WORKERS', '6')))
+        pool = ThreadPoolExecutor(max_workers=int(os.environ.get('SEMSEG_SWITCH_WORKERS', '2')))
         for sw, cs in SWITCH_CASES:
             _SWITCH_FARM[(sw, cs)] = pool.submit(_switch_child, sw, cs)
         pool.shutdown(wait=False)
