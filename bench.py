@@ -87,6 +87,16 @@ def ops_mode():
     return ops.CONV_MODE
 
 
+def side_by_side_stats():
+    """csrc/batch.h: scopes opened, launches recorded and launches the zip issued for them since the process started (the captured
+    step is recorded once; replays re-issue what was recorded), direct launches that forced a flush inside a scope"""
+    import ctypes
+    from mit_semseg import _native, ops
+    c = (ctypes.c_longlong * 4)()
+    _native.lib().semseg_batch_stats(c)
+    return {'enabled': bool(ops.BATCH_BRANCHES), 'scopes': int(c[0]), 'recorded': int(c[1]), 'issued': int(c[2]), 'forced_flushes': int(c[3])}
+
+
 def launch_plan_provenance():
     """where the (tile, split) launch plans of this run came from: the shipped performance database (plans measured on an MI355X
     by the same tuner, mit_semseg/perfdb), a read-write cache (SEMSEG_TUNE_CACHE), or timed in this process"""
@@ -801,6 +811,7 @@ def main():
                        'ddp_graph_selftest': selftest_ok,
                        'collectives': collectives_used(world),
                        'conv_path': ops_mode(),
+                       'side_by_side': side_by_side_stats(),
                        'launch_plans': launch_plan_provenance(),
                        'images_per_sec_per_gpu': round(per_gpu, 3),
                        'step_conv_tflops_per_gpu': round(per_gpu * gflop_img * 1e-3, 2),
@@ -837,6 +848,15 @@ def main():
             out['config']['other_configs'] = other_configs(args.config, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
+            # the GPU box has no /root/reference, so `kind` is "port" there; what the port is worth against the UNMODIFIED reference was
+            # measured where both run -- the build container, same thread count, interleaved (round-5 review, item 7b)
+            try:
+                pair = json.load(open(os.path.join(ROOT, 'profiles', 'r8_cpu_baseline_port_vs_reference.json')))
+                out['cpu_baseline']['port_vs_reference'] = {'ratio': pair['port_vs_reference'], 'reference_img_s': pair['reference_img_s'],
+                                                            'port_img_s': pair['port_img_s'], 'threads': 8,
+                                                            'source': 'profiles/r8_cpu_baseline_port_vs_reference.json (build container)'}
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     if world > 1:
         from mit_semseg import comm

@@ -1767,6 +1767,10 @@ def _take_addend(g):
     if rec is None or rec[0].shape != g.shape or rec[0].stride() != g.stride():
         return None
     rec[2][0] = True
+    if rec[1].is_cuda:
+        # the addend is read on the consumer's stream, which need not be the one it was allocated on (branch streams): the caching
+        # allocator must not hand its block out again before that read
+        rec[1].record_stream(torch.cuda.current_stream(rec[1].device))
     return rec[1]
 
 

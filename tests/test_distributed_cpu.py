@@ -205,7 +205,7 @@ def _w_trainstep_world2(rank, world):
     flats = [(b['flat'].data_ptr(), b['flat'].data_ptr() + b['flat'].numel() * 4) for b in ts.buckets.buckets]
     for n, p in sm.named_parameters():
         assert any(lo <= p.grad.data_ptr() < hi for lo, hi in flats), n
-    sgd = [a for name, a in lib.calls if name == 'semseg_sgd_step']
+    sgd = [a for name, a in lib.calls if name in ('semseg_sgd_step', 'semseg_sgd_step_fused')]
     assert sgd and all(abs(a[4] - 1.0 / world) < 1e-12 for a in sgd)
     nstats = sum(1 for name, _ in lib.calls if name in ('semseg_bn_stats', 'semseg_bn_stats_mm'))
     assert nstats > 0

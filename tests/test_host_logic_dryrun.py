@@ -77,14 +77,15 @@ def test_train_step_host_logic(stub, cfg, mode, monkeypatch):
     names = set(stub.calls)
     conv = {'f32': ('semseg_conv2d_fwd', 'semseg_conv2d_dgrad', 'semseg_conv2d_wgrad'),
             's3': ('semseg_split3', 'semseg_conv2d_fwd_s3', 'semseg_conv2d_dgrad_s3', 'semseg_conv2d_wgrad_s3', 'semseg_bias_grad'),
-            # h2 inside TrainStep on one rank: the weight gradients leave slabs, ONE multi-tensor launch sums them after backward
-            'h2': ('semseg_split_h2', 'semseg_conv2d_fwd_h2', 'semseg_conv2d_dgrad_h2', 'semseg_conv2d_wgrad_slabs_h2', 'semseg_reduce_slabs_multi',
-                   'semseg_bias_grad')}[mode]
+            # h2 inside TrainStep on one rank: the weight gradients leave slabs that the fused SGD kernel sums while it updates (round 6;
+            # before: ONE multi-tensor reduce launch after backward)
+            'h2': ('semseg_split_h2', 'semseg_conv2d_fwd_h2', 'semseg_conv2d_dgrad_h2', 'semseg_conv2d_wgrad_slabs_h2', 'semseg_bias_grad')}[mode]
     # h2: conv -> BN pairs run as the fused node (BN kernels that emit / consume split planes, multi-tensor weight prep)
     bn = ('semseg_bn_fwd_stats_fused', 'semseg_bn_apply_h2', 'semseg_bn_bwd_reduce_fused', 'semseg_bn_bwd_apply_h2',
-          'semseg_weights_prepare_h2') if mode == 'h2' else \
+          'semseg_weights_prepare_h2_after_sgd') if mode == 'h2' else \
          ('semseg_bn_stats', 'semseg_bn_apply', 'semseg_bn_bwd_reduce', 'semseg_bn_bwd_apply')
-    for must in conv + bn + ('semseg_log_softmax_fwd', 'semseg_nll_acc_fwd', 'semseg_nll_bwd', 'semseg_sgd_step'):
+    sgd = 'semseg_sgd_step_fused' if mode == 'h2' else 'semseg_sgd_step'
+    for must in conv + bn + ('semseg_log_softmax_fwd', 'semseg_nll_acc_fwd', 'semseg_nll_bwd', sgd):
         assert must in names, must
     if mode == 'h2' and arch_enc.startswith(('resnet', 'hrnet')):
         # the last BN of every residual block leaves its ReLU decisions as a bitmask for backward (no y read there); BNs without

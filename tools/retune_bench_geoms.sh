@@ -6,12 +6,12 @@ OUT=gpurun_out/retune; mkdir -p $OUT; export TMPDIR=/tmp
 python __graft_entry__.py > $OUT/build.log 2>&1 || { echo BUILD FAILED; exit 1; }
 export SEMSEG_TUNE_DB=0 SEMSEG_TUNE_CACHE=$PWD/$OUT/plans.json
 rm -f $SEMSEG_TUNE_CACHE
-for c in 1 2 4 3; do
+for c in ${RETUNE_CONFIGS:-1 2 4 3}; do      # RETUNE_CONFIGS="4": only that config's geometries are re-timed and merged
   timeout 900 python bench.py --config $c --steps 10 --warmup 4 --no-cpu-baseline --no-other-configs --no-box --no-scaling-model --repeats 0 \
       > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err
   echo "cfg$c rc=$? $(python -c "import json,sys; d=json.loads([l for l in open('$OUT/bench_cfg$c.json') if l.startswith('{')][-1]); print(d['ms_per_step'],'ms')" 2>/dev/null)"
 done
-timeout 300 python tools/bench_infer.py > $OUT/infer.log 2>&1; echo "infer rc=$?"
+[ -z "$RETUNE_CONFIGS" ] && { timeout 300 python tools/bench_infer.py > $OUT/infer.log 2>&1; echo "infer rc=$?"; }
 python - <<'PY'
 import json, os
 out = os.path.join('gpurun_out', 'retune')
