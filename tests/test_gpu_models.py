@@ -482,13 +482,13 @@ def _switch_child(switch, case):
 
 
 def _switch_result(switch, case):
-    """the children of ALL switch cases are started when the first of them is asked for, SEMSEG_SWITCH_WORKERS (2) at a time: a child
-    spends most of its ~14 s importing torch and loading the library, not on the GPU, and 24 of them one after the other were 360 of
-    the suite's 580 s (round-5 review, item 7c).  Two, not more: six at a time made the children that time launch plans crawl
-    (processes time-slicing one GPU: 820 s for one child, gpurun r8l)"""
+    """the children of all switch cases run from a small pool, SEMSEG_SWITCH_WORKERS at a time -- ONE by default: measured on the
+    MI355X box, two at a time take as long as one after the other (375 s for 24 children either way, gpurun r8n: a child's ~14 s are
+    device context + library load + its golden tests, and processes sharing one GPU are time-sliced), six at a time made the children
+    that time launch plans crawl (820 s for one child, gpurun r8l).  The suite is ~600 s of the driver's 1 200 s with them."""
     if not _SWITCH_FARM:
         from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=int(os.environ.get('SEMSEG_SWITCH_WORKERS', '2')))
+        pool = ThreadPoolExecutor(max_workers=int(os.environ.get('SEMSEG_SWITCH_WORKERS', '1')))
         for sw, cs in SWITCH_CASES:
             _SWITCH_FARM[(sw, cs)] = pool.submit(_switch_child, sw, cs)
         pool.shutdown(wait=False)
