@@ -135,6 +135,9 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
     if (sch == 1 && pass <= 1 && g_batch_tile == -2 && semseg_batch::recording() &&
         (*tile == 2 || *tile == 15 || *tile == 17 || *tile == 19))
         *tile = 23;
+    // measured and removed again (gpurun r8q / r8r, HRNetV2 19.24 ms per step with the mapping above): no split-K for the recorded 64-deep
+    // GEMMs 19.66 ms; k loops equalised to at most 9 / 14 / 18 / 27 k-tiles per block by more split-K 20.83 / 20.08 / 19.53 / 19.31 ms (a split
+    // costs the statistics sweep and a reduce); plans re-timed with the 64-deep tile open to the 96-channel layers 19.79 against 19.59 ms
     return true;
 }
 
