@@ -25,8 +25,8 @@ def family(name):
 def main():
     rows = load(sys.argv[1])
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    marker = sys.argv[3] if len(sys.argv) > 3 else 'sgd_kernel'
-    marks = [i for i, (s, e, n) in enumerate(rows) if marker in n]
+    marker = sys.argv[3] if len(sys.argv) > 3 else 'sgd_kernel,sgd_fused_kernel'      # the optimiser kernel ends a step (either form)
+    marks = [i for i, (s, e, n) in enumerate(rows) if any(m in n for m in marker.split(','))]
     # a step may launch the marker several times back to back: keep the LAST dispatch of every cluster
     ends = [i for k, i in enumerate(marks) if k + 1 == len(marks) or rows[marks[k + 1]][0] - rows[i][1] > 2_000_000]
     ends = ends[-(steps + 1):]
