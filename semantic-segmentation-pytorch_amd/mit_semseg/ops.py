@@ -1685,6 +1685,10 @@ class AddActFn(Function):
     def backward(ctx, dy):
         _native.next_unit()
         if not ctx.relu:
+            # the same tensor goes to TWO producers: if it is the first addend of a deferred fork sum, form the sum here -- one of
+            # the producers might not be a native consumer that looks the pair up (it would read the first addend alone)
+            if _ADDENDS:
+                dy = _materialize_sum(dy)
             return dy, dy, None
         (out,) = ctx.saved_tensors
         dy, dy_ld = as_nhwc(dy)
