@@ -10,6 +10,7 @@
 // Replaces nn.Conv2d forward at the 3x3 stride-1 call sites (resnet.py:61-66 dilated by models.py:209-251; models.py:163,
 // 456-457) when ops enables it.
 #include "common.h"
+#include "batch.h"
 #include "split_layout.h"
 
 struct WinoGeom {
@@ -48,7 +49,10 @@ struct WinoBounds {
 };
 
 // one thread = 4 channels of one tile: 16 float4 loads, 32 + 32 adds per channel, 16 rows x 8 B per plane
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int x_ld, uint16_t* __restrict__ planes,
+struct wino_input_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ x, int x_ld, uint16_t* __restrict__ planes,
                                                          size_t plane, int pitch, int* __restrict__ hdr, WinoGeom g, int Cp,
                                                          WinoBounds bounds) {
     // exponent from the bound 4 * max(bounds of x)
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
             }
         }
     }
-}
+    }
+};
 
 extern "C" int semseg_winograd_input_h2(const float* x, int x_ld, const float* const* bounds_host, int nbounds, void* v_planes,
                                         int N, int H, int W, int C, int dil, void* stream) {
@@ -141,7 +146,7 @@ extern "C" int semseg_winograd_input_h2(const float* x, int x_ld, const float* c
     int* hdr = const_cast<int*>(h2_exp_ptr(v_planes, rows, C));
     size_t blocks = ceil_div_sz((size_t)g.tiles * (Cp / 4), 256);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)v_planes,
+    SEMSEG_LAUNCH_BODY((wino_input_kernel_body), dim3((unsigned)blocks), 0, (hipStream_t)stream, x, x_ld, (uint16_t*)v_planes,
                        plane, pitch, hdr, g, Cp, b);
     SEMSEG_LAUNCH_CHECK();
     return 0;
@@ -151,7 +156,10 @@ extern "C" int semseg_winograd_input_h2(const float* x, int x_ld, const float* c
 // the BN backward kernel writes as planes only).  p0 + p1 is the value to 22 bits in the scaled domain of the planes;
 // |B^T d B| <= 4 max|d|, so the transform is formed with a factor 1/4 in that domain (exact in fp32) and the exponent of V is
 // the exponent of the source minus 2 -- no bound, no rescaling.
-__global__ __launch_bounds__(256) void wino_input_planes_kernel(const uint16_t* __restrict__ src, size_t src_plane, int src_pitch,
+struct wino_input_planes_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const uint16_t* __restrict__ src, size_t src_plane, int src_pitch,
                                                                 const int* __restrict__ src_hdr, uint16_t* __restrict__ planes,
                                                                 size_t plane, int pitch, int* __restrict__ hdr, WinoGeom g, int Cp) {
     if (blockIdx.x == 0) {
@@ -219,7 +227,8 @@ __global__ __launch_bounds__(256) void wino_input_planes_kernel(const uint16_t* 
             }
         }
     }
-}
+    }
+};
 
 // src_planes: h2 planes of a [N*H*W rows] x [C channels] tensor (e.g. dz of a conv whose data gradient runs in the Winograd domain)
 extern "C" int semseg_winograd_input_planes_h2(const void* src_planes, void* v_planes, int N, int H, int W, int C, int dil,
@@ -235,14 +244,17 @@ extern "C" int semseg_winograd_input_planes_h2(const void* src_planes, void* v_p
     int* hdr = const_cast<int*>(h2_exp_ptr(v_planes, rows, C));
     size_t blocks = ceil_div_sz((size_t)g.tiles * (Cp / 4), 256);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(wino_input_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src_planes,
+    SEMSEG_LAUNCH_BODY((wino_input_planes_kernel_body), dim3((unsigned)blocks), 0, (hipStream_t)stream, (const uint16_t*)src_planes,
                        src_plane, pitch, src_hdr, (uint16_t*)v_planes, plane, pitch, hdr, g, Cp);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }
 
 // one thread = 4 output channels of one tile: 16 float4 loads of M, 2x2 outputs
-__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, float* __restrict__ z, int z_ld, WinoGeom g) {
+struct wino_output_kernel_body {
+    static constexpr int THREADS = 256;
+    static __device__ __forceinline__ void run(const semseg_batch::U3 blockIdx, const semseg_batch::U3 gridDim,
+                                               const float* __restrict__ M, float* __restrict__ z, int z_ld, WinoGeom g) {
     const int K4 = g.K >> 2;
     const size_t total = (size_t)g.tiles * K4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -277,7 +289,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
             }
         }
     }
-}
+    }
+};
 
 extern "C" int semseg_winograd_output(const float* M, float* z, int z_ld, int N, int H, int W, int K, int dil, void* stream) {
     if (!M || !z || N <= 0 || H <= 0 || W <= 0 || K <= 0 || (K % 4) || (z_ld % 4) || z_ld < K || dil <= 0 || !aligned16(M) ||
@@ -286,7 +299,7 @@ extern "C" int semseg_winograd_output(const float* M, float* z, int z_ld, int N,
     const WinoGeom g = wino_geom(N, H, W, 1, K, dil);
     size_t blocks = ceil_div_sz((size_t)g.tiles * (K / 4), 256);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M, z, z_ld, g);
+    SEMSEG_LAUNCH_BODY((wino_output_kernel_body), dim3((unsigned)blocks), 0, (hipStream_t)stream, M, z, z_ld, g);
     SEMSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -131,6 +131,33 @@ def _join_streams(main, streams):
         main.wait_event(done)
 
 
+# While launches are only RECORDED, a kernel torch itself launches inside a branch -- autograd adding two gradients that meet at a tensor
+# with two consumers (use ops.fork), a .contiguous() / .clone() / arithmetic on tensors -- would run AT ONCE, ahead of the recorded
+# launches that produce its operands.  The models of this package keep such operations out of their branches; SEMSEG_BATCH_CHECK=1 (and
+# the GPU tests of the scopes) verifies it: every torch operator dispatched inside a scope must be one that launches nothing
+# (allocation, views, metadata), anything else raises.
+BATCH_CHECK = os.environ.get('SEMSEG_BATCH_CHECK', '0') == '1'
+_LAUNCHLESS = ('empty', 'empty_like', 'empty_strided', 'detach', 'detach_', 'alias', 'view', '_unsafe_view', 'reshape', '_reshape_alias', 'permute',
+               'transpose', 't', 'as_strided', 'slice', 'select', 'narrow', 'unsqueeze', 'squeeze', 'expand', 'unbind', 'split', 'chunk',
+               'view_as', 'is_same_size', 'stride', 'size', 'sym_size', 'sym_stride', 'sym_numel', 'sym_storage_offset', 'numel', 'dim',
+               'is_contiguous', 'is_pinned', 'record_stream', 'lift_fresh', 'set_', 'requires_grad_', '_version', 'data_ptr', 'is_leaf')
+
+
+def _no_torch_kernels():
+    """a TorchDispatchMode that lets only launch-free operators through (BATCH_CHECK)"""
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class NoTorchKernels(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = getattr(func, '__name__', str(func)).split('.')[0]
+            if name not in _LAUNCHLESS:
+                raise RuntimeError('torch operator %s ran inside a side-by-side scope (ops.run_branches): its kernel would overtake the '
+                                   'recorded launches that produce its operands -- keep it out of the branch (ops.fork for a tensor with '
+                                   'two consumers, the native ops for arithmetic)' % (func,))
+            return func(*args, **(kwargs or {}))
+    return NoTorchKernels()
+
+
 class _Recording:
     """the library records the launches of the C-ABI calls made inside (semseg_batch_begin ... _end on `main`)"""
 
@@ -148,7 +175,13 @@ class _Recording:
 
     def branch(self, i):
         _native.lib().semseg_batch_branch(i)
-        return torch.cuda.stream(self.streams[i])
+        if not BATCH_CHECK:
+            return torch.cuda.stream(self.streams[i])
+        import contextlib
+        stack = contextlib.ExitStack()
+        stack.enter_context(torch.cuda.stream(self.streams[i]))
+        stack.enter_context(_no_torch_kernels())
+        return stack
 
     def __exit__(self, et, ev, tb):
         L = _native.lib()
@@ -2004,7 +2037,11 @@ class AdaptiveAvgPoolFn(Function):
 
 def adaptive_avg_pool(x, size):
     oh, ow = (size, size) if isinstance(size, int) else size
-    return AdaptiveAvgPoolFn.apply(x, int(oh), int(ow))
+    y = AdaptiveAvgPoolFn.apply(x, int(oh), int(ow))
+    bound = bounds_of(x)
+    if bound is not None:
+        attach_absmax(y, bound)          # an average over a window of x: the bound of |x| holds
+    return y
 
 
 class MultiAdaptiveAvgPoolFn(Function):
@@ -2057,8 +2094,14 @@ def adaptive_avg_pool_multi(x, sizes):
     bins in total (PPM: 1 + 2 + 3 + 6); anything else pools scale by scale."""
     sizes = list(sizes)
     if 1 < len(sizes) <= 4 and all(isinstance(s, int) and s > 0 for s in sizes) and sum(sizes) <= 16 and x.shape[1] % 4 == 0:
-        return list(MultiAdaptiveAvgPoolFn.apply(x, tuple(sizes)))
-    return [adaptive_avg_pool(x, s) for s in sizes]
+        ys = list(MultiAdaptiveAvgPoolFn.apply(x, tuple(sizes)))
+    else:
+        return [adaptive_avg_pool(x, s) for s in sizes]
+    bound = bounds_of(x)
+    if bound is not None:
+        for y in ys:
+            attach_absmax(y, bound)      # an average over a window of x: the bound of |x| holds (the pyramid convs then split their
+    return ys                            # input from the bound: one launch that pairs up across the branches, no absmax pass)
 
 
 class BilinearFn(Function):

@@ -114,3 +114,31 @@ def test_product_never_imports_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b', src, re.M) or 'semseg_oracle' in src:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_side_by_side_scope_state_machine_on_the_host():
+    """csrc/batch.hip without a GPU: one scope per process, branches inside their range, ordinals only inside a scope, an empty scope
+    closes cleanly, abort always leaves no scope behind; the plan knob returns its previous value"""
+    from mit_semseg import _native
+    import ctypes
+    L = _native.lib()
+    EINVAL = -1
+    assert L.semseg_batch_active() == 0
+    assert L.semseg_batch_next_op() == EINVAL and L.semseg_batch_next_unit() == EINVAL and L.semseg_batch_branch(0) == EINVAL
+    assert L.semseg_batch_end() == EINVAL
+    assert L.semseg_batch_begin(0, None) == EINVAL and L.semseg_batch_begin(17, None) == EINVAL
+    c0 = (ctypes.c_longlong * 4)()
+    L.semseg_batch_stats(c0)
+    assert L.semseg_batch_begin(4, None) == 0 and L.semseg_batch_active() == 1
+    assert L.semseg_batch_begin(2, None) == EINVAL                                 # a scope inside a scope is refused
+    assert L.semseg_batch_branch(3) == 0 and L.semseg_batch_branch(4) == EINVAL and L.semseg_batch_branch(-1) == EINVAL
+    assert L.semseg_batch_next_op() == 0 and L.semseg_batch_next_unit() == 0
+    assert L.semseg_batch_flush() == 0                                             # nothing recorded: nothing launched
+    assert L.semseg_batch_end() == 0 and L.semseg_batch_active() == 0
+    assert L.semseg_batch_begin(1, None) == 0 and L.semseg_batch_abort() == 0 and L.semseg_batch_active() == 0
+    c1 = (ctypes.c_longlong * 4)()
+    L.semseg_batch_stats(c1)
+    assert c1[0] - c0[0] == 2 and c1[1] == c0[1] and c1[2] == c0[2] and c1[3] == c0[3]
+    prev = L.semseg_batch_plan(15, 0)
+    assert L.semseg_batch_plan(prev, 0) == 15
+    assert L.semseg_batch_stats(None) == EINVAL

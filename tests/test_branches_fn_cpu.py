@@ -125,3 +125,21 @@ def test_a_failing_branch_closes_the_scope(stub):
     with ops.batch_branches(True), pytest.raises(ZeroDivisionError):
         ops.run_branches([nn.Identity(), Boom()], xs)
     assert stub.log[-1] == ('abort',) and not stub.active and not ops._native.RECORDING[0] and not tuner.NO_TIMING[0]
+
+
+def test_batch_check_refuses_torch_kernels_inside_a_scope(stub, monkeypatch):
+    """SEMSEG_BATCH_CHECK: a torch operator that launches a kernel inside a branch (here: the whole branch is torch arithmetic) would
+    run ahead of the recorded launches; the dispatch-mode check raises and the scope is aborted.  Launch-free operators (views,
+    allocation) pass."""
+    monkeypatch.setattr(ops, 'BATCH_CHECK', True)
+    xs = [torch.randn(1, 2, 3, 3, requires_grad=True) for _ in range(2)]
+    with ops.batch_branches(True), pytest.raises(RuntimeError, match='side-by-side scope'):
+        ops.run_branches([Branch(2, []), Branch(2, [])], xs)
+    assert stub.log[-1] == ('abort',) and not stub.active
+
+    class Views(nn.Module):
+        def forward(self, x):
+            return x.permute(0, 2, 3, 1).detach().permute(0, 3, 1, 2)[:, :1].view_as(x[:, :1])
+    with ops.batch_branches(True):
+        ys = ops.run_branches([Views(), Views()], xs)
+    assert stub.log[-1] == ('end',) and tuple(ys[0].shape) == (1, 1, 3, 3)

@@ -348,6 +348,7 @@ def test_hrnet_branch_streams_equal_one_stream(monkeypatch):
     monkeypatch.setattr(tuner, 'ENABLED', False)          # heuristic launch plans: the runs must sum in the same order
     from mit_semseg import _native
     prev_tile = _native.lib().semseg_batch_plan(-1, 0)    # ... inside the scopes too (their own tile form changes the summation order)
+    monkeypatch.setattr(ops, 'BATCH_CHECK', True)         # and no torch-side kernel may run inside a scope (it would overtake the records)
     try:
         _hrnet_branch_forms(monkeypatch, ops, TrainStep)
     finally:
@@ -390,6 +391,33 @@ def _hrnet_branch_forms(monkeypatch, ops, TrainStep):
         assert res[key][1] == base[1], (key, res[key][1], base[1])
         for k, v in base[0].items():
             assert torch.equal(res[key][0][k], v), (key, k)
+
+
+@pytest.mark.parametrize('name', ['r50d_ppmds_64_train', 'r50_upernet_128_train', 'hrnetv2_c1_128_train'])
+def test_side_by_side_scopes_hold_no_torch_kernels(name, monkeypatch):
+    """the scopes of every model family that opens them (PPM pyramid branches; UPerNet pyramid / lateral / output branches; HRNetV2
+    branches, exchange chains and rows) under ops.BATCH_CHECK: two training steps in which every torch operator dispatched inside a
+    scope must be launch-free -- a torch kernel there would run ahead of the recorded launches it depends on"""
+    from mit_semseg import ops
+    from mit_semseg.engine import TrainStep
+    if not (ops.FUSE and ops.CONV_MODE == 'h2' and ops.BATCH_BRANCHES):
+        pytest.skip('no scopes in this process (a switch turns them off)')
+    monkeypatch.setattr(ops, 'BATCH_CHECK', True)
+    g = load_golden(name)
+    m = g['meta']
+    dev = torch.device('cuda:0')
+    sm, _, _ = build_native(g, dev)
+    img, lab = O.synth_batch(m['n'], m['h'], m['w'], m['seg_rate'], seed=304 + m['seed'])
+    ts = TrainStep(sm, lr_encoder=m['lr'], lr_decoder=m['lr'], max_iters=10 ** 9)
+    before = _batch_stats()
+    for _ in range(2):
+        loss, _ = ts.step({'img_data': img.to(dev), 'seg_label': lab.to(dev)})
+    torch.cuda.synchronize()
+    after = _batch_stats()
+    assert torch.isfinite(loss) and after['scopes'] - before['scopes'] >= 2, (before, after)
+    parity_line('%s: %d side-by-side scopes in two steps, %d recorded launches left as %d, %d direct launches inside a scope; no torch '
+                'kernel inside any of them' % (name, after['scopes'] - before['scopes'], after['recorded'] - before['recorded'],
+                                               after['issued'] - before['issued'], after['forced'] - before['forced']))
 
 
 # every environment switch of the product that survives in the code base, with the golden case(s) that exercise what it changes:

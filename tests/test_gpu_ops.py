@@ -1262,3 +1262,91 @@ def test_absmax_scalar(rows, c, ld):
     assert out.item() != out.item()
 
 
+
+
+# ---- side-by-side launches (csrc/batch.h) at operator level --------------------------------------------------------------------
+def _scope_stats():
+    import ctypes
+    from mit_semseg import _native
+    out = (ctypes.c_longlong * 4)()
+    _native.check(_native.lib().semseg_batch_stats(out), 'batch_stats')
+    return dict(scopes=out[0], recorded=out[1], issued=out[2], forced=out[3])
+
+
+def test_side_by_side_launches_equal_sequential_launches():
+    """ops.run_branches inside ops.batch_branches(): SIX branches of different sizes, each a short chain of converted kernels
+    (conv -> BN -> ReLU fused node, bilinear up-sampling with accumulate, add + ReLU) plus one UNCONVERTED kernel (max-pool: it forces a
+    flush and must still see its producer's result) -- outputs, input gradients and parameter gradients bit-identical to the same
+    branches run one after the other; six problems of one kernel leave as a group of four and a group of two (kMaxGroup), the padding
+    blocks between problems do nothing."""
+    from mit_semseg import ops, tuner
+    from mit_semseg.models.layers import Conv2d, BatchNorm2d, ConvBNReLU
+    dev = torch.device('cuda:0')
+    prev, prev_check = tuner.ENABLED, ops.BATCH_CHECK
+    tuner.ENABLED = False
+    ops.BATCH_CHECK = True                # every torch operator dispatched inside a scope must be launch-free
+    try:
+        geoms = [(2, 16, 24, 20), (1, 32, 9, 13), (2, 48, 16, 16), (1, 64, 7, 5), (2, 96, 12, 12), (1, 24, 33, 17)]     # n, c, h, w
+
+        def build(seed):
+            torch.manual_seed(seed)
+            mods, xs = [], []
+            for n, c, h, w in geoms:
+                m = ConvBNReLU(Conv2d(c, c + 8, 3, padding=1, bias=False), BatchNorm2d(c + 8)).to(dev).train()
+                mods.append(m)
+                xs.append(cl(torch.randn(n, c, h, w)).to(dev).requires_grad_(True))
+            return mods, xs
+
+        def branch(m, pool):
+            def run(x):
+                y = m(x)                                               # GEMM, BN finish, BN apply (+ planes)
+                if pool:
+                    y = ops.max_pool_3x3_s2(y)                         # not a body: flushes what is recorded, then launches
+                ya, yb = ops.fork(y)                                   # two consumers: the native fork (autograd's own accumulation
+                size = (y.shape[2] * 2, y.shape[3] * 2)                # would be a torch kernel ahead of the recorded launches)
+                return ops.add_act(ops.interpolate_bilinear(ya, size), ops.interpolate_bilinear(yb, size), relu=True)
+            return ops.Branch(run, [m])
+
+        results = []
+        for batched in (False, True):
+            mods, xs = build(3)
+            # the planes of the inputs and of the weights exist before the scope, as inside TrainStep (the absmax / split / transpose
+            # kernels that would make them are not bodies: at the start of every branch they would flush the earlier branches' records)
+            for x in xs:
+                ops.input_planes(x, 'h2')
+            ops.prepare_conv_weights([m._modules['0'].weight for m in mods])
+            before = _scope_stats()
+            with ops.batch_branches(batched):
+                ys = ops.run_branches([branch(m, i == 2) for i, m in enumerate(mods)], xs, side_streams=False)
+            loss = sum((y * y).sum() for y in ys)
+            with ops.batch_branches(batched):
+                loss.backward()
+            torch.cuda.synchronize()
+            after = _scope_stats()
+            if batched:
+                assert after['scopes'] - before['scopes'] == 2                                      # forward + backward
+                assert after['recorded'] - before['recorded'] > 1.5 * (after['issued'] - before['issued'])
+                assert after['forced'] - before['forced'] >= 1                                       # the max-pool of branch 2
+            else:
+                assert after['scopes'] == before['scopes']
+            results.append(([y.detach().clone() for y in ys], [x.grad.clone() for x in xs],
+                            [p.grad.clone() for m in mods for p in m.parameters()]))
+        for what, a, b in zip(('output', 'input gradient', 'parameter gradient'), results[0], results[1]):
+            for i, (t, u) in enumerate(zip(a, b)):
+                assert torch.equal(t, u), (what, i, float((t - u).abs().max()), float(t.abs().max()))
+        # ... and the check itself: autograd's own accumulation at a tensor with two consumers is a torch kernel inside the scope
+        mods, xs = build(4)
+        ops.prepare_conv_weights([m._modules['0'].weight for m in mods])
+        bad = [ops.Branch(lambda x, m=m: (lambda y: ops.add_act(y, y, relu=True))(m(x)), [m]) for m in mods[:2]]
+        with ops.batch_branches(True):
+            ys = ops.run_branches(bad, xs[:2], side_streams=False)
+            with pytest.raises(RuntimeError, match='side-by-side scope'):
+                sum((y * y).sum() for y in ys).backward()
+        assert not _native_active()
+    finally:
+        tuner.ENABLED, ops.BATCH_CHECK = prev, prev_check
+
+
+def _native_active():
+    from mit_semseg import _native
+    return bool(_native.lib().semseg_batch_active())
