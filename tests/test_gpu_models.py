@@ -505,7 +505,8 @@ def _switch_child(switch, case):
     k, v = switch.split('=')
     env = dict(os.environ, SEMSEG_SWITCH_CHILD='1', **{k: v})
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_models.py'), '-q', '-x', '-m', 'gpu',
-                        '-k', '%s and not switch' % case], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+                        '-k', '%s and (matches_reference_golden or gradients_vs_reference_anchor)' % case],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
     return r.returncode, r.stdout[-1500:], r.stderr[-1500:]
 
 
@@ -525,8 +526,9 @@ def _switch_result(switch, case):
 
 @pytest.mark.parametrize('switch,case', SWITCH_CASES, ids=[s for s, _ in SWITCH_CASES])
 def test_env_switch_keeps_model_parity(switch, case):
-    """the golden tests of `case` (forward bounds, post-step state and, where stored, every gradient against the float64
-    anchors) in a child process with `switch` set"""
+    """the golden tests of `case` (test_native_matches_reference_golden: forward bounds + post-step state; where stored,
+    test_native_gradients_vs_reference_anchor: every gradient against the float64 anchors, band and direction) in a child process
+    with `switch` set"""
     if os.environ.get('SEMSEG_SWITCH_CHILD'):
         pytest.skip('already inside a switch child')
     rc, tail, err = _switch_result(switch, case)

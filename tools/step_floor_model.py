@@ -6,7 +6,9 @@ far from what the hardware allows" without another GPU run.
 Constants: 2.5 PFLOP/s dense 16-bit MFMA at 2.4 GHz scaled to the 1.7 GHz the MFMA-dense kernels run at under load,
 5.5 TB/s for streaming kernels (what add / BN-apply / SGD reach here), 2.5 us per launch inside a hipGraph.
 The batched small weight gradients (wgrad_multi_kernel, one launch per 24 layers) carry no per-layer geometry in the call trace: they are
-priced by the bytes they moved only (their MFMA time is a few per cent of the launch)."""
+priced by the bytes they moved only (their MFMA time is a few per cent of the launch).
+Round 6: a side-by-side launch (csrc/batch.h many_kernel) carries several convolutions, so the one-to-one match of launches and
+C-ABI calls this model needs only holds with SEMSEG_BATCH_BRANCHES=0 (tools/gpu_pmc_step.sh sets nothing: run it that way for the floor)."""
 import csv
 import glob
 import os
@@ -22,6 +24,9 @@ CONV_CALLS = ('conv2d_dgrad_h2', 'conv2d_fwd_h2', 'conv2d_fwd_stats_h2', 'conv2d
 
 def short(n):
     n = re.sub(r'^void ', '', n)
+    m = re.match(r'semseg_batch::(one|many)_kernel<(\w+?)_body\b(.*)', n)      # csrc/batch.h: name the body the generic kernel runs
+    if m:
+        n = m.group(2) + m.group(3)
     return re.sub(r'\((?:[^()]|\([^()]*\))*\)$', '', n)[:56]
 
 
