@@ -55,7 +55,6 @@ bool recording();                                // a scope is open in this proc
 Record* new_record();                            // appended to the current branch
 int flush_recorded();                            // everything recorded so far leaves on the scope's stream; the scope stays open
 hipStream_t direct_stream(hipStream_t requested, const char* what = nullptr);   // for a launch that is NOT recorded: flush, then the scope's stream (no scope: `requested`)
-void count_launch(int problems);                 // statistics (semseg_batch_stats)
 void hint_cost(int cost);                        // for the NEXT launch_body of this thread's current branch (a GEMM: k-tiles per block)
 
 // ---- argument blocks ---------------------------------------------------------------------------------------------------------
@@ -132,7 +131,7 @@ struct SmemAttr {
 };
 
 template <class BODY>
-struct body_multi {      // a body may opt out of the many-problem form (`static constexpr bool MULTI = false`): it then flushes and launches alone
+struct body_multi {      // a body may opt out of the many-problem form (`static constexpr bool MULTI = false`): its records are issued one by one
     template <class B>
     static constexpr auto test(int) -> decltype(B::MULTI) { return B::MULTI; }
     template <class B>
@@ -149,7 +148,6 @@ struct Issue {
         if (int e = attr.ensure((const void*)one_kernel<BODY, A...>, smem)) return e;
         one_kernel<BODY, A...><<<grid, dim3(BODY::THREADS), smem, st>>>(bound...);
         const hipError_t e = hipGetLastError();
-        count_launch(1);
         return e == hipSuccess ? 0 : (int)e;
     }
     template <class H, class... T, class... B>
@@ -187,7 +185,6 @@ struct Issue {
             if (int e = attr.ensure((const void*)many_kernel<BODY, A...>, smem)) return e;
             many_kernel<BODY, A...><<<dim3((unsigned)blocks), dim3(BODY::THREADS), smem, st>>>(t);
             const hipError_t e = hipGetLastError();
-            count_launch(n);
             return e == hipSuccess ? 0 : (int)e;
         } else {
             return -1;               // the zip never groups records of max_group 1

@@ -18,7 +18,7 @@ struct State {
     int error = 0;                       // first error of a flush made on behalf of a direct launch (reported by end)
     std::vector<Record> list[kMaxBranches];
     int op[kMaxBranches] = {};
-    long recorded = 0, launches = 0, problems = 0, scopes = 0, flushed_launches = 0, flushed_problems = 0, forced = 0;
+    long recorded = 0, scopes = 0, flushed_launches = 0, forced = 0;      // semseg_batch_stats
 };
 static State g;
 static std::recursive_mutex g_mu;
@@ -54,15 +54,11 @@ void hint_cost(int cost) {
     if (g.active) g.next_cost = cost;
 }
 
-void count_launch(int problems) {
-    ++g.launches;
-    g.problems += problems;
-}
-
 // Zip: every branch's list is in issue order with non-decreasing op ordinals.  Walk the ordinals upwards; inside one ordinal (the
-// launches of one C-ABI call: e.g. GEMM [+ split-K reduce]) match the branches' records front to front -- the head of the first
-// branch that still has records of this ordinal names the kernel instantiation, every other branch whose head is the same
-// instantiation joins the group (up to kMaxGroup), the group leaves as one launch.  Branch order inside a group = branch index.
+// launches of one C-ABI call: e.g. GEMM [+ split-K reduce], or statistics sweep + finish) match the branches' records front to
+// front: one branch's head names the kernel instantiation that leaves next (see below which), every other branch whose head is the
+// same instantiation joins the group (up to kMaxGroup / the instantiation's own limit), the group leaves as one launch, its problems
+// ordered longest blocks first.  Records of a branch never overtake each other; branches do not depend on each other.
 int flush_recorded() {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!g.active) return 0;
@@ -113,7 +109,6 @@ int flush_recorded() {
                 fprintf(stderr, ")\n");
             }
             g.flushed_launches += 1;
-            g.flushed_problems += n;
             for (int i = 1; i < n; ++i)            // longest blocks first (stable insertion sort on the launch sites' hints)
                 for (int k = i; k > 0 && grp[k]->cost > grp[k - 1]->cost; --k) {
                     const Record* t = grp[k]; grp[k] = grp[k - 1]; grp[k - 1] = t;
