@@ -144,6 +144,11 @@ typedef struct {
 } semseg_wgrad_problem;
 int semseg_conv2d_wgrad_tile_h2(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int semseg_conv2d_wgrad_multi_h2(semseg_wgrad_problem* problems_host, int n, void* stream);
+/* member mode of the weight-gradient plans (round 6): while on, a pinned plan of a SMALL weight tensor (at most 4 tiles of 64 x 64:
+ * K, C <= 128; SEMSEG_WGRAD_MEMBER_TILES) on any other tile is read as the register-staged 64 x 64 tile with the same number of
+ * blocks -- the form semseg_conv2d_wgrad_multi_h2 batches.  The host turns it on around the calls of its deferral only
+ * (semseg_conv2d_wgrad_tile_h2 / _slabs_bytes / _slabs_h2 / _multi_h2), never while a plan is being timed.  Returns the previous mode. */
+int semseg_conv2d_wgrad_member_plan(int enable);
 size_t semseg_conv2d_h2_workspace_bytes(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 int semseg_conv2d_fwd_h2(const void* xs, const void* ws, const float* bias, float* y, int y_ld,
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

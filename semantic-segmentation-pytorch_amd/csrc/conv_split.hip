@@ -117,6 +117,34 @@ static bool batch_plan(int pass, int M, int Cout, int Cred, int* tile, int* spli
     return true;
 }
 
+// The plan of a SMALL weight gradient as a member of a batch (round 6).  The per-geometry plans were timed with the chip to one launch:
+// a 96 x 96 x 3 x 3 weight gradient wins on one 128 x 128 LDS-DMA tile split 24 ways (20 us) -- but inside TrainStep's deferral
+// (ops.defer_wgrad_reduces) the gradients whose plan is the register-staged 64 x 64 tile wait for backward to return and run 24
+// problems per launch (semseg_conv2d_wgrad_multi_h2), where the launch is shared.  While the host has the member mode on
+// (semseg_conv2d_wgrad_member_plan, around the deferral's own calls only -- never while the tuner times a plan), a plan on any
+// other tile becomes the 64 x 64 tile with the same number of blocks, for weight tensors of at most `max_tiles` 64 x 64 tiles
+// (default 4: K, C <= 128).  HRNetV2 (its 32 weight gradients of the 96-channel branch): 19.29 -> 18.36 ms per step (gpurun r9g).
+static int g_wgrad_member = 0, g_wgrad_member_tiles = [] { const char* e = getenv("SEMSEG_WGRAD_MEMBER_TILES"); return e ? atoi(e) : 4; }();
+static const int kWTiles[15][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
+                                    {128, 128}, {128, 128}, {64, 64}, {256, 256}, {256, 256}, {128, 128}, {128, 128}};
+static void wgrad_member_plan(int K, int C, int T, int* tile, int* split) {
+    if (!g_wgrad_member || *tile < 0 || *tile == 1 || *tile == 10 || *tile > 14) return;      // 10: the all-taps kernel wins its layers by fetching a third of the bytes
+    const int nt = ((K + 63) / 64) * ((C + 63) / 64);
+    if (nt > g_wgrad_member_tiles) return;
+    const long old_blocks = (long)((K + kWTiles[*tile][0] - 1) / kWTiles[*tile][0]) * ((C + kWTiles[*tile][1] - 1) / kWTiles[*tile][1]) * T *
+                            (*split > 0 ? *split : 1);
+    long sp = old_blocks / ((long)nt * T);
+    if (sp < 1) sp = 1;
+    if (sp > 64) sp = 64;
+    *tile = 1;
+    *split = (int)sp;
+}
+extern "C" int semseg_conv2d_wgrad_member_plan(int enable) {
+    const int prev = g_wgrad_member;
+    g_wgrad_member = enable ? 1 : 0;
+    return prev;
+}
+
 static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                         int* tile, int* split) {
     if (sch == 1 /* SchH2::ID */ && pass <= 1) {
@@ -129,6 +157,7 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
     if (it == g_plans.end()) return false;
     *tile = it->second.first;
     *split = it->second.second;
+    if (sch == 1 && pass == 2) wgrad_member_plan(K, C, R * S, tile, split);
     // SEMSEG_BATCH_TILE=-2 (default): inside a side-by-side scope every 64 x 64 form of the per-geometry plans (register staged,
     // 2- / 3- / 5-slot rings) becomes THE 64-deep form, split kept -- the branches' plans then name one kernel where they differed
     // only in the ring (the 96-channel branch could not take the 64-deep kernel when the plans were timed) and their GEMMs pair up
@@ -3640,8 +3669,7 @@ struct WPlan {
 // the tuner / overrides only
 // 10 = 64x64 with all nine taps of a 3x3 stride-1 conv in the block (wgrad_taps_kernel): tiles = tiles_k * tiles_c, not * T
 // 11 ... 14 (round 5): the LDS-DMA tiles on the ring of five half tiles with spread DMA issue: 256 x 256 on 16 / 8 waves, 128 x 128 on 8 / 4 waves
-static const int kWTiles[15][2] = {{128, 128}, {64, 64}, {128, 128}, {256, 128}, {256, 256}, {128, 128}, {256, 256}, {256, 256},
-                                    {128, 128}, {128, 128}, {64, 64}, {256, 256}, {256, 256}, {128, 128}, {128, 128}};
+// kWTiles: defined next to lookup_plan (the member plan above needs the tile extents)
 constexpr int kWTileTaps = 10;
 
 // tuning overrides: SEMSEG_W3_TILE=0..3, SEMSEG_W3_SPLIT=n

@@ -70,6 +70,7 @@ SIGNATURES = {
     'semseg_reduce_slabs_multi': (c_int, [ctypes.POINTER(SlabTensor), c_int, vp]),
     'semseg_conv2d_wgrad_tile_h2': (c_int, [c_int] * 10),
     'semseg_conv2d_wgrad_multi_h2': (c_int, [ctypes.POINTER(WgradProblem), c_int, vp]),
+    'semseg_conv2d_wgrad_member_plan': (c_int, [c_int]),
     'semseg_conv2d_h2_set_plan': (c_int, [c_int] * 13),
     'semseg_bias_grad': (c_int, [vp, c_int, vp, c_int, c_int, vp, c_sz, vp]),
     'semseg_bn_workspace_bytes': (c_sz, [c_int, c_int]),

@@ -872,6 +872,10 @@ DEFER_WGRAD_REDUCE = os.environ.get('SEMSEG_DEFER_WGRAD_REDUCE', '1') != '0'
 # and flush_wgrad_reduces runs the blocks of up to 24 of them side by side in one launch (semseg_conv2d_wgrad_multi_h2: the blocks
 # of the per-layer launches unchanged, bit-identical slabs).  SEMSEG_DEFER_WGRAD_LAUNCH=0 launches them where autograd reaches them.
 DEFER_WGRAD_LAUNCH = os.environ.get('SEMSEG_DEFER_WGRAD_LAUNCH', '1') != '0'
+# ... and a small weight gradient (K, C <= 128) whose own plan is another tile joins them on the 64 x 64 tile with the same number of
+# blocks (csrc/conv_split.hip wgrad_member_plan): its plan was timed with the chip to itself, the batched launch shares it.  HRNetV2's
+# 96-channel branch: 19.29 -> 18.36 ms per step.  SEMSEG_WGRAD_MEMBER_PLAN=0: every weight gradient on its own plan.
+WGRAD_MEMBER_PLAN = os.environ.get('SEMSEG_WGRAD_MEMBER_PLAN', '1') != '0'
 # ONE pass over the weights after backward (round 6): the fused SGD kernel sums the slabs of the deferred weight gradients itself and
 # leaves the maxima of the updated weights for the weight preparation (csrc/head.hip sgd_fused_kernel).  SEMSEG_SGD_FUSED=0: the
 # reduce launch, the plain SGD kernel and the absmax pass of the weight preparation, as before.
@@ -961,7 +965,11 @@ def flush_wgrad_reduces(mid_backward=False, into_sgd=False):
             if on_dev:                       # planes produced on a branch stream, read on this one
                 xs.record_stream(cur)
                 dys.record_stream(cur)
-        _native.check(_native.lib().semseg_conv2d_wgrad_multi_h2(parr, len(probs), _st()), 'conv2d_wgrad_multi_h2')
+        member = _native.lib().semseg_conv2d_wgrad_member_plan(1 if WGRAD_MEMBER_PLAN else 0)      # the plans the problems were queued under
+        try:
+            _native.check(_native.lib().semseg_conv2d_wgrad_multi_h2(parr, len(probs), _st()), 'conv2d_wgrad_multi_h2')
+        finally:
+            _native.lib().semseg_conv2d_wgrad_member_plan(member)
         for i, (xs, dys, slabs, out, geom, param, st) in enumerate(probs):
             _PENDING_SLABS.append((slabs, out, geom[4] * geom[5] * geom[6] * geom[3], int(parr[i].splits), param, st))
     if not mid_backward:
@@ -1037,15 +1045,21 @@ def _split_conv_grads(L, sch, scheme, geom, xs, dys, w, wtp, need_dx, need_dw, p
                           'conv2d_wgrad_' + scheme)
         tuner.ensure(scheme, 2, geom, launch_w)        # candidates are timed WITH their reduce: what a plan costs either way
         if _DEFER[0] and scheme == 'h2' and _may_defer(param):
-            nbytes = L.semseg_conv2d_wgrad_slabs_bytes(*geom)
-            slabs = torch.empty((max(16, nbytes) + 3) // 4, device=dev, dtype=torch.float32)
-            if DEFER_WGRAD_LAUNCH and L.semseg_conv2d_wgrad_tile_h2(*geom) == 1:
-                _PENDING_WGRADS.append((xs, dys, slabs, dwb, tuple(geom), param, _producer_stream(dwb)))
-            else:
-                splits = ctypes.c_int(0)
-                _native.check(L.semseg_conv2d_wgrad_slabs_h2(_p(xs), _p(dys), _p(slabs), slabs.numel() * 4, ctypes.byref(splits),
-                                                             *geom, _st()), 'conv2d_wgrad_slabs_h2')
-                _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value), param, _producer_stream(dwb)))
+            # member mode: a small weight gradient whose own plan is an LDS-DMA tile is read as the 64 x 64 tile the batched launch
+            # takes (same number of blocks) -- for these calls only, never while the tuner times a plan (tuner.ensure above)
+            member = L.semseg_conv2d_wgrad_member_plan(1 if (DEFER_WGRAD_LAUNCH and WGRAD_MEMBER_PLAN) else 0)
+            try:
+                nbytes = L.semseg_conv2d_wgrad_slabs_bytes(*geom)
+                slabs = torch.empty((max(16, nbytes) + 3) // 4, device=dev, dtype=torch.float32)
+                if DEFER_WGRAD_LAUNCH and L.semseg_conv2d_wgrad_tile_h2(*geom) == 1:
+                    _PENDING_WGRADS.append((xs, dys, slabs, dwb, tuple(geom), param, _producer_stream(dwb)))
+                else:
+                    splits = ctypes.c_int(0)
+                    _native.check(L.semseg_conv2d_wgrad_slabs_h2(_p(xs), _p(dys), _p(slabs), slabs.numel() * 4, ctypes.byref(splits),
+                                                                 *geom, _st()), 'conv2d_wgrad_slabs_h2')
+                    _PENDING_SLABS.append((slabs, dwb, k * r * s * c, int(splits.value), param, _producer_stream(dwb)))
+            finally:
+                L.semseg_conv2d_wgrad_member_plan(member)
         else:
             launch_w()
         dw = dwb.permute(0, 3, 1, 2)

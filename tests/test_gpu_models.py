@@ -485,6 +485,7 @@ SWITCH_CASES = [
     ('SEMSEG_TUNE_DB=0', 'r18d_ppmds_64_train'),
     ('SEMSEG_DEFER_WGRAD_REDUCE=0', 'r50d_ppmds_64_train'),  # one reduce launch per split weight gradient instead of ONE per step             # no shipped launch plans: every geometry timed in the process
     ('SEMSEG_DEFER_WGRAD_LAUNCH=0', 'hrnetv2_c1_128_train'), # every small weight gradient its own launch instead of 24 per launch
+    ('SEMSEG_WGRAD_MEMBER_PLAN=0', 'hrnetv2_c1_128_train'),  # every small weight gradient on its own plan instead of joining the batched launch
     ('SEMSEG_DEFER_FORK_SUMS=0', 'r50d_ppmds_64_train'),     # the gradient sums at the forks by add launches instead of inside the BN backward kernels
     ('SEMSEG_DEFER_FORK_SUMS=0', 'hrnetv2_c1_128_train'),
     ('SEMSEG_DMA64_SPREAD=0', 'r50d_ppmds_64_train'),        # the 64-deep GEMM tiles with their DMA pieces in one burst per k-tile
