@@ -166,7 +166,8 @@ static bool lookup_plan(int sch, int pass, int N, int H, int W, int C, int K, in
         *tile = 23;
     // measured and removed again (gpurun r8q / r8r, HRNetV2 19.24 ms per step with the mapping above): no split-K for the recorded 64-deep
     // GEMMs 19.66 ms; k loops equalised to at most 9 / 14 / 18 / 27 k-tiles per block by more split-K 20.83 / 20.08 / 19.53 / 19.31 ms (a split
-    // costs the statistics sweep and a reduce); plans re-timed with the 64-deep tile open to the 96-channel layers 19.79 against 19.59 ms
+    // costs the statistics sweep and a reduce); plans re-timed with the 64-deep tile open to the 96-channel layers 19.79 against 19.59 ms;
+    // the 128-wide forms mapped to the 64-deep 64 x 64 tile as well: 18.13 against 18.14 ms (gpurun r9j)
     return true;
 }
 

@@ -34,22 +34,28 @@ def main():
     case = sys.argv[1] if len(sys.argv) > 1 else 'hrnetv2_c1_128_train'
     if os.environ.get('BATCH_TRACE_WORKER') == '1':
         return worker(case)
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), case], env=dict(os.environ, BATCH_TRACE_WORKER='1', SEMSEG_BATCH_DEBUG='1'),
-                       capture_output=True, text=True, timeout=900)
+    if case.startswith('bench:'):
+        # the BASELINE configuration at full size: bench.py records the step ONCE into its hipGraph, so the trace is one step's scopes
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--config', case[6:], '--steps', '3', '--warmup', '3', '--no-cpu-baseline',
+               '--no-other-configs', '--no-box', '--no-scaling-model', '--repeats', '0']
+        r = subprocess.run(cmd, env=dict(os.environ, SEMSEG_BATCH_DEBUG='1'), capture_output=True, text=True, timeout=900)
+    else:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), case],
+                           env=dict(os.environ, BATCH_TRACE_WORKER='1', SEMSEG_BATCH_DEBUG='1'), capture_output=True, text=True, timeout=900)
     groups, forced = collections.Counter(), collections.Counter()
     for ln in r.stderr.splitlines():
         m = re.match(r'\[semseg_batch\] op \d+: (\d+) x (.*) \(branches', ln)
         if m:
-            groups[(re.sub(r'<.*', '', m.group(2)), int(m.group(1)))] += 1
+            groups[(m.group(2)[:70] if case.startswith('bench:') else re.sub(r'<.*', '', m.group(2)), int(m.group(1)))] += 1
         m = re.match(r'\[semseg_batch\] branch \d+ op \d+: direct launch of (.*) forces a flush', ln)
         if m:
             forced[m.group(1)[:100]] += 1
-    print('case %s, two eager steps: rc %d' % (case, r.returncode))
+    print('case %s (%s): rc %d' % (case, 'one recorded step' if case.startswith('bench:') else 'two eager steps', r.returncode))
     if r.returncode:
         print(r.stderr[-3000:])
     print('launches issued by the zip, by (kernel body, problems in the launch):')
     for (k, n), c in sorted(groups.items()):
-        print('  %-40s x%d  %5d' % (k, n, c))
+        print('  %-72s x%d  %5d' % (k, n, c))
     print('direct launches inside a scope (each forces a flush):')
     for k, c in forced.most_common():
         print('  %5d  %s' % (c, k))
