@@ -278,10 +278,16 @@ def choose(geom, candidates, default=0):
     return best[0]
 
 
+SEEN = None          # tools/step_plan_refine.py: a set that collects the plan keys the running model asks for
+RANKED = None        # ... and a dict key -> the fastest candidates of a timing sweep [(ms, tile, split), ...]
+
+
 def ensure(scheme, pass_id, geom, launch):
     """scheme = 'h2' | 's3'; geom = (N,H,W,C,K,R,S,stride,pad,dil); launch() issues the conv of this pass on the
     current stream."""
     key = (scheme, pass_id) + tuple(geom)
+    if SEEN is not None:
+        SEEN.add(key)
     if ENABLED and not _cache_loaded:
         _load_cache()
     if not ENABLED or key in _done:
@@ -348,6 +354,8 @@ def ensure(scheme, pass_id, geom, launch):
         # play-off: with ~200 candidates per geometry a 5 % timing outlier picks the wrong plan now and then; the three
         # fastest are timed again (more launches per round) and the best mean of the two measurements wins
         ranked.sort()
+        if RANKED is not None:
+            RANKED[key] = ranked[:6]
         finals = []
         for ms, tile, split in ranked[:3]:
             if tile < 0:
