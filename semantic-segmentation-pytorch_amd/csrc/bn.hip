@@ -666,19 +666,41 @@ struct bn_apply_h2_kernel_body {
                                                           size_t plane, int pitch, int* __restrict__ hdr, int P, int C,
                                                           int Cp, const uint32_t* __restrict__ blockbound, int nbound,
                                                           float* __restrict__ absmax_out, uint8_t* __restrict__ gate) {
+    // a thread keeps ONE group of 8 channels (scale / shift loaded once) and walks down the rows; consecutive threads own
+    // consecutive channel groups of a row, then the next row -- the coalescing of a flat index
+    // (32-bit index arithmetic: the host keeps gridDim.x * 256 below 2^31; a 64-bit division is a software loop on this part)
+    const unsigned G = (unsigned)Cp >> 3;
+    const unsigned threads = gridDim.x * blockDim.x;
+    const unsigned rows_step = threads / G;
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = rows_step != 0 && tid < rows_step * G;
+    const unsigned trow = tid / G;
+    const int c = in_range ? (int)(tid - trow * G) << 3 : 0;
+    const int prow = in_range ? (int)trow : 0;
+    const bool live = in_range && c < C;
+    // Everything that does not depend on the plane exponent is REQUESTED before the exponent's reduction (blockbound loads, two
+    // barriers): scale / shift and the thread's first row.  The grid is one wave of blocks that all start together, so behind the
+    // reduction each of these was a memory latency of its own at the head of a 5 - 10 us kernel.
+    float4 sc0 = f4zero(), sc1 = f4zero(), sh0 = f4zero(), sh1 = f4zero();
+    float4 v_first[2] = {f4zero(), f4zero()}, r_first[2] = {f4zero(), f4zero()};
+    auto load_row = [&](size_t p, float4 (&v)[2], float4 (&r)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v[h] = *reinterpret_cast<const float4*>(z + p * C + c + 4 * h);
+            if (RES) r[h] = *reinterpret_cast<const float4*>(res + p * res_ld + c + 4 * h);
+        }
+    };
+    const bool has_first = live && (size_t)prow < (size_t)P;
+    if (live) {
+        sc0 = *reinterpret_cast<const float4*>(scale + c); sc1 = *reinterpret_cast<const float4*>(scale + c + 4);
+        sh0 = *reinterpret_cast<const float4*>(shift + c); sh1 = *reinterpret_cast<const float4*>(shift + c + 4);
+        if (has_first) load_row((size_t)prow, v_first, r_first);
+    }
     const int ex = h2_exponent_from(hdr, blockbound, nbound, absmax_out, blockIdx.x == 0);
     const float sc2 = pow2i(ex);
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
         reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
-    // a thread keeps ONE group of 8 channels (scale / shift loaded once) and walks down the rows; consecutive threads own
-    // consecutive channel groups of a row, then the next row -- the coalescing of a flat index
-    const int G = Cp >> 3;
-    const size_t threads = (size_t)gridDim.x * blockDim.x;
-    const size_t rows_step = threads / G;
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (rows_step == 0 || tid >= rows_step * G) return;
-    const int c = (int)(tid % G) << 3;
-    const int prow = (int)(tid / G);
+    if (!in_range) return;
     if (c >= C) {                                  // padding groups of the plane pitch: zeros
         f16x8 zf;
 #pragma unroll
@@ -690,22 +712,15 @@ struct bn_apply_h2_kernel_body {
         }
         return;
     }
-    const float4 sc0 = *reinterpret_cast<const float4*>(scale + c), sc1 = *reinterpret_cast<const float4*>(scale + c + 4);
-    const float4 sh0 = *reinterpret_cast<const float4*>(shift + c), sh1 = *reinterpret_cast<const float4*>(shift + c + 4);
-#pragma unroll 4
-    for (size_t p = prow; p < (size_t)P; p += rows_step) {
+    auto finish_row = [&](size_t p, const float4 (&v)[2], const float4 (&r)[2]) {
         float o[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 v = *reinterpret_cast<const float4*>(z + p * C + c + 4 * h);
             const float4 sc = h ? sc1 : sc0, sh = h ? sh1 : sh0;
             float4 t;
-            t.x = fmaf(v.x, sc.x, sh.x); t.y = fmaf(v.y, sc.y, sh.y);
-            t.z = fmaf(v.z, sc.z, sh.z); t.w = fmaf(v.w, sc.w, sh.w);
-            if (RES) {
-                const float4 r = *reinterpret_cast<const float4*>(res + p * res_ld + c + 4 * h);
-                t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
-            }
+            t.x = fmaf(v[h].x, sc.x, sh.x); t.y = fmaf(v[h].y, sc.y, sh.y);
+            t.z = fmaf(v[h].z, sc.z, sh.z); t.w = fmaf(v[h].w, sc.w, sh.w);
+            if (RES) { t.x += r[h].x; t.y += r[h].y; t.z += r[h].z; t.w += r[h].w; }
             if (RELU) {
                 t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
             }
@@ -721,14 +736,21 @@ struct bn_apply_h2_kernel_body {
         f16x8 p0, p1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            _Float16 a, r;
-            h2_split_of(o[e] * sc2, a, r);
+            _Float16 a, r2;
+            h2_split_of(o[e] * sc2, a, r2);
             p0[e] = a;
-            p1[e] = r;
+            p1[e] = r2;
         }
         const size_t po = p * pitch + c;
         *reinterpret_cast<f16x8*>(planes + po) = p0;
         *reinterpret_cast<f16x8*>(planes + plane + po) = p1;
+    };
+    if (has_first) finish_row((size_t)prow, v_first, r_first);
+#pragma unroll 4
+    for (size_t p = (size_t)prow + rows_step; p < (size_t)P; p += rows_step) {
+        float4 v[2], r[2] = {f4zero(), f4zero()};
+        load_row(p, v, r);
+        finish_row(p, v, r);
     }
     }
 };
@@ -1006,21 +1028,76 @@ struct bn_bwd_apply_h2_kernel_body {
                                                               const uint32_t* __restrict__ blockbound, int nbound,
                                                               const float* __restrict__ dy2, int dy2_ld) {
     // dy2 != nullptr: the incoming gradient is dy + dy2 (see bn_bwd_mm_partial_kernel)
+    // A thread keeps ONE group of 8 channels and walks down the rows: the per-channel terms (1/std, gamma, mean, the two batch
+    // means, the gate's scale / shift: 26 loads) are fetched once instead of once per 8 outputs, and only dy / z (/ y) stream.
+    // Consecutive threads own consecutive channel groups of a row, then the next row -- the coalescing of a flat index.
+    const unsigned G = (unsigned)Cp >> 3;                 // 32-bit index arithmetic, as bn_apply_h2_kernel
+    const unsigned threads = gridDim.x * blockDim.x;
+    const unsigned rows_step = threads / G;               // rows covered per sweep; the last threads % G threads idle
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = rows_step != 0 && tid < rows_step * G;
+    const unsigned trow = tid / G;
+    const int c = in_range ? (int)(tid - trow * G) << 3 : 0;
+    const int prow = in_range ? (int)trow : 0;
+    const bool live = in_range && c < C;
+    const bool gate_z = RELU && gscale;
+    // The per-channel terms and the thread's first row are REQUESTED before the reduction that yields the plane exponent (as
+    // bn_apply_h2_kernel: one wave of blocks that start together; each dependent load was a latency at the head of the kernel).
+    struct Row { float4 g[2], h[2], v[2], y[2]; unsigned b; };
+    auto load_row = [&](size_t p, Row& r) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            r.g[h] = *reinterpret_cast<const float4*>(dy + p * dy_ld + c + 4 * h);
+            if (dy2) r.h[h] = *reinterpret_cast<const float4*>(dy2 + p * dy2_ld + c + 4 * h);      // grid-uniform
+            if (TRAIN || gate_z) r.v[h] = *reinterpret_cast<const float4*>(z + p * C + c + 4 * h);
+            if (RELU && !gate_z && y_ld) r.y[h] = *reinterpret_cast<const float4*>(y + p * y_ld + c + 4 * h);
+        }
+        // the forward's bitmask in place of y (semseg_bn_apply_h2_gate)
+        if (RELU && !gate_z && !y_ld) r.b = reinterpret_cast<const uint8_t*>(y)[p * (size_t)(C >> 3) + (c >> 3)];
+    };
+    float is[8], ga[8], mu[8], m[8], x[8], gs[8], gh[8];      // m / x: the sums as floats until 1 / n is known (below)
+    Row first;
+    first.b = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        first.g[h] = f4zero(); first.h[h] = f4zero(); first.v[h] = f4zero(); first.y[h] = f4zero();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            is[4 * h + e] = 0.f; ga[4 * h + e] = 0.f; mu[4 * h + e] = 0.f; gs[4 * h + e] = 0.f; gh[4 * h + e] = 0.f;
+            m[4 * h + e] = 0.f; x[4 * h + e] = 0.f;
+        }
+    }
+    const bool has_first = live && (size_t)prow < (size_t)P;
+    if (live) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cc = c + 4 * h;
+            const float4 is4 = *reinterpret_cast<const float4*>(invstd + cc);
+            const float4 ga4 = *reinterpret_cast<const float4*>(gamma + cc);
+            is[4 * h] = is4.x; is[4 * h + 1] = is4.y; is[4 * h + 2] = is4.z; is[4 * h + 3] = is4.w;
+            ga[4 * h] = ga4.x; ga[4 * h + 1] = ga4.y; ga[4 * h + 2] = ga4.z; ga[4 * h + 3] = ga4.w;
+            if (TRAIN) {
+                const float4 mu4 = *reinterpret_cast<const float4*>(mean + cc);
+                mu[4 * h] = mu4.x; mu[4 * h + 1] = mu4.y; mu[4 * h + 2] = mu4.z; mu[4 * h + 3] = mu4.w;
+                const double2 sa = *reinterpret_cast<const double2*>(sums + cc), sb = *reinterpret_cast<const double2*>(sums + cc + 2);
+                const double2 xa = *reinterpret_cast<const double2*>(sums + C + cc), xb = *reinterpret_cast<const double2*>(sums + C + cc + 2);
+                m[4 * h] = (float)sa.x; m[4 * h + 1] = (float)sa.y; m[4 * h + 2] = (float)sb.x; m[4 * h + 3] = (float)sb.y;
+                x[4 * h] = (float)xa.x; x[4 * h + 1] = (float)xa.y; x[4 * h + 2] = (float)xb.x; x[4 * h + 3] = (float)xb.y;
+            }
+            if (RELU && gscale) {
+                const float4 s4 = *reinterpret_cast<const float4*>(gscale + cc), h4 = *reinterpret_cast<const float4*>(gshift + cc);
+                gs[4 * h] = s4.x; gs[4 * h + 1] = s4.y; gs[4 * h + 2] = s4.z; gs[4 * h + 3] = s4.w;
+                gh[4 * h] = h4.x; gh[4 * h + 1] = h4.y; gh[4 * h + 2] = h4.z; gh[4 * h + 3] = h4.w;
+            }
+        }
+        if (has_first) load_row((size_t)prow, first);
+    }
+    const double n_count = TRAIN ? count[0] : 1.0;
     const int ex = h2_exponent_from(hdr, blockbound, nbound, nullptr, blockIdx.x == 0);
     const float sc2 = pow2i(ex);
     if (blockIdx.x == 0 && threadIdx.x < SPLIT_ZERO_TAIL_BYTES / 16)
         reinterpret_cast<uint4*>(planes + H2_NP * plane)[threadIdx.x] = make_uint4(0, 0, 0, 0);
-    const float inv_n = TRAIN ? (float)(1.0 / count[0]) : 0.f;
-    // A thread keeps ONE group of 8 channels and walks down the rows: the per-channel terms (1/std, gamma, mean, the two batch
-    // means, the gate's scale / shift: 26 loads) are fetched once instead of once per 8 outputs, and only dy / z (/ y) stream.
-    // Consecutive threads own consecutive channel groups of a row, then the next row -- the coalescing of a flat index.
-    const int G = Cp >> 3;
-    const size_t threads = (size_t)gridDim.x * blockDim.x;
-    const size_t rows_step = threads / G;                 // rows covered per sweep; the last threads % G threads idle
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (rows_step == 0 || tid >= rows_step * G) return;
-    const int c = (int)(tid % G) << 3;
-    const int prow = (int)(tid / G);
+    if (!in_range) return;
     if (c >= C) {                                          // padding groups of the plane pitch: zeros
         f16x8 zf;
 #pragma unroll
@@ -1032,58 +1109,23 @@ struct bn_bwd_apply_h2_kernel_body {
         }
         return;
     }
-    float is[8], ga[8], mu[8], m[8], x[8], gs[8], gh[8];
+    const float inv_n = TRAIN ? (float)(1.0 / n_count) : 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int cc = c + 4 * h;
-        const float4 is4 = *reinterpret_cast<const float4*>(invstd + cc);
-        const float4 ga4 = *reinterpret_cast<const float4*>(gamma + cc);
-        is[4 * h] = is4.x; is[4 * h + 1] = is4.y; is[4 * h + 2] = is4.z; is[4 * h + 3] = is4.w;
-        ga[4 * h] = ga4.x; ga[4 * h + 1] = ga4.y; ga[4 * h + 2] = ga4.z; ga[4 * h + 3] = ga4.w;
-        if (TRAIN) {
-            const float4 mu4 = *reinterpret_cast<const float4*>(mean + cc);
-            mu[4 * h] = mu4.x; mu[4 * h + 1] = mu4.y; mu[4 * h + 2] = mu4.z; mu[4 * h + 3] = mu4.w;
-            const double2 sa = *reinterpret_cast<const double2*>(sums + cc), sb = *reinterpret_cast<const double2*>(sums + cc + 2);
-            const double2 xa = *reinterpret_cast<const double2*>(sums + C + cc), xb = *reinterpret_cast<const double2*>(sums + C + cc + 2);
-            m[4 * h] = (float)sa.x * inv_n; m[4 * h + 1] = (float)sa.y * inv_n; m[4 * h + 2] = (float)sb.x * inv_n; m[4 * h + 3] = (float)sb.y * inv_n;
-            x[4 * h] = (float)xa.x * inv_n; x[4 * h + 1] = (float)xa.y * inv_n; x[4 * h + 2] = (float)xb.x * inv_n; x[4 * h + 3] = (float)xb.y * inv_n;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { mu[4 * h + e] = 0.f; m[4 * h + e] = 0.f; x[4 * h + e] = 0.f; }
-        }
-        if (RELU && gscale) {
-            const float4 s4 = *reinterpret_cast<const float4*>(gscale + cc), h4 = *reinterpret_cast<const float4*>(gshift + cc);
-            gs[4 * h] = s4.x; gs[4 * h + 1] = s4.y; gs[4 * h + 2] = s4.z; gs[4 * h + 3] = s4.w;
-            gh[4 * h] = h4.x; gh[4 * h + 1] = h4.y; gh[4 * h + 2] = h4.z; gh[4 * h + 3] = h4.w;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { gs[4 * h + e] = 0.f; gh[4 * h + e] = 0.f; }
-        }
-    }
-    const bool gate_z = RELU && gscale;
-#pragma unroll 4
-    for (size_t p = prow; p < (size_t)P; p += rows_step) {
+    for (int e = 0; e < 8; ++e) { m[e] *= inv_n; x[e] *= inv_n; }        // (float)sum * inv_n, as before
+    auto finish_row = [&](size_t p, const Row& r) {
         float g[8], v[8], yy[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float4 g4 = *reinterpret_cast<const float4*>(dy + p * dy_ld + c + 4 * h);
-            if (dy2) {                    // grid-uniform
-                const float4 h4 = *reinterpret_cast<const float4*>(dy2 + p * dy2_ld + c + 4 * h);
-                g4.x += h4.x; g4.y += h4.y; g4.z += h4.z; g4.w += h4.w;
-            }
+            float4 g4 = r.g[h];
+            if (dy2) { g4.x += r.h[h].x; g4.y += r.h[h].y; g4.z += r.h[h].z; g4.w += r.h[h].w; }
             g[4 * h] = g4.x; g[4 * h + 1] = g4.y; g[4 * h + 2] = g4.z; g[4 * h + 3] = g4.w;
-            float4 v4 = f4zero();
-            if (TRAIN || gate_z) v4 = *reinterpret_cast<const float4*>(z + p * C + c + 4 * h);
+            const float4 v4 = (TRAIN || gate_z) ? r.v[h] : f4zero();
             v[4 * h] = v4.x; v[4 * h + 1] = v4.y; v[4 * h + 2] = v4.z; v[4 * h + 3] = v4.w;
-            if (RELU && !gate_z && y_ld) {
-                const float4 y4 = *reinterpret_cast<const float4*>(y + p * y_ld + c + 4 * h);
-                yy[4 * h] = y4.x; yy[4 * h + 1] = y4.y; yy[4 * h + 2] = y4.z; yy[4 * h + 3] = y4.w;
-            }
+            yy[4 * h] = r.y[h].x; yy[4 * h + 1] = r.y[h].y; yy[4 * h + 2] = r.y[h].z; yy[4 * h + 3] = r.y[h].w;
         }
-        if (RELU && !gate_z && !y_ld) {          // the forward's bitmask in place of y (semseg_bn_apply_h2_gate)
-            const unsigned b = reinterpret_cast<const uint8_t*>(y)[p * (size_t)(C >> 3) + (c >> 3)];
+        if (RELU && !gate_z && !y_ld) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) yy[e] = (float)(b >> e & 1u);
+            for (int e = 0; e < 8; ++e) yy[e] = (float)(r.b >> e & 1u);
         }
         f16x8 p0, p1;
 #pragma unroll
@@ -1095,10 +1137,10 @@ struct bn_bwd_apply_h2_kernel_body {
             }
             g[e] = ge;
             const float t = TRAIN ? ga[e] * is[e] * (ge - m[e] - (v[e] - mu[e]) * is[e] * x[e]) : ga[e] * is[e] * ge;
-            _Float16 a, r;
-            h2_split_of(t * sc2, a, r);
+            _Float16 a, rr;
+            h2_split_of(t * sc2, a, rr);
             p0[e] = a;
-            p1[e] = r;
+            p1[e] = rr;
         }
         if (DRES) {
             *reinterpret_cast<float4*>(dres + p * C + c) = make_float4(g[0], g[1], g[2], g[3]);
@@ -1107,6 +1149,16 @@ struct bn_bwd_apply_h2_kernel_body {
         const size_t po = p * pitch + c;
         *reinterpret_cast<f16x8*>(planes + po) = p0;
         *reinterpret_cast<f16x8*>(planes + plane + po) = p1;
+    };
+    if (has_first) finish_row((size_t)prow, first);
+#pragma unroll 4
+    for (size_t p = (size_t)prow + rows_step; p < (size_t)P; p += rows_step) {
+        Row r;
+        r.b = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { r.h[h] = f4zero(); r.v[h] = f4zero(); r.y[h] = f4zero(); }
+        load_row(p, r);
+        finish_row(p, r);
     }
     }
 };
@@ -1200,6 +1252,16 @@ struct bn_fwd_finish_fused_kernel_body {
     double su = 0.0, sq = 0.0;
     float lo = INFINITY, hi = -INFINITY;
     if (PEER && threadIdx.x == 0) s_q = *pa.seq;
+    // the per-channel terms of the thread that finishes channel c, requested BEFORE the partial rows: they were last touched a
+    // step ago (HBM misses), and behind the reduction each of them was a memory latency of its own at the end of a ~5 us kernel
+    const bool fin = lane == 0 && c < C;
+    float p_gamma = 0.f, p_beta = 0.f, p_rmean = 0.f, p_rvar = 0.f, p_res = 0.f;
+    if (fin) {
+        p_gamma = gamma[c]; p_beta = beta[c];
+        if (running_mean) p_rmean = running_mean[c];
+        if (running_var) p_rvar = running_var[c];
+        if (res_absmax) p_res = res_absmax[0];
+    }
     if (c < C) {
         // 8 partial rows (32 loads) in flight per round; rows past the end are clamped loads whose values are not used.
         // Additions in the order of the plain loop (bit-identical sums).
@@ -1262,16 +1324,16 @@ struct bn_fwd_finish_fused_kernel_body {
         const float muf = (float)mu;
         mean[c] = muf;
         invstd[c] = is;
-        const float sc = gamma[c] * is;
-        const float sh = beta[c] - muf * sc;
+        const float sc = p_gamma * is;
+        const float sh = p_beta - muf * sc;
         scale[c] = sc;
         shift[c] = sh;
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
+        if (running_mean) running_mean[c] = (1.f - momentum) * p_rmean + momentum * muf;
         if (running_var) {
             const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            running_var[c] = (1.f - momentum) * p_rvar + momentum * (float)unbiased;
         }
-        const float rmax = res_absmax ? res_absmax[0] : 0.f;
+        const float rmax = p_res;
         const float e0 = fmaf(lo, sc, sh), e1 = fmaf(hi, sc, sh);
         const float bh = fmaxf(e0, e1) + rmax, bl = fminf(e0, e1) - rmax;
         const float b = relu ? fmaxf(bh, 0.f) : fmaxf(fabsf(bh), fabsf(bl));
@@ -1436,6 +1498,14 @@ struct bn_bwd_finish_fused_kernel_body {
     double su = 0.0, sq = 0.0;
     uint32_t gmx = 0;
     if (PEER && threadIdx.x == 0) s_q = *pa.seq;
+    // per-channel terms of the finishing thread requested before the partial rows (as bn_fwd_finish_fused_kernel)
+    const bool fin = lane == 0 && c < C;
+    float p_is = 0.f, p_gamma = 0.f, p_zlo = 0.f, p_zhi = 0.f, p_mean = 0.f;
+    double p_count = 1.0;
+    if (fin) {
+        p_is = invstd[c]; p_gamma = gamma[c];
+        if (training) { p_count = count[0]; p_zlo = zmm[c]; p_zhi = zmm[C + c]; p_mean = mean[c]; }
+    }
     if (c < C) {
         constexpr int U = 8;                   // as bn_fwd_finish_fused_kernel
         for (int b = lane; b < nparts; b += U * 16) {
@@ -1486,15 +1556,15 @@ struct bn_bwd_finish_fused_kernel_body {
     if (lane == 0 && c < C) {
         if (PEER) { su = xs[0][cl]; sq = xs[1][cl]; }
         sums[c] = su; sums[C + c] = sq;
-        const float is = invstd[c];
+        const float is = p_is;
         float b = __uint_as_float(gmx);
         if (training) {
-            const float inv_n = (float)(1.0 / count[0]);
+            const float inv_n = (float)(1.0 / p_count);
             const float m = fabsf((float)su * inv_n), x = fabsf((float)sq * inv_n);
-            const float xh = fmaxf(fabsf(zmm[c] - mean[c]), fabsf(zmm[C + c] - mean[c])) * is;
+            const float xh = fmaxf(fabsf(p_zlo - p_mean), fabsf(p_zhi - p_mean)) * is;
             b = b + m + xh * x;
         }
-        b = fabsf(gamma[c]) * is * b * 1.0009765625f;
+        b = fabsf(p_gamma) * is * b * 1.0009765625f;
         bits = absbits(b);
     }
     bits = block_max_u32(bits);
