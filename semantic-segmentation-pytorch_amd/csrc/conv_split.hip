@@ -598,16 +598,54 @@ struct KWalk {
 
 // 2^-(ea+eb) as two factors (each within the normal range; see the header comment of the h2 scheme)
 template <class SCH>
-__device__ __forceinline__ void descale_factors(const int* ea, const int* eb, float& f1, float& f2) {
+__device__ __forceinline__ void descale_factors_of(int s, float& f1, float& f2) {
     if constexpr (SCH::SCALED) {
-        const int s = *ea + *eb;           // |s| <= 200
-        const int h = s / 2;
+        const int h = s / 2;               // |s| <= 200
         f1 = pow2i(-h);
         f2 = pow2i(-(s - h));
     } else {
         f1 = 1.f;
         f2 = 1.f;
     }
+}
+template <class SCH>
+__device__ __forceinline__ void descale_factors(const int* ea, const int* eb, float& f1, float& f2) {
+    int s = 0;
+    if constexpr (SCH::SCALED) s = *ea + *eb;
+    descale_factors_of<SCH>(s, f1, f2);
+}
+// The two exponent words of a GEMM's operands are requested at the TOP of the kernel (exp_request) and settled in a scalar
+// register before the first LDS-DMA piece is issued (exp_settle): read in the epilogue they were one more memory latency at the end
+// of every block.  The settle point matters: the LDS-DMA rings below count their vmcnt by hand, so no other vector load may be in
+// flight among their pieces -- the value is consumed (readfirstlane) and a compiler-level memory barrier follows, so whatever load
+// the compiler chose (scalar or vector) was issued and waited for before the first piece.
+template <class SCH>
+__device__ __forceinline__ int exp_request(const int* ea, const int* eb) {
+    if constexpr (SCH::SCALED) return *ea + *eb;           // |sum| <= 200
+    else return 0;
+}
+// The LDS-DMA kernels fetch the sum with scalar loads of their own BEHIND the prologue's DMA pieces (exp_fetch): SMEM counts in
+// lgkmcnt, not in the vmcnt these kernels count by hand, and its latency hides behind the first tiles' flight.  One asm statement
+// incl. the wait: the outputs are valid when it ends (an `s_load` left in flight across compiler-generated code could be copied or
+// spilled before it lands).
+template <class SCH>
+__device__ __forceinline__ int exp_fetch(const int* ea, const int* eb) {
+    if constexpr (SCH::SCALED) {
+        int va, vb;
+        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(va), "=&s"(vb) : "s"(ea), "s"(eb) : "memory");
+        return va + vb;
+    } else {
+        return 0;
+    }
+}
+template <class SCH>
+__device__ __forceinline__ int exp_settle(int e) {
+    if constexpr (SCH::SCALED) {
+        e = __builtin_amdgcn_readfirstlane(e);
+        asm volatile("" : "+s"(e) : : "memory");
+    }
+    return e;
 }
 
 // LDS image of one operand tile: [part][row][4 x 16 B], the 16-byte slot of channel group q of row r stored at
@@ -622,7 +660,8 @@ __device__ __forceinline__ int s_slot(int row, int q) { return row * 4 + (q ^ ((
 // so that ONE partial row per block row tile reaches memory (tiles_m rows for the BN finish kernel instead of tiles_m x WGM).
 template <class SCH, int FM, int FN, int WGM, int BN>
 __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM][FN], int row0, int col0, int z, int bz, int lane,
-                                              int tm, int wm, int wcol, void* smem, const bool first_block) {
+                                              int tm, int wm, int wcol, void* smem, const bool first_block, const int esum) {
+    // esum: sum of the operands' exponent words (exp_request / exp_settle at the top of the kernel)
     // first_block: this is block (0, 0) of ITS launch's grid -- a parameter, not the built-in index: inside a side-by-side launch
     // (csrc/batch.h) a problem's first block sits anywhere in the combined grid
     float* dst;
@@ -636,7 +675,7 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
         dst_ld = p.Cout;
     }
     float f1, f2;
-    descale_factors<SCH>(p.in_exp, p.w_exp, f1, f2);
+    descale_factors_of<SCH>(esum, f1, f2);
     const int col_l = lane & 31;
     const int row_l = 4 * (lane >> 5);
     const bool stats = direct && p.st_sum != nullptr;            // uniform over the block
@@ -648,7 +687,12 @@ __device__ __forceinline__ void gemm_epilogue(const SParams& p, f32x16 (&acc)[FM
         su[j] = 0.0; sq[j] = 0.0; mn[j] = INFINITY; mx[j] = -INFINITY;
         const int col = col0 + j * 32 + col_l;
         if (col >= p.Cout) continue;
-        const float bvl = (direct && p.bias) ? p.bias[col] : 0.f;
+        float bvl = (direct && p.bias) ? p.bias[col] : 0.f;
+        // An UNCONDITIONAL use of the conditionally loaded bias: the one wait for its load happens here.  Without it every row's
+        // store sat behind an `s_waitcnt vmcnt(0)` of its own -- the rows are conditional blocks (row < M), the compiler cannot
+        // carry "already waited" across them, and on gfx9 vmcnt(0) also waits for the previous row's STORE to be acknowledged: 16 x
+        // FM x FN stores per thread went out one round trip at a time (the "8 us epilogue" of the 64 x 64 blocks).
+        asm volatile("" : "+v"(bvl));
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -744,6 +788,7 @@ struct igemm_rs_kernel_body {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    int esum = exp_request<SCH>(p.in_exp, p.w_exp);
 
     // block -> (tm, tn, z, batch): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
     // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows); the
@@ -920,6 +965,7 @@ struct igemm_rs_kernel_body {
         }
     };
 
+    esum = exp_settle<SCH>(esum);
     // steady state: tile kt is in LDS, tile kt+1 travels global -> registers behind the MFMAs of tile kt;
     // the last tile is peeled so that the loop body is branch free (keeps the accumulators in AGPRs)
     for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {
@@ -931,7 +977,7 @@ struct igemm_rs_kernel_body {
     }
     if (kt_begin < kt_end) compute_tile();
     S_MFMA_DRAIN();
-    gemm_epilogue<SCH, FM, FN, 2, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem4, blockIdx.x == 0 && blockIdx.y == 0);
+    gemm_epilogue<SCH, FM, FN, 2, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem4, blockIdx.x == 0 && blockIdx.y == 0, esum);
     }
 };
 
@@ -1008,6 +1054,7 @@ struct igemm_dma_kernel_body {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
+    int esum = 0;              // sum of the operands' exponent words: exp_fetch behind the prologue's DMA pieces
 
     // block -> (tm, tn, z, batch): the blocks of one XCD (consecutive ids after xcd_remap) walk tm fastest, so they share ONE
     // weight slice (tn, z) -- streamed once into that XCD's L2 -- and read adjacent pixel tiles (shared halo rows); the
@@ -1288,6 +1335,7 @@ struct igemm_dma_kernel_body {
 #pragma unroll
         for (int j = 0; j < NENT; ++j) issue_entry();        // A(0) B(0) A(1) B(1) A(2)
         frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+        esum = exp_fetch<SCH>(p.in_exp, p.w_exp);
         wait_vm_barrier<3 * PPE>();                           // entries 0 and 1 have landed for every wave
         int sa = 0, sb = 1;
         read_frags2(sa, sb, 0, a0, b0);
@@ -1306,7 +1354,7 @@ struct igemm_dma_kernel_body {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         S_MFMA_DRAIN();
-        gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0);
+        gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0, esum);
         return;
     }
     // Every iteration issues exactly LPT DMA instructions per wave (dummy zero-tail fetches past the end), so "all but
@@ -1358,6 +1406,7 @@ struct igemm_dma_kernel_body {
             issue_b();
         }
         frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+        esum = exp_fetch<SCH>(p.in_exp, p.w_exp);
         wait_vm_barrier<(RING - 1) * LPT>();                  // tile 0 has landed for every wave
         read_frags(0, 0, a0, b0);
         int slot = 0;
@@ -1376,11 +1425,12 @@ struct igemm_dma_kernel_body {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         S_MFMA_DRAIN();
-        gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0);
+        gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0, esum);
         return;
     }
     issue(kt_begin, 0);
     issue(kt_begin + 1, 1);
+    esum = exp_fetch<SCH>(p.in_exp, p.w_exp);                // every form below: behind the first two tiles' DMA pieces
     if constexpr (NSLOT >= 13) {
         // RING-slot ring (3 ... 5) with the same software pipeline: tile it+RING is issued into the slot of tile it right after the
         // barrier, RING - 1 k-tiles before it is needed (the 2-slot form leaves one).  Round 4 (slots 4 / 5): the short-reduction
@@ -1442,7 +1492,7 @@ struct igemm_dma_kernel_body {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
     SEMSEG_STAMP(2);
-    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0);
+    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0, esum);
     SEMSEG_STAMP(3);
     }
 };
@@ -1485,6 +1535,7 @@ struct igemm_dma64_kernel_body {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
+    int esum = 0;              // sum of the operands' exponent words: exp_fetch behind the prologue's DMA pieces
 
     const GemmBlock gb = gemm_block(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), p.tiles_m, p.tiles_n, p.splits,
                                     gridDim.z, p.tn_fast);
@@ -1681,6 +1732,7 @@ struct igemm_dma64_kernel_body {
 #pragma unroll
     for (int j = 0; j < NENT; ++j) issue_entry();
     frag a0[FM][NP], b0[FN][NP], a1[FM][NP], b1[FN][NP];
+    esum = exp_fetch<SCH>(p.in_exp, p.w_exp);
     wait_vm_barrier<3 * PPE>();                               // entries 0 and 1 have landed for every wave
     int sa = 0, sb = 1;
     read_frags(sa, sb, 0, a0, b0);
@@ -1709,7 +1761,7 @@ struct igemm_dma64_kernel_body {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S_MFMA_DRAIN();
-    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0);
+    gemm_epilogue<SCH, FM, FN, WGM, BN>(p, acc, m0 + wm * WM, n0 + wn * WN, z, bz, lane, tm, wm, wn * WN, smem, blockIdx.x == 0 && blockIdx.y == 0, esum);
     }
 };
 
