@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const IGemmParams p) {
     for (int j = 0; j < FN; ++j) {
         const int col = n0 + wn * WN + j * 32 + col_l;
         if (col >= p.Cout) continue;
-        const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
+        float bv = (direct && p.bias) ? p.bias[col] : 0.f;
+        asm volatile("" : "+v"(bv));      // one wait for the conditional load here, not one per stored row (conv_split.hip gemm_epilogue)
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
 #pragma unroll

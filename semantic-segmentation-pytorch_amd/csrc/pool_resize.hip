@@ -784,11 +784,29 @@ __global__ __launch_bounds__(256) void upsample_softmax_kernel(const float* __re
         const float* r11 = b + ((size_t)h1 * IW + w1) * x_ld;
         float v[K];
         float m = -INFINITY;
+        // All 4 K requests of the pixel leave together: unconditional loads at a clamped class index, then ONE point where they
+        // are consumed (the empty asm statements: without them the compiler sinks each k's loads back into its `c < C` branch and
+        // every k waits for a round trip of its own -- tools/isa_wait_lint.py).
+        float a00[K], a01[K], a10[K], a11[K], prev[K];
+        float* o = out + op * out_ld;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane + 64 * k;
+            const int cc = c < C ? c : C - 1;
+            a00[k] = r00[cc]; a01[k] = r01[cc]; a10[k] = r10[cc]; a11[k] = r11[cc];
+            prev[k] = ACC ? o[cc] : 0.f;               // the scores accumulated so far (eval.py:70), requested with the rest
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            asm volatile("" : "+v"(a00[k]), "+v"(a01[k]), "+v"(a10[k]), "+v"(a11[k]));
+            if (ACC) asm volatile("" : "+v"(prev[k]));
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = lane + 64 * k;
             // the association of bilinear_fwd_kernel (= torch upsample_bilinear2d)
-            v[k] = (c < C) ? lh0 * (lw0 * r00[c] + lw1 * r01[c]) + lh1 * (lw0 * r10[c] + lw1 * r11[c]) : -INFINITY;
+            v[k] = (c < C) ? lh0 * (lw0 * a00[k] + lw1 * a01[k]) + lh1 * (lw0 * a10[k] + lw1 * a11[k]) : -INFINITY;
             m = fmaxf(m, v[k]);
         }
         m = wave_max(m);
@@ -800,13 +818,12 @@ __global__ __launch_bounds__(256) void upsample_softmax_kernel(const float* __re
         }
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
-        float* o = out + op * out_ld;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = lane + 64 * k;
             if (c < C) {
                 const float pr = (v[k] * inv) * weight;        // softmax, then `/ len(imgSizes)` as eval.py:70 (weight = 1/n)
-                o[c] = ACC ? o[c] + pr : pr;
+                o[c] = ACC ? prev[k] + pr : pr;
             }
         }
     }

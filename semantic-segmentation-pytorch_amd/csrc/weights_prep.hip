@@ -100,6 +100,27 @@ __global__ __launch_bounds__(256) void wprep_split_kernel(const WPrepBatch b, in
     const int cg = threadIdx.x & 15;
     const int r0 = threadIdx.x >> 4;
     const int c = c0 + cg * 4;
+    // all 4 passes' weights are REQUESTED first (unconditional loads at clamped indices, one 16-byte load per pass where the
+    // channel count allows), then consumed: as 16 conditional scalar loads each waited for its own round trip (tools/isa_wait_lint.py)
+    float wv[4][4];
+    const bool vec4 = (C & 3) == 0;               // block-uniform: rows of 4 channels are 16-byte aligned
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int k = k0 + r0 + ps * 16;
+        const int kc = k < K ? k : K - 1;
+        const size_t row = ((size_t)kc * T + tap) * C;
+        if (vec4) {
+            const int c4 = c < C ? c : C - 4;
+            const float4 q = *reinterpret_cast<const float4*>(t.w + row + c4);
+            wv[ps][0] = q.x; wv[ps][1] = q.y; wv[ps][2] = q.z; wv[ps][3] = q.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wv[ps][e] = t.w[row + (c + e < C ? c + e : C - 1)];
+        }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) asm volatile("" : "+v"(wv[ps][0]), "+v"(wv[ps][1]), "+v"(wv[ps][2]), "+v"(wv[ps][3]));
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const int kl = r0 + ps * 16;
@@ -107,8 +128,7 @@ __global__ __launch_bounds__(256) void wprep_split_kernel(const WPrepBatch b, in
         f16x4 h0, h1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float v = 0.f;
-            if (k < K && c + e < C) v = t.w[((size_t)k * T + tap) * C + c + e];
+            const float v = (k < K && c + e < C) ? wv[ps][e] : 0.f;
             _Float16 a, r;
             h2_split_of(v * sc, a, r);
             h0[e] = a;
