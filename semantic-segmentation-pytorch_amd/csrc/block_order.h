@@ -34,18 +34,30 @@ SEMSEG_HD GemmBlock gemm_block(int hw_linear, int tiles_m, int tiles_n, int spli
     const int per_batch = tiles_m * tiles_n * splits;
     const int lin = xcd_remap(hw_linear, per_batch * batches);
     GemmBlock b;
-    b.batch = lin / per_batch;
+    // one division instead of three for the plain launch (no batches, no split-K: most of a step's GEMMs) -- on the device every
+    // division by a run-time divisor is a ~30-instruction dependent chain in front of the block's first DMA piece
+    b.batch = batches > 1 ? lin / per_batch : 0;
     const int lid = lin - b.batch * per_batch;
     if (tn_fast) {
-        b.tn = lid % tiles_n;
         const int tmz = lid / tiles_n;
-        b.tm = tmz % tiles_m;
-        b.z = tmz / tiles_m;
+        b.tn = lid - tmz * tiles_n;
+        if (splits > 1) {
+            b.z = tmz / tiles_m;
+            b.tm = tmz - b.z * tiles_m;
+        } else {
+            b.z = 0;
+            b.tm = tmz;
+        }
     } else {
-        b.tm = lid % tiles_m;
         const int tnz = lid / tiles_m;
-        b.tn = tnz % tiles_n;
-        b.z = tnz / tiles_n;
+        b.tm = lid - tnz * tiles_m;
+        if (splits > 1) {
+            b.z = tnz / tiles_n;
+            b.tn = tnz - b.z * tiles_n;
+        } else {
+            b.z = 0;
+            b.tn = tnz;
+        }
     }
     return b;
 }

@@ -575,10 +575,14 @@ struct KWalk {
     int cc, t, r, s;     // channel chunk, tap, tap row / column of the NEXT k-tile
     bool dirty;          // the tap changed since the last set_tap
     __device__ __forceinline__ void init(const SParams& p, int kt) {
-        cc = kt / p.T;
-        t = kt - cc * p.T;
-        r = t / p.S;
-        s = t - r * p.S;
+        if (kt == 0) {                     // wave-uniform; every launch without split-K: no divisions in the prologue
+            cc = 0; t = 0; r = 0; s = 0;
+        } else {
+            cc = kt / p.T;
+            t = kt - cc * p.T;
+            r = t / p.S;
+            s = t - r * p.S;
+        }
         dirty = true;
     }
     __device__ __forceinline__ void next_tap(const SParams& p) {
@@ -595,6 +599,41 @@ struct KWalk {
         }
     }
 };
+
+// Output pixel m -> (image n, row oh, column ow) in the prologue of the GEMM kernels.  An integer division by a run-time divisor
+// is a ~30-instruction dependent chain on this part and the prologue had up to six of them in front of the first DMA piece; for
+// m < 2^24 (every map of the path: 2 x 512 x 512 = 2^19) a float reciprocal + ONE correction step is exact (|q_est - m / d| < 1: the
+// product of an exactly represented m and a correctly rounded 1 / d is within 2^-23 of m / d relative, and q < 2^23 for d >= 2; d = 1
+// is exact) -- as wgrad_block_body has done since round 2.  Larger M takes the integer divisions.
+struct PixDiv {
+    int hw, w;
+    float inv_hw, inv_w;
+    bool small;
+};
+__device__ __forceinline__ PixDiv pix_div(int Hout, int Wout, int M) {
+    PixDiv d;
+    d.hw = Hout * Wout;
+    d.w = Wout;
+    d.inv_hw = 1.0f / (float)d.hw;
+    d.inv_w = 1.0f / (float)Wout;
+    d.small = M <= (1 << 24);
+    return d;
+}
+__device__ __forceinline__ void pix_of(const PixDiv& d, int m, int& n, int& oh, int& ow) {
+    if (d.small) {
+        n = (int)((float)m * d.inv_hw);
+        int rem = m - n * d.hw;
+        if (rem < 0) { --n; rem += d.hw; } else if (rem >= d.hw) { ++n; rem -= d.hw; }
+        oh = (int)((float)rem * d.inv_w);
+        ow = rem - oh * d.w;
+        if (ow < 0) { --oh; ow += d.w; } else if (ow >= d.w) { ++oh; ow -= d.w; }
+    } else {
+        n = m / d.hw;
+        const int rem = m - n * d.hw;
+        oh = rem / d.w;
+        ow = rem - oh * d.w;
+    }
+}
 
 // 2^-(ea+eb) as two factors (each within the normal range; see the header comment of the h2 scheme)
 template <class SCH>
@@ -804,15 +843,13 @@ struct igemm_rs_kernel_body {
     const int lrow = tid >> 2;
 
     int a_ih0[APASS], a_iw0[APASS], a_base[APASS];
-    const int HWout = p.Hout * p.Wout;
+    const PixDiv pd = pix_div(p.Hout, p.Wout, p.M);
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
         const int m = m0 + lrow + i * RPP;
         if (m < p.M) {
-            const int n = m / HWout;
-            const int rem = m - n * HWout;
-            const int oh = rem / p.Wout;
-            const int ow = rem - oh * p.Wout;
+            int n, oh, ow;
+            pix_of(pd, m, n, oh, ow);
             a_ih0[i] = oh * p.a + p.off;
             a_iw0[i] = ow * p.a + p.off;
             a_base[i] = n * p.Hin * p.Win + bz * p.batch_in_rows;
@@ -1077,15 +1114,13 @@ struct igemm_dma_kernel_body {
     const int q = (lane & 3) ^ ((lane >> 4) & 3);
 
     int a_ih0[AG], a_iw0[AG], a_base[AG];
-    const int HWout = p.Hout * p.Wout;
+    const PixDiv pd = pix_div(p.Hout, p.Wout, p.M);
 #pragma unroll
     for (int i = 0; i < AG; ++i) {
         const int m = m0 + (wave + NW * i) * 16 + lrow;
         if (m < p.M) {
-            const int n = m / HWout;
-            const int rem = m - n * HWout;
-            const int oh = rem / p.Wout;
-            const int ow = rem - oh * p.Wout;
+            int n, oh, ow;
+            pix_of(pd, m, n, oh, ow);
             a_ih0[i] = oh * p.a + p.off;
             a_iw0[i] = ow * p.a + p.off;
             a_base[i] = n * p.Hin * p.Win + bz * p.batch_in_rows;
@@ -1556,15 +1591,13 @@ struct igemm_dma64_kernel_body {
     const int q = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
 
     int a_ih0[G8], a_iw0[G8], a_base[G8];
-    const int HWout = p.Hout * p.Wout;
+    const PixDiv pd = pix_div(p.Hout, p.Wout, p.M);
 #pragma unroll
     for (int i = 0; i < G8; ++i) {
         const int m = m0 + (wave + NW * i) * 8 + lrow;
         if (m < p.M) {
-            const int n = m / HWout;
-            const int rem = m - n * HWout;
-            const int oh = rem / p.Wout;
-            const int ow = rem - oh * p.Wout;
+            int n, oh, ow;
+            pix_of(pd, m, n, oh, ow);
             a_ih0[i] = oh * p.a + p.off;
             a_iw0[i] = ow * p.a + p.off;
             a_base[i] = n * p.Hin * p.Win + bz * p.batch_in_rows;
